@@ -1,0 +1,90 @@
+"""TEST INFRASTRUCTURE ONLY — named model configurations as plain dicts.
+
+Each entry restates the model-shaping keys of a reference YAML (cited) or of a BASELINE.json
+config that the reference's own parser can express.  Task ORDER is the order
+`parse_task_dictionary` emits (TaskPrompter/utils/config.py:30-87), not YAML order:
+semseg, depth, human_parts, sal, normals, edge.
+"""
+
+PASCAL5 = (("semseg", 21), ("human_parts", 7), ("sal", 2), ("normals", 3), ("edge", 1))
+PASCAL6 = (("semseg", 21), ("depth", 1), ("human_parts", 7), ("sal", 2), ("normals", 3), ("edge", 1))
+NYUD4 = (("semseg", 40), ("depth", 1), ("normals", 3), ("edge", 1))
+NYUD2 = (("semseg", 40), ("depth", 1))
+CS2 = (("semseg", 19), ("depth", 1))
+
+VIT = {  # (embed_dim, depth, heads, select_list)
+    "tiny": (128, 4, 2, (1, 2, 3)),      # test-only miniature, same code path
+    "small": (384, 12, 6, (3, 6, 9)),
+    "base": (768, 12, 12, (3, 6, 9)),    # taskprompter.py:683
+    "large": (1024, 24, 16, (6, 12, 18)),  # taskprompter.py:675, vit.py:560
+}
+
+
+def taskprompter(name):
+    """TaskPrompter configs.  Keys: backbone, img_size, tasks, embed_dim(tar), final_embed_dim(F),
+    chan_nheads, use_ctr, prompt_len, head ('conv'|'deconv')."""
+    t = {
+        # TaskPrompter/configs/pascal/pascal_vitLp16_taskprompter.yml:26-33  (+depth = 6 tasks)
+        "ns6": dict(backbone="large", img_size=(512, 512), tasks=PASCAL6, embed_dim=300, final_embed_dim=350,
+                    chan_nheads=1, use_ctr=True, prompt_len=1, head="conv"),
+        "ns5": dict(backbone="large", img_size=(512, 512), tasks=PASCAL5, embed_dim=300, final_embed_dim=350,
+                    chan_nheads=1, use_ctr=True, prompt_len=1, head="conv"),
+        # TaskPrompter/configs/pascal/pascal_vitBp16_taskprompter.yml (cfg2)
+        "cfg2": dict(backbone="base", img_size=(512, 512), tasks=PASCAL5, embed_dim=780, final_embed_dim=1024,
+                     chan_nheads=16, use_ctr=True, prompt_len=1, head="conv"),
+        # TaskPrompter/configs/nyud/nyud_vitLp16_taskprompter.yml (cfg3)
+        "cfg3": dict(backbone="large", img_size=(448, 576), tasks=NYUD4, embed_dim=768, final_embed_dim=768,
+                     chan_nheads=16, use_ctr=False, prompt_len=1, head="conv"),
+        # BASELINE.json configs[4] as resolved by SURVEY §0 (ViT-L, DEConvHead, 2 dense tasks)
+        "cfg5": dict(backbone="large", img_size=(1024, 2048), tasks=CS2, embed_dim=300, final_embed_dim=350,
+                     chan_nheads=1, use_ctr=True, prompt_len=1, head="deconv"),
+        # miniatures for fast CPU parity (same code paths: odd dims, windows, ctr, deconv)
+        "mini_ctr": dict(backbone="tiny", img_size=(64, 96), tasks=PASCAL6, embed_dim=44, final_embed_dim=52,
+                         chan_nheads=1, use_ctr=True, prompt_len=1, head="conv"),
+        "mini_win": dict(backbone="tiny", img_size=(64, 96), tasks=NYUD4, embed_dim=48, final_embed_dim=40,
+                         chan_nheads=4, use_ctr=False, prompt_len=1, head="conv"),
+        "mini_deconv": dict(backbone="tiny", img_size=(64, 64), tasks=CS2, embed_dim=30, final_embed_dim=36,
+                            chan_nheads=1, use_ctr=True, prompt_len=1, head="deconv"),
+    }[name]
+    return dict(t, name=name, model="TaskPrompter")
+
+
+def invpt(name):
+    """InvPT configs.  Keys: backbone, img_size, tasks, embed_dim, pred_const, mtt_down."""
+    t = {
+        # InvPT/configs/pascal/pascal_vitLp16.yml:24-29 (cfg4; +depth = 6 tasks)
+        "cfg4_6": dict(backbone="large", img_size=(512, 512), tasks=PASCAL6, embed_dim=512, pred_const=64, mtt_down=2),
+        "cfg4_5": dict(backbone="large", img_size=(512, 512), tasks=PASCAL5, embed_dim=512, pred_const=64, mtt_down=2),
+        # BASELINE.json configs[0]: ViT-S built through the parametric constructor
+        "cfg1": dict(backbone="small", img_size=(256, 256), tasks=NYUD2, embed_dim=512, pred_const=64, mtt_down=2),
+        "mini": dict(backbone="tiny", img_size=(128, 128), tasks=NYUD2, embed_dim=32, pred_const=8, mtt_down=2),
+    }[name]
+    return dict(t, name=name, model="TransformerNet")
+
+
+def to_p(cfg, attrdict):
+    """Build the reference-style `p` (the EasyDict main.py passes to get_model) from a config dict."""
+    names = [n for n, _ in cfg["tasks"]]
+    nout = {n: c for n, c in cfg["tasks"]}
+    p = attrdict()
+    p.TASKS = attrdict(NAMES=names, NUM_OUTPUT=attrdict(nout))
+    H, W = cfg["img_size"]
+    p.TRAIN = attrdict(SCALE=(H, W))
+    p.spatial_dim = [[H // 16, W // 16] for _ in range(4)]
+    if cfg["model"] == "TaskPrompter":
+        p.embed_dim = cfg["embed_dim"]
+        p.final_embed_dim = cfg["final_embed_dim"]
+        p.prompt_len = cfg["prompt_len"]
+        p.chan_nheads = cfg["chan_nheads"]
+        p.use_ctr = cfg["use_ctr"]
+        p.head = cfg["head"]
+        p.backbone_channels = cfg["final_embed_dim"]
+    else:
+        C = VIT[cfg["backbone"]][0]
+        p.embed_dim = cfg["embed_dim"]
+        p.PRED_OUT_NUM_CONSTANT = cfg["pred_const"]
+        p.mtt_resolution_downsample_rate = cfg["mtt_down"]
+        p.backbone_channels = [C] * 4
+        p.final_embed_dim = cfg["embed_dim"] + cfg["pred_const"]
+        p.head = "mlp"
+    return p
