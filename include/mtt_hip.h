@@ -1,0 +1,201 @@
+/*
+ * mtt_hip.h — C ABI of libmtt_hip.so: the MI355X (gfx950) kernels behind the TaskPrompter / InvPT
+ * hot path.  This is the drop-in boundary BELOW the Python nn.Module mirror of the reference
+ * (SURVEY.md §8b).  Plain pointers and sizes only — no torch types.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, <0 = MTT_E_* argument error, >0 = hipError_t from the launch
+ *   - asynchronous on the caller's stream; no allocation, no synchronisation, no global state
+ *     (safe under hipGraph capture); every buffer is owned by the caller
+ *   - activations are token-major / NHWC: a feature map is a row-major [rows = B*H*W, channels]
+ *     matrix with a leading dimension (ld, in elements) that is a multiple of 8; 16-byte aligned
+ *   - dtype codes: MTT_F32 = 0, MTT_BF16 = 1
+ *   - prec: MTT_PREC_BF16 = 0 (bf16 MFMA, fp32 accumulate — the throughput path)
+ *           MTT_PREC_X3   = 1 (operands split hi+lo bf16, 3 MFMAs — fp32-class accuracy, the
+ *                              1e-3 parity gate; operands must be MTT_F32)
+ *
+ * Each entry names the reference code it replaces (paths relative to /root/reference).
+ */
+#ifndef MTT_HIP_H
+#define MTT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTT_ABI_VERSION 1
+
+enum { MTT_F32 = 0, MTT_BF16 = 1 };
+enum { MTT_PREC_BF16 = 0, MTT_PREC_X3 = 1 };
+enum { MTT_E_BADARG = -1, MTT_E_ALIGN = -2, MTT_E_UNSUPPORTED = -3 };
+
+/* operand layouts of mtt_gemm */
+enum {
+  MTT_OP_K = 0,     /* element(r,k) at base + r*ld + k   (reduction index contiguous)            */
+  MTT_OP_R = 1,     /* element(r,k) at base + k*ld + r   (row index contiguous; transposed view) */
+  MTT_OP_CONV_K = 2,/* A only: implicit im2col, r = output pixel, k = (tap, ci)                   */
+  MTT_OP_CONV_R = 3 /* B only: implicit im2col^T, k = pixel (reduction), r = (tap, ci)            */
+};
+enum { MTT_ACT_NONE = 0, MTT_ACT_GELU = 1, MTT_ACT_RELU = 2, MTT_ACT_GELU_BWD = 3, MTT_ACT_RELU_BWD = 4 };
+enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
+
+/* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */
+typedef struct {
+  int32_t H, W;     /* feature-map height/width (rows = B*H*W)                       */
+  int32_t C;        /* valid input channels                                           */
+  int32_t Cp;       /* channel pitch of the K ordering k = tap*Cp + ci (multiple of 8)*/
+  int32_t dil;      /* dilation (1, or 2 for InvPT UpEmbed, invpt.py:33)              */
+  int32_t flip;     /* 1: taps visited mirrored (dgrad)                               */
+} mtt_conv_geom;
+
+/*
+ * D[z][m,n] = epilogue( alpha * sum_k A[z][m,k] * B[z][n,k] )      m<M, n<N, k<K, z<batch
+ *
+ * Replaces every nn.Linear / 1x1 nn.Conv2d / 3x3 nn.Conv2d / nn.ConvTranspose2d(k=s=2) matmul of
+ * the hot path and their dgrad/wgrad (taskprompter.py:175-187,201,212,219,250 Linear; :362-366
+ * fea_fuse / fea_decode convs; :692-709 heads; timm Mlp fc1/fc2; invpt.py:108-113; vit.py:179-181;
+ * transformer_decoder.py:56-67,110).  Rows of A, D, aux and resid are addressed in groups:
+ *   row m -> base + (m / mb) * bs + (m % mb) * ld          (mb = 0 means one group)
+ * so a GEMM can read/write a token subset of a [B, N, C] buffer in place.
+ * Batch index z = zo*batch_inner + zi adds zo*?_zo + zi*?_zi elements to each base.
+ *
+ * epilogue, in order:  v = alpha*acc;  v = v*colscale[n] + colshift[n];
+ *   act: GELU(erf) / ReLU / GELU_BWD: v *= gelu'(aux_in[m,n]) / RELU_BWD: v *= (aux_in[m,n] > 0)
+ *   aux_out[m,n] = pre-activation value (optional, training)
+ *   v *= rowscale[(m / d_mb)*2 + ((m % d_mb) >= n_prompt)]   (DropPath per-sample scale, optional)
+ *   v += resid[m,n] (fp32, own row mapping; may alias D)
+ *   store D (dtype d_dtype); columns N <= n < n_store are written as zeros (channel padding).
+ */
+typedef struct {
+  const void* A; const void* B; void* D;
+  int32_t M, N, K;
+  int32_t a_op, b_op;            /* MTT_OP_* */
+  int32_t a_dtype, b_dtype, d_dtype;
+  int32_t prec;
+  int64_t lda, ldb, ldd;
+  int32_t a_mb; int64_t a_bs;
+  int32_t d_mb; int64_t d_bs;
+  int32_t batch, batch_inner;    /* batch >= 1; batch_inner >= 1 */
+  int64_t a_zo, a_zi, b_zo, b_zi, d_zo, d_zi;
+  mtt_conv_geom conv;            /* used when a_op/b_op is MTT_OP_CONV_* */
+  float alpha;
+  const float* colscale; const float* colshift; int64_t col_zo, col_zi;   /* [N] per batch */
+  int32_t act;
+  const void* aux_in; void* aux_out; int32_t aux_dtype; int64_t ldaux; int64_t aux_zo, aux_zi; /* rows mapped like D */
+  const float* rowscale; int32_t n_prompt;
+  const float* resid; int64_t ldr; int32_t r_mb; int64_t r_bs; int64_t r_zo, r_zi;
+  int32_t n_store;               /* >= N, <= ldd; 0 means N */
+  int32_t store_mode;            /* MTT_STORE_PIXSHUF2: n = (dy*2+dx)*Co + co, D is [B,2H,2W,ldd] (ConvTranspose2d k=s=2, taskprompter.py:705) */
+  int32_t ps_H, ps_W, ps_Co;
+} mtt_gemm_desc;
+
+int mtt_abi_version(void);
+/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom */
+size_t mtt_desc_size(int which);
+int mtt_gemm(const mtt_gemm_desc* d, void* stream);
+
+/*
+ * Fused global attention over [T prompts || hw patches] with the prompt-row logit side channel.
+ * Replaces Attention.forward's spatial part, taskprompter.py:201-210 (and vit.py:184-191 with T=0):
+ *   qkv   [B, N, 3, nH, 64]  (dtype act)   ->   out [B, N, nH*64] = softmax(q k^T / 8) v
+ *   rawlog[B, nH, T, N] fp32 = UNSCALED q.k of the first T query rows (what cal_task_feature reads,
+ *   taskprompter.py:436-438,482); never materialises the N x N matrix.  head_dim is fixed at 64.
+ */
+typedef struct {
+  const void* qkv; void* out; float* rawlog; float* lse;   /* lse [B,nH,N] fp32 (optional, for backward) */
+  int32_t B, N, nH, T;
+  int32_t dtype, prec;
+  float scale;
+} mtt_attn_desc;
+int mtt_attn_fwd(const mtt_attn_desc* d, void* stream);
+
+/* Row softmax (+ its backward) on a materialised score matrix: used by the InvPT decoder attention
+ * (invpt.py:232) and by the round-1 attention backward.  rows x cols, ld in elements.
+ *   fwd : P = softmax(scale * S)                         S fp32/bf16 -> P (dtype)
+ *   bwd : dS = scale * P * (dP - rowsum(dP*P)) (+ extra[r,c] for r < extra_rows, unscaled)  */
+typedef struct {
+  const void* S; void* P; const void* dP; void* dS; const float* extra;
+  int64_t rows, cols, ld; int32_t s_dtype, p_dtype; float scale;
+  int64_t rows_per_mat; int32_t extra_rows; int64_t extra_ld;
+} mtt_softmax_desc;
+int mtt_softmax_fwd(const mtt_softmax_desc* d, void* stream);
+int mtt_softmax_bwd(const mtt_softmax_desc* d, void* stream);
+
+/* LayerNorm over the last dim C (eps 1e-6 ViT: taskprompter.py:310; 1e-5 InvPT: invpt.py:256).
+ * x fp32 [rows, C] (ldx) -> y (y_dtype) [rows, C] (ldy); mean/rstd [rows] fp32 saved for backward.
+ * bwd: dx (fp32, ACCUMULATED into dx: dx += ...) , dgamma/dbeta += column sums (fp32 atomics). */
+typedef struct {
+  const float* x; void* y; const float* gamma; const float* beta; float* mean; float* rstd;
+  const void* dy; float* dx; float* dgamma; float* dbeta;
+  int64_t rows; int32_t C; int64_t ldx, ldy; int32_t y_dtype; float eps;
+} mtt_ln_desc;
+int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream);
+int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream);
+
+/* Patchify for the k=s=16 patch-embed conv (timm PatchEmbed used at taskprompter.py:313,393):
+ * img fp32 NCHW [B,3,H,W] -> cols [B*h*w, 768] (k = (c, py, px)), dtype out_dtype. */
+int mtt_patchify16(const float* img, void* cols, int B, int H, int W, int out_dtype, void* stream);
+
+/* Channel-attention logits, taskprompter.py:217-246:  rawchan[b,t,win,c] = sum_{p in win} q[b,t,p] * xn[b,p,c]
+ * q [B,T,hw] (dtype), xn = norm1-ed tokens [B, N, C] (dtype; patch rows start at row T), rawchan fp32 [B,T,nwin,C]. */
+typedef struct {
+  const void* q; const void* xn; float* rawchan;
+  int32_t B, T, N, C, h, w, nh, nw; int32_t dtype; int64_t ldq;
+} mtt_chanlogit_desc;
+int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream);
+
+/* Task-feature modulation, taskprompter.py:436-467: from x fp32 [B, hw, C] (row pitch/batch stride given)
+ *   out[2t  ][b,p,c] = x[b,p,c] * (1 + rawlog[b, c/64, t, T+p])
+ *   out[2t+1][b,p,c] = x[b,p,c] * (1 + rawchan[b, t, win(p), c])            out dtype act, [2T, B*hw, C] */
+typedef struct {
+  const float* x; int64_t x_ld, x_bs; const float* rawlog; const float* rawchan; void* out;
+  int32_t B, T, N, C, h, w, nh, nw; int32_t out_dtype;
+} mtt_modulate_desc;
+int mtt_modulate(const mtt_modulate_desc* d, void* stream);
+
+/* Cross-task reweighting, taskprompter.py:478-485: w[b,t,s] from the per-head MLP on the prompt<->prompt
+ * logits, then out[t][b,p,:] = sum_s w[b,t,s] * fea[s][b,p,:] (+= into acc when accumulate=1). */
+typedef struct {
+  const void* fea; void* out; const float* wmix;   /* fea [T, rows, ld]; wmix [B,T,T] fp32; out fp32 [T, rows, ld] */
+  int32_t T, B; int64_t rows_per_b, ld; int32_t C; int32_t fea_dtype; int32_t accumulate;
+} mtt_ctr_desc;
+int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream);
+
+/* Bilinear resize, align_corners=False (F.interpolate at taskprompter.py:420, taskprompter_wrapper.py:36,
+ * invpt.py:221,303,537, transformer_net.py:35-36).  NHWC in -> NHWC out or NCHW fp32 out.
+ * bwd: din (fp32) += scatter of dout (atomics). */
+typedef struct {
+  const void* in; void* out; int32_t B, C, Hin, Win, Hout, Wout; int64_t ld_in, ld_out;
+  int32_t in_dtype, out_dtype; int32_t out_nchw; int32_t accumulate;
+} mtt_resize_desc;
+int mtt_bilinear_fwd(const mtt_resize_desc* d, void* stream);
+int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream);   /* in = dout, out = din (fp32) */
+
+/* BatchNorm2d (+GELU/ReLU) on NHWC rows, training mode (batch statistics; nn.BatchNorm2d at
+ * taskprompter.py:362,692,705; SyncBatchNorm invpt.py:14).  stats: sum/sumsq [C] fp32 (atomics, caller zeroes).
+ * apply: y = act((x-mean)*rstd*gamma+beta).  bwd_reduce: sums of dz and dz*xhat; bwd_apply: dx. */
+typedef struct {
+  const void* x; void* y; const void* dy; void* dx;
+  float* sum; float* sumsq; const float* mean; const float* rstd; const float* gamma; const float* beta;
+  float* dsum; float* dsumxh;
+  int64_t rows; int32_t C; int64_t ld; int32_t dtype; int32_t act;
+} mtt_bn_desc;
+int mtt_bn_stats(const mtt_bn_desc* d, void* stream);
+int mtt_bn_apply(const mtt_bn_desc* d, void* stream);
+int mtt_bn_bwd_reduce(const mtt_bn_desc* d, void* stream);
+int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream);
+
+/* Small utilities: dtype cast / strided 2-D copy, column sums (bias gradients), axpy-style accumulate. */
+int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
+               int src_dtype, int dst_dtype, int zero_pad_cols, void* stream);
+int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream);
+int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype,
+                 float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTT_HIP_H */

@@ -1,0 +1,195 @@
+"""ctypes binding of libmtt_hip.so (include/mtt_hip.h).
+
+`call(name, **fields)` fills the descriptor struct of entry point `mtt_<name>` from keyword
+arguments — torch tensors (or views: only the base address is used) for pointer fields, ints /
+floats for the rest — launches it on torch's current HIP stream and raises on a non-zero status.
+
+There is NO fallback: if the shared library is missing or a tensor is not on a HIP device the
+call raises.  (tests/ may monkeypatch `call` with the CPU emulator in oracle/abi_emul.py to
+exercise the host-side wiring without a GPU; the product never does.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
+
+F32, BF16 = 0, 1
+PREC_BF16, PREC_X3 = 0, 1
+OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+STORE_ROWS, STORE_PIXSHUF2 = 0, 1
+
+i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("H", i32), ("W", i32), ("C", i32), ("Cp", i32), ("dil", i32), ("flip", i32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", ptr), ("B", ptr), ("D", ptr),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("a_op", i32), ("b_op", i32),
+        ("a_dtype", i32), ("b_dtype", i32), ("d_dtype", i32),
+        ("prec", i32),
+        ("lda", i64), ("ldb", i64), ("ldd", i64),
+        ("a_mb", i32), ("a_bs", i64),
+        ("d_mb", i32), ("d_bs", i64),
+        ("batch", i32), ("batch_inner", i32),
+        ("a_zo", i64), ("a_zi", i64), ("b_zo", i64), ("b_zi", i64), ("d_zo", i64), ("d_zi", i64),
+        ("conv", ConvGeom),
+        ("alpha", f32),
+        ("colscale", ptr), ("colshift", ptr), ("col_zo", i64), ("col_zi", i64),
+        ("act", i32),
+        ("aux_in", ptr), ("aux_out", ptr), ("aux_dtype", i32), ("ldaux", i64), ("aux_zo", i64), ("aux_zi", i64),
+        ("rowscale", ptr), ("n_prompt", i32),
+        ("resid", ptr), ("ldr", i64), ("r_mb", i32), ("r_bs", i64), ("r_zo", i64), ("r_zi", i64),
+        ("n_store", i32), ("store_mode", i32),
+        ("ps_H", i32), ("ps_W", i32), ("ps_Co", i32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("qkv", ptr), ("out", ptr), ("rawlog", ptr), ("lse", ptr),
+                ("B", i32), ("N", i32), ("nH", i32), ("T", i32), ("dtype", i32), ("prec", i32), ("scale", f32)]
+
+
+class SoftmaxDesc(C.Structure):
+    _fields_ = [("S", ptr), ("P", ptr), ("dP", ptr), ("dS", ptr), ("extra", ptr),
+                ("rows", i64), ("cols", i64), ("ld", i64), ("s_dtype", i32), ("p_dtype", i32), ("scale", f32),
+                ("rows_per_mat", i64), ("extra_rows", i32), ("extra_ld", i64)]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [("x", ptr), ("y", ptr), ("gamma", ptr), ("beta", ptr), ("mean", ptr), ("rstd", ptr),
+                ("dy", ptr), ("dx", ptr), ("dgamma", ptr), ("dbeta", ptr),
+                ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32)]
+
+
+class ChanLogitDesc(C.Structure):
+    _fields_ = [("q", ptr), ("xn", ptr), ("rawchan", ptr),
+                ("B", i32), ("T", i32), ("N", i32), ("C", i32), ("h", i32), ("w", i32), ("nh", i32), ("nw", i32),
+                ("dtype", i32), ("ldq", i64)]
+
+
+class ModulateDesc(C.Structure):
+    _fields_ = [("x", ptr), ("x_ld", i64), ("x_bs", i64), ("rawlog", ptr), ("rawchan", ptr), ("out", ptr),
+                ("B", i32), ("T", i32), ("N", i32), ("C", i32), ("h", i32), ("w", i32), ("nh", i32), ("nw", i32),
+                ("out_dtype", i32)]
+
+
+class CtrDesc(C.Structure):
+    _fields_ = [("fea", ptr), ("out", ptr), ("wmix", ptr), ("T", i32), ("B", i32), ("rows_per_b", i64), ("ld", i64),
+                ("C", i32), ("fea_dtype", i32), ("accumulate", i32)]
+
+
+class ResizeDesc(C.Structure):
+    _fields_ = [("in_", ptr), ("out", ptr), ("B", i32), ("C", i32), ("Hin", i32), ("Win", i32), ("Hout", i32), ("Wout", i32),
+                ("ld_in", i64), ("ld_out", i64), ("in_dtype", i32), ("out_dtype", i32), ("out_nchw", i32), ("accumulate", i32)]
+
+
+class BnDesc(C.Structure):
+    _fields_ = [("x", ptr), ("y", ptr), ("dy", ptr), ("dx", ptr),
+                ("sum", ptr), ("sumsq", ptr), ("mean", ptr), ("rstd", ptr), ("gamma", ptr), ("beta", ptr),
+                ("dsum", ptr), ("dsumxh", ptr),
+                ("rows", i64), ("C", i32), ("ld", i64), ("dtype", i32), ("act", i32)]
+
+
+# entry point -> (descriptor struct, size index in mtt_desc_size) ; None = positional-argument entry
+DESCS = {
+    "gemm": GemmDesc, "attn_fwd": AttnDesc, "softmax_fwd": SoftmaxDesc, "softmax_bwd": SoftmaxDesc,
+    "layernorm_fwd": LnDesc, "layernorm_bwd": LnDesc, "chan_logits": ChanLogitDesc, "modulate": ModulateDesc,
+    "ctr_mix": CtrDesc, "bilinear_fwd": ResizeDesc, "bilinear_bwd": ResizeDesc,
+    "bn_stats": BnDesc, "bn_apply": BnDesc, "bn_bwd_reduce": BnDesc, "bn_bwd_apply": BnDesc,
+}
+_SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom]
+POSITIONAL = {
+    "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
+    "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
+    "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr],
+    "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
+}
+EXPORTS = ["mtt_abi_version", "mtt_desc_size"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL)]
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and verify ABI version + descriptor sizes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU/eager fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mtt_abi_version.restype = C.c_int
+    lib.mtt_desc_size.restype = C.c_size_t
+    lib.mtt_desc_size.argtypes = [C.c_int]
+    if lib.mtt_abi_version() != 1:
+        raise RuntimeError("libmtt_hip.so ABI version mismatch")
+    for idx, st in enumerate(_SIZE_INDEX):
+        if lib.mtt_desc_size(idx) != C.sizeof(st):
+            raise RuntimeError(f"descriptor layout mismatch for {st.__name__}: C {lib.mtt_desc_size(idx)} vs ctypes {C.sizeof(st)}")
+    for name, st in DESCS.items():
+        fn = getattr(lib, "mtt_" + name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(st), ptr]
+    for name, at in POSITIONAL.items():
+        fn = getattr(lib, "mtt_" + name)
+        fn.restype = C.c_int
+        fn.argtypes = at
+    _lib = lib
+    return lib
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported tensor dtype {t.dtype}")
+
+
+def _addr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmtt_hip.so operates on HIP device memory only (tensor is on %s)" % t.device)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, **kw):
+    """Launch `mtt_<name>`; tensors in `kw` become device pointers.  For descriptor entry points
+    nested dict `conv={...}` fills mtt_conv_geom.  Positional entry points take `args=[...]`."""
+    lib = load()
+    fn = getattr(lib, "mtt_" + name)
+    if name in POSITIONAL:
+        args = [(_addr(a) if isinstance(a, torch.Tensor) else a) for a in kw["args"]]
+        rc = fn(*args, _stream())
+    else:
+        desc = DESCS[name]()
+        for k, v in kw.items():
+            if k == "in":
+                k = "in_"
+            if k == "conv":
+                for ck, cv in v.items():
+                    setattr(desc.conv, ck, int(cv))
+            elif isinstance(v, torch.Tensor):
+                setattr(desc, k, _addr(v))
+            elif v is None:
+                setattr(desc, k, None)
+            else:
+                setattr(desc, k, v)
+        rc = fn(C.byref(desc), _stream())
+    if rc != 0:
+        raise RuntimeError(f"mtt_{name} failed with status {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))

@@ -1,0 +1,424 @@
+// mtt_gemm: the one MFMA contraction kernel behind every Linear / 1x1 / 3x3 / ConvTranspose(k=s=2)
+// matmul of the hot path and their dgrad / wgrad (see include/mtt_hip.h for the contract).
+//
+// Structure (round 1, correctness first): 128 x 128 x 64 block tile, 256 threads = 4 waves in a
+// 2 x 2 grid, each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16 (64 fp32 accumulators per
+// lane).  Operands are register-staged global -> LDS (the stagers apply dtype conversion, the X3
+// hi/lo split, the im2col gather and, for transposed operands, an in-register 4x8 transpose), LDS is
+// double buffered with one barrier per K step, fragment reads are swizzled conflict-free
+// ds_read_b128.  Blocks are remapped so consecutive tiles of one XCD share A rows in its L2.
+#include "mtt_device.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per bf16 plane
+
+struct GemmP {
+  mtt_gemm_desc d;
+  FastDiv divW, divH, divCp, div3;   // conv geometry
+  FastDiv divAmb, divDmb, divRmb;    // row-group mappings
+  FastDiv divPsW, divPsH, divPsCo;   // pixel-shuffle store
+  int tiles_m, tiles_n;
+};
+
+MTT_DEV int64_t row_off(uint32_t m, int mb, int64_t bs, int64_t ld, FastDiv f) {
+  if (mb <= 0) return (int64_t)m * ld;
+  const uint32_t q = fdiv(m, f);
+  return (int64_t)q * bs + (int64_t)(m - q * (uint32_t)mb) * ld;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stagers: global -> registers (load) -> LDS tile (store).  All 256 threads take part.
+// ---------------------------------------------------------------------------------------------
+
+// reduction index contiguous in memory.  4 chunks of 8 elements per thread.
+template <bool X3, bool CONV>
+struct StagerK {
+  const void* base; int dtype; int K; int c;
+  int64_t roff[4]; bool rok[4];
+  int py[4], px[4];                 // CONV: pixel coordinates of each row
+  u32x4 hi[4], lo[4];
+
+  MTT_DEV void init(const GemmP& p, const void* b, int dt, int row0, int rows, int64_t ld, int mb, int64_t bs, FastDiv fmb) {
+    base = b; dtype = dt; K = p.d.K; c = threadIdx.x & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row0 + (threadIdx.x >> 3) + 32 * i;
+      rok[i] = r < rows;
+      const uint32_t rr = rok[i] ? (uint32_t)r : 0u;
+      if (CONV) {
+        const uint32_t t = fdiv(rr, p.divW);
+        px[i] = (int)(rr - t * (uint32_t)p.d.conv.W);
+        const uint32_t bb = fdiv(t, p.divH);
+        py[i] = (int)(t - bb * (uint32_t)p.d.conv.H);
+        roff[i] = (int64_t)rr * ld;
+      } else {
+        roff[i] = row_off(rr, mb, bs, ld, fmb);
+      }
+    }
+    ldx = ld;
+  }
+  int64_t ldx;
+
+  MTT_DEV void load(const GemmP& p, int k0) {
+    const int k = k0 + c * 8;
+    bool kok = k < K;
+    int64_t koff = k;
+    int dy = 0, dx = 0;
+    if (CONV) {
+      const uint32_t tap = fdiv((uint32_t)(kok ? k : 0), p.divCp);
+      const int ci = k - (int)tap * p.d.conv.Cp;
+      kok = kok && ci < p.d.conv.C;
+      int ty = (int)fdiv(tap, p.div3), tx = (int)tap - 3 * ty;
+      if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+      dy = (ty - 1) * p.d.conv.dil; dx = (tx - 1) * p.d.conv.dil;
+      koff = (int64_t)(dy * p.d.conv.W + dx) * ldx + ci;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = rok[i] && kok;
+      if (CONV) {
+        const int yy = py[i] + dy, xx = px[i] + dx;
+        ok = ok && yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W;
+      }
+      load8<X3>(base, roff[i] + koff, dtype, ok, hi[i], lo[i]);
+    }
+  }
+
+  MTT_DEV void store(unsigned char* t_hi, unsigned char* t_lo) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (threadIdx.x >> 3) + 32 * i;
+      *(u32x4*)(t_hi + lds_off(row, c)) = hi[i];
+      if (X3) *(u32x4*)(t_lo + lds_off(row, c)) = lo[i];
+    }
+  }
+};
+
+// row index contiguous in memory (transposed view): element(r, k) at base + k*ld + r.
+// Each thread owns a 4 (k) x 8 (rows) unit, transposes it in registers, writes 8 x 8-byte pieces.
+// CONV: B operand of the 3x3 wgrad — k = pixel, r = (tap, ci): base + pixel_shifted*ld + ci.
+template <bool X3, bool CONV>
+struct StagerR {
+  const void* base; int dtype; int K; int kq, rb;
+  int64_t roff; bool rok; int64_t ld;
+  int dy, dx;
+  u32x4 hi[4], lo[4];
+
+  MTT_DEV void init(const GemmP& p, const void* b, int dt, int row0, int rows, int64_t ld_) {
+    base = b; dtype = dt; K = p.d.K; ld = ld_;
+    kq = threadIdx.x & 15; rb = threadIdx.x >> 4;
+    const int r = row0 + rb * 8;
+    rok = r < rows;
+    roff = r; dy = dx = 0;
+    if (CONV) {
+      const uint32_t rr = rok ? (uint32_t)r : 0u;
+      const uint32_t tap = fdiv(rr, p.divCp);
+      const int ci = (int)rr - (int)tap * p.d.conv.Cp;
+      rok = rok && ci < p.d.conv.C;
+      const int ty = (int)fdiv(tap, p.div3), tx = (int)tap - 3 * ty;
+      dy = (ty - 1) * p.d.conv.dil; dx = (tx - 1) * p.d.conv.dil;
+      roff = (int64_t)(dy * p.d.conv.W + dx) * ld + ci;
+    }
+  }
+
+  MTT_DEV void load(const GemmP& p, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + kq * 4 + i;
+      bool ok = rok && k < K;
+      if (CONV) {
+        const uint32_t kk = ok ? (uint32_t)k : 0u;
+        const uint32_t t = fdiv(kk, p.divW);
+        const int x = (int)(kk - t * (uint32_t)p.d.conv.W);
+        const uint32_t bb = fdiv(t, p.divH);
+        const int y = (int)(t - bb * (uint32_t)p.d.conv.H);
+        const int yy = y + dy, xx = x + dx;
+        ok = ok && yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W;
+      }
+      load8<X3>(base, (int64_t)k * ld + roff, dtype, ok, hi[i], lo[i]);
+    }
+  }
+
+  MTT_DEV void store(unsigned char* t_hi, unsigned char* t_lo) const {
+    u32x2 piece[8];
+    transpose4x8(hi, piece);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = rb * 8 + j;
+      *(u32x2*)(t_hi + lds_off(row, kq >> 1) + (kq & 1) * 8) = piece[j];
+    }
+    if (X3) {
+      transpose4x8(lo, piece);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = rb * 8 + j;
+        *(u32x2*)(t_lo + lds_off(row, kq >> 1) + (kq & 1) * 8) = piece[j];
+      }
+    }
+  }
+};
+
+template <int OP, bool X3> struct StagerSel;
+template <bool X3> struct StagerSel<MTT_OP_K, X3> { typedef StagerK<X3, false> type; };
+template <bool X3> struct StagerSel<MTT_OP_CONV_K, X3> { typedef StagerK<X3, true> type; };
+template <bool X3> struct StagerSel<MTT_OP_R, X3> { typedef StagerR<X3, false> type; };
+template <bool X3> struct StagerSel<MTT_OP_CONV_R, X3> { typedef StagerR<X3, true> type; };
+
+template <int OP, bool X3, typename S>
+MTT_DEV void stager_init_a(S& s, const GemmP& p, const void* base, int row0) {
+  if constexpr (OP == MTT_OP_K || OP == MTT_OP_CONV_K)
+    s.init(p, base, p.d.a_dtype, row0, p.d.M, p.d.lda, p.d.a_mb, p.d.a_bs, p.divAmb);
+  else
+    s.init(p, base, p.d.a_dtype, row0, p.d.M, p.d.lda);
+}
+template <int OP, bool X3, typename S>
+MTT_DEV void stager_init_b(S& s, const GemmP& p, const void* base, int row0) {
+  if constexpr (OP == MTT_OP_K || OP == MTT_OP_CONV_K)
+    s.init(p, base, p.d.b_dtype, row0, p.d.N, p.d.ldb, 0, 0, p.divAmb);
+  else
+    s.init(p, base, p.d.b_dtype, row0, p.d.N, p.d.ldb);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int AOP, int BOP, bool X3>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NPL = X3 ? 2 : 1;
+  constexpr int STAGE = TILE_BYTES * 2 * NPL;   // A planes then B planes
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+
+  const int esA = p.d.a_dtype == MTT_F32 ? 4 : 2, esB = p.d.b_dtype == MTT_F32 ? 4 : 2;
+  const void* Abase = (const unsigned char*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi) * esA;
+  const void* Bbase = (const unsigned char*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi) * esB;
+
+  typename StagerSel<AOP, X3>::type sa;
+  typename StagerSel<BOP, X3>::type sb;
+  stager_init_a<AOP, X3>(sa, p, Abase, m0);
+  stager_init_b<BOP, X3>(sb, p, Bbase, n0);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.d.K + BK - 1) / BK;
+  sa.load(p, 0); sb.load(p, 0);
+  {
+    unsigned char* st = smem;
+    sa.store(st, st + TILE_BYTES);
+    sb.store(st + TILE_BYTES * NPL, st + TILE_BYTES * NPL + TILE_BYTES);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) { sa.load(p, (kt + 1) * BK); sb.load(p, (kt + 1) * BK); }
+
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    const unsigned char* Ah = st;
+    const unsigned char* Al = st + TILE_BYTES;
+    const unsigned char* Bh = st + TILE_BYTES * NPL;
+    const unsigned char* Bl = Bh + TILE_BYTES;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      u32x4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ra = wm * 64 + t * 16 + li, rbn = wn * 64 + t * 16 + li;
+        ah[t] = *(const u32x4*)(Ah + lds_off(ra, kh * 4 + lg));
+        bh[t] = *(const u32x4*)(Bh + lds_off(rbn, kh * 4 + lg));
+        if (X3) {
+          al[t] = *(const u32x4*)(Al + lds_off(ra, kh * 4 + lg));
+          bl[t] = *(const u32x4*)(Bl + lds_off(rbn, kh * 4 + lg));
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (X3) {
+            acc[a][b] = mfma16(al[a], bh[b], acc[a][b]);
+            acc[a][b] = mfma16(ah[a], bl[b], acc[a][b]);
+          }
+          acc[a][b] = mfma16(ah[a], bh[b], acc[a][b]);
+        }
+    }
+
+    if (more) {
+      unsigned char* sn = smem + ((kt + 1) & 1) * STAGE;
+      sa.store(sn, sn + TILE_BYTES);
+      sb.store(sn + TILE_BYTES * NPL, sn + TILE_BYTES * NPL + TILE_BYTES);
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------- epilogue --------------------------------------------------
+  const mtt_gemm_desc& d = p.d;
+  const int64_t zcol = (int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi;
+  const int64_t zD = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi;
+  const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi;
+  const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi;
+  const int n_store = d.n_store > d.N ? d.n_store : d.N;
+
+  float cs[4], sh[4]; int ncol[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = n0 + wn * 64 + b * 16 + li;
+    ncol[b] = n;
+    const bool nv = n < d.N;
+    cs[b] = (d.colscale && nv) ? d.colscale[zcol + n] : 1.0f;
+    sh[b] = (d.colshift && nv) ? d.colshift[zcol + n] : 0.0f;
+  }
+
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 64 + a * 16 + lg * 4 + r;
+      if (m >= d.M) continue;
+      int64_t doff, auxoff = 0, roff = 0;
+      float rs = 1.0f;
+      if (d.store_mode == MTT_STORE_PIXSHUF2) {
+        doff = 0;   // resolved per column below
+      } else {
+        doff = zD + row_off((uint32_t)m, d.d_mb, d.d_bs, d.ldd, p.divDmb);
+      }
+      if (d.aux_in || d.aux_out) {
+        // aux rows are mapped like D but with their own leading dimension
+        if (d.d_mb > 0) { const uint32_t q = fdiv((uint32_t)m, p.divDmb); auxoff = zAux + ((int64_t)q * d.d_mb + (m - q * d.d_mb)) * d.ldaux; }
+        else auxoff = zAux + (int64_t)m * d.ldaux;
+      }
+      if (d.resid) roff = zR + row_off((uint32_t)m, d.r_mb, d.r_bs, d.ldr, p.divRmb);
+      if (d.rowscale) {
+        uint32_t q = 0, rem = (uint32_t)m;
+        if (d.d_mb > 0) { q = fdiv((uint32_t)m, p.divDmb); rem = m - q * d.d_mb; }
+        rs = d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int n = ncol[b];
+        if (n >= n_store) continue;
+        float v = 0.0f;
+        if (n < d.N) {
+          v = acc[a][b][r] * d.alpha;
+          v = v * cs[b] + sh[b];
+          if (d.aux_out) st_elem(d.aux_out, auxoff + n, d.aux_dtype, v);
+          if (d.act == MTT_ACT_GELU) v = gelu_f(v);
+          else if (d.act == MTT_ACT_RELU) v = fmaxf(v, 0.0f);
+          else if (d.act == MTT_ACT_GELU_BWD) v *= gelu_grad_f(ld_elem(d.aux_in, auxoff + n, d.aux_dtype));
+          else if (d.act == MTT_ACT_RELU_BWD) v = ld_elem(d.aux_in, auxoff + n, d.aux_dtype) > 0.0f ? v : 0.0f;
+          v *= rs;
+          if (d.resid) v += d.resid[roff + n];
+        }
+        if (d.store_mode == MTT_STORE_PIXSHUF2) {
+          if (n >= d.N) continue;
+          const uint32_t q = fdiv((uint32_t)n, p.divPsCo);
+          const int co = n - (int)q * d.ps_Co;
+          const uint32_t t = fdiv((uint32_t)m, p.divPsW);
+          const int x = m - (int)t * d.ps_W;
+          const uint32_t bb = fdiv(t, p.divPsH);
+          const int y = (int)t - (int)bb * d.ps_H;
+          const int64_t orow = ((int64_t)bb * (2 * d.ps_H) + 2 * y + (int)(q >> 1)) * (2 * d.ps_W) + 2 * x + (int)(q & 1);
+          st_elem(d.D, zD + orow * d.ldd + co, d.d_dtype, v);
+        } else {
+          st_elem(d.D, doff + n, d.d_dtype, v);
+        }
+      }
+    }
+  }
+}
+
+FastDiv make_div(uint32_t dv) {
+  FastDiv f; f.d = dv ? dv : 1u;
+  uint32_t s = 0; while ((1ull << s) < f.d) ++s;
+  f.shift = s;
+  f.magic = (uint32_t)((((1ull << 32) * ((1ull << s) - f.d)) / f.d) + 1ull);
+  return f;
+}
+
+template <int AOP, int BOP, bool X3>
+int launch(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = TILE_BYTES * 2 * (X3 ? 2 : 1) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AOP, BOP, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.d.batch);
+  hipLaunchKernelGGL((gemm_kernel<AOP, BOP, X3>), grid, dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mtt_abi_version(void) { return MTT_ABI_VERSION; }
+
+// sizeof() of each descriptor, so a foreign-language binding can verify its struct mirror at load time
+extern "C" size_t mtt_desc_size(int which) {
+  switch (which) {
+    case 0: return sizeof(mtt_gemm_desc);
+    case 1: return sizeof(mtt_attn_desc);
+    case 2: return sizeof(mtt_softmax_desc);
+    case 3: return sizeof(mtt_ln_desc);
+    case 4: return sizeof(mtt_chanlogit_desc);
+    case 5: return sizeof(mtt_modulate_desc);
+    case 6: return sizeof(mtt_ctr_desc);
+    case 7: return sizeof(mtt_resize_desc);
+    case 8: return sizeof(mtt_bn_desc);
+    case 9: return sizeof(mtt_conv_geom);
+    default: return 0;
+  }
+}
+
+extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
+  if (!dd || !dd->A || !dd->B || !dd->D) return MTT_E_BADARG;
+  GemmP p; p.d = *dd;
+  mtt_gemm_desc& d = p.d;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0) return MTT_E_BADARG;
+  if (d.batch < 1) d.batch = 1;
+  if (d.batch_inner < 1) d.batch_inner = 1;
+  const bool a_k = d.a_op == MTT_OP_K || d.a_op == MTT_OP_CONV_K, b_k = d.b_op == MTT_OP_K;
+  if ((a_k || b_k) && (d.K % 8)) return MTT_E_ALIGN;
+  if ((d.lda % 8) || (d.ldb % 8)) return MTT_E_ALIGN;
+  if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return MTT_E_ALIGN;
+  if (d.prec == MTT_PREC_X3 && (d.a_dtype != MTT_F32 || d.b_dtype != MTT_F32)) return MTT_E_UNSUPPORTED;
+  if ((d.aux_in || d.aux_out) && d.ldaux <= 0) return MTT_E_BADARG;
+  const bool conv = d.a_op == MTT_OP_CONV_K || d.b_op == MTT_OP_CONV_R;
+  if (conv) {
+    if (d.conv.H <= 0 || d.conv.W <= 0 || d.conv.Cp % 8 || d.conv.C > d.conv.Cp || d.conv.dil < 1) return MTT_E_BADARG;
+    if (d.a_op == MTT_OP_CONV_K && d.K != 9 * d.conv.Cp) return MTT_E_BADARG;
+    if (d.b_op == MTT_OP_CONV_R && d.N != 9 * d.conv.Cp) return MTT_E_BADARG;
+  }
+  if (d.store_mode == MTT_STORE_PIXSHUF2 && (d.ps_H <= 0 || d.ps_W <= 0 || d.ps_Co <= 0 || d.N != 4 * d.ps_Co)) return MTT_E_BADARG;
+  p.divW = make_div(conv ? d.conv.W : 1); p.divH = make_div(conv ? d.conv.H : 1);
+  p.divCp = make_div(conv ? d.conv.Cp : 1); p.div3 = make_div(3);
+  p.divAmb = make_div(d.a_mb > 0 ? d.a_mb : 1); p.divDmb = make_div(d.d_mb > 0 ? d.d_mb : 1);
+  p.divRmb = make_div(d.r_mb > 0 ? d.r_mb : 1);
+  p.divPsW = make_div(d.ps_W > 0 ? d.ps_W : 1); p.divPsH = make_div(d.ps_H > 0 ? d.ps_H : 1);
+  p.divPsCo = make_div(d.ps_Co > 0 ? d.ps_Co : 1);
+  p.tiles_m = (d.M + BM - 1) / BM; p.tiles_n = (d.N + BN - 1) / BN;
+  hipStream_t s = (hipStream_t)stream;
+  const bool x3 = d.prec == MTT_PREC_X3;
+#define MTT_CASE(AO, BO) \
+  if (d.a_op == AO && d.b_op == BO) return x3 ? launch<AO, BO, true>(p, s) : launch<AO, BO, false>(p, s);
+  MTT_CASE(MTT_OP_K, MTT_OP_K)
+  MTT_CASE(MTT_OP_K, MTT_OP_R)
+  MTT_CASE(MTT_OP_R, MTT_OP_R)
+  MTT_CASE(MTT_OP_CONV_K, MTT_OP_K)
+  MTT_CASE(MTT_OP_R, MTT_OP_CONV_R)
+#undef MTT_CASE
+  return MTT_E_UNSUPPORTED;
+}

@@ -1,0 +1,100 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libmtt_hip.so.
+//
+// MFMA conventions used everywhere (v_mfma_f32_16x16x32_bf16, cdna_hip_programming.md §3):
+//   lane l:  i = l & 15, g = l >> 4
+//   A fragment (16 x 32): lane holds A[i][8g .. 8g+7]      (8 bf16, one 16-byte LDS read)
+//   B fragment (32 x 16): lane holds B[8g .. 8g+7][i]
+//   C/D (16 x 16)       : acc[r] = D[4g + r][i]
+// Both operands are staged into LDS as row-major [row][64 k] bf16 tiles (128 B per row) whose
+// 16-byte chunks are XOR-swizzled so that the 16-lane groups of ds_read_b128 hit 16 distinct slots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mtt_hip.h"
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define MTT_DEV __device__ __forceinline__
+
+MTT_DEV float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((unsigned)h) << 16); }
+MTT_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+MTT_DEV unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | (((unsigned)f2bf(b)) << 16); }
+MTT_DEV float lo_of(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+MTT_DEV float hi_of(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// load/store one element of runtime dtype
+MTT_DEV float ld_elem(const void* p, int64_t idx, int dtype) {
+  return dtype == MTT_F32 ? ((const float*)p)[idx] : bf2f(((const bf16_t*)p)[idx]);
+}
+MTT_DEV void st_elem(void* p, int64_t idx, int dtype, float v) {
+  if (dtype == MTT_F32) ((float*)p)[idx] = v; else ((bf16_t*)p)[idx] = f2bf(v);
+}
+
+MTT_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+MTT_DEV float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- LDS tile addressing: [rows][64] bf16, 8 chunks of 16 B per row, swizzled -------------------
+MTT_DEV int lds_swz(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
+MTT_DEV int lds_off(int row, int chunk) { return row * 128 + (((chunk ^ lds_swz(row)) & 7) << 4); }
+
+// ---- exact unsigned division by a runtime constant (magic computed on the host) -----------------
+struct FastDiv { uint32_t magic, shift, d; };
+MTT_DEV uint32_t fdiv(uint32_t n, FastDiv f) { return (__umulhi(n, f.magic) + n) >> f.shift; }
+
+// ---- 8 consecutive elements (runtime dtype) -> packed bf16 hi (and lo = residual for X3) ---------
+template <bool X3>
+MTT_DEV void load8(const void* base, int64_t idx, int dtype, bool ok, u32x4& hi, u32x4& lo) {
+  hi = (u32x4){0u, 0u, 0u, 0u};
+  if (X3) lo = hi;
+  if (!ok) return;
+  if (dtype == MTT_BF16) {
+    hi = *(const u32x4*)((const bf16_t*)base + idx);
+  } else {
+    const float4 v0 = *(const float4*)((const float*)base + idx);
+    const float4 v1 = *(const float4*)((const float*)base + idx + 4);
+    hi = (u32x4){pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w)};
+    if (X3) {
+      lo = (u32x4){pack2(v0.x - lo_of(hi.x), v0.y - hi_of(hi.x)), pack2(v0.z - lo_of(hi.y), v0.w - hi_of(hi.y)),
+                   pack2(v1.x - lo_of(hi.z), v1.y - hi_of(hi.z)), pack2(v1.z - lo_of(hi.w), v1.w - hi_of(hi.w))};
+    }
+  }
+}
+
+// 4 (k) x 8 (row) block held as 4 packed rows -> 8 pieces of 4 k-consecutive bf16 (one per row)
+MTT_DEV void transpose4x8(const u32x4 (&in)[4], u32x2 (&out)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned a0 = in[0][q], a1 = in[1][q], a2 = in[2][q], a3 = in[3][q];
+    out[2 * q][0] = (a0 & 0xffffu) | (a1 << 16);
+    out[2 * q][1] = (a2 & 0xffffu) | (a3 << 16);
+    out[2 * q + 1][0] = (a0 >> 16) | (a1 & 0xffff0000u);
+    out[2 * q + 1][1] = (a2 >> 16) | (a3 & 0xffff0000u);
+  }
+}
+
+MTT_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// XCD-aware bijective remap of a 1-D block id (8 XCDs, block b runs on XCD b % 8)
+MTT_DEV int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, in = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+}
+
+MTT_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+MTT_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,623 @@
+// HBM-bound row / elementwise kernels of the hot path: LayerNorm, row softmax, BatchNorm (training
+// statistics), patchify, channel-attention logits, task-feature modulation, cross-task mixing,
+// bilinear resize, casts and column sums.  All are coalesced over the channel (last) dimension with
+// 8 channels (16 B of bf16 / 32 B of fp32) per lane; reductions over rows use per-block LDS partials
+// and one fp32 atomic per column per block.
+#include "mtt_device.h"
+
+namespace {
+
+MTT_DEV void ld8(const void* p, int64_t idx, int dtype, float (&v)[8]) {
+  if (dtype == MTT_BF16) {
+    const u32x4 u = *(const u32x4*)((const bf16_t*)p + idx);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = lo_of(u[q]); v[2 * q + 1] = hi_of(u[q]); }
+  } else {
+    const float4 a = *(const float4*)((const float*)p + idx);
+    const float4 b = *(const float4*)((const float*)p + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+MTT_DEV void st8(void* p, int64_t idx, int dtype, const float (&v)[8]) {
+  if (dtype == MTT_BF16) {
+    *(u32x4*)((bf16_t*)p + idx) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+  } else {
+    *(float4*)((float*)p + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)p + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, 4 rows per block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const mtt_ln_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.rows) return;
+  const float* x = d.x + row * d.ldx;
+  const int C4 = d.C >> 2;
+  float s = 0.f;
+  for (int c = lane; c < C4; c += 64) { const float4 v = ((const float4*)x)[c]; s += (v.x + v.y) + (v.z + v.w); }
+  const float mean = wave_sum(s) / d.C;
+  float q = 0.f;
+  for (int c = lane; c < C4; c += 64) {
+    const float4 v = ((const float4*)x)[c];
+    const float a = v.x - mean, b = v.y - mean, e = v.z - mean, f = v.w - mean;
+    q += (a * a + b * b) + (e * e + f * f);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / d.C + d.eps);
+  if (lane == 0) { if (d.mean) d.mean[row] = mean; if (d.rstd) d.rstd[row] = rstd; }
+  for (int c = lane; c < C4; c += 64) {
+    const float4 v = ((const float4*)x)[c];
+    const float4 g = ((const float4*)d.gamma)[c];
+    const float4 bb = ((const float4*)d.beta)[c];
+    const float y0 = (v.x - mean) * rstd * g.x + bb.x, y1 = (v.y - mean) * rstd * g.y + bb.y;
+    const float y2 = (v.z - mean) * rstd * g.z + bb.z, y3 = (v.w - mean) * rstd * g.w + bb.w;
+    const int64_t o = row * d.ldy + (int64_t)c * 4;
+    if (d.y_dtype == MTT_F32) *(float4*)((float*)d.y + o) = make_float4(y0, y1, y2, y3);
+    else *(u32x2*)((bf16_t*)d.y + o) = (u32x2){pack2(y0, y1), pack2(y2, y3)};
+  }
+}
+
+// backward: dx += rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dgamma += dy*xhat; dbeta += dy
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const mtt_ln_desc d, int rows_per_block) {
+  extern __shared__ float lsm[];           // [2][C]
+  float* sg = lsm; float* sb = lsm + d.C;
+  for (int c = threadIdx.x; c < 2 * d.C; c += 256) lsm[c] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
+  for (int64_t row = r0 + wave; row < r1; row += 4) {
+    const float* x = d.x + row * d.ldx;
+    const float mean = d.mean[row], rstd = d.rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < d.C; c += 64) {
+      const float xh = (x[c] - mean) * rstd;
+      const float dy = ld_elem(d.dy, row * d.ldy + c, d.y_dtype);
+      const float g = dy * d.gamma[c];
+      s1 += g; s2 += g * xh;
+      if (d.dgamma) { atomicAdd(&sg[c], dy * xh); atomicAdd(&sb[c], dy); }
+    }
+    s1 = wave_sum(s1) / d.C; s2 = wave_sum(s2) / d.C;
+    if (d.dx) {
+      float* dx = d.dx + row * d.ldx;
+      for (int c = lane; c < d.C; c += 64) {
+        const float xh = (x[c] - mean) * rstd;
+        const float g = ld_elem(d.dy, row * d.ldy + c, d.y_dtype) * d.gamma[c];
+        dx[c] += rstd * (g - s1 - xh * s2);
+      }
+    }
+  }
+  __syncthreads();
+  if (d.dgamma)
+    for (int c = threadIdx.x; c < d.C; c += 256) { atomicAdd(&d.dgamma[c], sg[c]); atomicAdd(&d.dbeta[c], sb[c]); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row softmax on a materialised matrix (InvPT decoder attention, round-1 attention backward).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const mtt_softmax_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.rows) return;
+  const int64_t base = row * d.ld;
+  float mx = -INFINITY;
+  for (int64_t c = lane; c < d.cols; c += 64) mx = fmaxf(mx, ld_elem(d.S, base + c, d.s_dtype) * d.scale);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int64_t c = lane; c < d.cols; c += 64) s += __expf(ld_elem(d.S, base + c, d.s_dtype) * d.scale - mx);
+  const float inv = 1.0f / wave_sum(s);
+  for (int64_t c = lane; c < d.cols; c += 64)
+    st_elem(d.P, base + c, d.p_dtype, __expf(ld_elem(d.S, base + c, d.s_dtype) * d.scale - mx) * inv);
+  // zero the padding columns so a GEMM may read whole 8-element chunks
+  for (int64_t c = d.cols + lane; c < d.ld; c += 64) st_elem(d.P, base + c, d.p_dtype, 0.f);
+}
+
+// dS = scale * P * (dP - sum(dP*P))  (+ extra[r, c] for the first extra_rows rows of every matrix)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const mtt_softmax_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.rows) return;
+  const int64_t base = row * d.ld;
+  float s = 0.f;
+  for (int64_t c = lane; c < d.cols; c += 64)
+    s += ld_elem(d.dP, base + c, d.s_dtype) * ld_elem(d.P, base + c, d.p_dtype);
+  s = wave_sum(s);
+  const int64_t mat = d.rows_per_mat > 0 ? row / d.rows_per_mat : 0;
+  const int64_t rin = d.rows_per_mat > 0 ? row - mat * d.rows_per_mat : row;
+  const bool ex = d.extra != nullptr && rin < d.extra_rows;
+  for (int64_t c = lane; c < d.cols; c += 64) {
+    float v = d.scale * ld_elem(d.P, base + c, d.p_dtype) * (ld_elem(d.dP, base + c, d.s_dtype) - s);
+    if (ex) v += d.extra[(mat * d.extra_rows + rin) * d.extra_ld + c];
+    st_elem(d.dS, base + c, d.s_dtype, v);
+  }
+  for (int64_t c = d.cols + lane; c < d.ld; c += 64) st_elem(d.dS, base + c, d.s_dtype, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patchify: img fp32 NCHW -> cols [B*h*w, 768], k = (c*16 + dy)*16 + dx.  One thread = 8 dx.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* img, void* cols, int B, int H, int W, int out_dtype) {
+  const int h = H >> 4, w = W >> 4;
+  const int64_t total = (int64_t)B * h * w * 96;   // 768 / 8 chunks per patch
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int chunk = (int)(t % 96);
+    const int64_t patch = t / 96;
+    const int px = (int)(patch % w), py = (int)((patch / w) % h), b = (int)(patch / ((int64_t)w * h));
+    const int c = chunk >> 5, dy = (chunk >> 1) & 15, dx0 = (chunk & 1) * 8;
+    float v[8];
+    ld8(img, (((int64_t)b * 3 + c) * H + py * 16 + dy) * W + px * 16 + dx0, MTT_F32, v);
+    st8(cols, patch * 768 + chunk * 8, out_dtype, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel-attention logits: rawchan[b,t,win,c] += sum_{p in win, p in split} q[b,t,p] * xn[b,T+p,c]
+// grid (C/8/32 column groups, pixel splits, B*nwin); block = 32 column chunks x 8 pixel lanes.
+// ------------------------------------------------------------------------------------------------
+constexpr int CL_MAXT = 8;
+__global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc d, int tbase) {
+  const int nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw, P = wh * ww;
+  const int b = blockIdx.z / nwin, win = blockIdx.z % nwin;
+  const int wy = win / d.nw, wx = win % d.nw;
+  const int cchunk = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int plane = threadIdx.x >> 5;                 // 0..7
+  const int nT = d.T - tbase < CL_MAXT ? d.T - tbase : CL_MAXT;
+  float acc[CL_MAXT][8];
+#pragma unroll
+  for (int t = 0; t < CL_MAXT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  const bool cok = cchunk * 8 < d.C;
+  const int per = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = p0 + per < P ? p0 + per : P;
+  if (cok) {
+    for (int pi = p0 + plane; pi < p1; pi += 8) {
+      const int y = wy * wh + pi / ww, x = wx * ww + pi % ww;
+      const int pix = y * d.w + x;
+      float xv[8];
+      ld8(d.xn, ((int64_t)b * d.N + d.T + pix) * d.C + cchunk * 8, d.dtype, xv);
+#pragma unroll
+      for (int t = 0; t < CL_MAXT; ++t) {
+        if (t < nT) {
+          const float qv = ld_elem(d.q, ((int64_t)b * d.T + tbase + t) * d.ldq + pix, d.dtype);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[t][j] += qv * xv[j];
+        }
+      }
+    }
+  }
+  // reduce the 8 pixel lanes through LDS, then one atomic per (t, channel)
+  __shared__ float red[8][32][8];
+  for (int t = 0; t < nT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[plane][threadIdx.x & 31][j] = acc[t][j];
+    __syncthreads();
+    if (plane == 0 && cok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][threadIdx.x & 31][j];
+        atomicAdd(&d.rawchan[(((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + cchunk * 8 + j], s);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Task-feature modulation (taskprompter.py:436-467).  One thread = 8 channels of one token.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void modulate_kernel(const mtt_modulate_desc d) {
+  const int hw = d.h * d.w, C8 = d.C >> 3, nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw;
+  const int nH = d.C >> 6;
+  const int64_t total = (int64_t)d.B * hw * C8;
+  const int64_t plane = (int64_t)d.B * hw * d.C;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    const int64_t tok = t / C8;
+    const int p = (int)(tok % hw), b = (int)(tok / hw);
+    const int y = p / d.w, x = p % d.w;
+    const int win = (y / wh) * d.nw + (x / ww);
+    float xv[8], ov[8];
+    ld8(d.x, (int64_t)b * d.x_bs + (int64_t)p * d.x_ld + c8 * 8, MTT_F32, xv);
+    const int head = (c8 * 8) >> 6;
+    for (int tk = 0; tk < d.T; ++tk) {
+      const float a = d.rawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + p];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ov[j] = xv[j] * (1.0f + a);
+      st8(d.out, (int64_t)(2 * tk) * plane + tok * d.C + c8 * 8, d.out_dtype, ov);
+      float bw[8];
+      ld8(d.rawchan, (((int64_t)b * d.T + tk) * nwin + win) * d.C + c8 * 8, MTT_F32, bw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ov[j] = xv[j] * (1.0f + bw[j]);
+      st8(d.out, (int64_t)(2 * tk + 1) * plane + tok * d.C + c8 * 8, d.out_dtype, ov);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross-task mixing: out[t][row,:] (+)= sum_s wmix[b,t,s] * fea[s][row,:]
+// ------------------------------------------------------------------------------------------------
+constexpr int CTR_MAXT = 8;
+__global__ __launch_bounds__(256) void ctr_mix_kernel(const mtt_ctr_desc d) {
+  const int C8 = (d.C + 7) >> 3;
+  const int64_t rows = (int64_t)d.B * d.rows_per_b;
+  const int64_t total = rows * C8;
+  const int64_t plane = rows * d.ld;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t row = i / C8;
+    const int b = (int)(row / d.rows_per_b);
+    float f[CTR_MAXT][8];
+#pragma unroll
+    for (int s = 0; s < CTR_MAXT; ++s)
+      if (s < d.T) ld8(d.fea, (int64_t)s * plane + row * d.ld + c8 * 8, d.fea_dtype, f[s]);
+    for (int t = 0; t < d.T; ++t) {
+      float o[8];
+      const int64_t oi = (int64_t)t * plane + row * d.ld + c8 * 8;
+      if (d.accumulate) ld8(d.out, oi, MTT_F32, o);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < CTR_MAXT; ++s)
+        if (s < d.T) {
+          const float w = d.wmix[((int64_t)b * d.T + t) * d.T + s];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += w * f[s][j];
+        }
+      st8(d.out, oi, MTT_F32, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear resize, align_corners = False (PyTorch semantics: src = (o + .5) * in/out - .5, clamped at 0).
+// ------------------------------------------------------------------------------------------------
+MTT_DEV void src_index(int o, int in, int out, int& i0, int& i1, float& w1) {
+  const float scale = (float)in / (float)out;
+  float s = ((float)o + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 < in - 1 ? i0 + 1 : i0;
+  w1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const mtt_resize_desc d) {
+  const int C8 = (d.C + 7) >> 3;
+  const int64_t total = (int64_t)d.B * d.Hout * d.Wout * C8;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    const int64_t pix = t / C8;
+    const int ox = (int)(pix % d.Wout), oy = (int)((pix / d.Wout) % d.Hout), b = (int)(pix / ((int64_t)d.Wout * d.Hout));
+    int y0, y1, x0, x1; float wy, wx;
+    src_index(oy, d.Hin, d.Hout, y0, y1, wy);
+    src_index(ox, d.Win, d.Wout, x0, x1, wx);
+    const int64_t ib = (int64_t)b * d.Hin * d.Win;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    ld8(d.in, (ib + (int64_t)y0 * d.Win + x0) * d.ld_in + c8 * 8, d.in_dtype, v00);
+    ld8(d.in, (ib + (int64_t)y0 * d.Win + x1) * d.ld_in + c8 * 8, d.in_dtype, v01);
+    ld8(d.in, (ib + (int64_t)y1 * d.Win + x0) * d.ld_in + c8 * 8, d.in_dtype, v10);
+    ld8(d.in, (ib + (int64_t)y1 * d.Win + x1) * d.ld_in + c8 * 8, d.in_dtype, v11);
+    const int64_t oi = pix * d.ld_out + c8 * 8;
+    if (d.accumulate) ld8(d.out, oi, d.out_dtype, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float top = v00[j] * (1.f - wx) + v01[j] * wx, bot = v10[j] * (1.f - wx) + v11[j] * wx;
+      const float r = top * (1.f - wy) + bot * wy;
+      o[j] = d.accumulate ? o[j] + r : r;
+    }
+    st8(d.out, oi, d.out_dtype, o);
+  }
+}
+
+// NHWC in -> NCHW fp32 out (the module's output contract, taskprompter_wrapper.py:36)
+__global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const mtt_resize_desc d) {
+  const int64_t total = (int64_t)d.B * d.Hout * d.Wout;
+  for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(pix % d.Wout), oy = (int)((pix / d.Wout) % d.Hout), b = (int)(pix / ((int64_t)d.Wout * d.Hout));
+    int y0, y1, x0, x1; float wy, wx;
+    src_index(oy, d.Hin, d.Hout, y0, y1, wy);
+    src_index(ox, d.Win, d.Wout, x0, x1, wx);
+    const int64_t ib = (int64_t)b * d.Hin * d.Win;
+    const int64_t a00 = (ib + (int64_t)y0 * d.Win + x0) * d.ld_in, a01 = (ib + (int64_t)y0 * d.Win + x1) * d.ld_in;
+    const int64_t a10 = (ib + (int64_t)y1 * d.Win + x0) * d.ld_in, a11 = (ib + (int64_t)y1 * d.Win + x1) * d.ld_in;
+    for (int c = 0; c < d.C; ++c) {
+      const float top = ld_elem(d.in, a00 + c, d.in_dtype) * (1.f - wx) + ld_elem(d.in, a01 + c, d.in_dtype) * wx;
+      const float bot = ld_elem(d.in, a10 + c, d.in_dtype) * (1.f - wx) + ld_elem(d.in, a11 + c, d.in_dtype) * wx;
+      ((float*)d.out)[(((int64_t)b * d.C + c) * d.Hout + oy) * d.Wout + ox] = top * (1.f - wy) + bot * wy;
+    }
+  }
+}
+
+// backward: `in` = dout (NHWC of Hout x Wout, or NCHW fp32 when out_nchw), `out` = din fp32 NHWC, += via atomics
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const mtt_resize_desc d) {
+  const int C8 = d.out_nchw ? 1 : (d.C + 7) >> 3;
+  const int64_t total = (int64_t)d.B * d.Hout * d.Wout * C8;
+  float* din = (float*)d.out;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    const int64_t pix = t / C8;
+    const int ox = (int)(pix % d.Wout), oy = (int)((pix / d.Wout) % d.Hout), b = (int)(pix / ((int64_t)d.Wout * d.Hout));
+    int y0, y1, x0, x1; float wy, wx;
+    src_index(oy, d.Hin, d.Hout, y0, y1, wy);
+    src_index(ox, d.Win, d.Wout, x0, x1, wx);
+    const int64_t ib = (int64_t)b * d.Hin * d.Win;
+    const int64_t a00 = (ib + (int64_t)y0 * d.Win + x0) * d.ld_in, a01 = (ib + (int64_t)y0 * d.Win + x1) * d.ld_in;
+    const int64_t a10 = (ib + (int64_t)y1 * d.Win + x0) * d.ld_in, a11 = (ib + (int64_t)y1 * d.Win + x1) * d.ld_in;
+    if (d.out_nchw) {
+      for (int c = 0; c < d.C; ++c) {
+        const float g = ((const float*)d.in)[(((int64_t)b * d.C + c) * d.Hout + oy) * d.Wout + ox];
+        atomicAdd(&din[a00 + c], g * (1.f - wy) * (1.f - wx)); atomicAdd(&din[a01 + c], g * (1.f - wy) * wx);
+        atomicAdd(&din[a10 + c], g * wy * (1.f - wx)); atomicAdd(&din[a11 + c], g * wy * wx);
+      }
+    } else {
+      float g[8];
+      ld8(d.in, pix * d.ld_out + c8 * 8, d.in_dtype, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        if (c < d.C) {
+          atomicAdd(&din[a00 + c], g[j] * (1.f - wy) * (1.f - wx)); atomicAdd(&din[a01 + c], g[j] * (1.f - wy) * wx);
+          atomicAdd(&din[a10 + c], g[j] * wy * (1.f - wx)); atomicAdd(&din[a11 + c], g[j] * wy * wx);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column reductions over rows of a [rows, C] NHWC matrix.  MODE 0: sum & sumsq (BN statistics);
+// MODE 1: sum only (bias gradient); MODE 2: BN backward sums of du and du*xhat with du = dy*act'(u).
+// ------------------------------------------------------------------------------------------------
+MTT_DEV float act_fwd(float u, int act) { return act == MTT_ACT_GELU ? gelu_f(u) : (act == MTT_ACT_RELU ? fmaxf(u, 0.f) : u); }
+MTT_DEV float act_bwd(float u, int act) { return act == MTT_ACT_GELU ? gelu_grad_f(u) : (act == MTT_ACT_RELU ? (u > 0.f ? 1.f : 0.f) : 1.f); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const mtt_bn_desc d, int rows_per_block) {
+  extern __shared__ float lsm[];   // [2][C8*8]
+  const int C8 = (d.C + 7) >> 3, Cp = C8 * 8;
+  for (int c = threadIdx.x; c < 2 * Cp; c += 256) lsm[c] = 0.f;
+  __syncthreads();
+  const int lanes = 256 / C8 > 0 ? 256 / C8 : 1;     // row lanes per block
+  const int c8 = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a0[j] = a1[j] = 0.f;
+  float mu[8], rs[8], ga[8], be[8];
+  if (MODE == 2 && rl < lanes) {
+    ld8(d.mean, c8 * 8, MTT_F32, mu); ld8(d.rstd, c8 * 8, MTT_F32, rs);
+    ld8(d.gamma, c8 * 8, MTT_F32, ga); ld8(d.beta, c8 * 8, MTT_F32, be);
+  }
+  if (rl < lanes) {
+    for (int64_t r = r0 + rl; r < r1; r += lanes) {
+      float v[8];
+      if (MODE == 2) {
+        float x[8];
+        ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
+        ld8(d.dy, r * d.ld + c8 * 8, d.dtype, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (x[j] - mu[j]) * rs[j];
+          const float du = v[j] * act_bwd(xh * ga[j] + be[j], d.act);
+          a0[j] += du; a1[j] += du * xh;
+        }
+      } else {
+        ld8(MODE == 1 ? d.dy : d.x, r * d.ld + c8 * 8, d.dtype, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a0[j] += v[j]; if (MODE == 0) a1[j] += v[j] * v[j]; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { atomicAdd(&lsm[c8 * 8 + j], a0[j]); if (MODE != 1) atomicAdd(&lsm[Cp + c8 * 8 + j], a1[j]); }
+  }
+  __syncthreads();
+  float* o0 = MODE == 0 ? d.sum : d.dsum;
+  float* o1 = MODE == 0 ? d.sumsq : d.dsumxh;
+  for (int c = threadIdx.x; c < d.C; c += 256) { atomicAdd(&o0[c], lsm[c]); if (MODE != 1) atomicAdd(&o1[c], lsm[Cp + c]); }
+}
+
+// y = act((x - mean) * rstd * gamma + beta); channels >= C are written as zeros (padding)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const mtt_bn_desc d) {
+  const int C8 = (d.C + 7) >> 3;
+  const int64_t total = d.rows * C8;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    const int64_t r = t / C8;
+    float x[8], o[8];
+    ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      o[j] = c < d.C ? act_fwd((x[j] - d.mean[c]) * d.rstd[c] * d.gamma[c] + d.beta[c], d.act) : 0.f;
+    }
+    st8(d.y, r * d.ld + c8 * 8, d.dtype, o);
+  }
+}
+
+// dx = gamma*rstd * (du - dsum/rows - xhat * dsumxh/rows), du = dy * act'(u)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const mtt_bn_desc d) {
+  const int C8 = (d.C + 7) >> 3;
+  const int64_t total = d.rows * C8;
+  const float invn = 1.0f / (float)d.rows;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    const int64_t r = t / C8;
+    float x[8], g[8], o[8];
+    ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
+    ld8(d.dy, r * d.ld + c8 * 8, d.dtype, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      if (c < d.C) {
+        const float xh = (x[j] - d.mean[c]) * d.rstd[c];
+        const float du = g[j] * act_bwd(xh * d.gamma[c] + d.beta[c], d.act);
+        o[j] = d.gamma[c] * d.rstd[c] * (du - d.dsum[c] * invn - xh * d.dsumxh[c] * invn);
+      } else o[j] = 0.f;
+    }
+    st8(d.dx, r * d.ld + c8 * 8, d.dtype, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast2d_kernel(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd,
+                                                     int sdt, int ddt, int zero_pad) {
+  const int64_t wcols = zero_pad ? ldd : cols;
+  const int64_t total = rows * wcols;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / wcols, c = t % wcols;
+    st_elem(dst, r * ldd + c, ddt, c < cols ? ld_elem(src, r * lds_ + c, sdt) : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(const void* src, float* dst, int64_t rows, int cols, int64_t lds_, int64_t ldd,
+                                                       int sdt, float alpha) {
+  const int64_t total = rows * cols;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / cols, c = t % cols;
+    dst[r * ldd + c] += alpha * ld_elem(src, r * lds_ + c, sdt);
+  }
+}
+
+int grid_for(int64_t work_items) {
+  int64_t g = (work_items + 255) / 256;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+#define LAUNCH_OK() ((int)hipGetLastError())
+
+extern "C" int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream) {
+  if (!d || !d->x || !d->y || !d->gamma || !d->beta || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
+  if ((d->C % 4) || (d->ldx % 4) || (d->ldy % 4)) return MTT_E_ALIGN;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
+  if (!d || !d->x || !d->dy || !d->gamma || !d->mean || !d->rstd || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
+  if (d->C > 8192) return MTT_E_UNSUPPORTED;
+  int64_t nblk = (d->rows + 63) / 64; if (nblk > 1024) nblk = 1024;
+  const int rpb = (int)((d->rows + nblk - 1) / nblk);
+  nblk = (d->rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nblk), dim3(256), 2 * d->C * sizeof(float), S_, *d, rpb);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_softmax_fwd(const mtt_softmax_desc* d, void* stream) {
+  if (!d || !d->S || !d->P || d->rows <= 0 || d->cols <= 0 || d->ld < d->cols) return MTT_E_BADARG;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+extern "C" int mtt_softmax_bwd(const mtt_softmax_desc* d, void* stream) {
+  if (!d || !d->P || !d->dP || !d->dS || d->rows <= 0 || d->cols <= 0 || d->ld < d->cols) return MTT_E_BADARG;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_patchify16(const float* img, void* cols, int B, int H, int W, int out_dtype, void* stream) {
+  if (!img || !cols || B <= 0 || (H % 16) || (W % 16)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((int64_t)B * (H / 16) * (W / 16) * 96)), dim3(256), 0, S_, img, cols, B, H, W, out_dtype);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream) {
+  if (!d || !d->q || !d->xn || !d->rawchan) return MTT_E_BADARG;
+  if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
+  const int P = (d->h / d->nh) * (d->w / d->nw);
+  int splits = P / 64; if (splits < 1) splits = 1; if (splits > 32) splits = 32;
+  dim3 grid((d->C / 8 + 31) / 32, splits, d->B * d->nh * d->nw);
+  for (int tb = 0; tb < d->T; tb += CL_MAXT) hipLaunchKernelGGL(chanlogit_kernel, grid, dim3(256), 0, S_, *d, tb);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_modulate(const mtt_modulate_desc* d, void* stream) {
+  if (!d || !d->x || !d->rawlog || !d->rawchan || !d->out || (d->C % 64)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(modulate_kernel, dim3(grid_for((int64_t)d->B * d->h * d->w * (d->C / 8))), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream) {
+  if (!d || !d->fea || !d->out || !d->wmix || d->T <= 0 || d->T > CTR_MAXT || (d->ld % 8)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(ctr_mix_kernel, dim3(grid_for((int64_t)d->B * d->rows_per_b * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_bilinear_fwd(const mtt_resize_desc* d, void* stream) {
+  if (!d || !d->in || !d->out || d->B <= 0 || d->C <= 0) return MTT_E_BADARG;
+  if (d->out_nchw) {
+    hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3(grid_for((int64_t)d->B * d->Hout * d->Wout)), dim3(256), 0, S_, *d);
+  } else {
+    if ((d->ld_in % 8) || (d->ld_out % 8)) return MTT_E_ALIGN;
+    hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel, dim3(grid_for((int64_t)d->B * d->Hout * d->Wout * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
+  }
+  return LAUNCH_OK();
+}
+extern "C" int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream) {
+  if (!d || !d->in || !d->out || d->B <= 0 || d->C <= 0) return MTT_E_BADARG;
+  const int C8 = d->out_nchw ? 1 : (d->C + 7) / 8;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((int64_t)d->B * d->Hout * d->Wout * C8)), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+
+static int colreduce_cfg(const mtt_bn_desc* d, int& nblk, int& rpb) {
+  if (!d || d->rows <= 0 || d->C <= 0 || (d->ld % 8) || d->C > 2040) return MTT_E_BADARG;
+  int64_t nb = (d->rows + 255) / 256; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+  rpb = (int)((d->rows + nb - 1) / nb);
+  nblk = (int)((d->rows + rpb - 1) / rpb);
+  return 0;
+}
+extern "C" int mtt_bn_stats(const mtt_bn_desc* d, void* stream) {
+  int nblk, rpb; int e = colreduce_cfg(d, nblk, rpb); if (e) return e;
+  if (!d->x || !d->sum || !d->sumsq) return MTT_E_BADARG;
+  hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nblk), dim3(256), 2 * ((d->C + 7) / 8) * 8 * sizeof(float), S_, *d, rpb);
+  return LAUNCH_OK();
+}
+extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream) {
+  mtt_bn_desc d = {}; d.dy = src; d.dsum = dst; d.rows = rows; d.C = cols; d.ld = ld; d.dtype = src_dtype;
+  int nblk, rpb; int e = colreduce_cfg(&d, nblk, rpb); if (e) return e;
+  if (!src || !dst) return MTT_E_BADARG;
+  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 2 * ((d.C + 7) / 8) * 8 * sizeof(float), S_, d, rpb);
+  return LAUNCH_OK();
+}
+extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, void* stream) {
+  int nblk, rpb; int e = colreduce_cfg(d, nblk, rpb); if (e) return e;
+  if (!d->x || !d->dy || !d->dsum || !d->dsumxh || !d->mean || !d->rstd || !d->gamma || !d->beta) return MTT_E_BADARG;
+  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nblk), dim3(256), 2 * ((d->C + 7) / 8) * 8 * sizeof(float), S_, *d, rpb);
+  return LAUNCH_OK();
+}
+extern "C" int mtt_bn_apply(const mtt_bn_desc* d, void* stream) {
+  if (!d || !d->x || !d->y || !d->mean || !d->rstd || !d->gamma || !d->beta || (d->ld % 8)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(d->rows * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+extern "C" int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream) {
+  if (!d || !d->x || !d->dy || !d->dx || !d->mean || !d->rstd || !d->gamma || !d->beta || !d->dsum || !d->dsumxh || (d->ld % 8)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(d->rows * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd,
+                          int src_dtype, int dst_dtype, int zero_pad_cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;
+  hipLaunchKernelGGL(cast2d_kernel, dim3(grid_for(rows * (zero_pad_cols ? ldd : cols))), dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd,
+                     src_dtype, dst_dtype, zero_pad_cols);
+  return LAUNCH_OK();
+}
+extern "C" int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds_, int64_t ldd, int src_dtype,
+                            float alpha, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype, alpha);
+  return LAUNCH_OK();
+}

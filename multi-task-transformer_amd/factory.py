@@ -1,0 +1,89 @@
+"""Host-side mirror of the reference's model factory (TaskPrompter/utils/common_config.py:17-90,
+InvPT/utils/common_config.py:12-51): `get_model(p)` returns the drop-in nn.Module for a reference-style
+config object `p`.  `p` may be the reference's EasyDict or the `AttrDict` below — the models only use
+attribute access, item access and `keys()`.
+
+Extra (non-reference) key: `p.mtt_prec` in {'bf16', 'x3'} selects the arithmetic mode (default 'bf16').
+"""
+import torch
+
+
+class AttrDict(dict):
+    """Minimal EasyDict-compatible container (attribute access == item access, nested dicts wrapped)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            v = AttrDict(v)
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+PASCAL_NUM_OUTPUT = dict(semseg=21, human_parts=7, sal=2, normals=3, edge=1, depth=1)
+TASK_ORDER = ["semseg", "depth", "human_parts", "sal", "normals", "edge"]   # TaskPrompter/utils/config.py:30-87
+
+
+def make_p(tasks, img_size, model="TaskPrompter", backbone="TaskPrompter_vitL", head="conv", embed_dim=300,
+           final_embed_dim=350, prompt_len=1, chan_nheads=1, use_ctr=True, num_output=None, prec="bf16", **extra):
+    """Reference-style config for synthetic runs (what create_config would produce from a YAML)."""
+    nout = dict(PASCAL_NUM_OUTPUT, **(num_output or {}))
+    p = AttrDict(model=model, backbone=backbone, head=head, embed_dim=embed_dim, final_embed_dim=final_embed_dim,
+                 prompt_len=prompt_len, chan_nheads=chan_nheads, use_ctr=use_ctr, mtt_prec=prec)
+    p.TASKS = AttrDict(NAMES=list(tasks), NUM_OUTPUT=AttrDict({t: nout[t] for t in tasks}))
+    p.TRAIN = AttrDict(SCALE=tuple(img_size))
+    for k, v in extra.items():
+        p[k] = v
+    return p
+
+
+def get_backbone(p):
+    """TaskPrompter/utils/common_config.py:17-46 (pretrained weights are never downloaded: load a checkpoint)."""
+    from . import taskprompter as tp
+    if p['backbone'] == 'TaskPrompter_vitL':
+        backbone = tp.taskprompter_vit_large_patch16_384(p=p, pretrained=False, drop_path_rate=p.get('drop_path_rate', 0.15),
+                                                         img_size=p.TRAIN.SCALE)
+    elif p['backbone'] == 'TaskPrompter_vitB':
+        backbone = tp.taskprompter_vit_base_patch16_384(p=p, pretrained=False, drop_path_rate=p.get('drop_path_rate', 0.15),
+                                                        img_size=p.TRAIN.SCALE)
+    elif isinstance(p['backbone'], (tuple, list)):       # (embed_dim, depth, heads, select_list): miniature / ViT-S variants
+        C, depth, nH, select = p['backbone']
+        backbone = tp._create_task_prompter('custom', p=p, select_list=list(select), patch_size=16, embed_dim=C, depth=depth,
+                                            num_heads=nH, chan_nheads=p.chan_nheads,
+                                            drop_path_rate=p.get('drop_path_rate', 0.0), img_size=p.TRAIN.SCALE)
+    else:
+        raise NotImplementedError(p['backbone'])
+    p.backbone_channels = p.final_embed_dim
+    p.spatial_dim = [[p.TRAIN.SCALE[0] // 16, p.TRAIN.SCALE[1] // 16] for _ in range(4)]
+    return backbone, p.final_embed_dim
+
+
+def get_head(p, backbone_channels, task):
+    from . import taskprompter as tp
+    if task == '3ddet':
+        raise NotImplementedError('FCOS3D head depends on mmcv/mmdet3d (out of scope, SURVEY.md §2 #17)')
+    if p['head'] == 'conv':
+        return tp.ConvHead(backbone_channels, p.TASKS.NUM_OUTPUT[task])
+    if p['head'] == 'deconv':
+        return tp.DEConvHead(backbone_channels, p.TASKS.NUM_OUTPUT[task])
+    raise NotImplementedError(p['head'])
+
+
+def get_model(p):
+    """TaskPrompter/utils/common_config.py:76-90."""
+    if p['model'] == 'TaskPrompter':
+        from . import taskprompter as tp
+        backbone, ch = get_backbone(p)
+        heads = torch.nn.ModuleDict({task: get_head(p, ch, task) for task in p.TASKS.NAMES})
+        return tp.TaskPrompterWrapper(p, backbone, heads)
+    raise NotImplementedError('Unknown model {}'.format(p['model']))

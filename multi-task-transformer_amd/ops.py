@@ -1,0 +1,302 @@
+"""Forward/backward building blocks of the hot path on top of the C ABI (`_lib.call`).
+
+Data layout: every activation is a token-major (NHWC) 2-D or 3-D torch tensor `[..., rows, ld]` whose
+last dim is the channel pitch `ld = pad8(C)`; channels >= C are kept at zero.  `Prec` selects the
+arithmetic: BF16 = bf16 storage + bf16 MFMA (throughput path), X3 = fp32 storage + split-bf16 x3 MFMA
+(fp32-class accuracy: the 1e-3 parity gate).  The residual stream, logits side channels, statistics and
+all gradients of parameters are fp32 in both modes.
+
+Nothing here falls back to torch math: every function launches a HIP kernel through `_lib.call`.
+torch is used for allocation, views and the (tiny) parameter re-packing.
+"""
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, OP_CONV_K, OP_CONV_R, OP_K, OP_R, PREC_BF16, PREC_X3,
+                   dtype_code)
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class Prec:
+    """Arithmetic mode: name in {'bf16', 'x3'}."""
+
+    def __init__(self, name):
+        assert name in ("bf16", "x3")
+        self.name = name
+        self.code = PREC_BF16 if name == "bf16" else PREC_X3
+        self.adt = torch.bfloat16 if name == "bf16" else torch.float32
+
+    def __repr__(self):
+        return f"Prec({self.name})"
+
+
+def call(name, **kw):          # single indirection point (tests monkeypatch this with the CPU emulator)
+    return _lib.call(name, **kw)
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter packing (cached per parameter version)
+# ---------------------------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def _cached(key, params, build):
+    ver = tuple((p.data_ptr(), p._version) for p in params)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    val = build()
+    _pack_cache[key] = (ver, val)
+    return val
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+def cast2d(src, rows, cols, lds, dst_dtype, ldd=None, zero_pad=True):
+    ldd = ldd or pad8(cols)
+    dst = torch.empty(rows, ldd, dtype=dst_dtype, device=src.device)
+    call("cast2d", args=[src, dst, rows, cols, lds, ldd, dtype_code(src), dtype_code(dst), 1 if zero_pad else 0])
+    return dst
+
+
+def pack_matrix(w2d, prec):
+    """[N, K] fp32 -> [N, pad8(K)] in the activation dtype (zero padded)."""
+    N, K = w2d.shape
+    if prec.adt == torch.float32 and K % 8 == 0 and w2d.is_contiguous():
+        return w2d
+    return cast2d(w2d.contiguous(), N, K, K, prec.adt)
+
+
+def pack_linear(weights, prec, tag):
+    """List of Z parameters [N, K] (or 1x1 conv [N, K, 1, 1]) -> one [Z, N, Kp] buffer."""
+    def build():
+        with torch.no_grad():
+            mats = [pack_matrix(w.detach().reshape(w.shape[0], -1), prec) for w in weights]
+            return torch.stack(mats, 0) if len(mats) > 1 else mats[0][None]
+    return _cached((tag, prec.name, tuple(id(w) for w in weights)), weights, build)
+
+
+def pack_conv3(weights, prec, tag, transpose=False):
+    """List of Z conv weights [Co, Ci, 3, 3] -> [Z, Co, 9*Cip] with k = tap*Cip + ci (taps row-major).
+    transpose=True packs the dgrad operand [Z, Ci, 9*Cop] with k = tap*Cop + co."""
+    def build():
+        with torch.no_grad():
+            out = []
+            for w in weights:
+                w = w.detach()
+                w = w.permute(1, 2, 3, 0) if transpose else w.permute(0, 2, 3, 1)     # [R, 3, 3, Cin]
+                R, _, _, Cin = w.shape
+                Cp = pad8(Cin)
+                buf = torch.zeros(R, 9, Cp, dtype=torch.float32, device=w.device)
+                buf[:, :, :Cin] = w.reshape(R, 9, Cin)
+                out.append(pack_matrix(buf.reshape(R, 9 * Cp), prec))
+            return torch.stack(out, 0)
+    return _cached((tag, prec.name, transpose, tuple(id(w) for w in weights)), weights, build)
+
+
+def stack_vec(vs, tag):
+    def build():
+        with torch.no_grad():
+            return torch.stack([v.detach().float().reshape(-1) for v in vs], 0).contiguous()
+    return _cached((tag, tuple(id(v) for v in vs)), vs, build)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM-family forward ops
+# ---------------------------------------------------------------------------------------------
+def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, M=None,
+           a_rows=None, d_rows=None, resid=None, r_rows=None, rowscale=None, n_prompt=0, aux_out=None, aux_in=None,
+           colscale=None, alpha=1.0, batch_inner=1, d_z=None, ldd=None, n_store=None):
+    """out[z] = epi(x[z] @ wpack[z]^T)  (mtt_gemm, both operands reduction-contiguous).
+
+    x: [Z, M, lda] / [M, lda] (broadcast over Z) — or, with a_rows=(mb, bs, ld), any view whose first
+    element is row 0 (then pass M).  wpack [Z, N, Kp]; bias / colscale fp32 [Z, N] (or [1, N] broadcast).
+    out: None -> new [Z, M, pad8(N)] in `out_dtype` (default activation dtype); else a tensor / base view
+    addressed by d_rows=(mb, bs, ld) or, for a 3-D `out`, its own strides; d_z=(zo, zi) overrides the
+    per-batch offsets of D (z = zo*batch_inner + zi).  resid fp32 is added in the epilogue (r_rows mapping,
+    default = D's); may alias `out`."""
+    Z, Nw, Kp = wpack.shape
+    assert N <= Nw
+    if a_rows is not None:
+        a_mb, a_bs, lda = a_rows
+        a_z = 0
+    else:
+        xv = x if x.dim() == 3 else x[None]
+        if M is None:
+            M = xv.shape[1]
+        a_mb, a_bs, lda = 0, 0, xv.shape[2]
+        a_z = xv.stride(0) if xv.shape[0] > 1 else 0
+        assert xv.shape[0] in (1, Z) and lda >= Kp
+    Np = pad8(N)
+    if out is None:
+        out = torch.empty(Z, M, Np, dtype=out_dtype or prec.adt, device=x.device)
+    if d_rows is not None:
+        d_mb, d_bs, ldd_ = d_rows
+        dz = 0
+        nst = N
+    else:
+        d_mb, d_bs = 0, 0
+        ldd_ = ldd if ldd is not None else out.shape[-1]
+        dz = out.stride(0) if out.dim() == 3 else 0
+        nst = min(Np, ldd_)
+    if n_store is not None:
+        nst = n_store
+    kw = dict(A=x, B=wpack, D=out, M=M, N=N, K=Kp, a_op=OP_K, b_op=OP_K,
+              a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
+              lda=lda, ldb=Kp, ldd=ldd_, a_mb=a_mb, a_bs=a_bs, d_mb=d_mb, d_bs=d_bs,
+              batch=Z, batch_inner=batch_inner, alpha=alpha, act=act, n_store=nst)
+    # batch offsets: linear in z for A / B / bias; D may be two-level (d_z)
+    kw.update(a_zo=a_z * batch_inner, a_zi=a_z if batch_inner > 1 else 0,
+              b_zo=wpack.stride(0) * batch_inner, b_zi=wpack.stride(0) if batch_inner > 1 else 0)
+    if d_z is not None:
+        kw.update(d_zo=d_z[0], d_zi=d_z[1])
+    else:
+        kw.update(d_zo=dz * batch_inner, d_zi=dz if batch_inner > 1 else 0)
+    if bias is not None or colscale is not None:
+        ref = bias if bias is not None else colscale
+        cz = ref.stride(0) if (ref.dim() == 2 and ref.shape[0] > 1) else 0
+        kw.update(colshift=bias, colscale=colscale, col_zo=cz * batch_inner, col_zi=cz if batch_inner > 1 else 0)
+    if resid is not None:
+        rr = r_rows if r_rows is not None else (d_mb, d_bs, ldd_)
+        kw.update(resid=resid, r_mb=rr[0], r_bs=rr[1], ldr=rr[2])
+    if rowscale is not None:
+        kw.update(rowscale=rowscale, n_prompt=n_prompt)
+    if aux_out is not None or aux_in is not None:
+        aux = aux_out if aux_out is not None else aux_in
+        az = aux.stride(0) if aux.dim() == 3 else 0
+        kw.update(aux_out=aux_out, aux_in=aux_in, aux_dtype=dtype_code(aux), ldaux=aux.shape[-1],
+                  aux_zo=az * batch_inner, aux_zi=az if batch_inner > 1 else 0)
+    call("gemm", **kw)
+    return out
+
+
+def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=ACT_NONE, dil=1, flip=0, out_dtype=None):
+    """x [Z, B*H*W, Cp] -> [Z, B*H*W, pad8(Co)]; wpack [Z, Co, 9*Cp]; bias/colscale [Z, Co] fp32.
+    Implicit GEMM (no im2col buffer): A rows are gathered per 16-byte channel chunk."""
+    Z, rows, Cp = x.shape
+    assert rows == B * H * W and wpack.shape[-1] == 9 * Cp
+    Cop = pad8(Co)
+    out = torch.empty(Z, rows, Cop, dtype=out_dtype or prec.adt, device=x.device)
+    kw = dict(A=x, B=wpack, D=out, M=rows, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K,
+              a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
+              lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Z, batch_inner=1, a_zo=x.stride(0), b_zo=wpack.stride(0), d_zo=out.stride(0),
+              conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, act=act, n_store=Cop)
+    if bias is not None:
+        kw.update(colshift=bias, col_zo=bias.stride(0))
+    if colscale is not None:
+        kw.update(colscale=colscale)
+    call("gemm", **kw)
+    return out
+
+
+def deconv2x2(x, wpack, Co, Ci, B, H, W, prec, *, bias4=None, out_dtype=None):
+    """ConvTranspose2d(k=2, s=2) as a GEMM with a pixel-shuffle store (taskprompter.py:705).
+    x [B*H*W, Cip]; wpack [1, 4*Co, Cip] with n = (dy*2+dx)*Co + co; bias4 [4*Co].  -> [B*2H*2W, pad8(Co)]"""
+    Cop = pad8(Co)
+    out = torch.zeros(B * 4 * H * W, Cop, dtype=out_dtype or prec.adt, device=x.device)
+    kw = dict(A=x, B=wpack, D=out, M=B * H * W, N=4 * Co, K=wpack.shape[-1], a_op=OP_K, b_op=OP_K,
+              a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
+              lda=x.shape[-1], ldb=wpack.shape[-1], ldd=Cop, batch=1, batch_inner=1, alpha=1.0, b_zo=0,
+              store_mode=_lib.STORE_PIXSHUF2, ps_H=H, ps_W=W, ps_Co=Co)
+    if bias4 is not None:
+        kw.update(colshift=bias4)
+    call("gemm", **kw)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# row ops
+# ---------------------------------------------------------------------------------------------
+def layernorm(x, gamma, beta, eps, prec, save_stats=False, out_dtype=None):
+    """x fp32 [rows, C] -> y [rows, C] (activation dtype unless out_dtype).  Returns (y, mean, rstd)."""
+    rows, C = x.shape
+    y = torch.empty(rows, C, dtype=out_dtype or prec.adt, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    call("layernorm_fwd", x=x, y=y, gamma=gamma, beta=beta, mean=mean, rstd=rstd, rows=rows, C=C,
+         ldx=x.stride(0), ldy=C, y_dtype=dtype_code(y), eps=eps)
+    return y, mean, rstd
+
+
+def attention(qkv, B, N, nH, T, prec, want_lse=False):
+    """qkv [B*N, 3*nH*64] -> (out [B*N, nH*64], rawlog fp32 [B, nH, T, N] or None, lse or None)."""
+    C = nH * 64
+    out = torch.empty(B * N, C, dtype=qkv.dtype, device=qkv.device)
+    rawlog = torch.empty(B, nH, T, N, dtype=torch.float32, device=qkv.device) if T > 0 else None
+    lse = torch.empty(B, nH, N, dtype=torch.float32, device=qkv.device) if want_lse else None
+    call("attn_fwd", qkv=qkv, out=out, rawlog=rawlog, lse=lse, B=B, N=N, nH=nH, T=T,
+         dtype=dtype_code(qkv), prec=prec.code, scale=64 ** -0.5)
+    return out, rawlog, lse
+
+
+def patchify(img, prec):
+    B, _, H, W = img.shape
+    cols = torch.empty(B * (H // 16) * (W // 16), 768, dtype=prec.adt, device=img.device)
+    call("patchify16", args=[img.contiguous(), cols, B, H, W, dtype_code(cols)])
+    return cols
+
+
+def chan_logits(cq, xn, B, T, N, C, grid, nwin_hw):
+    """cq [B*T, ldq] (token_trans output), xn [B*N, C] (norm1 output) -> rawchan fp32 [B, T, nwin, C]."""
+    nh, nw = nwin_hw
+    rawchan = torch.zeros(B, T, nh * nw, C, dtype=torch.float32, device=xn.device)
+    call("chan_logits", q=cq, xn=xn, rawchan=rawchan, B=B, T=T, N=N, C=C, h=grid[0], w=grid[1], nh=nh, nw=nw,
+         dtype=dtype_code(xn), ldq=cq.shape[-1])
+    return rawchan
+
+
+def modulate(x, x_ld, x_bs, rawlog, rawchan, B, T, N, C, grid, nwin_hw, prec):
+    """x: fp32 base view of the patch rows ([B, hw, C] with row pitch x_ld, batch stride x_bs).
+    -> [2T, B*hw, C] activation dtype (spatially- then channel-modulated copy per task)."""
+    hw = grid[0] * grid[1]
+    out = torch.empty(2 * T, B * hw, C, dtype=prec.adt, device=x.device)
+    call("modulate", x=x, x_ld=x_ld, x_bs=x_bs, rawlog=rawlog, rawchan=rawchan, out=out, B=B, T=T, N=N, C=C,
+         h=grid[0], w=grid[1], nh=nwin_hw[0], nw=nwin_hw[1], out_dtype=dtype_code(out))
+    return out
+
+
+def ctr_mix(fea, wmix, B, C, acc=None):
+    """fea [T, rows, ld]; wmix fp32 [B, T, T] -> acc (+)= mix.  Returns fp32 [T, rows, ld]."""
+    T, rows, ld = fea.shape
+    out = acc if acc is not None else torch.empty(T, rows, ld, dtype=torch.float32, device=fea.device)
+    call("ctr_mix", fea=fea, out=out, wmix=wmix, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C,
+         fea_dtype=dtype_code(fea), accumulate=1 if acc is not None else 0)
+    return out
+
+
+def bilinear(x, B, C, Hin, Win, Hout, Wout, out_dtype, nchw=False):
+    """x [Z, B*Hin*Win, ld] -> [Z, B*Hout*Wout, ld] (NHWC) or fp32 NCHW [B, C, Hout, Wout] (Z must be 1)."""
+    Z, _, ld = x.shape
+    if nchw:
+        out = torch.empty(B, C, Hout, Wout, dtype=torch.float32, device=x.device)
+        call("bilinear_fwd", **{"in": x}, out=out, B=B, C=C, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, ld_in=ld, ld_out=0,
+             in_dtype=dtype_code(x), out_dtype=F32, out_nchw=1, accumulate=0)
+        return out
+    out = torch.empty(Z, B * Hout * Wout, ld, dtype=out_dtype, device=x.device)
+    # Z maps of the same geometry: fold Z into the batch dimension
+    call("bilinear_fwd", **{"in": x}, out=out, B=Z * B, C=ld, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, ld_in=ld, ld_out=ld,
+         in_dtype=dtype_code(x), out_dtype=dtype_code(out), out_nchw=0, accumulate=0)
+    return out
+
+
+def bn_batch_stats(x, C):
+    """x [rows, ld] -> (mean, biased var) fp32 [C] from one pass of column sums."""
+    rows, ld = x.shape
+    s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    call("bn_stats", x=x, sum=s[0], sumsq=s[1], rows=rows, C=C, ld=ld, dtype=dtype_code(x))
+    mean = s[0] / rows
+    var = torch.clamp_min(s[1] / rows - mean * mean, 0.0)
+    return mean, var
+
+
+def bn_apply(x, C, mean, rstd, gamma, beta, act):
+    rows, ld = x.shape
+    y = torch.empty_like(x)
+    call("bn_apply", x=x, y=y, mean=mean, rstd=rstd, gamma=gamma, beta=beta, rows=rows, C=C, ld=ld,
+         dtype=dtype_code(x), act=act)
+    return y

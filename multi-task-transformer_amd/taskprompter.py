@@ -1,0 +1,460 @@
+"""MI355X-native TaskPrompter: same nn.Module API, constructor arguments and state_dict layout as
+the reference (TaskPrompter/models/transformers/taskprompter.py, TaskPrompter/models/taskprompter_wrapper.py)
+so it drops into the reference's get_model / main.py / inference.py, but executed as a different, fused
+schedule on the libmtt_hip.so kernels:
+
+  * one token-major fp32 residual buffer XT [B, T+hw, C] holds prompts (first, as taskprompter.py:199)
+    and patches; norm1/norm2/MLP run once over all rows (the reference applies the same weights to x and
+    to the prompts separately, :272-277)
+  * LayerNorm -> qkv GEMM -> flash attention that also emits the T prompt-row logits (the only rows
+    cal_task_feature reads) -> proj GEMM with the residual add in its epilogue
+  * channel attention = token_trans GEMM + a coalesced logit kernel; the dead softmax / attn@v of
+    taskprompter.py:241-245 are skipped (parameters keep their reference names)
+  * cal_task_feature = one modulation kernel + task-batched GEMMs / implicit-GEMM 3x3 convs with bias,
+    eval-BatchNorm and GELU folded into epilogues, cross-task mixing fused with the 4-tap accumulation
+  * heads = x4 bilinear (NHWC) -> task-batched 3x3 conv + BN + GELU -> 1x1 -> bilinear to NCHW fp32
+
+The nn.Linear / nn.Conv2d / nn.BatchNorm2d / nn.LayerNorm children are parameter holders only (so
+`SyncBatchNorm.convert_sync_batchnorm`, `load_state_dict(strict=True)` and optimizers see the reference's
+parameters); their forward is never called.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_GELU, ACT_NONE
+
+BatchNorm2d = nn.BatchNorm2d
+INTERPOLATE_MODE = 'bilinear'
+
+
+def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
+    """timm 0.5.4 semantics (absolute cut-offs), used for init parity of freshly constructed models."""
+    with torch.no_grad():
+        lo = (1. + math.erf((a - mean) / std / math.sqrt(2.))) / 2.
+        hi = (1. + math.erf((b - mean) / std / math.sqrt(2.))) / 2.
+        tensor.uniform_(2 * lo - 1, 2 * hi - 1).erfinv_().mul_(std * math.sqrt(2.)).add_(mean).clamp_(min=a, max=b)
+    return tensor
+
+
+def _prec_of(p):
+    return ops.Prec(p.get('mtt_prec', 'bf16') if hasattr(p, 'get') else getattr(p, 'mtt_prec', 'bf16'))
+
+
+class PatchEmbed(nn.Module):
+    """Parameter holder with timm's PatchEmbed attribute surface (proj, grid_size, num_patches)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = tuple(img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size[0] // patch_size, img_size[1] // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    """Parameters of taskprompter.py:168-193 (qkv, proj, token_trans [hw<-C], token_trans1 [C<-hw])."""
+
+    def __init__(self, chan_nheads, resolution, dim, num_heads=8, qkv_bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.dim = dim
+        self.resolution = resolution
+        self.pixel_no = int(resolution[0] * resolution[1])
+        self.chan_nheads = chan_nheads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.token_trans = nn.Linear(dim, self.pixel_no)
+        self.token_trans1 = nn.Linear(self.pixel_no, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, chan_nheads, resolution, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop_path=0.,
+                 norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(chan_nheads, resolution, dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.drop_path_rate = float(drop_path)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+def _init_vit_weights(m):
+    if isinstance(m, nn.Linear):
+        trunc_normal_(m.weight, std=.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, (nn.LayerNorm, nn.BatchNorm2d)):
+        nn.init.zeros_(m.bias)
+        nn.init.ones_(m.weight)
+
+
+class TaskPrompter(nn.Module):
+    """TaskPrompter built upon ViT (taskprompter.py:281-487)."""
+
+    def __init__(self, p, select_list, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12,
+                 num_heads=12, chan_nheads=1, mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., embed_layer=None, norm_layer=None, act_layer=None, weight_init=''):
+        super().__init__()
+        assert patch_size == 16 and in_chans == 3 and embed_dim % 64 == 0 and embed_dim // num_heads == 64, \
+            "HIP path: patch 16, head_dim 64"
+        assert drop_rate == 0. and attn_drop_rate == 0., "reference never enables these (taskprompter.py:318)"
+        self.num_features = self.embed_dim = embed_dim
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        if isinstance(img_size, int):
+            img_size = (img_size, img_size)
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.resolution = [int(img_size[0] / patch_size), int(img_size[1] / patch_size)]
+        self.blocks = nn.Sequential(*[
+            Block(chan_nheads, self.resolution, dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                  qkv_bias=qkv_bias, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.select_list = list(select_list)
+        self.num_layers = 4
+        assert len(self.select_list) == self.num_layers - 1
+        self.num_heads = num_heads
+        self.chan_nheads = chan_nheads
+        task_no = len(p.TASKS.NAMES)
+        self.pixel_no = int(self.resolution[0] * self.resolution[1])
+        self.p = p
+        self.prompt_len = p.prompt_len
+        assert self.prompt_len == 1, "HIP path implements prompt_len == 1 (every reference config)"
+        self.prompts_len = task_no * p.prompt_len
+        self.task_prompts = nn.Parameter(torch.ones(self.prompts_len, embed_dim))
+        trunc_normal_(self.task_prompts, mean=1., std=1.)
+
+        self.fea_fuse = nn.ModuleList()
+        if p.use_ctr:
+            self.ctr_attn_conv = nn.ModuleList()
+        self.fea_decode_spa = nn.ModuleList()
+        self.fea_decode_chan = nn.ModuleList()
+        prompt_dim = num_heads * p.prompt_len
+        tar_dim = p.embed_dim
+        F = p.final_embed_dim
+        for _ in range(self.num_layers):
+            self.fea_fuse.append(nn.ModuleDict())
+            if p.use_ctr:
+                self.ctr_attn_conv.append(nn.ModuleDict())
+            self.fea_decode_spa.append(nn.ModuleDict())
+            self.fea_decode_chan.append(nn.ModuleDict())
+            for task in p.TASKS.NAMES:
+                self.fea_fuse[-1][task] = nn.Sequential(nn.Conv2d(tar_dim * 2, F, kernel_size=1),
+                                                        nn.Conv2d(F, F, kernel_size=3, padding=1), BatchNorm2d(F),
+                                                        nn.GELU(), nn.Conv2d(F, F, kernel_size=1))
+                if p.use_ctr:
+                    self.ctr_attn_conv[-1][task] = nn.Sequential(nn.Conv2d(prompt_dim, prompt_dim, kernel_size=1),
+                                                                 nn.GELU(), nn.Conv2d(prompt_dim, 1, kernel_size=1))
+                self.fea_decode_spa[-1][task] = nn.Sequential(nn.Conv2d(embed_dim, tar_dim, kernel_size=1))
+                self.fea_decode_chan[-1][task] = nn.Sequential(nn.Conv2d(embed_dim, tar_dim, kernel_size=1))
+        trunc_normal_(self.pos_embed, std=.02)
+        self.apply(_init_vit_weights)
+        self.prec = _prec_of(p)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'dist_token'}
+
+    # ------------------------------------------------------------------------------------------
+    def _tap_index(self, idx):
+        return self.select_list.index(idx + 1)
+
+    def forward(self, x):
+        """-> ({task: [B, F, 4h, 4w]} (channels-last views of the NHWC buffers), info) as taskprompter.py:392-422."""
+        fea = self.forward_nhwc(x)
+        B = x.shape[0]
+        F = self.p.final_embed_dim
+        h4, w4 = self.resolution[0] * 4, self.resolution[1] * 4
+        out = {t: fea[i].view(B, h4, w4, -1)[..., :F].permute(0, 3, 1, 2) for i, t in enumerate(self.p.TASKS.NAMES)}
+        return out, {}
+
+    def forward_nhwc(self, img):
+        """-> [T, B*4h*4w, pad8(F)] activation-dtype task features (x4-upsampled sum over the 4 taps)."""
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            from . import autograd_path
+            return autograd_path.backbone_forward(self, img)
+        return self._forward_nograd(img)
+
+    def _forward_nograd(self, img):
+        p, prec = self.p, self.prec
+        B = img.shape[0]
+        H, W = img.shape[-2:]
+        assert (H, W) == tuple(self.patch_embed.img_size), "input size must equal img_size (timm PatchEmbed assert)"
+        h, w = self.resolution
+        hw, T, C, nH = h * w, self.prompts_len, self.embed_dim, self.num_heads
+        N = T + hw
+        dev = img.device
+        nwin = int(math.isqrt(self.chan_nheads))
+        assert h % nwin == 0 and w % nwin == 0
+
+        # ---- patch embed + pos embed straight into the token buffer; prompts first ----------------
+        XT = torch.empty(B * N, C, dtype=torch.float32, device=dev)
+        XT.view(B, N, C)[:, :T] = self.task_prompts.detach()
+        cols = ops.patchify(img.float(), prec)
+        wpe = ops.pack_linear([self.patch_embed.proj.weight], prec, 'pe')
+        ops.linear(cols, wpe, C, prec, bias=self.patch_embed.proj.bias.detach()[None], out=XT.view(B, N, C)[:, T:],
+                   d_rows=(hw, N * C, C), resid=self.pos_embed.detach()[0, 1:], r_rows=(hw, 0, C), M=B * hw)
+
+        acc = None
+        rawlog = rawchan = None
+        for i, blk in enumerate(self.blocks):
+            XT, rawlog, rawchan = self._block(blk, i, XT, B, N, T, (h, w), nwin)
+            if (i + 1) in self.select_list:
+                acc = self._task_features(XT, XT.view(B, N, C)[:, T:], rawlog, rawchan, self._tap_index(i), B, acc)
+        xf, _, _ = ops.layernorm(XT, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps, prec,
+                                 out_dtype=torch.float32)
+        acc = self._task_features(xf, xf.view(B, N, C)[:, T:], rawlog, rawchan, 3, B, acc)
+        return ops.bilinear(acc, B, acc.shape[-1], h, w, 4 * h, 4 * w, prec.adt)
+
+    def _block(self, blk, i, XT, B, N, T, grid, nwin):
+        prec, C, nH = self.prec, self.embed_dim, self.num_heads
+        hw = grid[0] * grid[1]
+        a = blk.attn
+        tag = ('blk', i)
+        xn, _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec)
+        qkv = ops.linear(xn, ops.pack_linear([a.qkv.weight], prec, tag + ('qkv',)), 3 * C, prec,
+                         bias=a.qkv.bias.detach()[None])[0]
+        ao, rawlog, _ = ops.attention(qkv, B, N, nH, T, prec)
+        XT2 = torch.empty_like(XT)
+        ops.linear(ao, ops.pack_linear([a.proj.weight], prec, tag + ('proj',)), C, prec, bias=a.proj.bias.detach()[None],
+                   out=XT2, resid=XT)
+        # channel attention: queries token_trans(norm1(prompts)), keys norm1(x)^T, windowed (:216-250)
+        cq = ops.linear(xn, ops.pack_linear([a.token_trans.weight], prec, tag + ('tt',)), hw, prec,
+                        bias=a.token_trans.bias.detach()[None], a_rows=(T, N * C, C), M=B * T)[0]
+        rawchan = ops.chan_logits(cq, xn, B, T, N, C, grid, (nwin, nwin))
+        pr = XT2.view(B, N, C)[:, :T]
+        ops.linear(cq, ops.pack_linear([a.token_trans1.weight], prec, tag + ('tt1',)), C, prec,
+                   bias=a.token_trans1.bias.detach()[None], out=pr, d_rows=(T, N * C, C), resid=pr, M=B * T)
+        xn2, _, _ = ops.layernorm(XT2, blk.norm2.weight.detach(), blk.norm2.bias.detach(), blk.norm2.eps, prec)
+        hmid = ops.linear(xn2, ops.pack_linear([blk.mlp.fc1.weight], prec, tag + ('fc1',)), 4 * C, prec,
+                          bias=blk.mlp.fc1.bias.detach()[None], act=ACT_GELU)[0]
+        XT3 = torch.empty_like(XT)
+        ops.linear(hmid, ops.pack_linear([blk.mlp.fc2.weight], prec, tag + ('fc2',)), C, prec,
+                   bias=blk.mlp.fc2.bias.detach()[None], out=XT3, resid=XT2)
+        return XT3, rawlog, rawchan
+
+    # ---- cal_task_feature (taskprompter.py:424-487), all tasks at once -----------------------------
+    def _decoder_packs(self, il):
+        p, prec = self.p, self.prec
+        names = p.TASKS.NAMES
+        tar, F = p.embed_dim, p.final_embed_dim
+        tarp = ops.pad8(tar)
+        dec_w, dec_b = [], []
+        for t in names:
+            dec_w += [self.fea_decode_spa[il][t][0].weight, self.fea_decode_chan[il][t][0].weight]
+            dec_b += [self.fea_decode_spa[il][t][0].bias, self.fea_decode_chan[il][t][0].bias]
+        Wdec = ops.pack_linear(dec_w, prec, ('dec', il))
+        bdec = ops.stack_vec(dec_b, ('decb', il))
+        f0 = [self.fea_fuse[il][t][0].weight for t in names]
+
+        def build_f0():
+            with torch.no_grad():
+                buf = torch.zeros(len(names), F, 2 * tarp, dtype=torch.float32, device=f0[0].device)
+                for i, wt in enumerate(f0):
+                    w2 = wt.detach().reshape(F, 2 * tar)
+                    buf[i, :, :tar] = w2[:, :tar]
+                    buf[i, :, tarp:tarp + tar] = w2[:, tar:]
+                return buf.to(prec.adt)
+        W0 = ops._cached(('f0', il, prec.name, tuple(id(q) for q in f0)), f0, build_f0)
+        b0 = ops.stack_vec([self.fea_fuse[il][t][0].bias for t in names], ('f0b', il))
+        Wc = ops.pack_conv3([self.fea_fuse[il][t][1].weight for t in names], prec, ('f1', il))
+        bc = ops.stack_vec([self.fea_fuse[il][t][1].bias for t in names], ('f1b', il))
+        W4 = ops.pack_linear([self.fea_fuse[il][t][4].weight for t in names], prec, ('f4', il))
+        b4 = ops.stack_vec([self.fea_fuse[il][t][4].bias for t in names], ('f4b', il))
+        return Wdec, bdec, W0, b0, Wc, bc, W4, b4
+
+    def _ctr_weights(self, rawlog, il, B, T):
+        """[B, T, T] mixing weights: per-head MLP on the prompt<->prompt raw logits (:482-484); identity without ctr."""
+        if not self.p.use_ctr:
+            return torch.eye(T, dtype=torch.float32, device=rawlog.device)[None].expand(B, T, T).contiguous()
+        names = self.p.TASKS.NAMES
+        z = rawlog[:, :, :, :T].permute(0, 2, 3, 1)                                   # [B, t, s, nH]
+        W0 = torch.stack([self.ctr_attn_conv[il][t][0].weight.flatten(1) for t in names])   # [T, nH, nH]
+        b0 = torch.stack([self.ctr_attn_conv[il][t][0].bias for t in names])
+        W2 = torch.stack([self.ctr_attn_conv[il][t][2].weight.flatten() for t in names])     # [T, nH]
+        b2 = torch.stack([self.ctr_attn_conv[il][t][2].bias for t in names]).flatten()
+        z = torch.nn.functional.gelu(torch.einsum('btsh,tjh->btsj', z, W0) + b0[None, :, None, :])
+        return (torch.einsum('btsj,tj->bts', z, W2) + b2[None, :, None]).contiguous()
+
+    def _bn_fold(self, bns, conv_biases, tag):
+        """eval BatchNorm folded into the producing conv's epilogue: scale = g/sqrt(v+eps), shift = b + (cb - m)*scale."""
+        def build():
+            with torch.no_grad():
+                sc = torch.stack([bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps) for bn in bns])
+                cb = torch.stack([b.detach() for b in conv_biases])
+                sh = torch.stack([bn.bias.detach() - bn.running_mean * s for bn, s in zip(bns, sc)]) + cb * sc
+                return sc.contiguous(), sh.contiguous()
+        prm = [q for bn in bns for q in (bn.weight, bn.bias, bn.running_mean, bn.running_var)] + list(conv_biases)
+        return ops._cached((tag, tuple(id(q) for q in prm)), prm, build)
+
+    def _bn_train(self, y, bns, C, act):
+        """training-mode BatchNorm2d (+act) on [T, rows, ld] pre-activations; updates running stats like nn.BatchNorm2d."""
+        outs = []
+        rows = y.shape[1]
+        for t, bn in enumerate(bns):
+            mean, var = ops.bn_batch_stats(y[t], C)
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(mean * m)
+                bn.running_var.mul_(1 - m).add_(var * (rows / max(rows - 1, 1)) * m)
+                bn.num_batches_tracked += 1
+            rstd = torch.rsqrt(var + bn.eps)
+            outs.append(ops.bn_apply(y[t], C, mean, rstd, bn.weight.detach(), bn.bias.detach(), act))
+        return torch.stack(outs, 0)
+
+    def _task_features(self, xsrc, xview, rawlog, rawchan, il, B, acc):
+        p, prec = self.p, self.prec
+        names = p.TASKS.NAMES
+        T, C = len(names), self.embed_dim
+        h, w = self.resolution
+        hw, N = h * w, T + h * w
+        tar, F = p.embed_dim, p.final_embed_dim
+        tarp, Fp = ops.pad8(tar), ops.pad8(F)
+        nwin = int(math.isqrt(self.chan_nheads))
+        Wdec, bdec, W0, b0, Wc, bc, W4, b4 = self._decoder_packs(il)
+        mod = ops.modulate(xview, C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec)
+        cat = torch.empty(T, B * hw, 2 * tarp, dtype=prec.adt, device=xsrc.device)
+        ops.linear(mod, Wdec, tar, prec, bias=bdec, out=cat, batch_inner=2, d_z=(B * hw * 2 * tarp, tarp), ldd=2 * tarp,
+                   n_store=tarp)
+        y0 = ops.linear(cat, W0, F, prec, bias=b0)
+        bns = [self.fea_fuse[il][t][2] for t in names]
+        if self.training:
+            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, prec, bias=bc)
+            y1 = self._bn_train(y1, bns, F, ACT_GELU)
+        else:
+            sc, sh = self._bn_fold(bns, [self.fea_fuse[il][t][1].bias for t in names], ('f2', il))
+            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, prec, bias=sh, colscale=sc, act=ACT_GELU)
+        fea = ops.linear(y1, W4, F, prec, bias=b4)
+        wmix = self._ctr_weights(rawlog, il, B, T).detach()
+        return ops.ctr_mix(fea, wmix, B, F, acc)
+
+
+def _create_task_prompter(variant, pretrained=False, default_cfg=None, **kwargs):
+    if pretrained:
+        raise RuntimeError('pretrained ImageNet weights need network access (taskprompter.py:661 downloads them); '
+                           'construct with pretrained=False and load a checkpoint with load_state_dict')
+    kwargs.setdefault('in_chans', 3)
+    model = TaskPrompter(**kwargs)
+    model.default_cfg = dict(default_cfg or {}, variant=variant)
+    return model
+
+
+def taskprompter_vit_large_patch16_384(pretrained=False, **kwargs):
+    """ViT-L/16 TaskPrompter (taskprompter.py:671-677)."""
+    model_kwargs = dict(select_list=range(6, 24, 6), patch_size=16, embed_dim=1024, depth=24, num_heads=16,
+                        chan_nheads=kwargs['p'].chan_nheads, **kwargs)
+    return _create_task_prompter('vit_large_patch16_384', pretrained=pretrained, **model_kwargs)
+
+
+def taskprompter_vit_base_patch16_384(pretrained=False, **kwargs):
+    """ViT-B/16 TaskPrompter (taskprompter.py:679-685)."""
+    model_kwargs = dict(select_list=range(3, 12, 3), patch_size=16, embed_dim=768, depth=12, num_heads=12,
+                        chan_nheads=kwargs['p'].chan_nheads, **kwargs)
+    return _create_task_prompter('vit_base_patch16_384', pretrained=pretrained, **model_kwargs)
+
+
+class ConvHead(nn.Module):
+    """taskprompter.py:688-698 (parameter holder; executed task-batched by TaskPrompterWrapper)."""
+
+    def __init__(self, in_channels, num_classes):
+        super().__init__()
+        self.mt_proj = nn.Sequential(nn.Conv2d(in_channels, in_channels, 3, padding=1), BatchNorm2d(in_channels), nn.GELU())
+        trunc_normal_(self.mt_proj[0].weight, std=0.02)
+        self.linear_pred = nn.Conv2d(in_channels, num_classes, kernel_size=1)
+
+
+class DEConvHead(nn.Module):
+    """taskprompter.py:700-715."""
+
+    def __init__(self, in_channels, num_classes):
+        super().__init__()
+        self.mt_proj = nn.Sequential(
+            nn.ConvTranspose2d(in_channels, in_channels // 2, 2, stride=2, padding=0), BatchNorm2d(in_channels // 2), nn.GELU(),
+            nn.Conv2d(in_channels // 2, in_channels // 2, 3, padding=1), BatchNorm2d(in_channels // 2), nn.GELU())
+        self.linear_pred = nn.Conv2d(in_channels // 2, num_classes, kernel_size=1)
+        trunc_normal_(self.mt_proj[0].weight, std=0.02)
+        trunc_normal_(self.mt_proj[3].weight, std=0.02)
+        trunc_normal_(self.linear_pred.weight, std=0.02)
+
+
+class TaskPrompterWrapper(nn.Module):
+    """taskprompter_wrapper.py:9-40: backbone -> per-task head -> bilinear resize to the input size."""
+
+    def __init__(self, p, backbone, heads):
+        super().__init__()
+        self.tasks = p.TASKS.NAMES
+        self.backbone = backbone
+        self.heads = heads
+        self.target_size = p.dd_label_map_size if 'dd_label_map_size' in p.keys() else None
+
+    def forward(self, x):
+        img_size = tuple(x.shape[-2:])
+        target = tuple(self.target_size) if self.target_size is not None else img_size
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            from . import autograd_path
+            return autograd_path.wrapper_forward(self, x, target)
+        bb = self.backbone
+        B = x.shape[0]
+        fea = bb.forward_nhwc(x)                                            # [T, B*4h*4w, Fp]
+        h4, w4 = bb.resolution[0] * 4, bb.resolution[1] * 4
+        F = bb.p.final_embed_dim
+        prec = bb.prec
+        heads = [self.heads[t] for t in self.tasks]
+        out = {}
+        if all(isinstance(hd, ConvHead) for hd in heads):
+            Wc = ops.pack_conv3([hd.mt_proj[0].weight for hd in heads], prec, 'hc')
+            bc = ops.stack_vec([hd.mt_proj[0].bias for hd in heads], 'hcb')
+            bns = [hd.mt_proj[1] for hd in heads]
+            if self.training:
+                y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=bc)
+                y = bb._bn_train(y, bns, F, ACT_GELU)
+            else:
+                sc, sh = bb._bn_fold(bns, [hd.mt_proj[0].bias for hd in heads], 'hbn')
+                y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
+            for i, (t, hd) in enumerate(zip(self.tasks, heads)):
+                n_out = hd.linear_pred.weight.shape[0]
+                pred = ops.linear(y[i], ops.pack_linear([hd.linear_pred.weight], prec, ('hp', t)), n_out, prec,
+                                  bias=hd.linear_pred.bias.detach()[None], out_dtype=torch.float32)
+                out[t] = ops.bilinear(pred, B, n_out, h4, w4, target[0], target[1], torch.float32, nchw=True)
+        elif all(isinstance(hd, DEConvHead) for hd in heads):
+            F2 = F // 2
+            for i, (t, hd) in enumerate(zip(self.tasks, heads)):
+                wt = hd.mt_proj[0].weight                                   # [F, F2, 2, 2] -> rows n = (dy*2+dx)*F2 + co
+                Wd = ops._cached(('hd0', t, prec.name, id(wt)), [wt],
+                                 lambda wt=wt: ops.pack_matrix(wt.detach().permute(2, 3, 1, 0).reshape(4 * F2, F), prec)[None])
+                b4v = ops._cached(('hd0b', t, id(hd.mt_proj[0].bias)), [hd.mt_proj[0].bias],
+                                  lambda hd=hd: hd.mt_proj[0].bias.detach().repeat(4).contiguous())
+                y = ops.deconv2x2(fea[i], Wd, F2, F, B, h4, w4, prec, bias4=b4v)[None]      # [1, B*2h4*2w4, pad8(F2)]
+                Wc = ops.pack_conv3([hd.mt_proj[3].weight], prec, ('hd3', t))
+                bc = hd.mt_proj[3].bias.detach()[None].contiguous()
+                if self.training:
+                    y = bb._bn_train(y, [hd.mt_proj[1]], F2, ACT_GELU)
+                    y = ops.conv3x3(y, Wc, F2, F2, B, 2 * h4, 2 * w4, prec, bias=bc)
+                    y = bb._bn_train(y, [hd.mt_proj[4]], F2, ACT_GELU)
+                else:
+                    # BN1 cannot fold into the pixel-shuffle GEMM's epilogue (rows differ per tap? no: per channel) -> apply kernel
+                    bn1 = hd.mt_proj[1]
+                    y = ops.bn_apply(y[0], F2, bn1.running_mean, torch.rsqrt(bn1.running_var + bn1.eps), bn1.weight.detach(),
+                                     bn1.bias.detach(), ACT_GELU)[None]
+                    sc, sh = bb._bn_fold([hd.mt_proj[4]], [hd.mt_proj[3].bias], ('hd4', t))
+                    y = ops.conv3x3(y, Wc, F2, F2, B, 2 * h4, 2 * w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
+                n_out = hd.linear_pred.weight.shape[0]
+                pred = ops.linear(y[0], ops.pack_linear([hd.linear_pred.weight], prec, ('hp', t)), n_out, prec,
+                                  bias=hd.linear_pred.bias.detach()[None], out_dtype=torch.float32)
+                out[t] = ops.bilinear(pred, B, n_out, 2 * h4, 2 * w4, target[0], target[1], torch.float32, nchw=True)
+        else:
+            raise NotImplementedError('heads must all be ConvHead or all DEConvHead (the 3ddet FCOS3D head is out of scope)')
+        return out

@@ -1,0 +1,436 @@
+"""TEST INFRASTRUCTURE ONLY — CPU emulator of the libmtt_hip.so C ABI (include/mtt_hip.h).
+
+`call(name, **fields)` has the signature of `multi-task-transformer_amd/_lib.call` but executes the
+descriptor's CONTRACT with plain torch index arithmetic on the tensors' flat storages (fp64
+accumulation).  It is independent of the kernels: it is itself checked against torch.nn.functional
+ops in tests/test_abi_emul.py, then used (a) as the per-entry-point oracle of the `-m gpu` parity
+tests and (b) monkeypatched over `_lib.call` by CPU tests to exercise the product's host-side wiring
+(descriptor construction, strides, padding) without a GPU.  Never imported by the product.
+"""
+import math
+
+import torch
+
+F32, BF16 = 0, 1
+OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+
+ROUND_BF16_OPERANDS = True   # emulate the f32->bf16 operand rounding of MTT_PREC_BF16
+
+
+def flat(t):
+    """(1-D view of the whole storage, element offset of t's first element)."""
+    f = torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage())
+    return f, t.storage_offset()
+
+
+def _rd(t, idx, valid=None):
+    f, o = flat(t)
+    idx = idx + o
+    if valid is not None:
+        idx = torch.where(valid, idx, torch.zeros_like(idx))
+    v = f[idx].double()
+    if valid is not None:
+        v = torch.where(valid, v, torch.zeros_like(v))
+    return v
+
+
+def _wr(t, idx, val):
+    f, o = flat(t)
+    f[idx + o] = val.to(t.dtype)
+
+
+def _rowoff(m, mb, bs, ld):
+    if mb and mb > 0:
+        return (m // mb) * bs + (m % mb) * ld
+    return m * ld
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+
+
+def _bf16_round(v):
+    return v.float().bfloat16().double()
+
+
+def gemm(**kw):
+    g = lambda k, dflt=0: kw.get(k, dflt) if kw.get(k, dflt) is not None else dflt
+    A, B, D = kw["A"], kw["B"], kw["D"]
+    M, N, K = kw["M"], kw["N"], kw["K"]
+    a_op, b_op = g("a_op"), g("b_op")
+    lda, ldb, ldd = g("lda"), g("ldb"), g("ldd")
+    batch, bi = max(1, g("batch", 1)), max(1, g("batch_inner", 1))
+    conv = kw.get("conv") or {}
+    prec = g("prec")
+    alpha = kw.get("alpha", 1.0)
+    m = torch.arange(M)[:, None]
+    n = torch.arange(N)[:, None]
+    k = torch.arange(K)[None, :]
+
+    def conv_taps(idx_tap, flip):
+        ty, tx = idx_tap // 3, idx_tap % 3
+        if flip:
+            ty, tx = 2 - ty, 2 - tx
+        return (ty - 1) * conv["dil"], (tx - 1) * conv["dil"]
+
+    for z in range(batch):
+        zo, zi = divmod(z, bi)
+        za = zo * g("a_zo") + zi * g("a_zi")
+        zb = zo * g("b_zo") + zi * g("b_zi")
+        zd = zo * g("d_zo") + zi * g("d_zi")
+        # ---- A [M, K] ----
+        if a_op == OP_K:
+            Am = _rd(A, za + _rowoff(m, g("a_mb"), g("a_bs"), lda) + k)
+        elif a_op == OP_R:
+            Am = _rd(A, za + k * lda + m)
+        elif a_op == OP_CONV_K:
+            H, W, Cc, Cp = conv["H"], conv["W"], conv["C"], conv["Cp"]
+            tap, ci = k // Cp, k % Cp
+            dy, dx = conv_taps(tap, conv.get("flip", 0))
+            y, x = (m // W) % H, m % W
+            ok = (y + dy >= 0) & (y + dy < H) & (x + dx >= 0) & (x + dx < W) & (ci < Cc)
+            Am = _rd(A, za + (m + dy * W + dx) * lda + ci, ok)
+        else:
+            raise ValueError("bad a_op")
+        # ---- B [N, K] ----
+        if b_op == OP_K:
+            Bm = _rd(B, zb + n * ldb + k)
+        elif b_op == OP_R:
+            Bm = _rd(B, zb + k * ldb + n)
+        elif b_op == OP_CONV_R:
+            H, W, Cc, Cp = conv["H"], conv["W"], conv["C"], conv["Cp"]
+            tap, ci = n // Cp, n % Cp
+            dy, dx = conv_taps(tap, 0)
+            y, x = (k // W) % H, k % W
+            ok = (y + dy >= 0) & (y + dy < H) & (x + dx >= 0) & (x + dx < W) & (ci < Cc)
+            Bm = _rd(B, zb + (k + dy * W + dx) * ldb + ci, ok)
+        else:
+            raise ValueError("bad b_op")
+        if prec == 0 and ROUND_BF16_OPERANDS:
+            Am, Bm = _bf16_round(Am), _bf16_round(Bm)
+        v = alpha * (Am @ Bm.T)                                       # [M, N] fp64
+        # ---- epilogue ----
+        zc = zo * g("col_zo") + zi * g("col_zi")
+        ncol = torch.arange(N)
+        if kw.get("colscale") is not None:
+            v = v * _rd(kw["colscale"], zc + ncol)[None, :]
+        if kw.get("colshift") is not None:
+            v = v + _rd(kw["colshift"], zc + ncol)[None, :]
+        act = g("act")
+        d_mb, d_bs = g("d_mb"), g("d_bs")
+        mrow = torch.arange(M)
+        auxrow = ((mrow // d_mb) * d_mb + (mrow % d_mb)) if d_mb and d_mb > 0 else mrow
+        zaux = zo * g("aux_zo") + zi * g("aux_zi")
+        aux_idx = zaux + auxrow[:, None] * g("ldaux") + ncol[None, :]
+        if kw.get("aux_out") is not None:
+            _wr(kw["aux_out"], aux_idx, v)
+        if act == ACT_GELU:
+            v = _gelu(v)
+        elif act == ACT_RELU:
+            v = torch.clamp_min(v, 0.0)
+        elif act == ACT_GELU_BWD:
+            v = v * _gelu_grad(_rd(kw["aux_in"], aux_idx))
+        elif act == ACT_RELU_BWD:
+            v = torch.where(_rd(kw["aux_in"], aux_idx) > 0, v, torch.zeros_like(v))
+        if kw.get("rowscale") is not None:
+            q = (mrow // d_mb) if d_mb and d_mb > 0 else torch.zeros_like(mrow)
+            rem = (mrow % d_mb) if d_mb and d_mb > 0 else mrow
+            rs = _rd(kw["rowscale"], q * 2 + (rem >= g("n_prompt")).long())
+            v = v * rs[:, None]
+        if kw.get("resid") is not None:
+            zr = zo * g("r_zo") + zi * g("r_zi")
+            ridx = zr + _rowoff(mrow, g("r_mb"), g("r_bs"), g("ldr"))[:, None] + ncol[None, :]
+            v = v + _rd(kw["resid"], ridx)
+        if g("store_mode") == 1:
+            Hs, Ws, Co = kw["ps_H"], kw["ps_W"], kw["ps_Co"]
+            q, co = ncol // Co, ncol % Co
+            x, y, bb = mrow % Ws, (mrow // Ws) % Hs, mrow // (Ws * Hs)
+            orow = (bb[:, None] * (2 * Hs) + 2 * y[:, None] + (q // 2)[None, :]) * (2 * Ws) + 2 * x[:, None] + (q % 2)[None, :]
+            _wr(D, zd + orow * ldd + co[None, :], v)
+        else:
+            didx = zd + _rowoff(mrow, d_mb, d_bs, ldd)[:, None] + ncol[None, :]
+            _wr(D, didx, v)
+            n_store = g("n_store")
+            if n_store and n_store > N:
+                pad = torch.arange(N, n_store)
+                _wr(D, zd + _rowoff(mrow, d_mb, d_bs, ldd)[:, None] + pad[None, :], torch.zeros(M, n_store - N, dtype=torch.float64))
+
+
+def attn_fwd(**kw):
+    qkv, out = kw["qkv"], kw["out"]
+    B, N, nH, T = kw["B"], kw["N"], kw["nH"], kw["T"]
+    C = nH * 64
+    f, o = flat(qkv)
+    x = f[o:o + B * N * 3 * C].double().view(B, N, 3, nH, 64)
+    if kw.get("prec", 0) == 0 and ROUND_BF16_OPERANDS:
+        x = _bf16_round(x)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    raw = q @ k.transpose(-1, -2)
+    if kw.get("rawlog") is not None and T > 0:
+        _wr(kw["rawlog"], torch.arange(B * nH * T * N), raw[:, :, :T, :].reshape(-1))
+    s = raw * kw["scale"]
+    if kw.get("lse") is not None:
+        _wr(kw["lse"], torch.arange(B * nH * N), torch.logsumexp(s, dim=-1).reshape(-1))
+    y = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(-1)
+    _wr(out, torch.arange(B * N * C), y)
+
+
+def softmax_fwd(**kw):
+    rows, cols, ld = kw["rows"], kw["cols"], kw["ld"]
+    idx = torch.arange(rows)[:, None] * ld + torch.arange(cols)[None, :]
+    s = _rd(kw["S"], idx) * kw["scale"]
+    _wr(kw["P"], idx, torch.softmax(s, dim=-1))
+    if ld > cols:
+        pad = torch.arange(rows)[:, None] * ld + torch.arange(cols, ld)[None, :]
+        _wr(kw["P"], pad, torch.zeros(rows, ld - cols, dtype=torch.float64))
+
+
+def softmax_bwd(**kw):
+    rows, cols, ld = kw["rows"], kw["cols"], kw["ld"]
+    idx = torch.arange(rows)[:, None] * ld + torch.arange(cols)[None, :]
+    P, dP = _rd(kw["P"], idx), _rd(kw["dP"], idx)
+    dS = kw["scale"] * P * (dP - (dP * P).sum(-1, keepdim=True))
+    if kw.get("extra") is not None:
+        rpm, er, eld = kw["rows_per_mat"], kw["extra_rows"], kw["extra_ld"]
+        r = torch.arange(rows)
+        mat, rin = r // rpm, r % rpm
+        sel = rin < er
+        eidx = (mat[sel] * er + rin[sel])[:, None] * eld + torch.arange(cols)[None, :]
+        dS[sel] = dS[sel] + _rd(kw["extra"], eidx)
+    _wr(kw["dS"], idx, dS)
+    if ld > cols:
+        pad = torch.arange(rows)[:, None] * ld + torch.arange(cols, ld)[None, :]
+        _wr(kw["dS"], pad, torch.zeros(rows, ld - cols, dtype=torch.float64))
+
+
+def layernorm_fwd(**kw):
+    rows, Cn = kw["rows"], kw["C"]
+    r, c = torch.arange(rows)[:, None], torch.arange(Cn)[None, :]
+    x = _rd(kw["x"], r * kw["ldx"] + c)
+    mean = x.mean(-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + kw["eps"])
+    y = (x - mean) * rstd * _rd(kw["gamma"], c) + _rd(kw["beta"], c)
+    _wr(kw["y"], r * kw["ldy"] + c, y)
+    if kw.get("mean") is not None:
+        _wr(kw["mean"], torch.arange(rows), mean[:, 0])
+    if kw.get("rstd") is not None:
+        _wr(kw["rstd"], torch.arange(rows), rstd[:, 0])
+
+
+def layernorm_bwd(**kw):
+    rows, Cn = kw["rows"], kw["C"]
+    r, c = torch.arange(rows)[:, None], torch.arange(Cn)[None, :]
+    x = _rd(kw["x"], r * kw["ldx"] + c)
+    dy = _rd(kw["dy"], r * kw["ldy"] + c)
+    mean = _rd(kw["mean"], torch.arange(rows))[:, None]
+    rstd = _rd(kw["rstd"], torch.arange(rows))[:, None]
+    xh = (x - mean) * rstd
+    gm = dy * _rd(kw["gamma"], c)
+    if kw.get("dx") is not None:
+        dx = rstd * (gm - gm.mean(-1, keepdim=True) - xh * (gm * xh).mean(-1, keepdim=True))
+        idx = r * kw["ldx"] + c
+        _wr(kw["dx"], idx, _rd(kw["dx"], idx) + dx)
+    if kw.get("dgamma") is not None:
+        ci = torch.arange(Cn)
+        _wr(kw["dgamma"], ci, _rd(kw["dgamma"], ci) + (dy * xh).sum(0))
+        _wr(kw["dbeta"], ci, _rd(kw["dbeta"], ci) + dy.sum(0))
+
+
+def patchify16(args):
+    img, cols, B, H, W, odt = args[:6]
+    h, w = H // 16, W // 16
+    x = img.double().reshape(B, 3, h, 16, w, 16).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w * 768)
+    _wr(cols, torch.arange(B * h * w * 768), x)
+
+
+def chan_logits(**kw):
+    B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
+    f, o = flat(kw["xn"])
+    xn = f[o:o + B * N * Cn].double().view(B, N, Cn)[:, T:]
+    qi = (torch.arange(B)[:, None, None] * T + torch.arange(T)[None, :, None]) * kw["ldq"] + torch.arange(h * w)[None, None, :]
+    q = _rd(kw["q"], qi)                                              # [B,T,hw]
+    wh, ww = h // nh, w // nw
+    qw = q.view(B, T, nh, wh, nw, ww)
+    xw = xn.reshape(B, nh, wh, nw, ww, Cn)
+    r = torch.einsum("btiajk,biajkc->btijc", qw, xw).reshape(-1)      # [B,T,nwin,C]
+    idx = torch.arange(B * T * nh * nw * Cn)
+    _wr(kw["rawchan"], idx, _rd(kw["rawchan"], idx) + r)              # kernel accumulates (atomics)
+
+
+def modulate(**kw):
+    B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
+    hw, nH, nwin = h * w, Cn // 64, nh * nw
+    xi = torch.arange(B)[:, None, None] * kw["x_bs"] + torch.arange(hw)[None, :, None] * kw["x_ld"] + torch.arange(Cn)[None, None, :]
+    x = _rd(kw["x"], xi)
+    f, o = flat(kw["rawlog"])
+    rl = f[o:o + B * nH * T * N].double().view(B, nH, T, N)
+    f, o = flat(kw["rawchan"])
+    rc = f[o:o + B * T * nwin * Cn].double().view(B, T, nwin, Cn)
+    yy, xx = torch.arange(hw) // w, torch.arange(hw) % w
+    win = (yy // (h // nh)) * nw + (xx // (w // nw))
+    outs = []
+    for t in range(T):
+        a = rl[:, :, t, T:].transpose(1, 2).repeat_interleave(64, dim=2)     # [B,hw,C]
+        outs.append(x * (1 + a))
+        outs.append(x * (1 + rc[:, t][:, win]))
+    y = torch.stack(outs, 0).reshape(-1)
+    _wr(kw["out"], torch.arange(y.numel()), y)
+
+
+def ctr_mix(**kw):
+    T, B, rpb, ld, Cn = kw["T"], kw["B"], kw["rows_per_b"], kw["ld"], kw["C"]
+    rows = B * rpb
+    C8 = (Cn + 7) // 8 * 8
+    idx = (torch.arange(T)[:, None, None] * rows + torch.arange(rows)[None, :, None]) * ld + torch.arange(C8)[None, None, :]
+    fea = _rd(kw["fea"], idx).view(T, B, rpb, C8)
+    wm = _rd(kw["wmix"], torch.arange(B * T * T)).view(B, T, T)
+    out = torch.einsum("bts,sbrc->tbrc", wm, fea).reshape(T, rows, C8)
+    if kw.get("accumulate"):
+        out = out + _rd(kw["out"], idx)
+    _wr(kw["out"], idx, out)
+
+
+def _src(o, n_in, n_out):
+    scale = torch.tensor(n_in / n_out, dtype=torch.float32)
+    s = (torch.arange(n_out, dtype=torch.float32) + 0.5) * scale - 0.5
+    s = torch.clamp_min(s, 0.0)
+    i0 = torch.clamp_max(s.long(), n_in - 1)
+    i1 = torch.where(i0 < n_in - 1, i0 + 1, i0)
+    return i0, i1, (s - i0.float()).double()
+
+
+def bilinear_fwd(**kw):
+    B, Cn, Hi, Wi, Ho, Wo = (kw[k] for k in ("B", "C", "Hin", "Win", "Hout", "Wout"))
+    ii = (torch.arange(B * Hi * Wi)[:, None] * kw["ld_in"] + torch.arange(Cn)[None, :])
+    x = _rd(kw["in"], ii).view(B, Hi, Wi, Cn)
+    y0, y1, wy = _src(None, Hi, Ho)
+    x0, x1, wx = _src(None, Wi, Wo)
+    wy, wx = wy[None, :, None, None], wx[None, None, :, None]
+    top = x[:, y0][:, :, x0] * (1 - wx) + x[:, y0][:, :, x1] * wx
+    bot = x[:, y1][:, :, x0] * (1 - wx) + x[:, y1][:, :, x1] * wx
+    y = top * (1 - wy) + bot * wy                                     # [B,Ho,Wo,C]
+    if kw.get("out_nchw"):
+        _wr(kw["out"], torch.arange(B * Cn * Ho * Wo), y.permute(0, 3, 1, 2).reshape(-1))
+    else:
+        oi = torch.arange(B * Ho * Wo)[:, None] * kw["ld_out"] + torch.arange(Cn)[None, :]
+        v = y.reshape(B * Ho * Wo, Cn)
+        if kw.get("accumulate"):
+            v = v + _rd(kw["out"], oi)
+        _wr(kw["out"], oi, v)
+
+
+def bilinear_bwd(**kw):
+    """in = dout (Hout x Wout), out = din fp32 NHWC (Hin x Win), accumulated."""
+    B, Cn, Hi, Wi, Ho, Wo = (kw[k] for k in ("B", "C", "Hin", "Win", "Hout", "Wout"))
+    if kw.get("out_nchw"):
+        f, o = flat(kw["in"])
+        g = f[o:o + B * Cn * Ho * Wo].double().view(B, Cn, Ho, Wo).permute(0, 2, 3, 1)
+    else:
+        gi = torch.arange(B * Ho * Wo)[:, None] * kw["ld_out"] + torch.arange(Cn)[None, :]
+        g = _rd(kw["in"], gi).view(B, Ho, Wo, Cn)
+    y0, y1, wy = _src(None, Hi, Ho)
+    x0, x1, wx = _src(None, Wi, Wo)
+    din = torch.zeros(B, Hi, Wi, Cn, dtype=torch.float64)
+    wyv, wxv = wy[None, :, None, None], wx[None, None, :, None]
+    for ys, wyy in ((y0, 1 - wyv), (y1, wyv)):
+        for xs, wxx in ((x0, 1 - wxv), (x1, wxv)):
+            contrib = g * wyy * wxx
+            tmp = torch.zeros(B, Hi, Wo, Cn, dtype=torch.float64).index_add_(1, ys, contrib)
+            din.index_add_(2, xs, tmp)
+    di = torch.arange(B * Hi * Wi)[:, None] * kw["ld_in"] + torch.arange(Cn)[None, :]
+    _wr(kw["out"], di, _rd(kw["out"], di) + din.view(B * Hi * Wi, Cn))
+
+
+def _act(u, act):
+    return _gelu(u) if act == ACT_GELU else (torch.clamp_min(u, 0) if act == ACT_RELU else u)
+
+
+def _act_grad(u, act):
+    return _gelu_grad(u) if act == ACT_GELU else ((u > 0).double() if act == ACT_RELU else torch.ones_like(u))
+
+
+def _bn_idx(kw):
+    return torch.arange(kw["rows"])[:, None] * kw["ld"] + torch.arange(kw["C"])[None, :]
+
+
+def bn_stats(**kw):
+    x = _rd(kw["x"], _bn_idx(kw))
+    c = torch.arange(kw["C"])
+    _wr(kw["sum"], c, _rd(kw["sum"], c) + x.sum(0))
+    _wr(kw["sumsq"], c, _rd(kw["sumsq"], c) + (x * x).sum(0))
+
+
+def bn_apply(**kw):
+    c = torch.arange(kw["C"])
+    x = _rd(kw["x"], _bn_idx(kw))
+    u = (x - _rd(kw["mean"], c)) * _rd(kw["rstd"], c) * _rd(kw["gamma"], c) + _rd(kw["beta"], c)
+    _wr(kw["y"], _bn_idx(kw), _act(u, kw.get("act", 0)))
+    C8 = (kw["C"] + 7) // 8 * 8
+    if C8 > kw["C"]:
+        pad = torch.arange(kw["rows"])[:, None] * kw["ld"] + torch.arange(kw["C"], C8)[None, :]
+        _wr(kw["y"], pad, torch.zeros(kw["rows"], C8 - kw["C"], dtype=torch.float64))
+
+
+def bn_bwd_reduce(**kw):
+    c = torch.arange(kw["C"])
+    x, dy = _rd(kw["x"], _bn_idx(kw)), _rd(kw["dy"], _bn_idx(kw))
+    xh = (x - _rd(kw["mean"], c)) * _rd(kw["rstd"], c)
+    du = dy * _act_grad(xh * _rd(kw["gamma"], c) + _rd(kw["beta"], c), kw.get("act", 0))
+    _wr(kw["dsum"], c, _rd(kw["dsum"], c) + du.sum(0))
+    _wr(kw["dsumxh"], c, _rd(kw["dsumxh"], c) + (du * xh).sum(0))
+
+
+def bn_bwd_apply(**kw):
+    c = torch.arange(kw["C"])
+    x, dy = _rd(kw["x"], _bn_idx(kw)), _rd(kw["dy"], _bn_idx(kw))
+    rstd, gam = _rd(kw["rstd"], c), _rd(kw["gamma"], c)
+    xh = (x - _rd(kw["mean"], c)) * rstd
+    du = dy * _act_grad(xh * gam + _rd(kw["beta"], c), kw.get("act", 0))
+    n = kw["rows"]
+    dx = gam * rstd * (du - _rd(kw["dsum"], c) / n - xh * _rd(kw["dsumxh"], c) / n)
+    _wr(kw["dx"], _bn_idx(kw), dx)
+    C8 = (kw["C"] + 7) // 8 * 8
+    if C8 > kw["C"]:
+        pad = torch.arange(kw["rows"])[:, None] * kw["ld"] + torch.arange(kw["C"], C8)[None, :]
+        _wr(kw["dx"], pad, torch.zeros(kw["rows"], C8 - kw["C"], dtype=torch.float64))
+
+
+def cast2d(args):
+    src, dst, rows, cols, lds, ldd, sdt, ddt, zp = args[:9]
+    r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+    _wr(dst, r * ldd + c, _rd(src, r * lds + c))
+    if zp and ldd > cols:
+        _wr(dst, r * ldd + torch.arange(cols, ldd)[None, :], torch.zeros(rows, ldd - cols, dtype=torch.float64))
+
+
+def colsum(args):
+    src, dst, rows, cols, ld, sdt = args[:6]
+    r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+    ci = torch.arange(cols)
+    _wr(dst, ci, _rd(dst, ci) + _rd(src, r * ld + c).sum(0))
+
+
+def add_rows(args):
+    src, dst, rows, cols, lds, ldd, sdt, alpha = args[:8]
+    r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+    _wr(dst, r * ldd + c, _rd(dst, r * ldd + c) + alpha * _rd(src, r * lds + c))
+
+
+_TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
+              layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
+              ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
+              bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply)
+_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows)
+
+
+def call(name, **kw):
+    with torch.no_grad():
+        if name in _POS:
+            return _POS[name](kw["args"])
+        return _TABLE[name](**kw)

@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    return torch.cuda.is_available()
+
+
+def load_golden(name):
+    meta = json.load(open(os.path.join(GOLDEN, f"{name}.json")))
+    arrs = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    return meta, arrs
+
+
+def build_product_model(cfg, prec, device="cpu", drop_path_rate=0.0):
+    """Product nn.Module for an oracle/configs.py config dict."""
+    import mtt_amd
+    from oracle import configs
+    C, depth, nH, sel = configs.VIT[cfg["backbone"]]
+    p = mtt_amd.factory.make_p([t for t, _ in cfg["tasks"]], cfg["img_size"], backbone=(C, depth, nH, sel), head=cfg["head"],
+                               embed_dim=cfg["embed_dim"], final_embed_dim=cfg["final_embed_dim"], chan_nheads=cfg["chan_nheads"],
+                               use_ctr=cfg["use_ctr"], num_output=dict(cfg["tasks"]), prec=prec, drop_path_rate=drop_path_rate)
+    return mtt_amd.factory.get_model(p).to(device)
+
+
+@pytest.fixture
+def emulated(monkeypatch):
+    """Route the product's C-ABI calls to the CPU emulator (host-wiring tests without a GPU)."""
+    import mtt_amd
+    from oracle import abi_emul
+    monkeypatch.setattr(mtt_amd.ops, "call", abi_emul.call)
+    mtt_amd.ops.clear_pack_cache()
+    yield
+    mtt_amd.ops.clear_pack_cache()

@@ -1,0 +1,276 @@
+"""GPU parity cases: every C-ABI entry point of libmtt_hip.so against the CPU emulator
+(oracle/abi_emul.py) on identical seeded buffers.  Each case compares EVERY buffer's whole storage, so
+out-of-bounds / stray writes show up as well as wrong values.  Used by tests/test_gpu_ops.py (pytest,
+`-m gpu`) and tools/gpu_diag.py (runs all cases without stopping and writes a JSON report).
+"""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import abi_emul  # noqa: E402
+
+F32, BF16 = 0, 1
+OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
+DT = {0: torch.float32, 1: torch.bfloat16}
+
+
+def pkg():
+    return importlib.import_module("multi-task-transformer_amd")
+
+
+def rnd(g, *shape, dtype=torch.float32, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def run_case(name, kw, outputs, tol):
+    """Run entry `name` with CPU emulator and on the GPU; compare the `outputs` tensors' whole storages.
+    Returns dict(ok, errs={key: rel_err})."""
+    lib = pkg()._lib
+    tensors = {k: v for k, v in kw.items() if isinstance(v, torch.Tensor)}
+    if "args" in kw:
+        tensors = {f"a{i}": a for i, a in enumerate(kw["args"]) if isinstance(a, torch.Tensor)}
+    # GPU copies sharing storage structure
+    gpu_store, gpu_kw = {}, dict(kw)
+
+    def to_gpu(t):
+        key = t.untyped_storage().data_ptr()
+        if key not in gpu_store:
+            flat, _ = abi_emul.flat(t)
+            gpu_store[key] = (flat.clone().cuda(), flat)
+        return gpu_store[key][0].as_strided(t.size(), t.stride(), t.storage_offset())
+
+    if "args" in kw:
+        gpu_kw["args"] = [to_gpu(a) if isinstance(a, torch.Tensor) else a for a in kw["args"]]
+    else:
+        for k, t in tensors.items():
+            gpu_kw[k] = to_gpu(t)
+    lib.call(name, **gpu_kw)
+    torch.cuda.synchronize()
+    abi_emul.call(name, **kw)
+    errs, ok = {}, True
+    for key, (gflat, cflat) in gpu_store.items():
+        a, b = gflat.cpu().double(), cflat.double()
+        if not torch.isfinite(a).all():
+            errs[f"storage{len(errs)}"] = float("nan")
+            ok = False
+            continue
+        denom = float(b.norm()) + 1e-30
+        e = float((a - b).norm()) / denom
+        mx = float((a - b).abs().max())
+        errs[f"storage{len(errs)}(n={a.numel()},{cflat.dtype})"] = (e, mx)
+        t = tol["bf16"] if cflat.dtype == torch.bfloat16 else tol["f32"]
+        if e > t:
+            ok = False
+    return dict(ok=ok, errs=errs)
+
+
+# tolerances (norm-wise relative error over a whole storage)
+TOL_X3 = dict(f32=2e-5, bf16=5e-3)
+TOL_BF = dict(f32=2e-5, bf16=5e-3)        # emulator rounds operands to bf16 too -> only accumulation order differs
+TOL_ROW = dict(f32=1e-5, bf16=5e-3)
+
+
+def gemm_cases():
+    cases = []
+    g = torch.Generator().manual_seed(11)
+
+    def base(M, N, K, adt, bdt, ddt, prec, **extra):
+        ldd = (N + 7) // 8 * 8 + 8
+        kw = dict(A=rnd(g, M, K + 8, dtype=DT[adt]), B=rnd(g, N, K + 16, dtype=DT[bdt]),
+                  D=torch.full((M, ldd), 7.0, dtype=DT[ddt]), M=M, N=N, K=K, a_op=OP_K, b_op=OP_K,
+                  a_dtype=adt, b_dtype=bdt, d_dtype=ddt, prec=prec, lda=K + 8, ldb=K + 16, ldd=ldd,
+                  batch=1, batch_inner=1, alpha=1.0)
+        kw.update(extra)
+        return kw
+
+    # 1. plain NT, several tiles, ragged M/N/K tails
+    for prec, adt, ddt, tag in ((0, BF16, BF16, "bf16"), (0, F32, F32, "bf16-f32io"), (1, F32, F32, "x3")):
+        cases.append((f"gemm_plain_{tag}", "gemm", base(200, 150, 136, adt, adt, ddt, prec), TOL_X3 if prec else TOL_BF))
+    # 2. asymmetric identity check (A = I) catches transposed C layout
+    kw = base(128, 128, 128, F32, F32, F32, 1)
+    kw["A"] = torch.eye(128, 136)
+    cases.append(("gemm_identityA_x3", "gemm", kw, TOL_X3))
+    # 3. epilogue: bias, colscale, gelu, aux_out, resid (aliasing D), rowscale with row groups, n_store, alpha
+    for prec, adt in ((0, BF16), (1, F32)):
+        M, N, K = 2 * 37, 70, 64
+        Bn, Mb = 2, 37
+        XT = rnd(g, Bn, Mb + 5, 80)
+        kw = dict(A=rnd(g, M, K, dtype=DT[adt]), B=rnd(g, N, K, dtype=DT[adt]), D=XT[:, 5:], M=M, N=N, K=K, a_op=OP_K, b_op=OP_K,
+                  a_dtype=adt, b_dtype=adt, d_dtype=F32, prec=prec, lda=K, ldb=K, ldd=80, d_mb=Mb, d_bs=(Mb + 5) * 80,
+                  batch=1, batch_inner=1, alpha=0.5, colscale=rnd(g, N).abs() + 0.5, colshift=rnd(g, N), act=1,
+                  aux_out=torch.zeros(M, 72, dtype=DT[adt]), aux_dtype=adt, ldaux=72,
+                  rowscale=torch.tensor([[1.0, 0.5], [2.0, 0.0]]), n_prompt=3,
+                  resid=XT[:, 5:], ldr=80, r_mb=Mb, r_bs=(Mb + 5) * 80, n_store=N)
+        cases.append((f"gemm_epilogue_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+    # 4. batched two-level with broadcast resid rows and n_store padding
+    for prec, adt in ((0, BF16), (1, F32)):
+        Z, M, N, K = 4, 50, 20, 40
+        kw = dict(A=rnd(g, Z, M, K, dtype=DT[adt]), B=rnd(g, Z, N, K, dtype=DT[adt]),
+                  D=torch.full((2, M, 2 * 24), 3.0, dtype=DT[adt]), M=M, N=N, K=K, a_op=OP_K, b_op=OP_K,
+                  a_dtype=adt, b_dtype=adt, d_dtype=adt, prec=prec, lda=K, ldb=K, ldd=48, batch=Z, batch_inner=2,
+                  a_zo=2 * M * K, a_zi=M * K, b_zo=2 * N * K, b_zi=N * K, d_zo=M * 48, d_zi=24, alpha=1.0,
+                  colshift=rnd(g, Z, N), col_zo=2 * N, col_zi=N, n_store=24)
+        cases.append((f"gemm_batched2_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+    # 5. dgrad layout (A: K-contig, B: row-contig) with GELU_BWD on aux_in, and A row groups
+    for prec, adt in ((0, BF16), (1, F32)):
+        M, Nf, Kf = 90, 72, 136      # forward y[M,Nf] = x[M,Kf] W[Nf,Kf]^T ; dgrad: dx[M,Kf] = dy[M,Nf] W
+        kw = dict(A=rnd(g, M, Nf, dtype=DT[adt]), B=rnd(g, Nf, Kf, dtype=DT[adt]), D=torch.zeros(M, Kf, dtype=DT[adt]),
+                  M=M, N=Kf, K=Nf, a_op=OP_K, b_op=OP_R, a_dtype=adt, b_dtype=adt, d_dtype=adt, prec=prec,
+                  lda=Nf, ldb=Kf, ldd=Kf, batch=1, batch_inner=1, alpha=1.0, act=3,
+                  aux_in=rnd(g, M, Kf, dtype=DT[adt]), aux_dtype=adt, ldaux=Kf)
+        cases.append((f"gemm_dgrad_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+    # 6. wgrad layout (both row-contig, reduction over tokens not a multiple of 8)
+    for prec, adt in ((0, BF16), (1, F32)):
+        Mtok, Nf, Kf = 203, 72, 40
+        kw = dict(A=rnd(g, Mtok, Nf, dtype=DT[adt]), B=rnd(g, Mtok, Kf, dtype=DT[adt]), D=torch.zeros(Nf, Kf),
+                  M=Nf, N=Kf, K=Mtok, a_op=OP_R, b_op=OP_R, a_dtype=adt, b_dtype=adt, d_dtype=F32, prec=prec,
+                  lda=Nf, ldb=Kf, ldd=Kf, batch=1, batch_inner=1, alpha=1.0)
+        cases.append((f"gemm_wgrad_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+    # 7. implicit 3x3 conv forward / dgrad (flip) / dilation 2, C not a multiple of 8, batched over 2 "tasks"
+    for prec, adt in ((0, BF16), (1, F32)):
+        for dil, flip in ((1, 0), (2, 0), (1, 1)):
+            Bn, H, W, Ci, Co = 2, 9, 7, 20, 30
+            Cp, Cop = 24, 32
+            X = rnd(g, 2, Bn * H * W, Cp, dtype=DT[adt]); X[..., Ci:] = 0
+            Wt = rnd(g, 2, Co, 9, Cp, dtype=DT[adt]); Wt[..., Ci:] = 0
+            kw = dict(A=X, B=Wt, D=torch.zeros(2, Bn * H * W, Cop, dtype=DT[adt]), M=Bn * H * W, N=Co, K=9 * Cp,
+                      a_op=OP_CONV_K, b_op=OP_K, a_dtype=adt, b_dtype=adt, d_dtype=adt, prec=prec, lda=Cp, ldb=9 * Cp, ldd=Cop,
+                      batch=2, batch_inner=1, a_zo=Bn * H * W * Cp, b_zo=Co * 9 * Cp, d_zo=Bn * H * W * Cop,
+                      conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0,
+                      colshift=rnd(g, 2, Co), col_zo=Co, act=1, n_store=Cop)
+            cases.append((f"gemm_conv3_d{dil}f{flip}_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+    # 8. 3x3 conv wgrad (A = dY row-contig, B = gathered X)
+    for prec, adt in ((0, BF16), (1, F32)):
+        Bn, H, W, Ci, Co = 2, 9, 7, 20, 30
+        Cp, Cop = 24, 32
+        X = rnd(g, Bn * H * W, Cp, dtype=DT[adt]); X[..., Ci:] = 0
+        dY = rnd(g, Bn * H * W, Cop, dtype=DT[adt])
+        kw = dict(A=dY, B=X, D=torch.zeros(Co, 9 * Cp), M=Co, N=9 * Cp, K=Bn * H * W, a_op=OP_R, b_op=OP_CONV_R,
+                  a_dtype=adt, b_dtype=adt, d_dtype=F32, prec=prec, lda=Cop, ldb=Cp, ldd=9 * Cp, batch=1, batch_inner=1,
+                  conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=1, flip=0), alpha=1.0)
+        cases.append((f"gemm_conv3_wgrad_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+    # 9. ConvTranspose 2x2 pixel-shuffle store
+    for prec, adt in ((0, BF16), (1, F32)):
+        Bn, H, W, Ci, Co = 2, 5, 6, 24, 10
+        Cop = 16
+        kw = dict(A=rnd(g, Bn * H * W, Ci, dtype=DT[adt]), B=rnd(g, 4 * Co, Ci, dtype=DT[adt]),
+                  D=torch.zeros(Bn * 4 * H * W, Cop, dtype=DT[adt]), M=Bn * H * W, N=4 * Co, K=Ci, a_op=OP_K, b_op=OP_K,
+                  a_dtype=adt, b_dtype=adt, d_dtype=adt, prec=prec, lda=Ci, ldb=Ci, ldd=Cop, batch=1, batch_inner=1, alpha=1.0,
+                  colshift=rnd(g, 4 * Co), store_mode=1, ps_H=H, ps_W=W, ps_Co=Co)
+        cases.append((f"gemm_pixshuf_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+    return cases
+
+
+def attn_cases():
+    cases = []
+    g = torch.Generator().manual_seed(12)
+    for (B, N, nH, T) in ((2, 150, 2, 6), (1, 30, 2, 4), (1, 257, 1, 0)):
+        for prec, adt in ((0, BF16), (1, F32)):
+            C = nH * 64
+            kw = dict(qkv=rnd(g, B * N, 3 * C, dtype=DT[adt]), out=torch.zeros(B * N, C, dtype=DT[adt]),
+                      rawlog=torch.zeros(B, nH, max(T, 1), N) if T else None, lse=torch.zeros(B, nH, N),
+                      B=B, N=N, nH=nH, T=T, dtype=adt, prec=prec, scale=0.125)
+            cases.append((f"attn_B{B}N{N}T{T}_{'x3' if prec else 'bf16'}", "attn_fwd", kw,
+                          dict(f32=3e-5 if prec else 2e-3, bf16=6e-3)))
+    # softmax spike (forces large running-max jumps across tiles)
+    B, N, nH, T = 1, 200, 1, 2
+    q = rnd(g, B * N, 3 * 64)
+    q[70, 64:128] *= 12.0
+    kw = dict(qkv=q, out=torch.zeros(B * N, 64), rawlog=torch.zeros(B, nH, T, N), lse=torch.zeros(B, nH, N),
+              B=B, N=N, nH=nH, T=T, dtype=F32, prec=1, scale=0.125)
+    cases.append(("attn_spike_x3", "attn_fwd", kw, dict(f32=3e-5, bf16=6e-3)))
+    return cases
+
+
+def row_cases():
+    cases = []
+    g = torch.Generator().manual_seed(13)
+    for ydt in (F32, BF16):
+        rows, C = 37, 128
+        kw = dict(x=rnd(g, rows, C + 4), y=torch.zeros(rows, C, dtype=DT[ydt]), gamma=rnd(g, C), beta=rnd(g, C),
+                  mean=torch.zeros(rows), rstd=torch.zeros(rows), rows=rows, C=C, ldx=C + 4, ldy=C, y_dtype=ydt, eps=1e-6)
+        cases.append((f"ln_fwd_{ydt}", "layernorm_fwd", kw, TOL_ROW))
+        x = rnd(g, rows, C)
+        mean = x.mean(-1); rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
+        kw = dict(x=x, dy=rnd(g, rows, C, dtype=DT[ydt]), gamma=rnd(g, C), mean=mean, rstd=rstd, dx=rnd(g, rows, C),
+                  dgamma=torch.zeros(C), dbeta=torch.zeros(C), rows=rows, C=C, ldx=C, ldy=C, y_dtype=ydt, eps=1e-6)
+        cases.append((f"ln_bwd_{ydt}", "layernorm_bwd", kw, TOL_ROW))
+    for sdt in (F32, BF16):
+        rows, cols, ld = 50, 77, 80
+        kw = dict(S=rnd(g, rows, ld, dtype=DT[sdt]), P=torch.full((rows, ld), 9.0, dtype=DT[sdt]), rows=rows, cols=cols, ld=ld,
+                  s_dtype=sdt, p_dtype=sdt, scale=0.3)
+        cases.append((f"softmax_fwd_{sdt}", "softmax_fwd", kw, TOL_ROW))
+        P = torch.softmax(rnd(g, rows, ld), -1).to(DT[sdt])
+        kw = dict(P=P, dP=rnd(g, rows, ld, dtype=DT[sdt]), dS=torch.zeros(rows, ld, dtype=DT[sdt]), extra=rnd(g, 2 * 3, cols + 3),
+                  rows=rows, cols=cols, ld=ld, s_dtype=sdt, p_dtype=sdt, scale=0.3, rows_per_mat=25, extra_rows=3, extra_ld=cols + 3)
+        cases.append((f"softmax_bwd_{sdt}", "softmax_bwd", kw, TOL_ROW))
+    for odt in (F32, BF16):
+        B, H, W = 2, 32, 48
+        cases.append((f"patchify_{odt}", "patchify16",
+                      dict(args=[rnd(g, B, 3, H, W), torch.zeros(B * 6, 768, dtype=DT[odt]), B, H, W, odt]), TOL_ROW))
+    for dt in (F32, BF16):
+        for (h, w, nh) in ((4, 6, 1), (4, 6, 2)):
+            B, T, C = 2, 5, 128
+            N = T + h * w
+            ldq = (h * w + 7) // 8 * 8
+            kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.zeros(B, T, nh * nh, C),
+                      B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, dtype=dt, ldq=ldq)
+            cases.append((f"chanlogit_{dt}_win{nh}", "chan_logits", kw, TOL_ROW))
+            XT = rnd(g, B, N, C)
+            kw = dict(x=XT[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // 64, T, N), rawchan=rnd(g, B, T, nh * nh, C),
+                      out=torch.zeros(2 * T, B * h * w, C, dtype=DT[dt]), B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt)
+            cases.append((f"modulate_{dt}_win{nh}", "modulate", kw, TOL_ROW))
+    for dt in (F32, BF16):
+        for accum in (0, 1):
+            T, B, rpb, ld, C = 6, 2, 24, 56, 52
+            fea = rnd(g, T, B * rpb, ld, dtype=DT[dt]); fea[..., C:] = 0
+            kw = dict(fea=fea, out=rnd(g, T, B * rpb, ld), wmix=rnd(g, B, T, T), T=T, B=B, rows_per_b=rpb, ld=ld, C=C,
+                      fea_dtype=dt, accumulate=accum)
+            cases.append((f"ctr_mix_{dt}_acc{accum}", "ctr_mix", kw, TOL_ROW))
+    for dt in (F32, BF16):
+        for (Hi, Wi, Ho, Wo) in ((4, 6, 16, 24), (8, 8, 4, 4), (5, 7, 11, 9)):
+            B, C, ld = 2, 20, 24
+            x = rnd(g, B * Hi * Wi, ld, dtype=DT[dt])
+            kw = {"in": x, "out": torch.zeros(B * Ho * Wo, ld, dtype=DT[dt]), "B": B, "C": C, "Hin": Hi, "Win": Wi, "Hout": Ho, "Wout": Wo,
+                  "ld_in": ld, "ld_out": ld, "in_dtype": dt, "out_dtype": dt, "out_nchw": 0, "accumulate": 0}
+            cases.append((f"bilinear_nhwc_{dt}_{Hi}x{Wi}to{Ho}x{Wo}", "bilinear_fwd", kw, TOL_ROW))
+            kw = {"in": x, "out": torch.zeros(B, C, Ho, Wo), "B": B, "C": C, "Hin": Hi, "Win": Wi, "Hout": Ho, "Wout": Wo,
+                  "ld_in": ld, "ld_out": 0, "in_dtype": dt, "out_dtype": F32, "out_nchw": 1, "accumulate": 0}
+            cases.append((f"bilinear_nchw_{dt}_{Hi}x{Wi}to{Ho}x{Wo}", "bilinear_fwd", kw, TOL_ROW))
+            kw = {"in": rnd(g, B * Ho * Wo, ld, dtype=DT[dt]), "out": rnd(g, B * Hi * Wi, ld), "B": B, "C": C, "Hin": Hi, "Win": Wi,
+                  "Hout": Ho, "Wout": Wo, "ld_in": ld, "ld_out": ld, "in_dtype": dt, "out_dtype": F32, "out_nchw": 0, "accumulate": 1}
+            cases.append((f"bilinear_bwd_{dt}_{Hi}x{Wi}to{Ho}x{Wo}", "bilinear_bwd", kw, TOL_ROW))
+        kw = {"in": rnd(g, 2, 5, 16, 24), "out": torch.zeros(2 * 4 * 6, 8), "B": 2, "C": 5, "Hin": 4, "Win": 6, "Hout": 16, "Wout": 24,
+              "ld_in": 8, "ld_out": 0, "in_dtype": F32, "out_dtype": F32, "out_nchw": 1, "accumulate": 1}
+        cases.append((f"bilinear_bwd_nchw_{dt}", "bilinear_bwd", kw, TOL_ROW))
+    for dt in (F32, BF16):
+        rows, C, ld = 300, 52, 56
+        x = rnd(g, rows, ld, dtype=DT[dt]); x[:, C:] = 0
+        kw = dict(x=x, sum=torch.zeros(C), sumsq=torch.zeros(C), rows=rows, C=C, ld=ld, dtype=dt)
+        cases.append((f"bn_stats_{dt}", "bn_stats", kw, TOL_ROW))
+        mean, rstd, gam, bet = rnd(g, C) * 0.1, rnd(g, C).abs() + 0.5, rnd(g, C), rnd(g, C)
+        for act in (0, 1, 2):
+            kw = dict(x=x, y=torch.full((rows, ld), 5.0, dtype=DT[dt]), mean=mean, rstd=rstd, gamma=gam, beta=bet,
+                      rows=rows, C=C, ld=ld, dtype=dt, act=act)
+            cases.append((f"bn_apply_{dt}_act{act}", "bn_apply", kw, TOL_ROW))
+        dy = rnd(g, rows, ld, dtype=DT[dt])
+        kw = dict(x=x, dy=dy, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=torch.zeros(C), dsumxh=torch.zeros(C),
+                  rows=rows, C=C, ld=ld, dtype=dt, act=1)
+        cases.append((f"bn_bwd_reduce_{dt}", "bn_bwd_reduce", kw, TOL_ROW))
+        kw = dict(x=x, dy=dy, dx=torch.full((rows, ld), 5.0, dtype=DT[dt]), mean=mean, rstd=rstd, gamma=gam, beta=bet,
+                  dsum=rnd(g, C), dsumxh=rnd(g, C), rows=rows, C=C, ld=ld, dtype=dt, act=1)
+        cases.append((f"bn_bwd_apply_{dt}", "bn_bwd_apply", kw, TOL_ROW))
+        cases.append((f"cast2d_{dt}", "cast2d", dict(args=[rnd(g, 30, 20), torch.full((30, 24), 4.0, dtype=DT[dt]), 30, 18, 20, 24, F32, dt, 1]), TOL_ROW))
+        cases.append((f"colsum_{dt}", "colsum", dict(args=[rnd(g, 300, 56, dtype=DT[dt]), torch.zeros(52), 300, 52, 56, dt]), TOL_ROW))
+        cases.append((f"add_rows_{dt}", "add_rows", dict(args=[rnd(g, 30, 24, dtype=DT[dt]), rnd(g, 30, 32), 30, 20, 24, 32, dt, 0.5]), TOL_ROW))
+    return cases
+
+
+def all_cases():
+    return gemm_cases() + attn_cases() + row_cases()
