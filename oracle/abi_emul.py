@@ -307,6 +307,8 @@ def _src(o, n_in, n_out):
 
 def bilinear_fwd(**kw):
     B, Cn, Hi, Wi, Ho, Wo = (kw[k] for k in ("B", "C", "Hin", "Win", "Hout", "Wout"))
+    if not kw.get("out_nchw"):
+        Cn = (Cn + 7) // 8 * 8      # NHWC mode carries whole 8-channel chunks (zero padding in -> zero out)
     ii = (torch.arange(B * Hi * Wi)[:, None] * kw["ld_in"] + torch.arange(Cn)[None, :])
     x = _rd(kw["in"], ii).view(B, Hi, Wi, Cn)
     y0, y1, wy = _src(None, Hi, Ho)

@@ -1,0 +1,140 @@
+"""CPU: the C-ABI emulator (the per-entry-point oracle) against torch.nn.functional — this is what makes
+the emulator independent of the kernels it later judges."""
+import torch
+import torch.nn.functional as F
+
+from oracle import abi_emul as E
+
+E_F32 = 0
+
+
+def g_(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_gemm_linear_and_epilogue():
+    g = g_()
+    x, w, b = torch.randn(50, 40, generator=g), torch.randn(30, 40, generator=g), torch.randn(30, generator=g)
+    res = torch.randn(50, 32, generator=g)
+    out = torch.zeros(50, 32)
+    E.call("gemm", A=x, B=w, D=out, M=50, N=30, K=40, a_op=0, b_op=0, prec=1, lda=40, ldb=40, ldd=32, alpha=1.0,
+           colshift=b, act=1, resid=res, ldr=32, n_store=32)
+    ref = F.gelu(F.linear(x, w, b)) + res[:, :30]
+    assert torch.allclose(out[:, :30], ref, atol=1e-5) and float(out[:, 30:].abs().max()) == 0.0
+
+
+def test_gemm_dgrad_wgrad_layouts():
+    g = g_(1)
+    x, w, dy = torch.randn(50, 40, generator=g), torch.randn(24, 40, generator=g), torch.randn(50, 24, generator=g)
+    dx, dw = torch.zeros(50, 40), torch.zeros(24, 40)
+    E.call("gemm", A=dy, B=w, D=dx, M=50, N=40, K=24, a_op=0, b_op=1, prec=1, lda=24, ldb=40, ldd=40, alpha=1.0)
+    E.call("gemm", A=dy, B=x, D=dw, M=24, N=40, K=50, a_op=1, b_op=1, prec=1, lda=24, ldb=40, ldd=40, alpha=1.0)
+    assert torch.allclose(dx, dy @ w, atol=1e-5) and torch.allclose(dw, dy.t() @ x, atol=1e-5)
+
+
+def _pack(w):   # [Co,Ci,3,3] -> [Co, 9*Cp]
+    Co, Ci = w.shape[:2]
+    Cp = (Ci + 7) // 8 * 8
+    buf = torch.zeros(Co, 9, Cp)
+    buf[:, :, :Ci] = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+    return buf.reshape(Co, 9 * Cp), Cp
+
+
+def test_gemm_conv3x3_fwd_dgrad_wgrad():
+    g = g_(2)
+    B, H, W, Ci, Co = 2, 6, 5, 12, 10
+    for dil in (1, 2):
+        x = torch.randn(B, Ci, H, W, generator=g, requires_grad=True)
+        w = torch.randn(Co, Ci, 3, 3, generator=g, requires_grad=True)
+        y = F.conv2d(x, w, padding=dil, dilation=dil)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        wp, Cp = _pack(w.detach())
+        xn = torch.zeros(B * H * W, Cp); xn[:, :Ci] = x.detach().permute(0, 2, 3, 1).reshape(-1, Ci)
+        out = torch.zeros(B * H * W, 16)
+        geom = dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=0)
+        E.call("gemm", A=xn, B=wp, D=out, M=B * H * W, N=Co, K=9 * Cp, a_op=2, b_op=0, prec=1, lda=Cp, ldb=9 * Cp, ldd=16, alpha=1.0, conv=geom)
+        assert torch.allclose(out[:, :Co], y.detach().permute(0, 2, 3, 1).reshape(-1, Co), atol=1e-4)
+        # dgrad: weights packed [Ci, 9*Cop] (k = tap*Cop + co), taps mirrored by the loader
+        Cop = 16
+        wd = torch.zeros(Ci, 9, Cop); wd[:, :, :Co] = w.detach().permute(1, 2, 3, 0).reshape(Ci, 9, Co)
+        dyn = torch.zeros(B * H * W, Cop); dyn[:, :Co] = dy.permute(0, 2, 3, 1).reshape(-1, Co)
+        dxo = torch.zeros(B * H * W, Cp)
+        E.call("gemm", A=dyn, B=wd.reshape(Ci, 9 * Cop), D=dxo, M=B * H * W, N=Ci, K=9 * Cop, a_op=2, b_op=0, prec=1, lda=Cop,
+               ldb=9 * Cop, ldd=Cp, alpha=1.0, conv=dict(H=H, W=W, C=Co, Cp=Cop, dil=dil, flip=1))
+        assert torch.allclose(dxo[:, :Ci], x.grad.permute(0, 2, 3, 1).reshape(-1, Ci), atol=1e-4)
+        dwo = torch.zeros(Co, 9 * Cp)
+        E.call("gemm", A=dyn, B=xn, D=dwo, M=Co, N=9 * Cp, K=B * H * W, a_op=1, b_op=3, prec=1, lda=Cop, ldb=Cp, ldd=9 * Cp,
+               alpha=1.0, conv=geom)
+        ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+        assert torch.allclose(dwo.reshape(Co, 9, Cp)[:, :, :Ci], ref, atol=1e-3)
+
+
+def test_gemm_pixshuf_is_conv_transpose():
+    g = g_(3)
+    B, H, W, Ci, Co = 2, 3, 4, 8, 5
+    x, w, b = torch.randn(B, Ci, H, W, generator=g), torch.randn(Ci, Co, 2, 2, generator=g), torch.randn(Co, generator=g)
+    ref = F.conv_transpose2d(x, w, b, stride=2).permute(0, 2, 3, 1).reshape(-1, Co)
+    out = torch.zeros(B * 4 * H * W, 8)
+    E.call("gemm", A=x.permute(0, 2, 3, 1).reshape(-1, Ci).contiguous(), B=w.permute(2, 3, 1, 0).reshape(4 * Co, Ci).contiguous(), D=out,
+           M=B * H * W, N=4 * Co, K=Ci, a_op=0, b_op=0, prec=1, lda=Ci, ldb=Ci, ldd=8, alpha=1.0, colshift=b.repeat(4),
+           store_mode=1, ps_H=H, ps_W=W, ps_Co=Co)
+    assert torch.allclose(out[:, :Co], ref, atol=1e-5)
+
+
+def test_attention_and_bilinear_and_ln():
+    g = g_(4)
+    B, N, nH, T = 2, 20, 2, 3
+    qkv = torch.randn(B * N, 3 * 128, generator=g)
+    out, raw = torch.zeros(B * N, 128), torch.zeros(B, nH, T, N)
+    E.call("attn_fwd", qkv=qkv, out=out, rawlog=raw, B=B, N=N, nH=nH, T=T, dtype=0, prec=1, scale=0.125)
+    q, k, v = (qkv.view(B, N, 3, nH, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * N, 128)
+    assert torch.allclose(out, ref, atol=1e-5) and torch.allclose(raw, (q @ k.transpose(-1, -2))[:, :, :T], atol=1e-4)
+    for (Hi, Wi, Ho, Wo) in ((4, 6, 16, 24), (8, 8, 4, 4), (5, 7, 11, 9)):
+        x = torch.randn(2, 3, Hi, Wi, generator=g, requires_grad=True)
+        ref = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False)
+        xin = torch.zeros(2 * Hi * Wi, 8); xin[:, :3] = x.detach().permute(0, 2, 3, 1).reshape(-1, 3)
+        o = torch.zeros(2, 3, Ho, Wo)
+        E.call("bilinear_fwd", **{"in": xin}, out=o, B=2, C=3, Hin=Hi, Win=Wi, Hout=Ho, Wout=Wo, ld_in=8, ld_out=0, out_nchw=1)
+        assert torch.allclose(o, ref.detach(), atol=1e-5)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        din = torch.zeros(2 * Hi * Wi, 8)
+        E.call("bilinear_bwd", **{"in": dy}, out=din, B=2, C=3, Hin=Hi, Win=Wi, Hout=Ho, Wout=Wo, ld_in=8, ld_out=0, out_nchw=1)
+        assert torch.allclose(din[:, :3], x.grad.permute(0, 2, 3, 1).reshape(-1, 3), atol=1e-5)
+    x = torch.randn(9, 32, generator=g, requires_grad=True)
+    gam, bet = torch.randn(32, generator=g, requires_grad=True), torch.randn(32, generator=g, requires_grad=True)
+    ref = F.layer_norm(x, (32,), gam, bet, 1e-6)
+    y, mean, rstd = torch.zeros(9, 32), torch.zeros(9), torch.zeros(9)
+    E.call("layernorm_fwd", x=x.detach(), y=y, gamma=gam.detach(), beta=bet.detach(), mean=mean, rstd=rstd, rows=9, C=32, ldx=32, ldy=32, eps=1e-6)
+    assert torch.allclose(y, ref.detach(), atol=1e-5)
+    dy = torch.randn(9, 32, generator=g)
+    ref.backward(dy)
+    dx, dg, db = torch.zeros(9, 32), torch.zeros(32), torch.zeros(32)
+    E.call("layernorm_bwd", x=x.detach(), dy=dy, gamma=gam.detach(), mean=mean, rstd=rstd, dx=dx, dgamma=dg, dbeta=db, rows=9, C=32, ldx=32, ldy=32, eps=1e-6)
+    assert torch.allclose(dx, x.grad, atol=1e-5) and torch.allclose(dg, gam.grad, atol=1e-5) and torch.allclose(db, bet.grad, atol=1e-5)
+
+
+def test_bn_train_fwd_bwd():
+    g = g_(5)
+    rows, C = 40, 12
+    x = torch.randn(rows, C, generator=g, requires_grad=True)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xi = x.t().reshape(1, C, rows, 1).transpose(0, 2).reshape(rows, C, 1, 1)
+    ref = F.gelu(F.batch_norm(xi, None, None, gam, bet, True, 0.1, 1e-5))
+    dy = torch.randn(rows, C, generator=g)
+    ref.backward(dy.reshape(rows, C, 1, 1))
+    xp = torch.zeros(rows, 16); xp[:, :C] = x.detach()
+    s, ss = torch.zeros(C), torch.zeros(C)
+    E.call("bn_stats", x=xp, sum=s, sumsq=ss, rows=rows, C=C, ld=16)
+    mean = s / rows; var = ss / rows - mean * mean; rstd = torch.rsqrt(var + 1e-5)
+    y = torch.zeros(rows, 16)
+    E.call("bn_apply", x=xp, y=y, mean=mean, rstd=rstd, gamma=gam, beta=bet, rows=rows, C=C, ld=16, act=1)
+    assert torch.allclose(y[:, :C], ref.detach().reshape(rows, C), atol=1e-5)
+    dyp = torch.zeros(rows, 16); dyp[:, :C] = dy
+    ds, dsx = torch.zeros(C), torch.zeros(C)
+    E.call("bn_bwd_reduce", x=xp, dy=dyp, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=ds, dsumxh=dsx, rows=rows, C=C, ld=16, act=1)
+    dx = torch.zeros(rows, 16)
+    E.call("bn_bwd_apply", x=xp, dy=dyp, dx=dx, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=ds, dsumxh=dsx, rows=rows, C=C, ld=16, act=1)
+    assert torch.allclose(dx[:, :C], x.grad, atol=1e-4)

@@ -1,0 +1,52 @@
+"""CPU: the oracle restatement (oracle/taskprompter_oracle.py) against the golden fixtures produced by the
+UNMODIFIED reference (tests/golden/make_golden.py).  Pins forward (eval + train-mode BN), the BN running
+stat update and — through autograd of the restatement — per-parameter gradient statistics."""
+import numpy as np
+import pytest
+import torch
+
+import conftest
+from oracle import configs, taskprompter_oracle as tpo, weights
+from tests.golden.make_golden import loss_of
+
+TP_CASES = ["mini_ctr", "mini_win", "mini_deconv"]
+
+
+@pytest.mark.parametrize("name", TP_CASES)
+def test_oracle_forward_eval(name):
+    cfg = configs.taskprompter(name)
+    meta, gold = conftest.load_golden(name)
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    x = weights.synth_images(meta["batch"], cfg["img_size"], 1)
+    with torch.no_grad():
+        out = tpo.forward(sd, cfg, x)
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        assert float((out[t] - g).norm() / g.norm()) < 2e-5, t
+
+
+@pytest.mark.parametrize("name", TP_CASES)
+def test_oracle_train_forward_backward(name):
+    cfg = configs.taskprompter(name)
+    meta, gold = conftest.load_golden(name)
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    full = dict(sd, **params)
+    x = weights.synth_images(2, cfg["img_size"], 2)
+    upd = {}
+    out = tpo.forward(full, cfg, x, training=True, bn_updates=upd)
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"train/{t}"])
+        assert float((out[t].detach()[:, :, ::2, ::2] - g).norm() / g.norm()) < 2e-5, t
+    for k, v in upd.items():
+        g = torch.from_numpy(gold[f"bn/{k}"])
+        assert float((v - g).abs().max()) < 1e-4, k
+    loss_of(out).backward()
+    bad = []
+    for k, st in meta["grad_stats"].items():
+        if st is None:
+            continue
+        gn = float(params[k].grad.double().norm()) if params[k].grad is not None else 0.0
+        if abs(gn - st[0]) > 2e-3 * max(st[0], 1e-6) + 1e-7:
+            bad.append((k, gn, st[0]))
+    assert not bad, bad[:5]
