@@ -7,6 +7,8 @@
  *   - return 0 on success, <0 = MTT_E_* argument error, >0 = hipError_t from the launch
  *   - asynchronous on the caller's stream; no allocation, no synchronisation, no global state
  *     (safe under hipGraph capture); every buffer is owned by the caller
+ *   - reduction-contiguous GEMM operands (MTT_OP_K) are read in 8-element chunks: when K is not a multiple
+ *     of 8 the elements K..pad8(K)-1 of every row must exist and be zero (ld >= pad8(K))
  *   - activations are token-major / NHWC: a feature map is a row-major [rows = B*H*W, channels]
  *     matrix with a leading dimension (ld, in elements) that is a multiple of 8; 16-byte aligned
  *   - dtype codes: MTT_F32 = 0, MTT_BF16 = 1
@@ -146,6 +148,8 @@ typedef struct {
   int32_t B, T, N, C, h, w, nh, nw; int32_t dtype; int64_t ldq;
 } mtt_chanlogit_desc;
 int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream);
+/* backward: dq[b,t,p] = sum_c drawchan*xn (written, dq_dtype, pitch ldq); dxn[b,T+p,c] += sum_t drawchan*q (fp32 [B,N,C]). */
+int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* drawchan, void* dq, int dq_dtype, float* dxn, void* stream);
 
 /* Task-feature modulation, taskprompter.py:436-467: from x fp32 [B, hw, C] (row pitch/batch stride given)
  *   out[2t  ][b,p,c] = x[b,p,c] * (1 + rawlog[b, c/64, t, T+p])
@@ -155,6 +159,9 @@ typedef struct {
   int32_t B, T, N, C, h, w, nh, nw; int32_t out_dtype;
 } mtt_modulate_desc;
 int mtt_modulate(const mtt_modulate_desc* d, void* stream);
+/* backward: dout [2T, B*hw, C] (d->out_dtype) -> dx += (fp32, same addressing as x), drawlog[b,head,t,T+p] = (fp32 [B,nH,T,N],
+ * caller zeroes the first T columns), drawchan += (fp32 [B,T,nwin,C], caller zeroes). */
+int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, void* stream);
 
 /* Cross-task reweighting, taskprompter.py:478-485: w[b,t,s] from the per-head MLP on the prompt<->prompt
  * logits, then out[t][b,p,:] = sum_s w[b,t,s] * fea[s][b,p,:] (+= into acc when accumulate=1). */
@@ -163,6 +170,8 @@ typedef struct {
   int32_t T, B; int64_t rows_per_b, ld; int32_t C; int32_t fea_dtype; int32_t accumulate;
 } mtt_ctr_desc;
 int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream);
+/* dwmix[b,t,s] += sum_{rows of b, c} dout[t][row,c] * fea[s][row,c]   (dout fp32 [T, rows, ld], caller zeroes dwmix) */
+int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dwmix, void* stream);
 
 /* Bilinear resize, align_corners=False (F.interpolate at taskprompter.py:420, taskprompter_wrapper.py:36,
  * invpt.py:221,303,537, transformer_net.py:35-36).  NHWC in -> NHWC out or NCHW fp32 out.
@@ -191,6 +200,9 @@ int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream);
 /* Small utilities: dtype cast / strided 2-D copy, column sums (bias gradients), axpy-style accumulate. */
 int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
                int src_dtype, int dst_dtype, int zero_pad_cols, void* stream);
+/* dst[r,:] = rowscale[(r/mb)*2 + ((r%mb) >= n_prompt)] * src[r,:] with dtype cast (DropPath scale of a branch gradient) */
+int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
+                      const float* rowscale, int32_t mb, int32_t n_prompt, void* stream);
 int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream);
 int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype,
                  float alpha, void* stream);

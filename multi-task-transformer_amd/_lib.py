@@ -112,8 +112,15 @@ POSITIONAL = {
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
+    "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
 }
-EXPORTS = ["mtt_abi_version", "mtt_desc_size"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL)]
+# descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)
+DESC_EXTRA = {
+    "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr]),
+    "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
+    "ctr_dw": (CtrDesc, [ptr, ptr]),
+}
+EXPORTS = ["mtt_abi_version", "mtt_desc_size"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 
@@ -144,6 +151,10 @@ def load():
         fn = getattr(lib, "mtt_" + name)
         fn.restype = C.c_int
         fn.argtypes = at
+    for name, (st, extra) in DESC_EXTRA.items():
+        fn = getattr(lib, "mtt_" + name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(st)] + extra + [ptr]
     _lib = lib
     return lib
 
@@ -177,8 +188,16 @@ def call(name, **kw):
         args = [(_addr(a) if isinstance(a, torch.Tensor) else a) for a in kw["args"]]
         rc = fn(*args, _stream())
     else:
-        desc = DESCS[name]()
+        extra = None
+        if name in DESC_EXTRA:
+            st, _ = DESC_EXTRA[name]
+            desc = st()
+            extra = [(_addr(a) if isinstance(a, torch.Tensor) else a) for a in kw["extra"]]
+        else:
+            desc = DESCS[name]()
         for k, v in kw.items():
+            if k == "extra":
+                continue
             if k == "in":
                 k = "in_"
             if k == "conv":
@@ -190,6 +209,6 @@ def call(name, **kw):
                 setattr(desc, k, None)
             else:
                 setattr(desc, k, v)
-        rc = fn(C.byref(desc), _stream())
+        rc = fn(C.byref(desc), *extra, _stream()) if extra is not None else fn(C.byref(desc), _stream())
     if rc != 0:
         raise RuntimeError(f"mtt_{name} failed with status {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))

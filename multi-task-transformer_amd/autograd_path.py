@@ -1,0 +1,590 @@
+"""Training path of TaskPrompter: the same HIP kernels wrapped as torch.autograd.Functions with
+hand-written backward passes (dgrad / wgrad are the same MFMA GEMM kernel with transposed operand
+views: MTT_OP_R; conv dgrad = the implicit-GEMM conv with mirrored taps; conv wgrad = MTT_OP_CONV_R).
+
+The forward schedule is identical to TaskPrompter._forward_nograd; autograd only carries the fp32
+residual stream, the logit side channels and the decoder feature maps between Functions.  Round 1
+attention backward materialises P per (batch, head) with the batched GEMM + row-softmax kernels
+(no N x N tensor ever leaves the backward), see DESIGN.md.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops
+from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code
+
+pad8 = ops.pad8
+
+
+def _gemm(A, B, D, M, N, K, prec, **kw):
+    args = dict(A=A, B=B, D=D, M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=dtype_code(A), b_dtype=dtype_code(B),
+                d_dtype=dtype_code(D), prec=prec.code, batch=1, batch_inner=1, alpha=1.0)
+    args.update(kw)
+    ops.call("gemm", **args)
+    return D
+
+
+def _colsum(x2d, cols):
+    out = torch.zeros(cols, dtype=torch.float32, device=x2d.device)
+    ops.call("colsum", args=[x2d, out, x2d.shape[0], cols, x2d.stride(0), dtype_code(x2d)])
+    return out
+
+
+def _scaled(g, rowscale, mb, n_prompt, prec):
+    """g * per-row DropPath scale, cast to the activation dtype (identity when no DropPath)."""
+    if rowscale is None:
+        return g
+    out = torch.empty(g.shape, dtype=prec.adt, device=g.device)
+    ops.call("rowscale_cast", args=[g, out, g.shape[0], g.shape[1], g.stride(0), out.stride(0), dtype_code(g), dtype_code(out),
+                                    rowscale, mb, n_prompt])
+    return out
+
+
+def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
+    """dW[N, Kp] = dy[rows, :N]^T @ x[rows, :Kp]  (both operands row-contiguous views)."""
+    rows = rows if rows is not None else dy.shape[0]
+    dW = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
+    return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda or dy.stride(0), ldb=ldb or x.stride(0), ldd=Kp)
+
+
+def _dgrad(dy, wpack2d, M, N_in, K_out, prec, out_dtype, **epi):
+    """dx[M, N_in] = dy[M, :K_out] @ W[K_out, N_in]   (W stored [K_out, ldw], read transposed)."""
+    dx = torch.empty(M, N_in, dtype=out_dtype, device=dy.device)
+    return _gemm(dy, wpack2d, dx, M, N_in, K_out, prec, b_op=OP_R, lda=dy.stride(0), ldb=wpack2d.stride(0), ldd=N_in,
+                 n_store=N_in, **epi)
+
+
+# =================================================================================================
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, prec, out_dtype):
+        y, mean, rstd = ops.layernorm(x, gamma, beta, eps, prec, save_stats=True, out_dtype=out_dtype)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dg, db = torch.zeros_like(x), torch.zeros_like(gamma), torch.zeros_like(gamma)
+        ops.call("layernorm_bwd", x=x, dy=dy, gamma=gamma, mean=mean, rstd=rstd, dx=dx, dgamma=dg, dbeta=db,
+                 rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=ctx.eps)
+        return dx, dg, db, None, None, None
+
+
+# =================================================================================================
+def attention_bwd(qkv, dao, drawlog, B, N, nH, T, prec):
+    """Backward of ops.attention: recompute P per (batch, head) with the batched GEMM + row softmax."""
+    C, Np, Z = nH * 64, pad8(N), B * nH
+    dev, adt = qkv.device, prec.adt
+    scale = 64 ** -0.5
+    S = torch.empty(Z, N, Np, dtype=adt, device=dev)
+    zS = dict(batch=Z, batch_inner=nH, d_zo=nH * N * Np, d_zi=N * Np)
+    zq = dict(a_zo=N * 3 * C, a_zi=64)
+    _gemm(qkv, qkv[:, C:], S, N, N, 64, prec, lda=3 * C, ldb=3 * C, ldd=Np, b_zo=N * 3 * C, b_zi=64, n_store=Np, **zq, **zS)
+    ops.call("softmax_fwd", S=S, P=S, rows=Z * N, cols=N, ld=Np, s_dtype=dtype_code(S), p_dtype=dtype_code(S), scale=scale)
+    dP = torch.empty(Z, N, Np, dtype=adt, device=dev)
+    _gemm(dao, qkv[:, 2 * C:], dP, N, N, 64, prec, lda=C, ldb=3 * C, ldd=Np, a_zo=N * C, a_zi=64, b_zo=N * 3 * C, b_zi=64,
+          n_store=Np, **zS)
+    ops.call("softmax_bwd", P=S, dP=dP, dS=dP, extra=drawlog, rows=Z * N, cols=N, ld=Np, s_dtype=dtype_code(S),
+             p_dtype=dtype_code(S), scale=scale, rows_per_mat=N, extra_rows=T if drawlog is not None else 0, extra_ld=N)
+    dqkv = torch.empty(B * N, 3 * C, dtype=adt, device=dev)
+    zP = dict(batch=Z, batch_inner=nH, a_zo=nH * N * Np, a_zi=N * Np, d_zo=N * 3 * C, d_zi=64)
+    # dV = P^T dO ; dQ = dS K ; dK = dS^T Q
+    _gemm(S, dao, dqkv[:, 2 * C:], N, 64, N, prec, a_op=OP_R, b_op=OP_R, lda=Np, ldb=C, ldd=3 * C, b_zo=N * C, b_zi=64, **zP)
+    _gemm(dP, qkv[:, C:], dqkv, N, 64, N, prec, b_op=OP_R, lda=Np, ldb=3 * C, ldd=3 * C, b_zo=N * 3 * C, b_zi=64, **zP)
+    _gemm(dP, qkv, dqkv[:, C:], N, 64, N, prec, a_op=OP_R, b_op=OP_R, lda=Np, ldb=3 * C, ldd=3 * C, b_zo=N * 3 * C, b_zi=64, **zP)
+    return dqkv
+
+
+class AttnBlockFn(Function):
+    """xn -> qkv GEMM -> flash attention (+ prompt-row logits) -> proj GEMM + residual (taskprompter.py:199-214, :273)."""
+
+    @staticmethod
+    def forward(ctx, xn, XT, Wqkv, bqkv, Wproj, bproj, rowscale, geo, prec, tag):
+        B, N, nH, T = geo
+        C = nH * 64
+        wq = ops.pack_linear([Wqkv], prec, tag + ('qkv',))
+        wp = ops.pack_linear([Wproj], prec, tag + ('proj',))
+        qkv = ops.linear(xn, wq, 3 * C, prec, bias=bqkv[None])[0]
+        ao, rawlog, _ = ops.attention(qkv, B, N, nH, T, prec)
+        XT2 = torch.empty_like(XT)
+        ops.linear(ao, wp, C, prec, bias=bproj[None], out=XT2, resid=XT, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
+                   M=B * N)
+        ctx.save_for_backward(xn, qkv, ao, wq, wp, rowscale)
+        ctx.geo, ctx.prec = geo, prec
+        if rawlog is None:
+            rawlog = torch.zeros(0, device=xn.device)
+        return XT2, rawlog
+
+    @staticmethod
+    def backward(ctx, dXT2, drawlog):
+        xn, qkv, ao, wq, wp, rowscale = ctx.saved_tensors
+        B, N, nH, T = ctx.geo
+        prec, C, M = ctx.prec, nH * 64, B * N
+        dXT2 = dXT2.contiguous()
+        g = _scaled(dXT2, rowscale, N, T, prec)
+        dWproj = _wgrad(g, ao, C, C, prec)
+        dbproj = _colsum(g, C)
+        dao = _dgrad(g, wp[0], M, C, C, prec, prec.adt)
+        dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
+        dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
+        dWqkv = _wgrad(dqkv, xn, 3 * C, C, prec)
+        dbqkv = _colsum(dqkv, 3 * C)
+        dxn = _dgrad(dqkv, wq[0], M, C, 3 * C, prec, torch.float32)
+        return dxn, dXT2, dWqkv, dbqkv, dWproj, dbproj, None, None, None, None
+
+
+class ChanAttnFn(Function):
+    """Channel attention (taskprompter.py:216-250): token_trans GEMM on the prompt rows, windowed logits,
+    token_trans1 GEMM accumulated into the prompt rows of XT2 (in place)."""
+
+    @staticmethod
+    def forward(ctx, xn, XT2, Wtt, btt, Wtt1, btt1, rowscale, geo, prec, tag):
+        B, N, nH, T, h, w, nwin = geo
+        C, hw = nH * 64, h * w
+        wt = ops.pack_linear([Wtt], prec, tag + ('tt',))
+        wt1 = ops.pack_linear([Wtt1], prec, tag + ('tt1',))
+        cq = ops.linear(xn, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
+        rawchan = ops.chan_logits(cq, xn, B, T, N, C, (h, w), (nwin, nwin))
+        pr = XT2.view(B, N, C)[:, :T]
+        ops.linear(cq, wt1, C, prec, bias=btt1[None], out=pr, d_rows=(T, N * C, C), resid=pr, rowscale=rowscale, n_prompt=T,
+                   M=B * T)
+        ctx.mark_dirty(XT2)
+        ctx.save_for_backward(xn, cq, wt, wt1, rowscale)
+        ctx.geo, ctx.prec = geo, prec
+        return XT2, rawchan
+
+    @staticmethod
+    def backward(ctx, dXT2, drawchan):
+        xn, cq, wt, wt1, rowscale = ctx.saved_tensors
+        B, N, nH, T, h, w, nwin = ctx.geo
+        prec, C, hw = ctx.prec, nH * 64, h * w
+        hwp = cq.shape[-1]
+        dXT2 = dXT2.contiguous()
+        gp = dXT2.view(B, N, C)[:, :T].reshape(B * T, C)                  # tiny copy (B*T rows)
+        if rowscale is not None:
+            gp = gp * rowscale[:, 0].repeat_interleave(T)[:, None]
+        dWtt1 = _wgrad(gp, cq, C, hwp, prec)
+        dbtt1 = _colsum(gp, C)
+        dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
+        dxn = torch.zeros(B * N, C, dtype=torch.float32, device=xn.device)
+        dq2 = torch.zeros(B * T, hwp, dtype=torch.float32, device=xn.device)
+        if drawchan is not None:
+            ops.call("chan_logits_bwd", q=cq, xn=xn, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
+                     dtype=dtype_code(xn), ldq=hwp, extra=[drawchan.contiguous(), dq2, F32, dxn])
+        dcq = dcq + dq2                                                    # [B*T, hwp] fp32 (tiny)
+        xnp = xn.view(B, N, C)[:, :T].reshape(B * T, C)
+        dWtt = _wgrad(dcq, xnp, hw, C, prec)
+        dbtt = _colsum(dcq, hw)
+        dp = dxn.view(B, N, C)[:, :T]
+        _gemm(dcq, wt[0], dp, B * T, C, hw, prec, b_op=OP_R, lda=hwp, ldb=wt.shape[-1], ldd=C, d_mb=T, d_bs=N * C,
+              resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
+        return dxn, dXT2, dWtt[:, :C], dbtt, dWtt1[:, :hw], dbtt1, None, None, None, None
+
+
+class MlpFn(Function):
+    """fc1 + GELU + fc2 + residual over prompts and patches at once (timm Mlp at taskprompter.py:274,277)."""
+
+    @staticmethod
+    def forward(ctx, xn2, XT2, W1, b1, W2, b2, rowscale, geo, prec, tag):
+        B, N, T = geo
+        C, Hd = W1.shape[1], W1.shape[0]
+        w1 = ops.pack_linear([W1], prec, tag + ('fc1',))
+        w2 = ops.pack_linear([W2], prec, tag + ('fc2',))
+        z = torch.empty(B * N, Hd, dtype=prec.adt, device=xn2.device)
+        hmid = ops.linear(xn2, w1, Hd, prec, bias=b1[None], act=ACT_GELU, aux_out=z)[0]
+        XT3 = torch.empty_like(XT2)
+        ops.linear(hmid, w2, C, prec, bias=b2[None], out=XT3, resid=XT2, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
+                   M=B * N)
+        ctx.save_for_backward(xn2, z, hmid, w1, w2, rowscale)
+        ctx.geo, ctx.prec = geo, prec
+        return XT3
+
+    @staticmethod
+    def backward(ctx, dXT3):
+        xn2, z, hmid, w1, w2, rowscale = ctx.saved_tensors
+        B, N, T = ctx.geo
+        prec, M = ctx.prec, B * N
+        C, Hd = xn2.shape[1], z.shape[1]
+        dXT3 = dXT3.contiguous()
+        g = _scaled(dXT3, rowscale, N, T, prec)
+        dW2 = _wgrad(g, hmid, C, Hd, prec)
+        db2 = _colsum(g, C)
+        dz = _dgrad(g, w2[0], M, Hd, C, prec, prec.adt, act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
+        dW1 = _wgrad(dz, xn2, Hd, C, prec)
+        db1 = _colsum(dz, Hd)
+        dxn2 = _dgrad(dz, w1[0], M, C, Hd, prec, prec.adt)
+        return dxn2, dXT3, dW1, db1, dW2, db2, None, None, None, None
+
+
+class PatchEmbedFn(Function):
+    """patchify + k=s=16 conv as GEMM + pos-embed add, prompts copied in front (taskprompter.py:393-397)."""
+
+    @staticmethod
+    def forward(ctx, img, Wpe, bpe, pos, prompts, geo, prec):
+        B, N, T, hw = geo
+        C = Wpe.shape[0]
+        XT = torch.empty(B * N, C, dtype=torch.float32, device=img.device)
+        XT.view(B, N, C)[:, :T] = prompts
+        cols = ops.patchify(img.float(), prec)
+        wpe = ops.pack_linear([Wpe], prec, 'pe')
+        ops.linear(cols, wpe, C, prec, bias=bpe[None], out=XT.view(B, N, C)[:, T:], d_rows=(hw, N * C, C),
+                   resid=pos[0, 1:], r_rows=(hw, 0, C), M=B * hw)
+        ctx.save_for_backward(cols)
+        ctx.geo, ctx.prec, ctx.wshape = geo, prec, Wpe.shape
+        return XT
+
+    @staticmethod
+    def backward(ctx, dXT):
+        (cols,) = ctx.saved_tensors
+        B, N, T, hw = ctx.geo
+        C = ctx.wshape[0]
+        d3 = dXT.contiguous().view(B, N, C)
+        dpatch = d3[:, T:].reshape(B * hw, C)
+        dW = _wgrad(dpatch, cols, C, 768, ctx.prec).view(ctx.wshape)
+        db = _colsum(dpatch, C)
+        dpos = torch.zeros(1, hw + 1, C, dtype=torch.float32, device=dXT.device)
+        dpos[0, 1:] = d3[:, T:].sum(0)
+        return None, dW, db, dpos, d3[:, :T].sum(0), None, None
+
+
+class ModulateFn(Function):
+    """cal_task_feature's (1 + logit) modulation for all tasks (taskprompter.py:436-467)."""
+
+    @staticmethod
+    def forward(ctx, xsrc, rawlog, rawchan, geo, prec):
+        B, N, T, C, h, w, nwin = geo
+        mod = ops.modulate(xsrc.view(B, N, C)[:, T:], C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec)
+        ctx.save_for_backward(xsrc, rawlog, rawchan)
+        ctx.geo = geo
+        return mod
+
+    @staticmethod
+    def backward(ctx, dmod):
+        xsrc, rawlog, rawchan = ctx.saved_tensors
+        B, N, T, C, h, w, nwin = ctx.geo
+        dmod = dmod.contiguous()
+        dx = torch.zeros_like(xsrc)
+        dl, dc = torch.zeros_like(rawlog), torch.zeros_like(rawchan)
+        ops.call("modulate_bwd", x=xsrc.view(B, N, C)[:, T:], x_ld=C, x_bs=N * C, rawlog=rawlog, rawchan=rawchan, out=None,
+                 B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin, out_dtype=dtype_code(dmod),
+                 extra=[dmod, dx.view(B, N, C)[:, T:], dl, dc])
+        return dx, dl, dc, None, None
+
+
+# =================================================================================================
+class BLinearFn(Function):
+    """Task-batched linear / 1x1 conv: y[z] = x[z] @ W[z]^T + b[z].  layout 'plain' -> [Z, M, pad8(N)];
+    'catpair' -> [Z/2, M, 2*pad8(N)] (z = 2t+s written at column offset s*pad8(N): the reference's
+    torch.cat([spa, chan], dim=1), taskprompter.py:471).  kmap = optional (Kp, [(dst0, src0, len), ...])
+    column remap used when the input is such a padded concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, N, layout, kmap, out_dtype, prec, tag, *wb):
+        Z = len(wb) // 2
+        ws, bs = wb[:Z], wb[Z:]
+        if kmap is None:
+            wpack = ops.pack_linear(list(ws), prec, tag)
+        else:
+            Kp, segs = kmap
+
+            def build():
+                with torch.no_grad():
+                    buf = torch.zeros(Z, N, Kp, dtype=torch.float32, device=ws[0].device)
+                    for i, wt in enumerate(ws):
+                        w2 = wt.detach().reshape(N, -1)
+                        for (d0, s0, ln) in segs:
+                            buf[i, :, d0:d0 + ln] = w2[:, s0:s0 + ln]
+                    return buf.to(prec.adt)
+            wpack = ops._cached((tag, prec.name, 'kmap', tuple(id(q) for q in ws)), list(ws), build)
+        bias = ops.stack_vec(list(bs), (tag, 'b'))
+        M, Np = x.shape[-2], pad8(N)
+        if layout == 'catpair':
+            out = torch.empty(Z // 2, M, 2 * Np, dtype=out_dtype or prec.adt, device=x.device)
+            ops.linear(x, wpack, N, prec, bias=bias, out=out, batch_inner=2, d_z=(M * 2 * Np, Np), ldd=2 * Np, n_store=Np)
+        else:
+            out = ops.linear(x, wpack, N, prec, bias=bias, out_dtype=out_dtype)
+        ctx.save_for_backward(x, wpack)
+        ctx.meta = (Z, N, layout, kmap, prec, [tuple(w.shape) for w in ws])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wpack = ctx.saved_tensors
+        Z, N, layout, kmap, prec, wshapes = ctx.meta
+        dy = dy.contiguous()
+        M, Np, Kp = x.shape[-2], pad8(N), wpack.shape[-1]
+        if layout == 'catpair':
+            az = dict(batch=Z, batch_inner=2, a_zo=M * 2 * Np, a_zi=Np)
+            lda = 2 * Np
+        else:
+            az = dict(batch=Z, batch_inner=1, a_zo=M * Np)
+            lda = Np
+        xz = x.stride(0) if (x.dim() == 3 and x.shape[0] > 1) else 0
+        bi = az['batch_inner']
+        dx = torch.empty(Z, M, Kp, dtype=x.dtype, device=x.device)
+        _gemm(dy, wpack, dx, M, Kp, N, prec, b_op=OP_R, lda=lda, ldb=Kp, ldd=Kp, b_zo=wpack.stride(0) * bi,
+              b_zi=wpack.stride(0) if bi > 1 else 0, d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
+        dW = torch.empty(Z, N, Kp, dtype=torch.float32, device=x.device)
+        _gemm(dy, x, dW, N, Kp, M, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=x.shape[-1], ldd=Kp, b_zo=xz * bi,
+              b_zi=xz if bi > 1 else 0, d_zo=N * Kp * bi, d_zi=N * Kp if bi > 1 else 0, **az)
+        dys = dy.view(-1, M, lda)
+        dws, dbs = [], []
+        for z in range(Z):
+            view = dys[z // 2][:, (z % 2) * Np:] if layout == 'catpair' else dys[z]
+            dbs.append(_colsum(view, N))
+            if kmap is None:
+                dws.append(dW[z][:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
+            else:
+                g = torch.empty(N, math.prod(wshapes[z][1:]), dtype=torch.float32, device=x.device)
+                for (d0, s0, ln) in kmap[1]:
+                    g[:, s0:s0 + ln] = dW[z][:, d0:d0 + ln]
+                dws.append(g.reshape(wshapes[z]))
+        if x.dim() == 3 and x.shape[0] == 1 and Z > 1:
+            dx = dx.sum(0, keepdim=True)
+        elif x.dim() == 2:
+            dx = dx.sum(0)
+        return (dx, None, None, None, None, None, None) + tuple(dws) + tuple(dbs)
+
+
+class Conv3x3Fn(Function):
+    """Task-batched 3x3 conv (+bias) as implicit GEMM; dgrad = same kernel with mirrored taps on the
+    transposed pack; wgrad = MTT_OP_CONV_R (taskprompter.py:362 fea_fuse[1], :692/:706 head convs)."""
+
+    @staticmethod
+    def forward(ctx, x, geo, prec, tag, *wb):
+        B, H, W, Co, Ci = geo
+        Z = len(wb) // 2
+        ws, bs = wb[:Z], wb[Z:]
+        wpack = ops.pack_conv3(list(ws), prec, tag)
+        y = ops.conv3x3(x, wpack, Co, Ci, B, H, W, prec, bias=ops.stack_vec(list(bs), (tag, 'b')))
+        ctx.save_for_backward(x, *ws)
+        ctx.meta = (geo, prec, tag, Z)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        (B, H, W, Co, Ci), prec, tag, Z = ctx.meta
+        dy = dy.contiguous()
+        rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
+        wd = ops.pack_conv3(list(ws), prec, tag, transpose=True)                     # [Z, Ci, 9*Cop]
+        dx = ops.conv3x3(dy, wd, Ci, Co, B, H, W, prec, flip=1, out_dtype=x.dtype)
+        dW = torch.empty(Z, Co, 9 * Cip, dtype=torch.float32, device=x.device)
+        _gemm(dy, x, dW, Co, 9 * Cip, rows, prec, a_op=OP_R, b_op=OP_CONV_R, lda=Cop, ldb=Cip, ldd=9 * Cip, batch=Z,
+              a_zo=rows * Cop, b_zo=rows * Cip, d_zo=Co * 9 * Cip, conv=dict(H=H, W=W, C=Ci, Cp=Cip, dil=1, flip=0))
+        dws = [dW[z].view(Co, 3, 3, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous() for z in range(Z)]
+        dbs = [_colsum(dy[z], Co) for z in range(Z)]
+        return (dx, None, None, None) + tuple(dws) + tuple(dbs)
+
+
+def _sync_stats(t, bn):
+    if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+        return dist.get_world_size()
+    return 1
+
+
+class BnActFn(Function):
+    """BatchNorm2d (+GELU) on one [rows, ld] map.  training: batch statistics (all-reduced across ranks when the
+    module is a SyncBatchNorm, main.py:92) + running-stat update; eval: running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, C, act, training):
+        rows, ld = x.shape
+        if training:
+            s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+            ops.call("bn_stats", x=x, sum=s[0], sumsq=s[1], rows=rows, C=C, ld=ld, dtype=dtype_code(x))
+            world = _sync_stats(s, bn)
+            n = rows * world
+            mean = s[0] / n
+            var = torch.clamp_min(s[1] / n - mean * mean, 0.0)
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(mean * m)
+                bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)) * m)
+                bn.num_batches_tracked += 1
+        else:
+            mean, var, n = bn.running_mean, bn.running_var, rows
+        rstd = torch.rsqrt(var + bn.eps)
+        y = ops.bn_apply(x, C, mean, rstd, gamma, beta, act)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.meta = (C, act, training, n, bn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        C, act, training, n, bn = ctx.meta
+        rows, ld = x.shape
+        dy = dy.contiguous()
+        s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+        kw = dict(x=x, dy=dy, mean=mean, rstd=rstd, gamma=gamma, beta=beta, rows=rows, C=C, ld=ld, dtype=dtype_code(x), act=act)
+        ops.call("bn_bwd_reduce", dsum=s[0], dsumxh=s[1], **kw)
+        dgamma, dbeta = s[1].clone(), s[0].clone()
+        if training:
+            world = _sync_stats(s, bn)
+            red = s * (rows / float(n))        # kernel divides by its local row count
+        else:
+            red = torch.zeros_like(s)
+        dx = torch.empty_like(x)
+        ops.call("bn_bwd_apply", dx=dx, dsum=red[0], dsumxh=red[1], **kw)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+class CtrMixFn(Function):
+    """acc (+)= sum_s wmix[b,t,s] * fea[s]  — cross-task reweighting fused with the 4-tap sum (taskprompter.py:411,484)."""
+
+    @staticmethod
+    def forward(ctx, fea, wmix, acc, B, C):
+        out = ops.ctr_mix(fea, wmix, B, C, acc)
+        if acc is not None:
+            ctx.mark_dirty(acc)
+        ctx.save_for_backward(fea, wmix)
+        ctx.meta = (B, C, acc is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fea, wmix = ctx.saved_tensors
+        B, C, had_acc = ctx.meta
+        dout = dout.contiguous()
+        T, rows, ld = fea.shape
+        dfea32 = ops.ctr_mix(dout, wmix.transpose(1, 2).contiguous(), B, C, None)
+        dfea = dfea32 if fea.dtype == torch.float32 else ops.cast2d(dfea32.view(T * rows, ld), T * rows, ld, ld, fea.dtype, ldd=ld).view(T, rows, ld)
+        dw = torch.zeros_like(wmix)
+        ops.call("ctr_dw", fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C, fea_dtype=dtype_code(fea),
+                 accumulate=0, extra=[dout, dw])
+        return dfea, dw, (dout if had_acc else None), None, None
+
+
+class BilinearFn(Function):
+    """F.interpolate(mode='bilinear', align_corners=False) on NHWC maps; nchw=True -> fp32 [B, C, Ho, Wo]."""
+
+    @staticmethod
+    def forward(ctx, x, geo, out_dtype, nchw):
+        B, C, Hi, Wi, Ho, Wo = geo
+        ctx.meta = (geo, nchw, x.shape, x.dtype)
+        return ops.bilinear(x, B, C, Hi, Wi, Ho, Wo, out_dtype, nchw=nchw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (B, C, Hi, Wi, Ho, Wo), nchw, xshape, xdtype = ctx.meta
+        dy = dy.contiguous()
+        Z, _, ld = xshape
+        din = torch.zeros(xshape, dtype=torch.float32, device=dy.device)
+        if nchw:
+            ops.call("bilinear_bwd", **{"in": dy}, out=din, B=B, C=C, Hin=Hi, Win=Wi, Hout=Ho, Wout=Wo, ld_in=ld, ld_out=0,
+                     in_dtype=F32, out_dtype=F32, out_nchw=1, accumulate=1)
+        else:
+            ops.call("bilinear_bwd", **{"in": dy}, out=din, B=Z * B, C=ld, Hin=Hi, Win=Wi, Hout=Ho, Wout=Wo, ld_in=ld, ld_out=ld,
+                     in_dtype=dtype_code(dy), out_dtype=F32, out_nchw=0, accumulate=1)
+        if xdtype != torch.float32:
+            din = ops.cast2d(din.view(-1, ld), din.numel() // ld, ld, ld, xdtype, ldd=ld).view(xshape)
+        return din, None, None, None
+
+
+# =================================================================================================
+def _drop_scales(model, blk, i, B, device):
+    """The reference's 4 independent per-sample DropPath draws of a block (taskprompter.py:273-277), as the two
+    [B, 2] (prompt rows, patch rows) scale tables of the attention and MLP residual epilogues."""
+    rate = blk.drop_path_rate
+    override = getattr(model, "_drop_override", None)       # tests inject the oracle's masks: [4, B] already mask / keep
+    if not model.training or (rate <= 0.0 and override is None):
+        return None, None
+    if override is not None:
+        d = override[i].to(device)
+    else:
+        keep = 1.0 - rate
+        d = torch.bernoulli(torch.full((4, B), keep, device=device)) / keep
+    return torch.stack([d[2], d[0]], 1).contiguous(), torch.stack([d[3], d[1]], 1).contiguous()
+
+
+def _bn_act(y, bns, C, act, training):
+    outs = [BnActFn.apply(y[t], bn.weight, bn.bias, bn, C, act, training) for t, bn in enumerate(bns)]
+    return torch.stack(outs, 0)
+
+
+def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
+    p, prec = model.p, model.prec
+    names = p.TASKS.NAMES
+    T, C = len(names), model.embed_dim
+    h, w = model.resolution
+    N = T + h * w
+    tar, F = p.embed_dim, p.final_embed_dim
+    tarp = pad8(tar)
+    nwin = int(math.isqrt(model.chan_nheads))
+    mod = ModulateFn.apply(xsrc, rawlog, rawchan, (B, N, T, C, h, w, nwin), prec)
+    dec_w, dec_b = [], []
+    for t in names:
+        dec_w += [model.fea_decode_spa[il][t][0].weight, model.fea_decode_chan[il][t][0].weight]
+        dec_b += [model.fea_decode_spa[il][t][0].bias, model.fea_decode_chan[il][t][0].bias]
+    cat = BLinearFn.apply(mod, tar, 'catpair', None, None, prec, ('dec', il), *dec_w, *dec_b)
+    ff = [model.fea_fuse[il][t] for t in names]
+    kmap = (2 * tarp, [(0, 0, tar), (tarp, tar, tar)])
+    y0 = BLinearFn.apply(cat, F, 'plain', kmap, None, prec, ('f0', il), *[m[0].weight for m in ff], *[m[0].bias for m in ff])
+    y1 = Conv3x3Fn.apply(y0, (B, h, w, F, F), prec, ('f1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
+    y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)
+    fea = BLinearFn.apply(y1, F, 'plain', None, None, prec, ('f4', il), *[m[4].weight for m in ff], *[m[4].bias for m in ff])
+    wmix = model._ctr_weights(rawlog, il, B, T)
+    return CtrMixFn.apply(fea, wmix, acc, B, F)
+
+
+def backbone_forward(model, img):
+    """Autograd twin of TaskPrompter._forward_nograd -> [T, B*4h*4w, pad8(F)] task features."""
+    p, prec = model.p, model.prec
+    B = img.shape[0]
+    assert tuple(img.shape[-2:]) == tuple(model.patch_embed.img_size)
+    h, w = model.resolution
+    hw, T, C, nH = h * w, model.prompts_len, model.embed_dim, model.num_heads
+    N = T + hw
+    nwin = int(math.isqrt(model.chan_nheads))
+    XT = PatchEmbedFn.apply(img, model.patch_embed.proj.weight, model.patch_embed.proj.bias, model.pos_embed,
+                            model.task_prompts, (B, N, T, hw), prec)
+    acc = None
+    rawlog = rawchan = None
+    for i, blk in enumerate(model.blocks):
+        a = blk.attn
+        rs_attn, rs_mlp = _drop_scales(model, blk, i, B, img.device)
+        xn = LayerNormFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, prec, None)
+        XT2, rawlog = AttnBlockFn.apply(xn, XT, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, rs_attn,
+                                        (B, N, nH, T), prec, ('blk', i))
+        XT2, rawchan = ChanAttnFn.apply(xn, XT2, a.token_trans.weight, a.token_trans.bias, a.token_trans1.weight,
+                                        a.token_trans1.bias, rs_attn, (B, N, nH, T, h, w, nwin), prec, ('blk', i))
+        xn2 = LayerNormFn.apply(XT2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, prec, None)
+        XT = MlpFn.apply(xn2, XT2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp,
+                         (B, N, T), prec, ('blk', i))
+        if (i + 1) in model.select_list:
+            acc = _task_features(model, XT, rawlog, rawchan, model._tap_index(i), B, acc)
+    xf = LayerNormFn.apply(XT, model.norm.weight, model.norm.bias, model.norm.eps, prec, torch.float32)
+    acc = _task_features(model, xf, rawlog, rawchan, 3, B, acc)
+    return BilinearFn.apply(acc, (B, acc.shape[-1], h, w, 4 * h, 4 * w), prec.adt, False)
+
+
+def wrapper_forward(wrapper, x, target):
+    """Autograd twin of TaskPrompterWrapper.forward."""
+    from .taskprompter import ConvHead, DEConvHead
+    bb = wrapper.backbone
+    B = x.shape[0]
+    fea = backbone_forward(bb, x)
+    h4, w4 = bb.resolution[0] * 4, bb.resolution[1] * 4
+    F, prec = bb.p.final_embed_dim, bb.prec
+    heads = [wrapper.heads[t] for t in wrapper.tasks]
+    out = {}
+    if all(isinstance(hd, ConvHead) for hd in heads):
+        y = Conv3x3Fn.apply(fea, (B, h4, w4, F, F), prec, 'hc', *[hd.mt_proj[0].weight for hd in heads],
+                            *[hd.mt_proj[0].bias for hd in heads])
+        y = _bn_act(y, [hd.mt_proj[1] for hd in heads], F, ACT_GELU, wrapper.training)
+        for i, (t, hd) in enumerate(zip(wrapper.tasks, heads)):
+            n_out = hd.linear_pred.weight.shape[0]
+            pred = BLinearFn.apply(y[i][None], n_out, 'plain', None, torch.float32, prec, ('hp', t), hd.linear_pred.weight,
+                                   hd.linear_pred.bias)
+            out[t] = BilinearFn.apply(pred, (B, n_out, h4, w4, target[0], target[1]), torch.float32, True)
+        return out
+    raise NotImplementedError('training path: ConvHead heads only in round 1 (DEConvHead inference is supported)')

@@ -391,7 +391,9 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (d.batch < 1) d.batch = 1;
   if (d.batch_inner < 1) d.batch_inner = 1;
   const bool a_k = d.a_op == MTT_OP_K || d.a_op == MTT_OP_CONV_K, b_k = d.b_op == MTT_OP_K;
-  if ((a_k || b_k) && (d.K % 8)) return MTT_E_ALIGN;
+  const int Kp8 = (d.K + 7) / 8 * 8;
+  if ((a_k && d.a_op == MTT_OP_K && d.lda < Kp8) || (b_k && d.ldb < Kp8)) return MTT_E_ALIGN;
+  if (d.a_op == MTT_OP_CONV_K && (d.K % 8)) return MTT_E_ALIGN;
   if ((d.lda % 8) || (d.ldb % 8)) return MTT_E_ALIGN;
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return MTT_E_ALIGN;
   if (d.prec == MTT_PREC_X3 && (d.a_dtype != MTT_F32 || d.b_dtype != MTT_F32)) return MTT_E_UNSUPPORTED;

@@ -486,6 +486,205 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const void* src, float* d
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the task-feature modulation.  grid (C/8/32 column groups, pixel splits, B*nwin); block =
+// 32 column chunks x 8 pixel lanes (same shape as chanlogit_kernel).
+//   dx[b,p,c]              += sum_t dout[2t]*(1+a) + dout[2t+1]*(1+bw)
+//   drawlog[b,head,t,T+p]   = sum_{c in head} dout[2t][b,p,c] * x[b,p,c]         (unique owner: 8 lanes)
+//   drawchan[b,t,win,c]    += sum_{p in win} dout[2t+1][b,p,c] * x[b,p,c]        (LDS reduce + 1 atomic)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_desc d, const void* dout, float* dx,
+                                                           float* drawlog, float* drawchan, int tbase) {
+  const int nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw, P = wh * ww, hw = d.h * d.w;
+  const int nH = d.C >> 6;
+  const int b = blockIdx.z / nwin, win = blockIdx.z % nwin;
+  const int wy = win / d.nw, wx = win % d.nw;
+  const int cl = threadIdx.x & 31, plane = threadIdx.x >> 5;
+  const int cchunk = blockIdx.x * 32 + cl;
+  const bool cok = cchunk * 8 < d.C;
+  const int nT = d.T - tbase < CL_MAXT ? d.T - tbase : CL_MAXT;
+  const int64_t planeElems = (int64_t)d.B * hw * d.C;
+  float acc[CL_MAXT][8];
+#pragma unroll
+  for (int t = 0; t < CL_MAXT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  const int per = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = p0 + per < P ? p0 + per : P;
+  const int head = (cchunk * 8) >> 6;
+  for (int pi0 = p0; pi0 < p1; pi0 += 8) {
+    const int pi = pi0 + plane;
+    const bool pok = pi < p1 && cok;
+    const int pic = pi < p1 ? pi : p1 - 1;
+    const int y = wy * wh + pic / ww, x = wx * ww + pic % ww;
+    const int pix = y * d.w + x;
+    const int64_t tok = (int64_t)b * hw + pix;
+    float xv[8], dxa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xv[j] = 0.f; dxa[j] = 0.f; }
+    if (pok) ld8(d.x, (int64_t)b * d.x_bs + (int64_t)pix * d.x_ld + cchunk * 8, MTT_F32, xv);
+#pragma unroll
+    for (int t = 0; t < CL_MAXT; ++t) {
+      if (t < nT) {
+        const int tk = tbase + t;
+        float gs[8], gc[8], bw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gs[j] = gc[j] = bw[j] = 0.f; }
+        float a = 0.f;
+        if (pok) {
+          ld8(dout, (int64_t)(2 * tk) * planeElems + tok * d.C + cchunk * 8, d.out_dtype, gs);
+          ld8(dout, (int64_t)(2 * tk + 1) * planeElems + tok * d.C + cchunk * 8, d.out_dtype, gc);
+          ld8(d.rawchan, (((int64_t)b * d.T + tk) * nwin + win) * d.C + cchunk * 8, MTT_F32, bw);
+          a = d.rawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + pix];
+        }
+        float dl = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          dxa[j] += gs[j] * (1.0f + a) + gc[j] * (1.0f + bw[j]);
+          dl += gs[j] * xv[j];
+          acc[t][j] += gc[j] * xv[j];
+        }
+        // the 8 chunks of one head are 8 consecutive lanes
+        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+        if (pok && (cl & 7) == 0) drawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + pix] = dl;
+      }
+    }
+    if (pok && tbase == 0) {
+      float cur[8];
+      const int64_t xi = (int64_t)b * d.x_bs + (int64_t)pix * d.x_ld + cchunk * 8;
+      ld8(dx, xi, MTT_F32, cur);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cur[j] += dxa[j];
+      st8(dx, xi, MTT_F32, cur);
+    } else if (pok) {
+      float cur[8];
+      const int64_t xi = (int64_t)b * d.x_bs + (int64_t)pix * d.x_ld + cchunk * 8;
+      ld8(dx, xi, MTT_F32, cur);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cur[j] += dxa[j];
+      st8(dx, xi, MTT_F32, cur);
+    }
+  }
+  __shared__ float red[8][32][8];
+  for (int t = 0; t < nT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[plane][cl][j] = acc[t][j];
+    __syncthreads();
+    if (plane == 0 && cok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][cl][j];
+        atomicAdd(&drawchan[(((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + cchunk * 8 + j], s);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the channel-attention logits: one wave per patch token.
+//   dq[b,t,p]      = sum_c drawchan[b,t,win(p),c] * xn[b,T+p,c]
+//   dxn[b,T+p,c]  += sum_t drawchan[b,t,win(p),c] * q[b,t,p]           (fp32 accumulate)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chanlogit_bwd_kernel(const mtt_chanlogit_desc d, const float* drawchan, void* dq, int dq_dtype,
+                                                            float* dxn) {
+  const int lane = threadIdx.x & 63;
+  const int hw = d.h * d.w, nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw;
+  const int64_t tokid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tokid >= (int64_t)d.B * hw) return;
+  const int b = (int)(tokid / hw), p = (int)(tokid % hw);
+  const int y = p / d.w, x = p % d.w;
+  const int win = (y / wh) * d.nw + (x / ww);
+  const int64_t xrow = ((int64_t)b * d.N + d.T + p) * d.C;
+  for (int t = 0; t < d.T; ++t) {
+    const float* g = drawchan + (((int64_t)b * d.T + t) * nwin + win) * d.C;
+    float s = 0.f;
+    for (int c = lane; c < d.C; c += 64) s += g[c] * ld_elem(d.xn, xrow + c, d.dtype);
+    s = wave_sum(s);
+    if (lane == 0) st_elem(dq, ((int64_t)b * d.T + t) * d.ldq + p, dq_dtype, s);
+  }
+  for (int c = lane; c < d.C; c += 64) {
+    float s = 0.f;
+    for (int t = 0; t < d.T; ++t)
+      s += drawchan[(((int64_t)b * d.T + t) * nwin + win) * d.C + c] * ld_elem(d.q, ((int64_t)b * d.T + t) * d.ldq + p, d.dtype);
+    dxn[xrow + c] += s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dwmix[b,t,s] += sum_{rows in b, c} dout[t][row,c] * fea[s][row,c]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ctr_dw_kernel(const mtt_ctr_desc d, const float* dout, float* dw, int rows_per_block) {
+  __shared__ float red[CTR_MAXT * CTR_MAXT];
+  for (int i = threadIdx.x; i < CTR_MAXT * CTR_MAXT; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int C8 = (d.C + 7) >> 3;
+  const int b = blockIdx.y;
+  const int64_t rows = (int64_t)d.B * d.rows_per_b, plane = rows * d.ld;
+  const int64_t r0 = (int64_t)b * d.rows_per_b + (int64_t)blockIdx.x * rows_per_block;
+  const int64_t rend = (int64_t)(b + 1) * d.rows_per_b;
+  const int64_t r1 = r0 + rows_per_block < rend ? r0 + rows_per_block : rend;
+  float acc[CTR_MAXT][CTR_MAXT];
+#pragma unroll
+  for (int t = 0; t < CTR_MAXT; ++t)
+#pragma unroll
+    for (int s = 0; s < CTR_MAXT; ++s) acc[t][s] = 0.f;
+  const int64_t total = (r1 - r0) * C8;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t row = r0 + i / C8;
+    float f[CTR_MAXT][8];
+#pragma unroll
+    for (int s = 0; s < CTR_MAXT; ++s)
+      if (s < d.T) ld8(d.fea, (int64_t)s * plane + row * d.ld + c8 * 8, d.fea_dtype, f[s]);
+#pragma unroll
+    for (int t = 0; t < CTR_MAXT; ++t)
+      if (t < d.T) {
+        float g[8];
+        ld8(dout, (int64_t)t * plane + row * d.ld + c8 * 8, MTT_F32, g);
+#pragma unroll
+        for (int s = 0; s < CTR_MAXT; ++s)
+          if (s < d.T) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += g[j] * f[s][j];
+            acc[t][s] += v;
+          }
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < CTR_MAXT; ++t)
+#pragma unroll
+    for (int s = 0; s < CTR_MAXT; ++s)
+      if (t < d.T && s < d.T) {
+        const float v = wave_sum(acc[t][s]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[t * CTR_MAXT + s], v);
+      }
+  __syncthreads();
+  for (int i = threadIdx.x; i < d.T * d.T; i += 256) {
+    const int t = i / d.T, s = i % d.T;
+    atomicAdd(&dw[((int64_t)b * d.T + t) * d.T + s], red[t * CTR_MAXT + s]);
+  }
+}
+
+// dst[r, :] = rowscale(r) * src[r, :]  (dtype cast; DropPath scale of the branch gradient)
+__global__ __launch_bounds__(256) void rowscale_cast_kernel(const void* src, void* dst, int64_t rows, int cols, int64_t lds_, int64_t ldd,
+                                                            int sdt, int ddt, const float* rowscale, int mb, int n_prompt) {
+  const int64_t total = rows * cols;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / cols, c = t % cols;
+    float rs = 1.0f;
+    if (rowscale) {
+      const int64_t q = mb > 0 ? r / mb : 0, rem = mb > 0 ? r % mb : r;
+      rs = rowscale[q * 2 + (rem >= n_prompt ? 1 : 0)];
+    }
+    st_elem(dst, r * ldd + c, ddt, rs * ld_elem(src, r * lds_ + c, sdt));
+  }
+}
+
 int grid_for(int64_t work_items) {
   int64_t g = (work_items + 255) / 256;
   if (g > 256 * 8) g = 256 * 8;
@@ -619,5 +818,41 @@ extern "C" int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t c
                             float alpha, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;
   hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype, alpha);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, void* stream) {
+  if (!d || !d->x || !d->rawlog || !d->rawchan || !dout || !dx || !drawlog || !drawchan || (d->C % 64)) return MTT_E_BADARG;
+  if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw)) return MTT_E_BADARG;
+  const int P = (d->h / d->nh) * (d->w / d->nw);
+  int splits = P / 64; if (splits < 1) splits = 1; if (splits > 32) splits = 32;
+  dim3 grid((d->C / 8 + 31) / 32, splits, d->B * d->nh * d->nw);
+  for (int tb = 0; tb < d->T; tb += CL_MAXT)
+    hipLaunchKernelGGL(modulate_bwd_kernel, grid, dim3(256), 0, S_, *d, dout, dx, drawlog, drawchan, tb);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* drawchan, void* dq, int dq_dtype, float* dxn, void* stream) {
+  if (!d || !d->q || !d->xn || !drawchan || !dq || !dxn) return MTT_E_BADARG;
+  if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw)) return MTT_E_BADARG;
+  const int64_t toks = (int64_t)d->B * d->h * d->w;
+  hipLaunchKernelGGL(chanlogit_bwd_kernel, dim3((unsigned)((toks + 3) / 4)), dim3(256), 0, S_, *d, drawchan, dq, dq_dtype, dxn);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dw, void* stream) {
+  if (!d || !d->fea || !dout || !dw || d->T <= 0 || d->T > CTR_MAXT || (d->ld % 8)) return MTT_E_BADARG;
+  int nb = (int)((d->rows_per_b + 127) / 128); if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  const int rpb = (int)((d->rows_per_b + nb - 1) / nb);
+  nb = (int)((d->rows_per_b + rpb - 1) / rpb);
+  hipLaunchKernelGGL(ctr_dw_kernel, dim3(nb, d->B), dim3(256), 0, S_, *d, dout, dw, rpb);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds_, int64_t ldd, int src_dtype,
+                                 int dst_dtype, const float* rowscale, int32_t mb, int32_t n_prompt, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;
+  hipLaunchKernelGGL(rowscale_cast_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype,
+                     dst_dtype, rowscale, mb, n_prompt);
   return LAUNCH_OK();
 }

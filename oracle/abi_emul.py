@@ -424,11 +424,79 @@ def add_rows(args):
     _wr(dst, r * ldd + c, _rd(dst, r * ldd + c) + alpha * _rd(src, r * lds + c))
 
 
+
+def modulate_bwd(**kw):
+    dout, dx, drawlog, drawchan = kw["extra"]
+    B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
+    hw, nH, nwin = h * w, Cn // 64, nh * nw
+    xi = torch.arange(B)[:, None, None] * kw["x_bs"] + torch.arange(hw)[None, :, None] * kw["x_ld"] + torch.arange(Cn)[None, None, :]
+    x = _rd(kw["x"], xi)
+    f, o = flat(kw["rawlog"]); rl = f[o:o + B * nH * T * N].double().view(B, nH, T, N)
+    f, o = flat(kw["rawchan"]); rc = f[o:o + B * T * nwin * Cn].double().view(B, T, nwin, Cn)
+    f, o = flat(dout); g = f[o:o + 2 * T * B * hw * Cn].double().view(T, 2, B, hw, Cn)
+    yy, xx = torch.arange(hw) // w, torch.arange(hw) % w
+    win = (yy // (h // nh)) * nw + (xx // (w // nw))
+    dxv = torch.zeros(B, hw, Cn, dtype=torch.float64)
+    dl = torch.zeros(B, nH, T, N, dtype=torch.float64)
+    dc = torch.zeros(B, T, nwin, Cn, dtype=torch.float64)
+    for t in range(T):
+        a = rl[:, :, t, T:].transpose(1, 2).repeat_interleave(64, dim=2)
+        dxv += g[t, 0] * (1 + a) + g[t, 1] * (1 + rc[:, t][:, win])
+        dl[:, :, t, T:] = (g[t, 0] * x).view(B, hw, nH, 64).sum(-1).transpose(1, 2)
+        dc[:, t].index_add_(1, win, g[t, 1] * x)
+    _wr(dx, xi, _rd(dx, xi) + dxv)
+    li = torch.arange(B * nH * T)[:, None] * N + torch.arange(T, N)[None, :]
+    _wr(drawlog, li, dl.view(B * nH * T, N)[:, T:])
+    ci = torch.arange(B * T * nwin * Cn)
+    _wr(drawchan, ci, _rd(drawchan, ci) + dc.reshape(-1))
+
+
+def chan_logits_bwd(**kw):
+    drawchan, dq, dq_dtype, dxn = kw["extra"]
+    B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
+    hw, nwin = h * w, nh * nw
+    f, o = flat(kw["xn"]); xn = f[o:o + B * N * Cn].double().view(B, N, Cn)[:, T:]
+    qi = (torch.arange(B)[:, None, None] * T + torch.arange(T)[None, :, None]) * kw["ldq"] + torch.arange(hw)[None, None, :]
+    q = _rd(kw["q"], qi)
+    f, o = flat(drawchan); g = f[o:o + B * T * nwin * Cn].double().view(B, T, nwin, Cn)
+    yy, xx = torch.arange(hw) // w, torch.arange(hw) % w
+    win = (yy // (h // nh)) * nw + (xx // (w // nw))
+    gp = g[:, :, win]                                                  # [B,T,hw,C]
+    _wr(dq, qi, torch.einsum("btpc,bpc->btp", gp, xn))
+    xi = (torch.arange(B)[:, None, None] * N + T + torch.arange(hw)[None, :, None]) * Cn + torch.arange(Cn)[None, None, :]
+    _wr(dxn, xi, _rd(dxn, xi) + torch.einsum("btpc,btp->bpc", gp, q))
+
+
+def ctr_dw(**kw):
+    dout, dw = kw["extra"]
+    T, B, rpb, ld, Cn = kw["T"], kw["B"], kw["rows_per_b"], kw["ld"], kw["C"]
+    rows = B * rpb
+    C8 = (Cn + 7) // 8 * 8
+    idx = (torch.arange(T)[:, None, None] * rows + torch.arange(rows)[None, :, None]) * ld + torch.arange(C8)[None, None, :]
+    fea = _rd(kw["fea"], idx).view(T, B, rpb, C8)
+    g = _rd(dout, idx).view(T, B, rpb, C8)
+    wi = torch.arange(B * T * T)
+    _wr(dw, wi, _rd(dw, wi) + torch.einsum("tbrc,sbrc->bts", g, fea).reshape(-1))
+
+
+def rowscale_cast(args):
+    src, dst, rows, cols, lds, ldd, sdt, ddt, rowscale, mb, n_prompt = args[:11]
+    r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+    v = _rd(src, r * lds + c)
+    if rowscale is not None:
+        rr = torch.arange(rows)
+        q = (rr // mb) if mb > 0 else torch.zeros_like(rr)
+        rem = (rr % mb) if mb > 0 else rr
+        v = v * _rd(rowscale, q * 2 + (rem >= n_prompt).long())[:, None]
+    _wr(dst, r * ldd + c, v)
+
+
 _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
-              bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply)
-_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows)
+              bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply,
+              modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw)
+_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast)
 
 
 def call(name, **kw):

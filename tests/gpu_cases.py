@@ -33,8 +33,6 @@ def run_case(name, kw, outputs, tol):
     Returns dict(ok, errs={key: rel_err})."""
     lib = pkg()._lib
     tensors = {k: v for k, v in kw.items() if isinstance(v, torch.Tensor)}
-    if "args" in kw:
-        tensors = {f"a{i}": a for i, a in enumerate(kw["args"]) if isinstance(a, torch.Tensor)}
     # GPU copies sharing storage structure
     gpu_store, gpu_kw = {}, dict(kw)
 
@@ -45,11 +43,11 @@ def run_case(name, kw, outputs, tol):
             gpu_store[key] = (flat.clone().cuda(), flat)
         return gpu_store[key][0].as_strided(t.size(), t.stride(), t.storage_offset())
 
-    if "args" in kw:
-        gpu_kw["args"] = [to_gpu(a) if isinstance(a, torch.Tensor) else a for a in kw["args"]]
-    else:
-        for k, t in tensors.items():
-            gpu_kw[k] = to_gpu(t)
+    for lk in ("args", "extra"):
+        if lk in kw:
+            gpu_kw[lk] = [to_gpu(a) if isinstance(a, torch.Tensor) else a for a in kw[lk]]
+    for k, t in tensors.items():
+        gpu_kw[k] = to_gpu(t)
     lib.call(name, **gpu_kw)
     torch.cuda.synchronize()
     abi_emul.call(name, **kw)
@@ -226,6 +224,30 @@ def row_cases():
             kw = dict(x=XT[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // 64, T, N), rawchan=rnd(g, B, T, nh * nh, C),
                       out=torch.zeros(2 * T, B * h * w, C, dtype=DT[dt]), B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt)
             cases.append((f"modulate_{dt}_win{nh}", "modulate", kw, TOL_ROW))
+    # backward-only kernels
+    for dt in (F32, BF16):
+        for (h, w, nh) in ((4, 6, 1), (4, 6, 2)):
+            B, T, C = 2, 5, 128
+            N = T + h * w
+            ldq = (h * w + 7) // 8 * 8
+            XT = rnd(g, B, N, C)
+            dXT = rnd(g, B, N, C)
+            kw = dict(x=XT[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // 64, T, N), rawchan=rnd(g, B, T, nh * nh, C),
+                      out=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt,
+                      extra=[rnd(g, 2 * T, B * h * w, C, dtype=DT[dt]), dXT[:, T:], torch.zeros(B, C // 64, T, N), torch.zeros(B, T, nh * nh, C)])
+            cases.append((f"modulate_bwd_{dt}_win{nh}", "modulate_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
+            kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=None,
+                      B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, dtype=dt, ldq=ldq,
+                      extra=[rnd(g, B, T, nh * nh, C), torch.zeros(B * T, ldq, dtype=DT[dt]), dt, rnd(g, B * N, C)])
+            cases.append((f"chanlogit_bwd_{dt}_win{nh}", "chan_logits_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
+        T, B, rpb, ld, C = 6, 2, 300, 56, 52
+        fea = rnd(g, T, B * rpb, ld, dtype=DT[dt]); fea[..., C:] = 0
+        kw = dict(fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rpb, ld=ld, C=C, fea_dtype=dt, accumulate=0,
+                  extra=[rnd(g, T, B * rpb, ld), torch.zeros(B, T, T)])
+        cases.append((f"ctr_dw_{dt}", "ctr_dw", kw, dict(f32=2e-5, bf16=5e-3)))
+        cases.append((f"rowscale_cast_{dt}", "rowscale_cast",
+                      dict(args=[rnd(g, 2 * 13, 24), torch.zeros(26, 32, dtype=DT[dt]), 26, 20, 24, 32, F32, dt,
+                                 torch.tensor([[0.5, 2.0], [0.0, 1.5]]), 13, 3]), TOL_ROW))
     for dt in (F32, BF16):
         for accum in (0, 1):
             T, B, rpb, ld, C = 6, 2, 24, 56, 52

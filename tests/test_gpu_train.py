@@ -1,0 +1,37 @@
+"""-m gpu: one training step (forward + hand-written backward through the C ABI) vs the oracle's autograd."""
+import pytest
+import torch
+
+import train_check
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win"])
+def test_gradients_x3(name):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fwd, errs = train_check.grad_errors(name, "x3", "cuda")
+    assert max(fwd.values()) < 1e-3
+    worst, med = train_check.summarize(errs)
+    assert worst[0] < 1e-2 and med < 1e-3, (worst, med)     # tolerance: 1e-3 typical, 1e-2 on the smallest gradients
+
+
+@pytest.mark.gpu
+def test_gradients_bf16_are_bf16_accurate():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fwd, errs = train_check.grad_errors("mini_ctr", "bf16", "cuda")
+    assert max(fwd.values()) < 4e-2
+    worst, med = train_check.summarize(errs, floor=1e-4)
+    assert med < 6e-2, (worst, med)
+
+
+@pytest.mark.gpu
+def test_gradients_with_droppath_masks():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    g = torch.Generator().manual_seed(3)
+    drop = [(torch.bernoulli(torch.full((4, 2), 0.6), generator=g) / 0.6) for _ in range(4)]
+    fwd, errs = train_check.grad_errors("mini_ctr", "x3", "cuda", drop=drop)
+    worst, med = train_check.summarize(errs)
+    assert max(fwd.values()) < 1e-3 and med < 1e-3, (worst, med)

@@ -76,3 +76,24 @@ def test_wiring_train_mode_batchnorm(emulated, name):
     for k in sd:
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert float((sd[k] - torch.from_numpy(gold[f"bn/{k}"])).abs().max()) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win"])
+def test_training_gradients_on_emulator(emulated, name):
+    """Every backward descriptor (dgrad/wgrad views, conv wgrad, attention bwd, modulation bwd, BN bwd, ...) on the
+    ABI emulator vs the oracle's autograd: all parameter gradients within 1e-3 relative."""
+    import train_check
+    fwd, errs = train_check.grad_errors(name, "x3", "cpu")
+    assert max(fwd.values()) < 5e-5
+    worst, med = train_check.summarize(errs)
+    assert worst[0] < 1e-3, worst
+
+
+def test_training_with_injected_droppath_masks(emulated):
+    import train_check
+    g = torch.Generator().manual_seed(3)
+    drop = [(torch.bernoulli(torch.full((4, 2), 0.6), generator=g) / 0.6) for _ in range(4)]
+    fwd, errs = train_check.grad_errors("mini_ctr", "x3", "cpu", drop=drop)
+    assert max(fwd.values()) < 5e-5
+    worst, med = train_check.summarize(errs)
+    assert worst[0] < 1e-3, worst

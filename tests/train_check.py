@@ -1,0 +1,36 @@
+"""Shared helper: one training step's forward + backward of the product vs the oracle's autograd."""
+import torch
+
+import conftest
+from oracle import configs, taskprompter_oracle as tpo, weights
+from tests.golden.make_golden import loss_of
+
+
+def grad_errors(name, prec, device, drop=None, seed=0):
+    cfg = configs.taskprompter(name)
+    meta, _ = conftest.load_golden(name)
+    sd = weights.synth_state_dict(meta["contract"], seed)
+    model = conftest.build_product_model(cfg, prec, device, drop_path_rate=0.3 if drop is not None else 0.0)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    x = weights.synth_images(2, cfg["img_size"], 2)
+    if drop is not None:
+        model.backbone._drop_override = drop
+    out = model(x.to(device))
+    loss_of({k: v.cpu() for k, v in out.items()}).backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    ref_out = tpo.forward(dict(sd, **params), cfg, x, training=True, drop=drop)
+    loss_of(ref_out).backward()
+    fwd = {t: float((out[t].detach().cpu() - ref_out[t].detach()).norm() / ref_out[t].detach().norm()) for t in ref_out}
+    errs = {}
+    for k, prm in model.named_parameters():
+        ref = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+        assert prm.grad is not None, f"{k}: no gradient (reference gives every TaskPrompter parameter one)"
+        errs[k] = (float((prm.grad.cpu() - ref).norm()), float(ref.norm()))
+    return fwd, errs
+
+
+def summarize(errs, floor=1e-6):
+    rel = sorted(((e / n, k) for k, (e, n) in errs.items() if n > floor), reverse=True)
+    med = rel[len(rel) // 2][0]
+    return rel[0], med
