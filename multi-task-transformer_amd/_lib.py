@@ -192,11 +192,11 @@ def call(name, **kw):
         if name in DESC_EXTRA:
             st, _ = DESC_EXTRA[name]
             desc = st()
-            extra = [(_addr(a) if isinstance(a, torch.Tensor) else a) for a in kw["extra"]]
+            extra = [(_addr(a) if isinstance(a, torch.Tensor) else a) for a in kw["xargs"]]
         else:
             desc = DESCS[name]()
         for k, v in kw.items():
-            if k == "extra":
+            if k == "xargs":
                 continue
             if k == "in":
                 k = "in_"

@@ -177,7 +177,7 @@ class ChanAttnFn(Function):
         dq2 = torch.zeros(B * T, hwp, dtype=torch.float32, device=xn.device)
         if drawchan is not None:
             ops.call("chan_logits_bwd", q=cq, xn=xn, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
-                     dtype=dtype_code(xn), ldq=hwp, extra=[drawchan.contiguous(), dq2, F32, dxn])
+                     dtype=dtype_code(xn), ldq=hwp, xargs=[drawchan.contiguous(), dq2, F32, dxn])
         dcq = dcq + dq2                                                    # [B*T, hwp] fp32 (tiny)
         xnp = xn.view(B, N, C)[:, :T].reshape(B * T, C)
         dWtt = _wgrad(dcq, xnp, hw, C, prec)
@@ -274,7 +274,7 @@ class ModulateFn(Function):
         dl, dc = torch.zeros_like(rawlog), torch.zeros_like(rawchan)
         ops.call("modulate_bwd", x=xsrc.view(B, N, C)[:, T:], x_ld=C, x_bs=N * C, rawlog=rawlog, rawchan=rawchan, out=None,
                  B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin, out_dtype=dtype_code(dmod),
-                 extra=[dmod, dx.view(B, N, C)[:, T:], dl, dc])
+                 xargs=[dmod, dx.view(B, N, C)[:, T:], dl, dc])
         return dx, dl, dc, None, None
 
 
@@ -385,7 +385,8 @@ class Conv3x3Fn(Function):
 
 
 def _sync_stats(t, bn):
-    if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    sync = isinstance(bn, nn.SyncBatchNorm) or getattr(bn, "_mtt_sync", False)   # _mtt_sync: CPU/gloo tests (DDP rejects SyncBN on CPU)
+    if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t)
         return dist.get_world_size()
     return 1
@@ -460,7 +461,7 @@ class CtrMixFn(Function):
         dfea = dfea32 if fea.dtype == torch.float32 else ops.cast2d(dfea32.view(T * rows, ld), T * rows, ld, ld, fea.dtype, ldd=ld).view(T, rows, ld)
         dw = torch.zeros_like(wmix)
         ops.call("ctr_dw", fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C, fea_dtype=dtype_code(fea),
-                 accumulate=0, extra=[dout, dw])
+                 accumulate=0, xargs=[dout, dw])
         return dfea, dw, (dout if had_acc else None), None, None
 
 

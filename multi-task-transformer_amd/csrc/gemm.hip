@@ -33,12 +33,12 @@ MTT_DEV int64_t row_off(uint32_t m, int mb, int64_t bs, int64_t ld, FastDiv f) {
 // ---------------------------------------------------------------------------------------------
 
 // reduction index contiguous in memory.  4 chunks of 8 elements per thread.
-template <bool X3, bool CONV>
+template <bool X3, bool CONV, bool F32>
 struct StagerK {
   const void* base; int dtype; int K; int c;
   int64_t roff[4]; bool rok[4];
   int py[4], px[4];                 // CONV: pixel coordinates of each row
-  u32x4 hi[4], lo[4];
+  Raw8<F32> raw[4]; unsigned okm;
 
   MTT_DEV void init(const GemmP& p, const void* b, int dt, int row0, int rows, int64_t ld, int mb, int64_t bs, FastDiv fmb) {
     base = b; dtype = dt; K = p.d.K; c = threadIdx.x & 7;
@@ -75,6 +75,7 @@ struct StagerK {
       dy = (ty - 1) * p.d.conv.dil; dx = (tx - 1) * p.d.conv.dil;
       koff = (int64_t)(dy * p.d.conv.W + dx) * ldx + ci;
     }
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bool ok = rok[i] && kok;
@@ -82,7 +83,8 @@ struct StagerK {
         const int yy = py[i] + dy, xx = px[i] + dx;
         ok = ok && yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W;
       }
-      load8<X3>(base, roff[i] + koff, dtype, ok, hi[i], lo[i]);
+      okm |= (ok ? 1u : 0u) << i;
+      load8_raw<F32>(base, roff[i] + koff, ok, raw[i]);
     }
   }
 
@@ -90,8 +92,10 @@ struct StagerK {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (threadIdx.x >> 3) + 32 * i;
-      *(u32x4*)(t_hi + lds_off(row, c)) = hi[i];
-      if (X3) *(u32x4*)(t_lo + lds_off(row, c)) = lo[i];
+      u32x4 hi, lo;
+      cvt8<X3, F32>((okm >> i) & 1u, raw[i], hi, lo);
+      *(u32x4*)(t_hi + lds_off(row, c)) = hi;
+      if (X3) *(u32x4*)(t_lo + lds_off(row, c)) = lo;
     }
   }
 };
@@ -99,12 +103,12 @@ struct StagerK {
 // row index contiguous in memory (transposed view): element(r, k) at base + k*ld + r.
 // Each thread owns a 4 (k) x 8 (rows) unit, transposes it in registers, writes 8 x 8-byte pieces.
 // CONV: B operand of the 3x3 wgrad — k = pixel, r = (tap, ci): base + pixel_shifted*ld + ci.
-template <bool X3, bool CONV>
+template <bool X3, bool CONV, bool F32>
 struct StagerR {
   const void* base; int dtype; int K; int kq, rb;
   int64_t roff; bool rok; int64_t ld;
   int dy, dx;
-  u32x4 hi[4], lo[4];
+  Raw8<F32> raw[4]; unsigned okm;
 
   MTT_DEV void init(const GemmP& p, const void* b, int dt, int row0, int rows, int64_t ld_) {
     base = b; dtype = dt; K = p.d.K; ld = ld_;
@@ -124,6 +128,7 @@ struct StagerR {
   }
 
   MTT_DEV void load(const GemmP& p, int k0) {
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + kq * 4 + i;
@@ -137,11 +142,15 @@ struct StagerR {
         const int yy = y + dy, xx = x + dx;
         ok = ok && yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W;
       }
-      load8<X3>(base, (int64_t)k * ld + roff, dtype, ok, hi[i], lo[i]);
+      okm |= (ok ? 1u : 0u) << i;
+      load8_raw<F32>(base, (int64_t)k * ld + roff, ok, raw[i]);
     }
   }
 
   MTT_DEV void store(unsigned char* t_hi, unsigned char* t_lo) const {
+    u32x4 hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cvt8<X3, F32>((okm >> i) & 1u, raw[i], hi[i], lo[i]);
     u32x2 piece[8];
     transpose4x8(hi, piece);
 #pragma unroll
@@ -160,11 +169,11 @@ struct StagerR {
   }
 };
 
-template <int OP, bool X3> struct StagerSel;
-template <bool X3> struct StagerSel<MTT_OP_K, X3> { typedef StagerK<X3, false> type; };
-template <bool X3> struct StagerSel<MTT_OP_CONV_K, X3> { typedef StagerK<X3, true> type; };
-template <bool X3> struct StagerSel<MTT_OP_R, X3> { typedef StagerR<X3, false> type; };
-template <bool X3> struct StagerSel<MTT_OP_CONV_R, X3> { typedef StagerR<X3, true> type; };
+template <int OP, bool X3, bool F32> struct StagerSel;
+template <bool X3, bool F32> struct StagerSel<MTT_OP_K, X3, F32> { typedef StagerK<X3, false, F32> type; };
+template <bool X3, bool F32> struct StagerSel<MTT_OP_CONV_K, X3, F32> { typedef StagerK<X3, true, F32> type; };
+template <bool X3, bool F32> struct StagerSel<MTT_OP_R, X3, F32> { typedef StagerR<X3, false, F32> type; };
+template <bool X3, bool F32> struct StagerSel<MTT_OP_CONV_R, X3, F32> { typedef StagerR<X3, true, F32> type; };
 
 template <int OP, bool X3, typename S>
 MTT_DEV void stager_init_a(S& s, const GemmP& p, const void* base, int row0) {
@@ -182,8 +191,10 @@ MTT_DEV void stager_init_b(S& s, const GemmP& p, const void* base, int row0) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int AOP, int BOP, bool X3>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+// MODE: 0 = bf16 MFMA, A and B bf16;  1 = bf16 MFMA, A f32 (converted while staging), B bf16;  2 = X3 (both f32)
+template <int AOP, int BOP, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
+  constexpr bool X3 = MODE == 2, AF32 = MODE >= 1, BF32 = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPL = X3 ? 2 : 1;
   constexpr int STAGE = TILE_BYTES * 2 * NPL;   // A planes then B planes
@@ -198,8 +209,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const void* Abase = (const unsigned char*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi) * esA;
   const void* Bbase = (const unsigned char*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi) * esB;
 
-  typename StagerSel<AOP, X3>::type sa;
-  typename StagerSel<BOP, X3>::type sb;
+  typename StagerSel<AOP, X3, AF32>::type sa;
+  typename StagerSel<BOP, X3, BF32>::type sb;
   stager_init_a<AOP, X3>(sa, p, Abase, m0);
   stager_init_b<BOP, X3>(sb, p, Bbase, n0);
 
@@ -231,29 +242,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const unsigned char* Al = st + TILE_BYTES;
     const unsigned char* Bh = st + TILE_BYTES * NPL;
     const unsigned char* Bl = Bh + TILE_BYTES;
+    if constexpr (!X3) {
+      // all 16 fragment reads of this K step are issued before the 32 MFMAs (the compiler then places
+      // counted lgkmcnt waits, so LDS latency overlaps the first MFMAs instead of stalling every group)
+      u32x4 fa[2][4], fb[2][4];
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      u32x4 ah[4], al[4], bh[4], bl[4];
+      for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ra = wm * 64 + t * 16 + li, rbn = wn * 64 + t * 16 + li;
-        ah[t] = *(const u32x4*)(Ah + lds_off(ra, kh * 4 + lg));
-        bh[t] = *(const u32x4*)(Bh + lds_off(rbn, kh * 4 + lg));
-        if (X3) {
+        for (int t = 0; t < 4; ++t) {
+          fa[kh][t] = *(const u32x4*)(Ah + lds_off(wm * 64 + t * 16 + li, kh * 4 + lg));
+          fb[kh][t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[kh][a], fb[kh][b], acc[a][b]);
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        u32x4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ra = wm * 64 + t * 16 + li, rbn = wn * 64 + t * 16 + li;
+          ah[t] = *(const u32x4*)(Ah + lds_off(ra, kh * 4 + lg));
+          bh[t] = *(const u32x4*)(Bh + lds_off(rbn, kh * 4 + lg));
           al[t] = *(const u32x4*)(Al + lds_off(ra, kh * 4 + lg));
           bl[t] = *(const u32x4*)(Bl + lds_off(rbn, kh * 4 + lg));
         }
-      }
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (X3) {
+          for (int b = 0; b < 4; ++b) {
             acc[a][b] = mfma16(al[a], bh[b], acc[a][b]);
             acc[a][b] = mfma16(ah[a], bl[b], acc[a][b]);
+            acc[a][b] = mfma16(ah[a], bh[b], acc[a][b]);
           }
-          acc[a][b] = mfma16(ah[a], bh[b], acc[a][b]);
-        }
+      }
     }
 
     if (more) {
@@ -265,78 +292,140 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
 
   // ------------------------------- epilogue --------------------------------------------------
+  // Accumulators go through LDS (two 64-row halves, [64][132] fp32) so that every thread owns 8 consecutive
+  // columns of a row: column constants are loaded once, row addressing once per 8 outputs, and D / resid / aux
+  // are moved with coalesced 16/32-byte accesses.
   const mtt_gemm_desc& d = p.d;
   const int64_t zcol = (int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi;
   const int64_t zD = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi;
   const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi;
   const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi;
   const int n_store = d.n_store > d.N ? d.n_store : d.N;
+  constexpr int EP_LD = 132;
+  float* const ep = (float*)smem;
 
-  float cs[4], sh[4]; int ncol[4];
+  const int c8 = threadIdx.x & 15;                 // this thread's 8-column chunk of the 128-wide tile
+  const int ncol0 = n0 + c8 * 8;
+  float cs[8], sh[8];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int n = n0 + wn * 64 + b * 16 + li;
-    ncol[b] = n;
+  for (int j = 0; j < 8; ++j) {
+    const int n = ncol0 + j;
     const bool nv = n < d.N;
-    cs[b] = (d.colscale && nv) ? d.colscale[zcol + n] : 1.0f;
-    sh[b] = (d.colshift && nv) ? d.colshift[zcol + n] : 0.0f;
+    cs[j] = (d.colscale && nv) ? d.colscale[zcol + n] : 1.0f;
+    sh[j] = (d.colshift && nv) ? d.colshift[zcol + n] : 0.0f;
   }
+  const bool full_chunk = ncol0 + 8 <= d.N && d.store_mode == MTT_STORE_ROWS;
 
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wm * 64 + a * 16 + lg * 4 + r;
-      if (m >= d.M) continue;
-      int64_t doff, auxoff = 0, roff = 0;
-      float rs = 1.0f;
-      if (d.store_mode == MTT_STORE_PIXSHUF2) {
-        doff = 0;   // resolved per column below
-      } else {
-        doff = zD + row_off((uint32_t)m, d.d_mb, d.d_bs, d.ldd, p.divDmb);
-      }
-      if (d.aux_in || d.aux_out) {
-        // aux rows are mapped like D but with their own leading dimension
-        if (d.d_mb > 0) { const uint32_t q = fdiv((uint32_t)m, p.divDmb); auxoff = zAux + ((int64_t)q * d.d_mb + (m - q * d.d_mb)) * d.ldaux; }
-        else auxoff = zAux + (int64_t)m * d.ldaux;
-      }
-      if (d.resid) roff = zR + row_off((uint32_t)m, d.r_mb, d.r_bs, d.ldr, p.divRmb);
-      if (d.rowscale) {
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ep[(a * 16 + lg * 4 + r) * EP_LD + wn * 64 + b * 16 + li] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (ncol0 < n_store || (d.store_mode == MTT_STORE_PIXSHUF2 && ncol0 < d.N)) {
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int rl = (threadIdx.x >> 4) + 16 * i;
+        const int m = m0 + half * 64 + rl;
+        if (m >= d.M) continue;
+        float v[8];
+        {
+          const float4 lo4 = *(const float4*)(ep + rl * EP_LD + c8 * 8);
+          const float4 hi4 = *(const float4*)(ep + rl * EP_LD + c8 * 8 + 4);
+          v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+        }
         uint32_t q = 0, rem = (uint32_t)m;
         if (d.d_mb > 0) { q = fdiv((uint32_t)m, p.divDmb); rem = m - q * d.d_mb; }
-        rs = d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)];
-      }
+        const int64_t doff = zD + (d.d_mb > 0 ? (int64_t)q * d.d_bs + (int64_t)rem * d.ldd : (int64_t)m * d.ldd) + ncol0;
+        const int64_t auxoff = zAux + (int64_t)m * d.ldaux + ncol0;
+        const float rs = d.rowscale ? d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)] : 1.0f;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int n = ncol[b];
-        if (n >= n_store) continue;
-        float v = 0.0f;
-        if (n < d.N) {
-          v = acc[a][b][r] * d.alpha;
-          v = v * cs[b] + sh[b];
-          if (d.aux_out) st_elem(d.aux_out, auxoff + n, d.aux_dtype, v);
-          if (d.act == MTT_ACT_GELU) v = gelu_f(v);
-          else if (d.act == MTT_ACT_RELU) v = fmaxf(v, 0.0f);
-          else if (d.act == MTT_ACT_GELU_BWD) v *= gelu_grad_f(ld_elem(d.aux_in, auxoff + n, d.aux_dtype));
-          else if (d.act == MTT_ACT_RELU_BWD) v = ld_elem(d.aux_in, auxoff + n, d.aux_dtype) > 0.0f ? v : 0.0f;
-          v *= rs;
-          if (d.resid) v += d.resid[roff + n];
-        }
-        if (d.store_mode == MTT_STORE_PIXSHUF2) {
-          if (n >= d.N) continue;
-          const uint32_t q = fdiv((uint32_t)n, p.divPsCo);
-          const int co = n - (int)q * d.ps_Co;
-          const uint32_t t = fdiv((uint32_t)m, p.divPsW);
-          const int x = m - (int)t * d.ps_W;
-          const uint32_t bb = fdiv(t, p.divPsH);
-          const int y = (int)t - (int)bb * d.ps_H;
-          const int64_t orow = ((int64_t)bb * (2 * d.ps_H) + 2 * y + (int)(q >> 1)) * (2 * d.ps_W) + 2 * x + (int)(q & 1);
-          st_elem(d.D, zD + orow * d.ldd + co, d.d_dtype, v);
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha * cs[j] + sh[j];
+        if (full_chunk) {
+          if (d.aux_out) {
+            if (d.aux_dtype == MTT_F32) {
+              *(float4*)((float*)d.aux_out + auxoff) = make_float4(v[0], v[1], v[2], v[3]);
+              *(float4*)((float*)d.aux_out + auxoff + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              *(u32x4*)((bf16_t*)d.aux_out + auxoff) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            }
+          }
+          if (d.act == MTT_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+          } else if (d.act == MTT_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
+          } else if (d.act == MTT_ACT_GELU_BWD || d.act == MTT_ACT_RELU_BWD) {
+            float z[8];
+            if (d.aux_dtype == MTT_F32) {
+              const float4 z0 = *(const float4*)((const float*)d.aux_in + auxoff);
+              const float4 z1 = *(const float4*)((const float*)d.aux_in + auxoff + 4);
+              z[0] = z0.x; z[1] = z0.y; z[2] = z0.z; z[3] = z0.w; z[4] = z1.x; z[5] = z1.y; z[6] = z1.z; z[7] = z1.w;
+            } else {
+              const u32x4 u = *(const u32x4*)((const bf16_t*)d.aux_in + auxoff);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { z[2 * t] = lo_of(u[t]); z[2 * t + 1] = hi_of(u[t]); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = d.act == MTT_ACT_GELU_BWD ? v[j] * gelu_grad_f(z[j]) : (z[j] > 0.0f ? v[j] : 0.0f);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= rs;
+          if (d.resid) {
+            const int64_t roff = zR + row_off((uint32_t)m, d.r_mb, d.r_bs, d.ldr, p.divRmb) + ncol0;
+            const float4 r0 = *(const float4*)(d.resid + roff);
+            const float4 r1 = *(const float4*)(d.resid + roff + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+          }
+          if (d.d_dtype == MTT_F32) {
+            *(float4*)((float*)d.D + doff) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)((float*)d.D + doff + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            *(u32x4*)((bf16_t*)d.D + doff) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+          }
         } else {
-          st_elem(d.D, doff + n, d.d_dtype, v);
+          // ragged chunk (N tail / channel padding) or pixel-shuffle store: element by element
+          int64_t roff = 0;
+          if (d.resid) roff = zR + row_off((uint32_t)m, d.r_mb, d.r_bs, d.ldr, p.divRmb) + ncol0;
+#pragma unroll 1
+          for (int j = 0; j < 8; ++j) {
+            const int n = ncol0 + j;
+            float w = 0.0f;
+            if (n < d.N) {
+              w = v[j];
+              if (d.aux_out) st_elem(d.aux_out, auxoff + j, d.aux_dtype, w);
+              if (d.act == MTT_ACT_GELU) w = gelu_f(w);
+              else if (d.act == MTT_ACT_RELU) w = fmaxf(w, 0.0f);
+              else if (d.act == MTT_ACT_GELU_BWD) w *= gelu_grad_f(ld_elem(d.aux_in, auxoff + j, d.aux_dtype));
+              else if (d.act == MTT_ACT_RELU_BWD) w = ld_elem(d.aux_in, auxoff + j, d.aux_dtype) > 0.0f ? w : 0.0f;
+              w *= rs;
+              if (d.resid) w += d.resid[roff + j];
+            }
+            if (d.store_mode == MTT_STORE_PIXSHUF2) {
+              if (n >= d.N) continue;
+              const uint32_t qq = fdiv((uint32_t)n, p.divPsCo);
+              const int co = n - (int)qq * d.ps_Co;
+              const uint32_t t = fdiv((uint32_t)m, p.divPsW);
+              const int x = m - (int)t * d.ps_W;
+              const uint32_t bb = fdiv(t, p.divPsH);
+              const int y = (int)t - (int)bb * d.ps_H;
+              const int64_t orow = ((int64_t)bb * (2 * d.ps_H) + 2 * y + (int)(qq >> 1)) * (2 * d.ps_W) + 2 * x + (int)(qq & 1);
+              st_elem(d.D, zD + orow * d.ldd + co, d.d_dtype, w);
+            } else if (n < n_store) {
+              st_elem(d.D, doff + j, d.d_dtype, w);
+            }
+          }
         }
       }
     }
+    __syncthreads();
   }
 }
 
@@ -348,17 +437,17 @@ FastDiv make_div(uint32_t dv) {
   return f;
 }
 
-template <int AOP, int BOP, bool X3>
+template <int AOP, int BOP, int MODE>
 int launch(const GemmP& p, hipStream_t stream) {
-  constexpr int smem = TILE_BYTES * 2 * (X3 ? 2 : 1) * 2;
+  constexpr int smem = TILE_BYTES * 2 * (MODE == 2 ? 2 : 1) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AOP, BOP, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AOP, BOP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.d.batch);
-  hipLaunchKernelGGL((gemm_kernel<AOP, BOP, X3>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<AOP, BOP, MODE>), grid, dim3(256), smem, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -397,7 +486,9 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if ((d.lda % 8) || (d.ldb % 8)) return MTT_E_ALIGN;
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return MTT_E_ALIGN;
   if (d.prec == MTT_PREC_X3 && (d.a_dtype != MTT_F32 || d.b_dtype != MTT_F32)) return MTT_E_UNSUPPORTED;
-  if ((d.aux_in || d.aux_out) && d.ldaux <= 0) return MTT_E_BADARG;
+  if ((d.aux_in || d.aux_out) && (d.ldaux <= 0 || (d.ldaux % 8))) return MTT_E_BADARG;
+  if ((d.ldd % 8) || ((uintptr_t)d.D & 15) || (d.d_bs % 8) || (d.d_zo % 8) || (d.d_zi % 8)) return MTT_E_ALIGN;
+  if (d.resid && ((d.ldr % 4) || ((uintptr_t)d.resid & 15) || (d.r_bs % 4))) return MTT_E_ALIGN;
   const bool conv = d.a_op == MTT_OP_CONV_K || d.b_op == MTT_OP_CONV_R;
   if (conv) {
     if (d.conv.H <= 0 || d.conv.W <= 0 || d.conv.Cp % 8 || d.conv.C > d.conv.Cp || d.conv.dil < 1) return MTT_E_BADARG;
@@ -413,9 +504,13 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   p.divPsCo = make_div(d.ps_Co > 0 ? d.ps_Co : 1);
   p.tiles_m = (d.M + BM - 1) / BM; p.tiles_n = (d.N + BN - 1) / BN;
   hipStream_t s = (hipStream_t)stream;
-  const bool x3 = d.prec == MTT_PREC_X3;
+  int mode;
+  if (d.prec == MTT_PREC_X3) mode = 2;
+  else if (d.b_dtype != MTT_BF16) return MTT_E_UNSUPPORTED;      /* bf16 mode: B must be bf16 (A may be f32) */
+  else mode = d.a_dtype == MTT_F32 ? 1 : 0;
 #define MTT_CASE(AO, BO) \
-  if (d.a_op == AO && d.b_op == BO) return x3 ? launch<AO, BO, true>(p, s) : launch<AO, BO, false>(p, s);
+  if (d.a_op == AO && d.b_op == BO) \
+    return mode == 2 ? launch<AO, BO, 2>(p, s) : (mode == 1 ? launch<AO, BO, 1>(p, s) : launch<AO, BO, 0>(p, s));
   MTT_CASE(MTT_OP_K, MTT_OP_K)
   MTT_CASE(MTT_OP_K, MTT_OP_R)
   MTT_CASE(MTT_OP_R, MTT_OP_R)

@@ -66,6 +66,43 @@ MTT_DEV void load8(const void* base, int64_t idx, int dtype, bool ok, u32x4& hi,
   }
 }
 
+// Raw 8-element fetch for the register stagers: branch-free (invalid chunks read element 0 of the tensor
+// and are zeroed at conversion time), conversion / X3 split deferred so that all loads of a K step are
+// in flight together.  The source dtype is a compile-time parameter (bf16: 16 B, f32: 32 B per chunk).
+template <bool F32> struct Raw8;
+template <> struct Raw8<false> { u32x4 r0; };
+template <> struct Raw8<true> { u32x4 r0, r1; };
+
+template <bool F32>
+MTT_DEV void load8_raw(const void* base, int64_t idx, bool ok, Raw8<F32>& r) {
+  idx = ok ? idx : 0;
+  if constexpr (F32) {
+    r.r0 = *(const u32x4*)((const float*)base + idx);
+    r.r1 = *(const u32x4*)((const float*)base + idx + 4);
+  } else {
+    r.r0 = *(const u32x4*)((const bf16_t*)base + idx);
+  }
+}
+template <bool X3, bool F32>
+MTT_DEV void cvt8(bool ok, const Raw8<F32>& r, u32x4& hi, u32x4& lo) {
+  const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+  if (X3) lo = zero;
+  if constexpr (!F32) {
+    hi = ok ? r.r0 : zero;
+  } else {
+    const float f0 = __builtin_bit_cast(float, r.r0.x), f1 = __builtin_bit_cast(float, r.r0.y), f2 = __builtin_bit_cast(float, r.r0.z),
+                f3 = __builtin_bit_cast(float, r.r0.w), f4 = __builtin_bit_cast(float, r.r1.x), f5 = __builtin_bit_cast(float, r.r1.y),
+                f6 = __builtin_bit_cast(float, r.r1.z), f7 = __builtin_bit_cast(float, r.r1.w);
+    hi = (u32x4){pack2(f0, f1), pack2(f2, f3), pack2(f4, f5), pack2(f6, f7)};
+    if (X3) {
+      lo = (u32x4){pack2(f0 - lo_of(hi.x), f1 - hi_of(hi.x)), pack2(f2 - lo_of(hi.y), f3 - hi_of(hi.y)),
+                   pack2(f4 - lo_of(hi.z), f5 - hi_of(hi.z)), pack2(f6 - lo_of(hi.w), f7 - hi_of(hi.w))};
+      lo = ok ? lo : zero;
+    }
+    hi = ok ? hi : zero;
+  }
+}
+
 // 4 (k) x 8 (row) block held as 4 packed rows -> 8 pieces of 4 k-consecutive bf16 (one per row)
 MTT_DEV void transpose4x8(const u32x4 (&in)[4], u32x2 (&out)[8]) {
 #pragma unroll

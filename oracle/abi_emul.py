@@ -426,7 +426,7 @@ def add_rows(args):
 
 
 def modulate_bwd(**kw):
-    dout, dx, drawlog, drawchan = kw["extra"]
+    dout, dx, drawlog, drawchan = kw["xargs"]
     B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
     hw, nH, nwin = h * w, Cn // 64, nh * nw
     xi = torch.arange(B)[:, None, None] * kw["x_bs"] + torch.arange(hw)[None, :, None] * kw["x_ld"] + torch.arange(Cn)[None, None, :]
@@ -452,7 +452,7 @@ def modulate_bwd(**kw):
 
 
 def chan_logits_bwd(**kw):
-    drawchan, dq, dq_dtype, dxn = kw["extra"]
+    drawchan, dq, dq_dtype, dxn = kw["xargs"]
     B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
     hw, nwin = h * w, nh * nw
     f, o = flat(kw["xn"]); xn = f[o:o + B * N * Cn].double().view(B, N, Cn)[:, T:]
@@ -468,7 +468,7 @@ def chan_logits_bwd(**kw):
 
 
 def ctr_dw(**kw):
-    dout, dw = kw["extra"]
+    dout, dw = kw["xargs"]
     T, B, rpb, ld, Cn = kw["T"], kw["B"], kw["rows_per_b"], kw["ld"], kw["C"]
     rows = B * rpb
     C8 = (Cn + 7) // 8 * 8

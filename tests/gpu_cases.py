@@ -43,7 +43,7 @@ def run_case(name, kw, outputs, tol):
             gpu_store[key] = (flat.clone().cuda(), flat)
         return gpu_store[key][0].as_strided(t.size(), t.stride(), t.storage_offset())
 
-    for lk in ("args", "extra"):
+    for lk in ("args", "xargs"):
         if lk in kw:
             gpu_kw[lk] = [to_gpu(a) if isinstance(a, torch.Tensor) else a for a in kw[lk]]
     for k, t in tensors.items():
@@ -88,8 +88,15 @@ def gemm_cases():
         return kw
 
     # 1. plain NT, several tiles, ragged M/N/K tails
-    for prec, adt, ddt, tag in ((0, BF16, BF16, "bf16"), (0, F32, F32, "bf16-f32io"), (1, F32, F32, "x3")):
-        cases.append((f"gemm_plain_{tag}", "gemm", base(200, 150, 136, adt, adt, ddt, prec), TOL_X3 if prec else TOL_BF))
+    for prec, adt, bdt, ddt, tag in ((0, BF16, BF16, BF16, "bf16"), (0, F32, BF16, F32, "bf16-f32A"), (1, F32, F32, F32, "x3")):
+        cases.append((f"gemm_plain_{tag}", "gemm", base(200, 150, 136, adt, bdt, ddt, prec), TOL_X3 if prec else TOL_BF))
+    # f32 A operand (converted while staging) in the transposed layouts used by dgrad / wgrad of the fp32 residual-stream gradient
+    kw = dict(A=rnd(g, 203, 72), B=rnd(g, 203, 40, dtype=torch.bfloat16), D=torch.zeros(72, 40), M=72, N=40, K=203, a_op=OP_R, b_op=OP_R,
+              a_dtype=F32, b_dtype=BF16, d_dtype=F32, prec=0, lda=72, ldb=40, ldd=40, batch=1, batch_inner=1, alpha=1.0)
+    cases.append(("gemm_wgrad_f32A_bf16", "gemm", kw, TOL_BF))
+    kw = dict(A=rnd(g, 90, 72), B=rnd(g, 72, 136, dtype=torch.bfloat16), D=torch.zeros(90, 136, dtype=torch.bfloat16), M=90, N=136, K=72,
+              a_op=OP_K, b_op=OP_R, a_dtype=F32, b_dtype=BF16, d_dtype=BF16, prec=0, lda=72, ldb=136, ldd=136, batch=1, batch_inner=1, alpha=1.0)
+    cases.append(("gemm_dgrad_f32A_bf16", "gemm", kw, TOL_BF))
     # 2. asymmetric identity check (A = I) catches transposed C layout
     kw = base(128, 128, 128, F32, F32, F32, 1)
     kw["A"] = torch.eye(128, 136)
@@ -234,16 +241,16 @@ def row_cases():
             dXT = rnd(g, B, N, C)
             kw = dict(x=XT[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // 64, T, N), rawchan=rnd(g, B, T, nh * nh, C),
                       out=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt,
-                      extra=[rnd(g, 2 * T, B * h * w, C, dtype=DT[dt]), dXT[:, T:], torch.zeros(B, C // 64, T, N), torch.zeros(B, T, nh * nh, C)])
+                      xargs=[rnd(g, 2 * T, B * h * w, C, dtype=DT[dt]), dXT[:, T:], torch.zeros(B, C // 64, T, N), torch.zeros(B, T, nh * nh, C)])
             cases.append((f"modulate_bwd_{dt}_win{nh}", "modulate_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
             kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=None,
                       B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, dtype=dt, ldq=ldq,
-                      extra=[rnd(g, B, T, nh * nh, C), torch.zeros(B * T, ldq, dtype=DT[dt]), dt, rnd(g, B * N, C)])
+                      xargs=[rnd(g, B, T, nh * nh, C), torch.zeros(B * T, ldq, dtype=DT[dt]), dt, rnd(g, B * N, C)])
             cases.append((f"chanlogit_bwd_{dt}_win{nh}", "chan_logits_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
         T, B, rpb, ld, C = 6, 2, 300, 56, 52
         fea = rnd(g, T, B * rpb, ld, dtype=DT[dt]); fea[..., C:] = 0
         kw = dict(fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rpb, ld=ld, C=C, fea_dtype=dt, accumulate=0,
-                  extra=[rnd(g, T, B * rpb, ld), torch.zeros(B, T, T)])
+                  xargs=[rnd(g, T, B * rpb, ld), torch.zeros(B, T, T)])
         cases.append((f"ctr_dw_{dt}", "ctr_dw", kw, dict(f32=2e-5, bf16=5e-3)))
         cases.append((f"rowscale_cast_{dt}", "rowscale_cast",
                       dict(args=[rnd(g, 2 * 13, 24), torch.zeros(26, 32, dtype=DT[dt]), 26, 20, 24, 32, F32, dt,
