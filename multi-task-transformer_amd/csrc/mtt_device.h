@@ -71,14 +71,14 @@ MTT_DEV void load8(const void* base, int64_t idx, int dtype, bool ok, u32x4& hi,
 // in flight together.  The source dtype is a compile-time parameter (bf16: 16 B, f32: 32 B per chunk).
 template <bool F32> struct Raw8;
 template <> struct Raw8<false> { u32x4 r0; };
-template <> struct Raw8<true> { u32x4 r0, r1; };
+template <> struct Raw8<true> { float4 v0, v1; };
 
 template <bool F32>
 MTT_DEV void load8_raw(const void* base, int64_t idx, bool ok, Raw8<F32>& r) {
   idx = ok ? idx : 0;
   if constexpr (F32) {
-    r.r0 = *(const u32x4*)((const float*)base + idx);
-    r.r1 = *(const u32x4*)((const float*)base + idx + 4);
+    r.v0 = *(const float4*)((const float*)base + idx);
+    r.v1 = *(const float4*)((const float*)base + idx + 4);
   } else {
     r.r0 = *(const u32x4*)((const bf16_t*)base + idx);
   }
@@ -90,9 +90,7 @@ MTT_DEV void cvt8(bool ok, const Raw8<F32>& r, u32x4& hi, u32x4& lo) {
   if constexpr (!F32) {
     hi = ok ? r.r0 : zero;
   } else {
-    const float f0 = __builtin_bit_cast(float, r.r0.x), f1 = __builtin_bit_cast(float, r.r0.y), f2 = __builtin_bit_cast(float, r.r0.z),
-                f3 = __builtin_bit_cast(float, r.r0.w), f4 = __builtin_bit_cast(float, r.r1.x), f5 = __builtin_bit_cast(float, r.r1.y),
-                f6 = __builtin_bit_cast(float, r.r1.z), f7 = __builtin_bit_cast(float, r.r1.w);
+    const float f0 = r.v0.x, f1 = r.v0.y, f2 = r.v0.z, f3 = r.v0.w, f4 = r.v1.x, f5 = r.v1.y, f6 = r.v1.z, f7 = r.v1.w;
     hi = (u32x4){pack2(f0, f1), pack2(f2, f3), pack2(f4, f5), pack2(f6, f7)};
     if (X3) {
       lo = (u32x4){pack2(f0 - lo_of(hi.x), f1 - hi_of(hi.x)), pack2(f2 - lo_of(hi.y), f3 - hi_of(hi.y)),

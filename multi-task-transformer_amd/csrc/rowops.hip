@@ -784,10 +784,15 @@ extern "C" int mtt_bn_stats(const mtt_bn_desc* d, void* stream) {
   return LAUNCH_OK();
 }
 extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream) {
-  mtt_bn_desc d = {}; d.dy = src; d.dsum = dst; d.rows = rows; d.C = cols; d.ld = ld; d.dtype = src_dtype;
-  int nblk, rpb; int e = colreduce_cfg(&d, nblk, rpb); if (e) return e;
-  if (!src || !dst) return MTT_E_BADARG;
-  hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 2 * ((d.C + 7) / 8) * 8 * sizeof(float), S_, d, rpb);
+  if (!src || !dst || rows <= 0 || cols <= 0 || (ld % 8)) return MTT_E_BADARG;
+  const int es = src_dtype == MTT_F32 ? 4 : 2;
+  for (int c0 = 0; c0 < cols; c0 += 2040) {             // 255 chunks of 8 columns per launch
+    mtt_bn_desc d = {};
+    d.dy = (const unsigned char*)src + (int64_t)c0 * es; d.dsum = dst + c0; d.rows = rows;
+    d.C = cols - c0 < 2040 ? cols - c0 : 2040; d.ld = ld; d.dtype = src_dtype;
+    int nblk, rpb; int e = colreduce_cfg(&d, nblk, rpb); if (e) return e;
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 2 * ((d.C + 7) / 8) * 8 * sizeof(float), S_, d, rpb);
+  }
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, void* stream) {
