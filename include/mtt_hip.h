@@ -95,7 +95,8 @@ typedef struct {
 } mtt_gemm_desc;
 
 int mtt_abi_version(void);
-/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom */
+/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom,
+ * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
 
@@ -206,6 +207,47 @@ int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, in
 int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream);
 int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype,
                  float alpha, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------------------
+ * InvPT decoder kernels (InvPT/models/transformers/invpt.py, transformer_decoder.py)
+ * --------------------------------------------------------------------------------------------------------- */
+/* Depthwise 3x3 stride-2 pad-1 conv, the query projection of invpt.py:124-138 (bias-free), Z tasks at once.
+ * x [Z, B*H*W, ld] -> y [Z, B*Ho*Wo, ld], Ho = (H-1)/2+1; w fp32 [Z, 9, ld] (tap-major); optional per-channel
+ * scale/shift [Z, ld] = eval BatchNorm folded in. */
+typedef struct {
+  const void* x; const float* w; void* y; const float* scale; const float* shift;
+  int32_t Z, B, H, W; int64_t ld; int32_t dtype;
+} mtt_dwconv_desc;
+int mtt_dwconv3x3s2(const mtt_dwconv_desc* d, void* stream);
+
+/* nn.AvgPool2d(kernel=stride=k, padding=0, ceil_mode=True) on NHWC (keys/values, invpt.py:139-149). */
+typedef struct { const void* x; void* y; int32_t B, H, W, k; int64_t ld; int32_t dtype; } mtt_pool_desc;
+int mtt_avgpool_ceil(const mtt_pool_desc* d, void* stream);
+
+/* LayerNorm over the concatenated channels of all T tasks (norm_mts, invpt.py:482,526): x fp32 [T, rows, ldx],
+ * gamma/beta fp32 [T*D] -> y [T, rows, ldy] (channels >= D written as zeros). */
+typedef struct {
+  const float* x; void* y; const float* gamma; const float* beta;
+  int64_t rows; int32_t T, D; int64_t ldx, ldy; int32_t y_dtype; float eps;
+} mtt_lnmt_desc;
+int mtt_layernorm_mt(const mtt_lnmt_desc* d, void* stream);
+
+/* Cross-stage attention message fusion (invpt.py:208-229): previous-stage scores upsampled x2 per task and mixed with
+ * the current scores by the 1x1 conv fuse_attn [heads, 2*heads].  cur/out fp32 [B, heads, T*qh*qw, ldk],
+ * prev fp32 [B, heads, T*(qh/2)*(qw/2), ldkp]; K valid key columns. */
+typedef struct {
+  const float* cur; const float* prev; float* out; const float* w; const float* bias;
+  int32_t B, heads, T, qh, qw, K; int64_t ldk, ldkp;
+} mtt_attnmsg_desc;
+int mtt_attn_msg(const mtt_attnmsg_desc* d, void* stream);
+
+/* Gather half of nn.ConvTranspose2d(k=3, s=2, p=1, output_padding=1) (scale_embed[0], transformer_decoder.py:64):
+ * yall [B*H*W, 9*Cop] = x @ Wall^T computed by mtt_gemm (column = tap*Cop + co) -> out [B*2H*2W, Cop] (+ bias[Cop]). */
+typedef struct {
+  const void* yall; void* out; const float* bias; int32_t B, H, W, Cop; int32_t dtype, out_dtype;
+} mtt_convt_desc;
+int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

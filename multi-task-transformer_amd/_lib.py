@@ -99,14 +99,41 @@ class BnDesc(C.Structure):
                 ("rows", i64), ("C", i32), ("ld", i64), ("dtype", i32), ("act", i32)]
 
 
+class DwconvDesc(C.Structure):
+    _fields_ = [("x", ptr), ("w", ptr), ("y", ptr), ("scale", ptr), ("shift", ptr),
+                ("Z", i32), ("B", i32), ("H", i32), ("W", i32), ("ld", i64), ("dtype", i32)]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [("x", ptr), ("y", ptr), ("B", i32), ("H", i32), ("W", i32), ("k", i32), ("ld", i64), ("dtype", i32)]
+
+
+class LnMtDesc(C.Structure):
+    _fields_ = [("x", ptr), ("y", ptr), ("gamma", ptr), ("beta", ptr), ("rows", i64), ("T", i32), ("D", i32),
+                ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32)]
+
+
+class AttnMsgDesc(C.Structure):
+    _fields_ = [("cur", ptr), ("prev", ptr), ("out", ptr), ("w", ptr), ("bias", ptr),
+                ("B", i32), ("heads", i32), ("T", i32), ("qh", i32), ("qw", i32), ("K", i32), ("ldk", i64), ("ldkp", i64)]
+
+
+class ConvtDesc(C.Structure):
+    _fields_ = [("yall", ptr), ("out", ptr), ("bias", ptr), ("B", i32), ("H", i32), ("W", i32), ("Cop", i32),
+                ("dtype", i32), ("out_dtype", i32)]
+
+
 # entry point -> (descriptor struct, size index in mtt_desc_size) ; None = positional-argument entry
 DESCS = {
     "gemm": GemmDesc, "attn_fwd": AttnDesc, "softmax_fwd": SoftmaxDesc, "softmax_bwd": SoftmaxDesc,
     "layernorm_fwd": LnDesc, "layernorm_bwd": LnDesc, "chan_logits": ChanLogitDesc, "modulate": ModulateDesc,
     "ctr_mix": CtrDesc, "bilinear_fwd": ResizeDesc, "bilinear_bwd": ResizeDesc,
     "bn_stats": BnDesc, "bn_apply": BnDesc, "bn_bwd_reduce": BnDesc, "bn_bwd_apply": BnDesc,
+    "dwconv3x3s2": DwconvDesc, "avgpool_ceil": PoolDesc, "layernorm_mt": LnMtDesc, "attn_msg": AttnMsgDesc,
+    "convt3x3s2_gather": ConvtDesc,
 }
-_SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom]
+_SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom,
+               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc]
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],

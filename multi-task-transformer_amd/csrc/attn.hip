@@ -17,8 +17,9 @@ constexpr int KTILE = KV * HD * 2;   // 8 KiB per bf16 plane
 
 struct AttnP { mtt_attn_desc d; };
 
-template <bool X3>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+// F32: storage dtype of qkv / out (compile time); X3 implies F32
+template <bool X3, bool F32>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPL = X3 ? 2 : 1;
   constexpr int STAGE = KTILE * 2 * NPL;            // K planes, then Vt planes
@@ -37,32 +38,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   {
     const int qrow = qb * QB + wave * 16 + li;
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-      load8<X3>(d.qkv, ((tok0 + qrow) * 3 + 0) * C + h * HD + kh * 32 + lg * 8, d.dtype, qrow < N, qh[kh], ql[kh]);
+    for (int kh = 0; kh < 2; ++kh) {
+      Raw8<F32> rq;
+      load8_raw<F32>(d.qkv, (tok0 + qrow) * 3 * C + h * HD + kh * 32 + lg * 8, qrow < N, rq);
+      cvt8<X3, F32>(qrow < N, rq, qh[kh], ql[kh]);
+    }
   }
 
   // ---- staging roles: waves 0,1 transpose V, waves 2,3 copy K --------------------------------
   const bool isV = tid < 128;
-  u32x4 sh[4], sl[4];
+  Raw8<F32> raw[4];
+  unsigned okm = 0;
   const int kq = tid & 15, rb = (tid >> 4) & 7;     // V: 4 keys x 8 d unit
   const int kt_ = tid - 128;                        // K: chunk id base
 
   auto stage_load = [&](int kv0) {
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (isV) {
-        const int key = kv0 + kq * 4 + i;
-        load8<X3>(d.qkv, ((tok0 + key) * 3 + 2) * C + h * HD + rb * 8, d.dtype, key < N, sh[i], sl[i]);
-      } else {
-        const int idx = kt_ + 128 * i, row = idx >> 3, c = idx & 7;
-        const int key = kv0 + row;
-        load8<X3>(d.qkv, ((tok0 + key) * 3 + 1) * C + h * HD + c * 8, d.dtype, key < N, sh[i], sl[i]);
-      }
+      // V: 4 keys x 8 d unit (transposed at store time);  K: 16-byte chunk (row = key, c = d chunk)
+      const int idx = kt_ + 128 * i;
+      const int key = isV ? kv0 + kq * 4 + i : kv0 + (idx >> 3);
+      const int col = isV ? 2 * C + rb * 8 : C + (idx & 7) * 8;
+      const bool ok = key < N;
+      okm |= (ok ? 1u : 0u) << i;
+      load8_raw<F32>(d.qkv, (tok0 + key) * 3 * C + col + h * HD, ok, raw[i]);
     }
   };
   auto stage_store = [&](unsigned char* st) {
     unsigned char* Kh = st;
     unsigned char* Vh = st + KTILE * NPL;
+    u32x4 sh[4], sl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cvt8<X3, F32>((okm >> i) & 1u, raw[i], sh[i], sl[i]);
     if (isV) {
       u32x2 piece[8];
       transpose4x8(sh, piece);
@@ -141,24 +149,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     }
     // ---- online softmax ----------------------------------------------------------------------
     float alpha[4];
+    const bool full_tile = kv0 + KV <= N;            // block-uniform: only the last key tile needs masking
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float mx = -INFINITY;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int key = kv0 + nt * 16 + li;
-        const float t = key < N ? s[nt][r] * sc2 : -INFINITY;
+        float t = s[nt][r] * sc2;
+        if (!full_tile) t = (kv0 + nt * 16 + li) < N ? t : -INFINITY;
         s[nt][r] = t;
         mx = fmaxf(mx, t);
       }
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
       const float m_new = fmaxf(m_run[r], mx);
-      alpha[r] = exp2f(m_run[r] - m_new);
+      alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const float pv = exp2f(s[nt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(s[nt][r] - m_new);
         s[nt][r] = pv;
         rs += pv;
       }
@@ -183,7 +192,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
         *(bf16_t*)(Pw + off) = ph;
         if (X3) *(bf16_t*)(Pw + PT + off) = f2bf(s[nt][r] - bf2f(ph));
       }
-    __syncthreads();
+    // Pw is private to this wave and a wave's LDS operations execute in issue order: no block barrier needed,
+    // only keep the compiler from moving the fragment reads above the stores.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     // ---- O += P V -----------------------------------------------------------------------------
 #pragma unroll
@@ -215,24 +227,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     const float inv = 1.0f / l_run[r];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      st_elem(d.out, (tok0 + qrow) * C + h * HD + dt * 16 + li, d.dtype, o[dt][r] * inv);
+      st_elem(d.out, (tok0 + qrow) * C + h * HD + dt * 16 + li, F32 ? MTT_F32 : MTT_BF16, o[dt][r] * inv);
     if (d.lse && li == 0)
       d.lse[((int64_t)b * d.nH + h) * N + qrow] = (m_run[r] + log2f(l_run[r])) * 0.6931471805599453f;
   }
 }
 
-template <bool X3>
+template <bool X3, bool F32>
 int launch_attn(const AttnP& p, hipStream_t s) {
   constexpr int NPL = X3 ? 2 : 1;
   constexpr int smem = 2 * (KTILE * 2 * NPL) + 4 * (16 * KV * 2) * NPL;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<X3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<X3, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   dim3 grid((p.d.N + QB - 1) / QB, p.d.nH, p.d.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<X3>), grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<X3, F32>), grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }
 
@@ -244,5 +256,6 @@ extern "C" int mtt_attn_fwd(const mtt_attn_desc* dd, void* stream) {
   if (dd->prec == MTT_PREC_X3 && dd->dtype != MTT_F32) return MTT_E_UNSUPPORTED;
   if ((uintptr_t)dd->qkv & 15) return MTT_E_ALIGN;
   AttnP p; p.d = *dd;
-  return dd->prec == MTT_PREC_X3 ? launch_attn<true>(p, (hipStream_t)stream) : launch_attn<false>(p, (hipStream_t)stream);
+  if (dd->prec == MTT_PREC_X3) return launch_attn<true, true>(p, (hipStream_t)stream);
+  return dd->dtype == MTT_F32 ? launch_attn<false, true>(p, (hipStream_t)stream) : launch_attn<false, false>(p, (hipStream_t)stream);
 }

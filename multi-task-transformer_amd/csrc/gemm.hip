@@ -468,6 +468,11 @@ extern "C" size_t mtt_desc_size(int which) {
     case 7: return sizeof(mtt_resize_desc);
     case 8: return sizeof(mtt_bn_desc);
     case 9: return sizeof(mtt_conv_geom);
+    case 10: return sizeof(mtt_dwconv_desc);
+    case 11: return sizeof(mtt_pool_desc);
+    case 12: return sizeof(mtt_lnmt_desc);
+    case 13: return sizeof(mtt_attnmsg_desc);
+    case 14: return sizeof(mtt_convt_desc);
     default: return 0;
   }
 }

@@ -79,8 +79,32 @@ def get_head(p, backbone_channels, task):
     raise NotImplementedError(p['head'])
 
 
+def get_invpt_backbone(p):
+    """InvPT/utils/common_config.py:12-25."""
+    from . import invpt
+    prec = p.get('mtt_prec', 'bf16')
+    if p['backbone'] == 'vitL':
+        backbone = invpt.vit_large_patch16_384(pretrained=False, drop_path_rate=p.get('drop_path_rate', 0.15), img_size=p.TRAIN.SCALE, prec=prec)
+        C = 1024
+    elif isinstance(p['backbone'], (tuple, list)):
+        C, depth, nH, select = p['backbone']
+        backbone = invpt._create_vision_transformer('custom', select_list=list(select), patch_size=16, embed_dim=C, depth=depth, num_heads=nH,
+                                                    drop_path_rate=p.get('drop_path_rate', 0.0), img_size=p.TRAIN.SCALE, prec=prec)
+    else:
+        raise NotImplementedError(p['backbone'])
+    p.backbone_channels = [C for _ in range(4)]
+    p.spatial_dim = [[p.TRAIN.SCALE[0] // 16, p.TRAIN.SCALE[1] // 16] for _ in range(4)]
+    p.final_embed_dim = p.embed_dim + p.PRED_OUT_NUM_CONSTANT
+    return backbone, p.backbone_channels
+
+
 def get_model(p):
-    """TaskPrompter/utils/common_config.py:76-90."""
+    """TaskPrompter/utils/common_config.py:76-90 and InvPT/utils/common_config.py:39-51."""
+    if p['model'] == 'TransformerNet':
+        from . import invpt
+        backbone, ch = get_invpt_backbone(p)
+        heads = torch.nn.ModuleDict({task: invpt.MLPHead(p.final_embed_dim, p.TASKS.NUM_OUTPUT[task]) for task in p.TASKS.NAMES})
+        return invpt.TransformerNet(p, backbone, ch, heads)
     if p['model'] == 'TaskPrompter':
         from . import taskprompter as tp
         backbone, ch = get_backbone(p)

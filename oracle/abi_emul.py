@@ -491,11 +491,83 @@ def rowscale_cast(args):
     _wr(dst, r * ldd + c, v)
 
 
+
+def dwconv3x3s2(**kw):
+    Z, B, H, W, ld = kw["Z"], kw["B"], kw["H"], kw["W"], kw["ld"]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = _rd(kw["x"], torch.arange(Z * B * H * W * ld)).view(Z * B, H, W, ld).permute(0, 3, 1, 2)
+    w = _rd(kw["w"], torch.arange(Z * 9 * ld)).view(Z, 3, 3, ld).permute(0, 3, 1, 2)            # [Z, ld, 3, 3]
+    ys = []
+    for z in range(Z):
+        y = torch.nn.functional.conv2d(x[z * B:(z + 1) * B], w[z][:, None], None, stride=2, padding=1, groups=ld)
+        if kw.get("scale") is not None:
+            sc = _rd(kw["scale"], z * ld + torch.arange(ld)); sh = _rd(kw["shift"], z * ld + torch.arange(ld))
+            y = y * sc[None, :, None, None] + sh[None, :, None, None]
+        ys.append(y.permute(0, 2, 3, 1).reshape(-1))
+    y = torch.cat(ys)
+    _wr(kw["y"], torch.arange(y.numel()), y)
+
+
+def avgpool_ceil(**kw):
+    B, H, W, k, ld = kw["B"], kw["H"], kw["W"], kw["k"], kw["ld"]
+    x = _rd(kw["x"], torch.arange(B * H * W * ld)).view(B, H, W, ld).permute(0, 3, 1, 2)
+    y = torch.nn.functional.avg_pool2d(x, k, k, 0, ceil_mode=True).permute(0, 2, 3, 1).reshape(-1)
+    _wr(kw["y"], torch.arange(y.numel()), y)
+
+
+def layernorm_mt(**kw):
+    rows, T, D, ldx, ldy = kw["rows"], kw["T"], kw["D"], kw["ldx"], kw["ldy"]
+    idx = (torch.arange(T)[:, None, None] * rows + torch.arange(rows)[None, :, None]) * ldx + torch.arange(D)[None, None, :]
+    x = _rd(kw["x"], idx)                                               # [T, rows, D]
+    cat = x.permute(1, 0, 2).reshape(rows, T * D)
+    mean = cat.mean(-1, keepdim=True); var = ((cat - mean) ** 2).mean(-1, keepdim=True)
+    y = (cat - mean) * torch.rsqrt(var + kw["eps"]) * _rd(kw["gamma"], torch.arange(T * D)) + _rd(kw["beta"], torch.arange(T * D))
+    y = y.view(rows, T, D).permute(1, 0, 2)
+    full = torch.zeros(T, rows, ldy, dtype=torch.float64); full[..., :D] = y
+    oi = (torch.arange(T)[:, None, None] * rows + torch.arange(rows)[None, :, None]) * ldy + torch.arange(ldy)[None, None, :]
+    _wr(kw["y"], oi, full)
+
+
+def attn_msg(**kw):
+    B, heads, T, qh, qw, K, ldk, ldkp = (kw[k] for k in ("B", "heads", "T", "qh", "qw", "K", "ldk", "ldkp"))
+    Q, sh, sw = T * qh * qw, qh // 2, qw // 2
+    Qp = T * sh * sw
+    ci = torch.arange(B * heads * Q)[:, None] * ldk + torch.arange(K)[None, :]
+    cur = _rd(kw["cur"], ci).view(B, heads, Q, K)
+    pi = torch.arange(B * heads * Qp)[:, None] * ldkp + torch.arange(K)[None, :]
+    prev = _rd(kw["prev"], pi).view(B, heads, T, sh, sw, K)
+    up = torch.nn.functional.interpolate(prev.permute(0, 1, 2, 5, 3, 4).reshape(B * heads * T, K, sh, sw), scale_factor=2,
+                                         mode="bilinear", align_corners=False)
+    up = up.view(B, heads, T, K, qh * qw).permute(0, 1, 2, 4, 3).reshape(B, heads, Q, K)
+    w = _rd(kw["w"], torch.arange(heads * 2 * heads)).view(heads, 2 * heads)
+    out = torch.einsum("oh,bhqk->boqk", w, torch.cat([cur, up], 1)) + _rd(kw["bias"], torch.arange(heads))[None, :, None, None]
+    _wr(kw["out"], ci, out.reshape(B * heads * Q, K))
+
+
+def convt3x3s2_gather(**kw):
+    B, H, W, Cop = kw["B"], kw["H"], kw["W"], kw["Cop"]
+    ya = _rd(kw["yall"], torch.arange(B * H * W * 9 * Cop)).view(B, H, W, 3, 3, Cop)
+    out = torch.zeros(B, 2 * H, 2 * W, Cop, dtype=torch.float64) + _rd(kw["bias"], torch.arange(Cop))
+    for ky in range(3):
+        for kx in range(3):
+            for iy in range(H):
+                oy = 2 * iy - 1 + ky
+                if oy < 0 or oy >= 2 * H:
+                    continue
+                for ix in range(W):
+                    ox = 2 * ix - 1 + kx
+                    if 0 <= ox < 2 * W:
+                        out[:, oy, ox] += ya[:, iy, ix, ky, kx]
+    _wr(kw["out"], torch.arange(out.numel()), out.reshape(-1))
+
+
 _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
               bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply,
-              modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw)
+              modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw,
+              dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
+              convt3x3s2_gather=convt3x3s2_gather)
 _POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast)
 
 

@@ -57,7 +57,7 @@ def invpt(name):
         "cfg4_5": dict(backbone="large", img_size=(512, 512), tasks=PASCAL5, embed_dim=512, pred_const=64, mtt_down=2),
         # BASELINE.json configs[0]: ViT-S built through the parametric constructor
         "cfg1": dict(backbone="small", img_size=(256, 256), tasks=NYUD2, embed_dim=512, pred_const=64, mtt_down=2),
-        "mini": dict(backbone="tiny", img_size=(128, 128), tasks=NYUD2, embed_dim=32, pred_const=8, mtt_down=2),
+        "mini": dict(backbone="tiny", img_size=(128, 64), tasks=NYUD2, embed_dim=32, pred_const=8, mtt_down=2),
     }[name]
     return dict(t, name=name, model="TransformerNet")
 

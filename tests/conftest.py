@@ -33,6 +33,12 @@ def build_product_model(cfg, prec, device="cpu", drop_path_rate=0.0):
     import mtt_amd
     from oracle import configs
     C, depth, nH, sel = configs.VIT[cfg["backbone"]]
+    if cfg["model"] == "TransformerNet":
+        p = mtt_amd.factory.make_p([t for t, _ in cfg["tasks"]], cfg["img_size"], model="TransformerNet", backbone=(C, depth, nH, sel),
+                                   head="mlp", embed_dim=cfg["embed_dim"], num_output=dict(cfg["tasks"]), prec=prec,
+                                   PRED_OUT_NUM_CONSTANT=cfg["pred_const"], mtt_resolution_downsample_rate=cfg["mtt_down"],
+                                   drop_path_rate=drop_path_rate)
+        return mtt_amd.factory.get_model(p).to(device)
     p = mtt_amd.factory.make_p([t for t, _ in cfg["tasks"]], cfg["img_size"], backbone=(C, depth, nH, sel), head=cfg["head"],
                                embed_dim=cfg["embed_dim"], final_embed_dim=cfg["final_embed_dim"], chan_nheads=cfg["chan_nheads"],
                                use_ctr=cfg["use_ctr"], num_output=dict(cfg["tasks"]), prec=prec, drop_path_rate=drop_path_rate)

@@ -22,7 +22,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import configs, ref_build, weights  # noqa: E402
 
-CASES = [("TP", "mini_ctr", 1), ("TP", "mini_win", 1), ("TP", "mini_deconv", 2), ("IP", "mini", 2)]
+CASES = [("TP", "mini_ctr", 1), ("TP", "mini_win", 1), ("TP", "mini_deconv", 2), ("IP", "mini", 1)]
+EVAL_STRIDE = {"mini": 2}      # InvPT also returns inter_preds: store every 2nd pixel to keep the fixture small
 
 
 def loss_of(out, seed=7):
@@ -51,12 +52,13 @@ def main(only=None):
         model.eval()
         with torch.no_grad():
             out = model(x)
+        es = EVAL_STRIDE.get(name, 1)
         for k, v in out.items():
             if k == "inter_preds":
                 for kk, vv in v.items():
-                    arrays[f"eval/inter/{kk}"] = vv.numpy()
+                    arrays[f"eval/inter/{kk}"] = vv[:, :, ::es, ::es].numpy()
             else:
-                arrays[f"eval/{k}"] = v.numpy()
+                arrays[f"eval/{k}"] = v[:, :, ::es, ::es].numpy()
         # train mode: batch statistics in BN, DropPath rate 0 (stochastic depth is not reproducible)
         model.train()
         x2 = weights.synth_images(2, cfg["img_size"], seed=2)
@@ -77,7 +79,7 @@ def main(only=None):
         for k, v in model.state_dict().items():
             if k.endswith("running_mean") or k.endswith("running_var"):
                 arrays[f"bn/{k}"] = v.numpy()
-        meta = dict(kind=kind, name=name, batch=batch, contract=contract, grad_stats=gstat,
+        meta = dict(kind=kind, name=name, batch=batch, eval_stride=es, contract=contract, grad_stats=gstat,
                     torch=torch.__version__)
         with open(os.path.join(HERE, f"{name}.json"), "w") as f:
             json.dump(meta, f)

@@ -301,5 +301,35 @@ def row_cases():
     return cases
 
 
+def invpt_cases():
+    cases = []
+    g = torch.Generator().manual_seed(14)
+    for dt in (F32, BF16):
+        Z, B, H, W, ld = 2, 2, 6, 4, 24
+        kw = dict(x=rnd(g, Z, B * H * W, ld, dtype=DT[dt]), w=rnd(g, Z, 9, ld), y=torch.zeros(Z, B * 3 * 2, ld, dtype=DT[dt]),
+                  scale=rnd(g, Z, ld), shift=rnd(g, Z, ld), Z=Z, B=B, H=H, W=W, ld=ld, dtype=dt)
+        cases.append((f"dwconv_{dt}", "dwconv3x3s2", kw, TOL_ROW))
+        kw = dict(kw, scale=None, shift=None, H=5, W=3, x=rnd(g, Z, B * 15, ld, dtype=DT[dt]), y=torch.zeros(Z, B * 3 * 2, ld, dtype=DT[dt]))
+        cases.append((f"dwconv_odd_{dt}", "dwconv3x3s2", kw, TOL_ROW))
+        for (H, W, k) in ((4, 6, 2), (5, 7, 4), (8, 8, 8)):
+            Ho, Wo = -(-H // k), -(-W // k)
+            kw = dict(x=rnd(g, 2 * H * W, 16, dtype=DT[dt]), y=torch.zeros(2 * Ho * Wo, 16, dtype=DT[dt]), B=2, H=H, W=W, k=k, ld=16, dtype=dt)
+            cases.append((f"avgpool_{dt}_{H}x{W}k{k}", "avgpool_ceil", kw, TOL_ROW))
+        T, rows, D = 3, 37, 20
+        kw = dict(x=rnd(g, T, rows, 24), y=torch.full((T, rows, 24), 3.0, dtype=DT[dt]), gamma=rnd(g, T * D), beta=rnd(g, T * D),
+                  rows=rows, T=T, D=D, ldx=24, ldy=24, y_dtype=dt, eps=1e-5)
+        cases.append((f"ln_mt_{dt}", "layernorm_mt", kw, TOL_ROW))
+        B, H, W, Cop = 2, 3, 4, 16
+        kw = dict(yall=rnd(g, B * H * W, 9 * Cop, dtype=DT[dt]), out=torch.zeros(B * 4 * H * W, Cop, dtype=DT[dt]), bias=rnd(g, Cop),
+                  B=B, H=H, W=W, Cop=Cop, dtype=dt, out_dtype=dt)
+        cases.append((f"convt_gather_{dt}", "convt3x3s2_gather", kw, TOL_ROW))
+    B, heads, T, qh, qw, K = 2, 2, 3, 4, 2, 9
+    Q = T * qh * qw
+    kw = dict(cur=rnd(g, B, heads, Q, 16), prev=rnd(g, B, heads, Q // 4, 16), out=torch.zeros(B, heads, Q, 16), w=rnd(g, heads, 2 * heads),
+              bias=rnd(g, heads), B=B, heads=heads, T=T, qh=qh, qw=qw, K=K, ldk=16, ldkp=16)
+    cases.append(("attn_msg", "attn_msg", kw, TOL_ROW))
+    return cases
+
+
 def all_cases():
-    return gemm_cases() + attn_cases() + row_cases()
+    return gemm_cases() + attn_cases() + row_cases() + invpt_cases()

@@ -68,3 +68,17 @@ def test_forward_matches_oracle_on_fresh_inputs_larger_batch():
         out = model(x.cuda())
     for t, _ in cfg["tasks"]:
         assert _rel(out[t].cpu(), ref[t]) < REL_TOL_X3, t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("x3", REL_TOL_X3), ("bf16", REL_TOL_BF16)])
+def test_invpt_forward_matches_reference_golden(prec, tol):
+    """InvPT (ViT taps + TransformerDecoder + InvPT stages + MLPHead): eval and train-mode forward vs the unmodified reference."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from test_host_cpu import _invpt_outputs_vs_golden
+    cfg = configs.invpt("mini")
+    meta, gold = conftest.load_golden("mini")
+    model = conftest.build_product_model(cfg, prec, "cuda")
+    model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=True)
+    _invpt_outputs_vs_golden(model, cfg, meta, gold, tol, device="cuda")

@@ -97,3 +97,30 @@ def test_training_with_injected_droppath_masks(emulated):
     assert max(fwd.values()) < 5e-5
     worst, med = train_check.summarize(errs)
     assert worst[0] < 1e-3, worst
+
+
+def _invpt_outputs_vs_golden(model, cfg, meta, gold, tol, device="cpu"):
+    es = meta["eval_stride"]
+    model.eval()
+    with torch.no_grad():
+        out = model(weights.synth_images(meta["batch"], cfg["img_size"], 1).to(device))
+    for t, _ in cfg["tasks"]:
+        for key, val in ((f"eval/{t}", out[t]), (f"eval/inter/{t}", out["inter_preds"][t])):
+            g = torch.from_numpy(gold[key])
+            assert float((val.cpu()[:, :, ::es, ::es] - g).norm() / g.norm()) < tol, key
+    model.train()
+    with torch.no_grad():
+        out = model(weights.synth_images(2, cfg["img_size"], 2).to(device))
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"train/{t}"])
+        assert float((out[t].cpu()[:, :, ::2, ::2] - g).norm() / g.norm()) < tol * 2, t
+
+
+@pytest.mark.parametrize("prec,tol", [("x3", 2e-5), ("bf16", 4e-2)])
+def test_invpt_contract_and_wiring_on_emulator(emulated, prec, tol):
+    cfg = configs.invpt("mini")
+    meta, gold = conftest.load_golden("mini")
+    model = conftest.build_product_model(cfg, prec)
+    assert [(k, list(v.shape)) for k, v in model.state_dict().items()] == [(k, list(s)) for k, s in meta["contract"]]
+    model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=True)
+    _invpt_outputs_vs_golden(model, cfg, meta, gold, tol)

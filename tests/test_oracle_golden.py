@@ -50,3 +50,24 @@ def test_oracle_train_forward_backward(name):
         if abs(gn - st[0]) > 2e-3 * max(st[0], 1e-6) + 1e-7:
             bad.append((k, gn, st[0]))
     assert not bad, bad[:5]
+
+
+def test_invpt_oracle_matches_reference_golden():
+    from oracle import invpt_oracle as ipo
+    cfg = configs.invpt("mini")
+    meta, gold = conftest.load_golden("mini")
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    es = meta["eval_stride"]
+    with torch.no_grad():
+        out = ipo.forward(sd, cfg, weights.synth_images(meta["batch"], cfg["img_size"], 1))
+        upd = {}
+        out_tr = ipo.forward(sd, cfg, weights.synth_images(2, cfg["img_size"], 2), training=True, bn_updates=upd)
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        assert float((out[t][:, :, ::es, ::es] - g).norm() / g.norm()) < 2e-5, t
+        g = torch.from_numpy(gold[f"eval/inter/{t}"])
+        assert float((out["inter_preds"][t][:, :, ::es, ::es] - g).norm() / g.norm()) < 2e-5, t
+        g = torch.from_numpy(gold[f"train/{t}"])
+        assert float((out_tr[t][:, :, ::2, ::2] - g).norm() / g.norm()) < 2e-5, t
+    for k, v in upd.items():
+        assert float((v - torch.from_numpy(gold[f"bn/{k}"])).abs().max()) < 1e-4, k
