@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
     return ap.parse_args()
 
 
@@ -71,12 +72,14 @@ class GemmTimer:
         return flops, ms, len(self.rec)
 
 
-def cpu_baseline(p, batch):
-    """Oracle (CPU restatement of the reference) forward + backward on a bounded sample; images/s on the host cores."""
+def _cpu_baseline_worker(batch, threads, q):
+    """Runs in a subprocess: oracle (CPU restatement of the reference) forward + loss + backward on a bounded sample."""
+    import torch as T
+    T.set_num_threads(threads)
     from oracle import configs, taskprompter_oracle as tpo, weights
     import mtt_amd
     cfg = dict(configs.taskprompter("ns6"))
-    torch.set_num_threads(os.cpu_count() or 1)
+    p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (512, 512), backbone="TaskPrompter_vitL", head="conv")
     model = mtt_amd.factory.get_model(p)                         # only for the state-dict contract (names, shapes)
     contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
     del model
@@ -88,8 +91,24 @@ def cpu_baseline(p, batch):
     t0 = time.time()
     out = tpo.forward(dict(sd, **params), cfg, x, training=True)
     crit(out, gt)["total"].backward()
-    dt = time.time() - t0
-    return dict(value=batch / dt, unit="images/s", cores=torch.get_num_threads(), kind="port",
+    q.put(time.time() - t0)
+
+
+def cpu_baseline(batch, threads=16, limit_s=150):
+    """images/s of one oracle training step on `threads` host cores; bounded by a subprocess timeout."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(batch, threads, q))
+    pr.start()
+    pr.join(limit_s)
+    if pr.is_alive():
+        pr.terminate()
+        pr.join()
+        return dict(value=None, unit="images/s", cores=threads, kind="port",
+                    sample=f"1 oracle training step at batch {batch} did not finish within {limit_s} s on {threads} threads")
+    dt = q.get(timeout=5)
+    return dict(value=batch / dt, unit="images/s", cores=threads, kind="port",
                 sample=f"1 training step (fwd+loss+bwd, no optimizer) of the same config at batch {batch} on the CPU oracle, {dt:.1f} s")
 
 
@@ -175,7 +194,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(p, a.cpu_sample_batch)
+            cpu = cpu_baseline(a.cpu_sample_batch, a.cpu_threads)
         except Exception as e:  # noqa: BLE001
             cpu = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e!r}")
     if rank == 0:
@@ -186,7 +205,7 @@ def main():
                     config=dict(workload="TaskPrompter ViT-L/16 (taskprompter_vit_large_patch16_384), PASCAL-Context 5 tasks + depth = 6 tasks, "
                                          "512x512, ConvHead, embed 300/350, ctr; random-init weights",
                                 per_gpu_batch=a.batch, global_batch=a.batch * world, parallelism=f"dp{world}",
-                                optimizer="Adam(fused) + clip_grad_norm 10", loss=float(loss)),
+                                optimizer="Adam(fused) + clip_grad_norm 10", loss=float(loss.detach())),
                     fwd_ms_per_img=round(fwd_ms_img, 3),
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                       fwd=round(GFLOP_FWD_PER_IMG / fwd_ms_img, 1)),
