@@ -18,6 +18,7 @@ from . import ops
 from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code
 
 pad8 = ops.pad8
+SPLITK_MIN_ROWS = 4096      # reduction length from which few-tile weight gradients are split over the batch dimension
 
 
 def _gemm(A, B, D, M, N, K, prec, **kw):
@@ -45,10 +46,26 @@ def _scaled(g, rowscale, mb, n_prompt, prec):
 
 
 def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
-    """dW[N, Kp] = dy[rows, :N]^T @ x[rows, :Kp]  (both operands row-contiguous views)."""
+    """dW[N, Kp] = dy[rows, :N]^T @ x[rows, :Kp]  (both operands row-contiguous views).
+
+    When the output has only a few 128x128 tiles but the reduction (tokens / pixels) is long, the reduction is split
+    over the GEMM's batch dimension into fp32 slabs that are summed afterwards (split-K: fills the 256 CUs instead of
+    running thousands of K steps in a handful of workgroups)."""
     rows = rows if rows is not None else dy.shape[0]
+    lda, ldb = lda or dy.stride(0), ldb or x.stride(0)
+    tiles = -(-N // 128) * -(-Kp // 128)
+    if tiles < 96 and rows >= SPLITK_MIN_ROWS:
+        Z = max(2, min(64, 256 // tiles, max(2, rows // 512)))
+        c = rows // Z
+        rem = rows - c * Z
+        slabs = torch.empty(Z + (1 if rem else 0), N, Kp, dtype=torch.float32, device=dy.device)
+        _gemm(dy, x, slabs, N, Kp, c, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp, batch=Z, a_zo=c * lda, b_zo=c * ldb,
+              d_zo=N * Kp)
+        if rem:
+            _gemm(dy[c * Z:], x[c * Z:], slabs[Z], N, Kp, rem, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
+        return slabs.sum(0)
     dW = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
-    return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda or dy.stride(0), ldb=ldb or x.stride(0), ldd=Kp)
+    return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
 
 
 def _dgrad(dy, wpack2d, M, N_in, K_out, prec, out_dtype, **epi):
@@ -331,9 +348,12 @@ class BLinearFn(Function):
         dx = torch.empty(Z, M, Kp, dtype=x.dtype, device=x.device)
         _gemm(dy, wpack, dx, M, Kp, N, prec, b_op=OP_R, lda=lda, ldb=Kp, ldd=Kp, b_zo=wpack.stride(0) * bi,
               b_zi=wpack.stride(0) if bi > 1 else 0, d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
-        dW = torch.empty(Z, N, Kp, dtype=torch.float32, device=x.device)
-        _gemm(dy, x, dW, N, Kp, M, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=x.shape[-1], ldd=Kp, b_zo=xz * bi,
-              b_zi=xz if bi > 1 else 0, d_zo=N * Kp * bi, d_zi=N * Kp if bi > 1 else 0, **az)
+        if Z == 1 and layout == 'plain':
+            dW = _wgrad(dy.view(M, lda), x.reshape(M, x.shape[-1]), N, Kp, prec)[None]
+        else:
+            dW = torch.empty(Z, N, Kp, dtype=torch.float32, device=x.device)
+            _gemm(dy, x, dW, N, Kp, M, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=x.shape[-1], ldd=Kp, b_zo=xz * bi,
+                  b_zi=xz if bi > 1 else 0, d_zo=N * Kp * bi, d_zi=N * Kp if bi > 1 else 0, **az)
         dys = dy.view(-1, M, lda)
         dws, dbs = [], []
         for z in range(Z):

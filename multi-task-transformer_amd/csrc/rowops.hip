@@ -59,39 +59,57 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const mtt_ln_desc d) {
   }
 }
 
-// backward: dx += rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dgamma += dy*xhat; dbeta += dy
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const mtt_ln_desc d, int rows_per_block) {
+// backward, part 1 (one wave per row): dx += rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const mtt_ln_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.rows) return;
+  const float* x = d.x + row * d.ldx;
+  const float mean = d.mean[row], rstd = d.rstd[row];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < d.C; c += 64) {
+    const float xh = (x[c] - mean) * rstd;
+    const float g = ld_elem(d.dy, row * d.ldy + c, d.y_dtype) * d.gamma[c];
+    s1 += g; s2 += g * xh;
+  }
+  s1 = wave_sum(s1) / d.C; s2 = wave_sum(s2) / d.C;
+  float* dx = d.dx + row * d.ldx;
+  for (int c = lane; c < d.C; c += 64) {
+    const float xh = (x[c] - mean) * rstd;
+    const float g = ld_elem(d.dy, row * d.ldy + c, d.y_dtype) * d.gamma[c];
+    dx[c] += rstd * (g - s1 - xh * s2);
+  }
+}
+
+// backward, part 2 (column-parallel): dgamma += sum_rows dy*xhat, dbeta += sum_rows dy.  Thread = one column group of 4,
+// row slices across blockIdx.y-style chunks; partials combined through LDS then one atomic per column per block.
+__global__ __launch_bounds__(256) void ln_bwd_dgb_kernel(const mtt_ln_desc d, int rows_per_block) {
   extern __shared__ float lsm[];           // [2][C]
-  float* sg = lsm; float* sb = lsm + d.C;
   for (int c = threadIdx.x; c < 2 * d.C; c += 256) lsm[c] = 0.f;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = d.C >> 2;
+  const int lanes = 256 / C4 > 0 ? 256 / C4 : 1;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
-  for (int64_t row = r0 + wave; row < r1; row += 4) {
-    const float* x = d.x + row * d.ldx;
-    const float mean = d.mean[row], rstd = d.rstd[row];
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < d.C; c += 64) {
-      const float xh = (x[c] - mean) * rstd;
-      const float dy = ld_elem(d.dy, row * d.ldy + c, d.y_dtype);
-      const float g = dy * d.gamma[c];
-      s1 += g; s2 += g * xh;
-      if (d.dgamma) { atomicAdd(&sg[c], dy * xh); atomicAdd(&sb[c], dy); }
+  for (int c4 = threadIdx.x % (C4 < 256 ? C4 : 256); c4 < C4; c4 += 256) {
+    const int rl = C4 < 256 ? threadIdx.x / C4 : 0;
+    if (rl >= lanes) break;
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0 + rl; r < r1; r += lanes) {
+      const float mean = d.mean[r], rstd = d.rstd[r];
+      const float4 xv = *(const float4*)(d.x + r * d.ldx + c4 * 4);
+      float dy[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dy[j] = ld_elem(d.dy, r * d.ldy + c4 * 4 + j, d.y_dtype);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ag[j] += dy[j] * (xs[j] - mean) * rstd; ab[j] += dy[j]; }
     }
-    s1 = wave_sum(s1) / d.C; s2 = wave_sum(s2) / d.C;
-    if (d.dx) {
-      float* dx = d.dx + row * d.ldx;
-      for (int c = lane; c < d.C; c += 64) {
-        const float xh = (x[c] - mean) * rstd;
-        const float g = ld_elem(d.dy, row * d.ldy + c, d.y_dtype) * d.gamma[c];
-        dx[c] += rstd * (g - s1 - xh * s2);
-      }
-    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { atomicAdd(&lsm[c4 * 4 + j], ag[j]); atomicAdd(&lsm[d.C + c4 * 4 + j], ab[j]); }
   }
   __syncthreads();
-  if (d.dgamma)
-    for (int c = threadIdx.x; c < d.C; c += 256) { atomicAdd(&d.dgamma[c], sg[c]); atomicAdd(&d.dbeta[c], sb[c]); }
+  for (int c = threadIdx.x; c < d.C; c += 256) { atomicAdd(&d.dgamma[c], lsm[c]); atomicAdd(&d.dbeta[c], lsm[d.C + c]); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,16 +120,30 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const mtt_softmax_desc
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= d.rows) return;
   const int64_t base = row * d.ld;
+  const int nch = (int)(d.ld >> 3);
   float mx = -INFINITY;
-  for (int64_t c = lane; c < d.cols; c += 64) mx = fmaxf(mx, ld_elem(d.S, base + c, d.s_dtype) * d.scale);
+  for (int ch = lane; ch < nch; ch += 64) {
+    float v[8];
+    ld8(d.S, base + ch * 8, d.s_dtype, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (ch * 8 + j < d.cols) mx = fmaxf(mx, v[j] * d.scale);
+  }
   mx = wave_max(mx);
   float s = 0.f;
-  for (int64_t c = lane; c < d.cols; c += 64) s += __expf(ld_elem(d.S, base + c, d.s_dtype) * d.scale - mx);
+  for (int ch = lane; ch < nch; ch += 64) {
+    float v[8];
+    ld8(d.S, base + ch * 8, d.s_dtype, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (ch * 8 + j < d.cols) s += __expf(v[j] * d.scale - mx);
+  }
   const float inv = 1.0f / wave_sum(s);
-  for (int64_t c = lane; c < d.cols; c += 64)
-    st_elem(d.P, base + c, d.p_dtype, __expf(ld_elem(d.S, base + c, d.s_dtype) * d.scale - mx) * inv);
-  // zero the padding columns so a GEMM may read whole 8-element chunks
-  for (int64_t c = d.cols + lane; c < d.ld; c += 64) st_elem(d.P, base + c, d.p_dtype, 0.f);
+  for (int ch = lane; ch < nch; ch += 64) {
+    float v[8];
+    ld8(d.S, base + ch * 8, d.s_dtype, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ch * 8 + j < d.cols ? __expf(v[j] * d.scale - mx) * inv : 0.f;   // padding columns -> 0
+    st8(d.P, base + ch * 8, d.p_dtype, v);
+  }
 }
 
 // dS = scale * P * (dP - sum(dP*P))  (+ extra[r, c] for the first extra_rows rows of every matrix)
@@ -120,19 +152,35 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const mtt_softmax_desc
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= d.rows) return;
   const int64_t base = row * d.ld;
+  const int nch = (int)(d.ld >> 3);
   float s = 0.f;
-  for (int64_t c = lane; c < d.cols; c += 64)
-    s += ld_elem(d.dP, base + c, d.s_dtype) * ld_elem(d.P, base + c, d.p_dtype);
+  for (int ch = lane; ch < nch; ch += 64) {
+    float pv[8], gv[8];
+    ld8(d.P, base + ch * 8, d.p_dtype, pv);
+    ld8(d.dP, base + ch * 8, d.s_dtype, gv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (ch * 8 + j < d.cols) s += pv[j] * gv[j];
+  }
   s = wave_sum(s);
   const int64_t mat = d.rows_per_mat > 0 ? row / d.rows_per_mat : 0;
   const int64_t rin = d.rows_per_mat > 0 ? row - mat * d.rows_per_mat : row;
   const bool ex = d.extra != nullptr && rin < d.extra_rows;
-  for (int64_t c = lane; c < d.cols; c += 64) {
-    float v = d.scale * ld_elem(d.P, base + c, d.p_dtype) * (ld_elem(d.dP, base + c, d.s_dtype) - s);
-    if (ex) v += d.extra[(mat * d.extra_rows + rin) * d.extra_ld + c];
-    st_elem(d.dS, base + c, d.s_dtype, v);
+  for (int ch = lane; ch < nch; ch += 64) {
+    float pv[8], gv[8];
+    ld8(d.P, base + ch * 8, d.p_dtype, pv);
+    ld8(d.dP, base + ch * 8, d.s_dtype, gv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ch * 8 + j;
+      float v = 0.f;
+      if (c < d.cols) {
+        v = d.scale * pv[j] * (gv[j] - s);
+        if (ex) v += d.extra[(mat * d.extra_rows + rin) * d.extra_ld + c];
+      }
+      gv[j] = v;
+    }
+    st8(d.dS, base + ch * 8, d.s_dtype, gv);
   }
-  for (int64_t c = d.cols + lane; c < d.ld; c += 64) st_elem(d.dS, base + c, d.s_dtype, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,38 +383,76 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const mtt_resize
   }
 }
 
-// backward: `in` = dout (NHWC of Hout x Wout, or NCHW fp32 when out_nchw), `out` = din fp32 NHWC, += via atomics
+// backward as a GATHER (deterministic, no atomics): `in` = dout (NHWC of Hout x Wout, or NCHW fp32 when out_nchw),
+// `out` = din fp32 NHWC, accumulated (+=).  An input pixel i receives from the output pixels o whose source interval
+// touches i: o in (  (i - 0.5)/s - 0.5 ,  (i + 1.5)/s - 0.5 ),  s = in/out  (plus the clamped borders).
+MTT_DEV void gather_range(int i, int in, int out, int& lo, int& hi) {
+  const float inv = (float)out / (float)in;
+  float flo = ((float)i - 0.5f) * inv - 0.5f, fhi = ((float)i + 1.5f) * inv - 0.5f;
+  lo = (int)floorf(flo) - 1; hi = (int)ceilf(fhi) + 1;
+  if (i == 0) lo = 0;                    // clamped sources (src < 0 -> 0) all land on row 0
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+MTT_DEV float tap_weight(int o, int i, int in, int out) {
+  int i0, i1; float w1;
+  src_index(o, in, out, i0, i1, w1);
+  float w = 0.f;
+  if (i0 == i) w += 1.f - w1;
+  if (i1 == i) w += w1;
+  return w;
+}
+
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const mtt_resize_desc d) {
-  const int C8 = d.out_nchw ? 1 : (d.C + 7) >> 3;
-  const int64_t total = (int64_t)d.B * d.Hout * d.Wout * C8;
   float* din = (float*)d.out;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int c8 = (int)(t % C8);
-    const int64_t pix = t / C8;
-    const int ox = (int)(pix % d.Wout), oy = (int)((pix / d.Wout) % d.Hout), b = (int)(pix / ((int64_t)d.Wout * d.Hout));
-    int y0, y1, x0, x1; float wy, wx;
-    src_index(oy, d.Hin, d.Hout, y0, y1, wy);
-    src_index(ox, d.Win, d.Wout, x0, x1, wx);
-    const int64_t ib = (int64_t)b * d.Hin * d.Win;
-    const int64_t a00 = (ib + (int64_t)y0 * d.Win + x0) * d.ld_in, a01 = (ib + (int64_t)y0 * d.Win + x1) * d.ld_in;
-    const int64_t a10 = (ib + (int64_t)y1 * d.Win + x0) * d.ld_in, a11 = (ib + (int64_t)y1 * d.Win + x1) * d.ld_in;
-    if (d.out_nchw) {
-      for (int c = 0; c < d.C; ++c) {
-        const float g = ((const float*)d.in)[(((int64_t)b * d.C + c) * d.Hout + oy) * d.Wout + ox];
-        atomicAdd(&din[a00 + c], g * (1.f - wy) * (1.f - wx)); atomicAdd(&din[a01 + c], g * (1.f - wy) * wx);
-        atomicAdd(&din[a10 + c], g * wy * (1.f - wx)); atomicAdd(&din[a11 + c], g * wy * wx);
+  if (d.out_nchw) {
+    // one thread per (input pixel, channel): reads a small window of the NCHW gradient plane
+    const int64_t total = (int64_t)d.B * d.Hin * d.Win * d.C;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+      const int ix = (int)(t % d.Win);
+      int64_t r = t / d.Win;
+      const int iy = (int)(r % d.Hin); r /= d.Hin;
+      const int c = (int)(r % d.C);
+      const int b = (int)(r / d.C);
+      int ylo, yhi, xlo, xhi;
+      gather_range(iy, d.Hin, d.Hout, ylo, yhi);
+      gather_range(ix, d.Win, d.Wout, xlo, xhi);
+      const float* g = (const float*)d.in + ((int64_t)b * d.C + c) * d.Hout * d.Wout;
+      float acc = 0.f;
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = tap_weight(oy, iy, d.Hin, d.Hout);
+        if (wy == 0.f) continue;
+        float rowacc = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) rowacc += tap_weight(ox, ix, d.Win, d.Wout) * g[(int64_t)oy * d.Wout + ox];
+        acc += wy * rowacc;
       }
-    } else {
-      float g[8];
-      ld8(d.in, pix * d.ld_out + c8 * 8, d.in_dtype, g);
+      din[(((int64_t)b * d.Hin + iy) * d.Win + ix) * d.ld_in + c] += acc;
+    }
+  } else {
+    const int C8 = (d.C + 7) >> 3;
+    const int64_t total = (int64_t)d.B * d.Hin * d.Win * C8;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+      const int c8 = (int)(t % C8);
+      const int64_t pix = t / C8;
+      const int ix = (int)(pix % d.Win), iy = (int)((pix / d.Win) % d.Hin), b = (int)(pix / ((int64_t)d.Win * d.Hin));
+      int ylo, yhi, xlo, xhi;
+      gather_range(iy, d.Hin, d.Hout, ylo, yhi);
+      gather_range(ix, d.Win, d.Wout, xlo, xhi);
+      float acc[8];
+      ld8(din, pix * d.ld_in + c8 * 8, MTT_F32, acc);
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = tap_weight(oy, iy, d.Hin, d.Hout);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float w = wy * tap_weight(ox, ix, d.Win, d.Wout);
+          if (w == 0.f) continue;
+          float g[8];
+          ld8(d.in, (((int64_t)b * d.Hout + oy) * d.Wout + ox) * d.ld_out + c8 * 8, d.in_dtype, g);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = c8 * 8 + j;
-        if (c < d.C) {
-          atomicAdd(&din[a00 + c], g[j] * (1.f - wy) * (1.f - wx)); atomicAdd(&din[a01 + c], g[j] * (1.f - wy) * wx);
-          atomicAdd(&din[a10 + c], g[j] * wy * (1.f - wx)); atomicAdd(&din[a11 + c], g[j] * wy * wx);
+          for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
         }
       }
+      st8(din, pix * d.ld_in + c8 * 8, MTT_F32, acc);
     }
   }
 }
@@ -706,21 +792,27 @@ extern "C" int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream) {
 
 extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
   if (!d || !d->x || !d->dy || !d->gamma || !d->mean || !d->rstd || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
-  if (d->C > 8192) return MTT_E_UNSUPPORTED;
-  int64_t nblk = (d->rows + 63) / 64; if (nblk > 1024) nblk = 1024;
-  const int rpb = (int)((d->rows + nblk - 1) / nblk);
-  nblk = (d->rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nblk), dim3(256), 2 * d->C * sizeof(float), S_, *d, rpb);
+  if (d->C > 8192 || (d->C % 4) || (d->ldx % 4)) return MTT_E_UNSUPPORTED;
+  if (d->dx) hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
+  if (d->dgamma) {
+    if (!d->dbeta) return MTT_E_BADARG;
+    int64_t nblk = (d->rows + 31) / 32; if (nblk > 1024) nblk = 1024;
+    const int rpb = (int)((d->rows + nblk - 1) / nblk);
+    nblk = (d->rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(ln_bwd_dgb_kernel, dim3((unsigned)nblk), dim3(256), 2 * d->C * sizeof(float), S_, *d, rpb);
+  }
   return LAUNCH_OK();
 }
 
 extern "C" int mtt_softmax_fwd(const mtt_softmax_desc* d, void* stream) {
   if (!d || !d->S || !d->P || d->rows <= 0 || d->cols <= 0 || d->ld < d->cols) return MTT_E_BADARG;
+  if (d->ld % 8) return MTT_E_ALIGN;
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }
 extern "C" int mtt_softmax_bwd(const mtt_softmax_desc* d, void* stream) {
   if (!d || !d->P || !d->dP || !d->dS || d->rows <= 0 || d->cols <= 0 || d->ld < d->cols) return MTT_E_BADARG;
+  if (d->ld % 8) return MTT_E_ALIGN;
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }
@@ -765,14 +857,15 @@ extern "C" int mtt_bilinear_fwd(const mtt_resize_desc* d, void* stream) {
 }
 extern "C" int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream) {
   if (!d || !d->in || !d->out || d->B <= 0 || d->C <= 0) return MTT_E_BADARG;
-  const int C8 = d->out_nchw ? 1 : (d->C + 7) / 8;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((int64_t)d->B * d->Hout * d->Wout * C8)), dim3(256), 0, S_, *d);
+  const int64_t work = d->out_nchw ? (int64_t)d->B * d->Hin * d->Win * d->C : (int64_t)d->B * d->Hin * d->Win * ((d->C + 7) / 8);
+  if (!d->out_nchw && (d->ld_in % 8)) return MTT_E_ALIGN;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(work)), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }
 
 static int colreduce_cfg(const mtt_bn_desc* d, int& nblk, int& rpb) {
   if (!d || d->rows <= 0 || d->C <= 0 || (d->ld % 8) || d->C > 2040) return MTT_E_BADARG;
-  int64_t nb = (d->rows + 255) / 256; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+  int64_t nb = (d->rows + 63) / 64; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
   rpb = (int)((d->rows + nb - 1) / nb);
   nblk = (int)((d->rows + rpb - 1) / rpb);
   return 0;

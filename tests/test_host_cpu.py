@@ -124,3 +124,14 @@ def test_invpt_contract_and_wiring_on_emulator(emulated, prec, tol):
     assert [(k, list(v.shape)) for k, v in model.state_dict().items()] == [(k, list(s)) for k, s in meta["contract"]]
     model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=True)
     _invpt_outputs_vs_golden(model, cfg, meta, gold, tol)
+
+
+def test_training_gradients_with_forced_split_k(emulated, monkeypatch):
+    """Same gradient check with the split-K weight-gradient path forced on (production uses it for >= 4096-row reductions)."""
+    import mtt_amd
+    import train_check
+    monkeypatch.setattr(mtt_amd.autograd_path if hasattr(mtt_amd, "autograd_path") else __import__("importlib").import_module(
+        "multi-task-transformer_amd.autograd_path"), "SPLITK_MIN_ROWS", 8)
+    fwd, errs = train_check.grad_errors("mini_ctr", "x3", "cpu")
+    worst, med = train_check.summarize(errs)
+    assert worst[0] < 1e-3, worst
