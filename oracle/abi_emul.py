@@ -330,6 +330,8 @@ def bilinear_fwd(**kw):
 def bilinear_bwd(**kw):
     """in = dout (Hout x Wout), out = din fp32 NHWC (Hin x Win), accumulated."""
     B, Cn, Hi, Wi, Ho, Wo = (kw[k] for k in ("B", "C", "Hin", "Win", "Hout", "Wout"))
+    if not kw.get("out_nchw"):
+        Cn = (Cn + 7) // 8 * 8      # NHWC mode carries whole 8-channel chunks
     if kw.get("out_nchw"):
         f, o = flat(kw["in"])
         g = f[o:o + B * Cn * Ho * Wo].double().view(B, Cn, Ho, Wo).permute(0, 2, 3, 1)
