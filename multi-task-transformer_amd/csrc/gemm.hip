@@ -8,6 +8,7 @@
 // double buffered with one barrier per K step, fragment reads are swizzled conflict-free
 // ds_read_b128.  Blocks are remapped so consecutive tiles of one XCD share A rows in its L2.
 #include "mtt_device.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -191,106 +192,12 @@ MTT_DEV void stager_init_b(S& s, const GemmP& p, const void* base, int row0) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// MODE: 0 = bf16 MFMA, A and B bf16;  1 = bf16 MFMA, A f32 (converted while staging), B bf16;  2 = X3 (both f32)
-template <int AOP, int BOP, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
-  constexpr bool X3 = MODE == 2, AF32 = MODE >= 1, BF32 = MODE == 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NPL = X3 ? 2 : 1;
-  constexpr int STAGE = TILE_BYTES * 2 * NPL;   // A planes then B planes
-
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int z = blockIdx.z;
-  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
-
-  const int esA = p.d.a_dtype == MTT_F32 ? 4 : 2, esB = p.d.b_dtype == MTT_F32 ? 4 : 2;
-  const void* Abase = (const unsigned char*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi) * esA;
-  const void* Bbase = (const unsigned char*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi) * esB;
-
-  typename StagerSel<AOP, X3, AF32>::type sa;
-  typename StagerSel<BOP, X3, BF32>::type sb;
-  stager_init_a<AOP, X3>(sa, p, Abase, m0);
-  stager_init_b<BOP, X3>(sb, p, Bbase, n0);
-
+// Shared epilogue of the 128 x 128 / 4-wave kernels (acc[a][b][r] = D[wm*64 + a*16 + lg*4 + r][wn*64 + b*16 + li]).
+// ---------------------------------------------------------------------------------------------
+MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4], unsigned char* smem, int m0, int n0, int zo, int zi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (p.d.K + BK - 1) / BK;
-  sa.load(p, 0); sb.load(p, 0);
-  {
-    unsigned char* st = smem;
-    sa.store(st, st + TILE_BYTES);
-    sb.store(st + TILE_BYTES * NPL, st + TILE_BYTES * NPL + TILE_BYTES);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) { sa.load(p, (kt + 1) * BK); sb.load(p, (kt + 1) * BK); }
-
-    const unsigned char* st = smem + (kt & 1) * STAGE;
-    const unsigned char* Ah = st;
-    const unsigned char* Al = st + TILE_BYTES;
-    const unsigned char* Bh = st + TILE_BYTES * NPL;
-    const unsigned char* Bl = Bh + TILE_BYTES;
-    if constexpr (!X3) {
-      // all 16 fragment reads of this K step are issued before the 32 MFMAs (the compiler then places
-      // counted lgkmcnt waits, so LDS latency overlaps the first MFMAs instead of stalling every group)
-      u32x4 fa[2][4], fb[2][4];
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          fa[kh][t] = *(const u32x4*)(Ah + lds_off(wm * 64 + t * 16 + li, kh * 4 + lg));
-          fb[kh][t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
-        }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[kh][a], fb[kh][b], acc[a][b]);
-    } else {
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        u32x4 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int ra = wm * 64 + t * 16 + li, rbn = wn * 64 + t * 16 + li;
-          ah[t] = *(const u32x4*)(Ah + lds_off(ra, kh * 4 + lg));
-          bh[t] = *(const u32x4*)(Bh + lds_off(rbn, kh * 4 + lg));
-          al[t] = *(const u32x4*)(Al + lds_off(ra, kh * 4 + lg));
-          bl[t] = *(const u32x4*)(Bl + lds_off(rbn, kh * 4 + lg));
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            acc[a][b] = mfma16(al[a], bh[b], acc[a][b]);
-            acc[a][b] = mfma16(ah[a], bl[b], acc[a][b]);
-            acc[a][b] = mfma16(ah[a], bh[b], acc[a][b]);
-          }
-      }
-    }
-
-    if (more) {
-      unsigned char* sn = smem + ((kt + 1) & 1) * STAGE;
-      sa.store(sn, sn + TILE_BYTES);
-      sb.store(sn + TILE_BYTES * NPL, sn + TILE_BYTES * NPL + TILE_BYTES);
-    }
-    __syncthreads();
-  }
-
   // ------------------------------- epilogue --------------------------------------------------
   // Accumulators go through LDS (two 64-row halves, [64][132] fp32) so that every thread owns 8 consecutive
   // columns of a row: column constants are loaded once, row addressing once per 8 outputs, and D / resid / aux
@@ -429,6 +336,216 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MODE: 0 = bf16 MFMA, A and B bf16;  1 = bf16 MFMA, A f32 (converted while staging), B bf16;  2 = X3 (both f32)
+template <int AOP, int BOP, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
+  constexpr bool X3 = MODE == 2, AF32 = MODE >= 1, BF32 = MODE == 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NPL = X3 ? 2 : 1;
+  constexpr int STAGE = TILE_BYTES * 2 * NPL;   // A planes then B planes
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+
+  const int esA = p.d.a_dtype == MTT_F32 ? 4 : 2, esB = p.d.b_dtype == MTT_F32 ? 4 : 2;
+  const void* Abase = (const unsigned char*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi) * esA;
+  const void* Bbase = (const unsigned char*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi) * esB;
+
+  typename StagerSel<AOP, X3, AF32>::type sa;
+  typename StagerSel<BOP, X3, BF32>::type sb;
+  stager_init_a<AOP, X3>(sa, p, Abase, m0);
+  stager_init_b<BOP, X3>(sb, p, Bbase, n0);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.d.K + BK - 1) / BK;
+  sa.load(p, 0); sb.load(p, 0);
+  {
+    unsigned char* st = smem;
+    sa.store(st, st + TILE_BYTES);
+    sb.store(st + TILE_BYTES * NPL, st + TILE_BYTES * NPL + TILE_BYTES);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) { sa.load(p, (kt + 1) * BK); sb.load(p, (kt + 1) * BK); }
+
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    const unsigned char* Ah = st;
+    const unsigned char* Al = st + TILE_BYTES;
+    const unsigned char* Bh = st + TILE_BYTES * NPL;
+    const unsigned char* Bl = Bh + TILE_BYTES;
+    if constexpr (!X3) {
+      // all 16 fragment reads of this K step are issued before the 32 MFMAs (the compiler then places
+      // counted lgkmcnt waits, so LDS latency overlaps the first MFMAs instead of stalling every group)
+      u32x4 fa[2][4], fb[2][4];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fa[kh][t] = *(const u32x4*)(Ah + lds_off(wm * 64 + t * 16 + li, kh * 4 + lg));
+          fb[kh][t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[kh][a], fb[kh][b], acc[a][b]);
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        u32x4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ra = wm * 64 + t * 16 + li, rbn = wn * 64 + t * 16 + li;
+          ah[t] = *(const u32x4*)(Ah + lds_off(ra, kh * 4 + lg));
+          bh[t] = *(const u32x4*)(Bh + lds_off(rbn, kh * 4 + lg));
+          al[t] = *(const u32x4*)(Al + lds_off(ra, kh * 4 + lg));
+          bl[t] = *(const u32x4*)(Bl + lds_off(rbn, kh * 4 + lg));
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            acc[a][b] = mfma16(al[a], bh[b], acc[a][b]);
+            acc[a][b] = mfma16(ah[a], bl[b], acc[a][b]);
+            acc[a][b] = mfma16(ah[a], bh[b], acc[a][b]);
+          }
+      }
+    }
+
+    if (more) {
+      unsigned char* sn = smem + ((kt + 1) & 1) * STAGE;
+      sa.store(sn, sn + TILE_BYTES);
+      sb.store(sn + TILE_BYTES * NPL, sn + TILE_BYTES * NPL + TILE_BYTES);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue(p, acc, smem, m0, n0, zo, zi);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: both operands bf16 and reduction-contiguous, K % 64 == 0.  Tiles go HBM -> LDS directly
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction; the XOR swizzle is applied to the per-lane SOURCE chunk
+// so the LDS image stays lane-linear), through a ring of FSTAGES stages with counted vmcnt waits and raw barriers:
+// FSTAGES-2 tiles stay in flight across every barrier, one barrier per K step, no staging registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int FSTAGES = 4;
+
+MTT_DEV void glds16(const bf16_t* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_fast_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int STAGE = TILE_BYTES * 2;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  const bf16_t* Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
+  const bf16_t* Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // per-lane source pointers: wave w streams rows [32w, 32w+32) of each tile as 4 x (8 rows x 128 B)
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ lds_swz(row);
+    int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;      // ragged edge: re-read the last valid row (results unused)
+    int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
+    pa[i] = Abase + row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + c * 8;
+    pb[i] = Bbase + (int64_t)rb * p.d.ldb + c * 8;
+  }
+  auto issue = [&](int stage, int kt) {
+    unsigned char* sA = smem + stage * STAGE + wave * 4096;
+    unsigned char* sB = sA + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(pa[i] + kt * BK, sA + i * 1024);
+      glds16(pb[i] + kt * BK, sB + i * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.d.K / BK;
+#pragma unroll
+  for (int s = 0; s < FSTAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most min(FSTAGES-2, tiles issued after it) x 8 of this wave's loads are outstanding
+    const int after = nk - 1 - kt;
+    if (after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave's part of tile kt is in LDS; everyone is done reading stage (kt-1)
+    if (kt + FSTAGES - 1 < nk) issue((kt + FSTAGES - 1) % FSTAGES, kt + FSTAGES - 1);
+
+    const unsigned char* Ah = smem + (kt % FSTAGES) * STAGE;
+    const unsigned char* Bh = Ah + TILE_BYTES;
+    u32x4 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[kh][t] = *(const u32x4*)(Ah + lds_off(wm * 64 + t * 16 + li, kh * 4 + lg));
+        fb[kh][t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[kh][a], fb[kh][b], acc[a][b]);
+  }
+  __syncthreads();                          // all waves done with the last stage before LDS is reused by the epilogue
+  gemm_epilogue(p, acc, smem, m0, n0, zo, zi);
+}
+
+int launch_fast(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = TILE_BYTES * 2 * FSTAGES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.d.batch);
+  hipLaunchKernelGGL(gemm_fast_kernel, grid, dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
 FastDiv make_div(uint32_t dv) {
   FastDiv f; f.d = dv ? dv : 1u;
   uint32_t s = 0; while ((1ull << s) < f.d) ++s;
@@ -513,6 +630,9 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (d.prec == MTT_PREC_X3) mode = 2;
   else if (d.b_dtype != MTT_BF16) return MTT_E_UNSUPPORTED;      /* bf16 mode: B must be bf16 (A may be f32) */
   else mode = d.a_dtype == MTT_F32 ? 1 : 0;
+  static const bool fast_ok = []() { const char* e = getenv("MTT_GEMM_FAST"); return !(e && e[0] == '0'); }();
+  if (fast_ok && mode == 0 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16)
+    return launch_fast(p, s);
 #define MTT_CASE(AO, BO) \
   if (d.a_op == AO && d.b_op == BO) \
     return mode == 2 ? launch<AO, BO, 2>(p, s) : (mode == 1 ? launch<AO, BO, 1>(p, s) : launch<AO, BO, 0>(p, s));

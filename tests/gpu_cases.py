@@ -97,6 +97,20 @@ def gemm_cases():
     kw = dict(A=rnd(g, 90, 72), B=rnd(g, 72, 136, dtype=torch.bfloat16), D=torch.zeros(90, 136, dtype=torch.bfloat16), M=90, N=136, K=72,
               a_op=OP_K, b_op=OP_R, a_dtype=F32, b_dtype=BF16, d_dtype=BF16, prec=0, lda=72, ldb=136, ldd=136, batch=1, batch_inner=1, alpha=1.0)
     cases.append(("gemm_dgrad_f32A_bf16", "gemm", kw, TOL_BF))
+    # 1b. direct-to-LDS fast path (bf16, K % 64 == 0): many K tiles (ring wrap-around), ragged M / N, row groups, two-level batch
+    for (M, N, K) in ((200, 150, 256), (128, 128, 64), (300, 260, 704), (48, 1024, 1024)):
+        cases.append((f"gemm_fast_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0), TOL_BF))
+    Bn, Mb, K = 3, 37, 128
+    XA = rnd(g, Bn, Mb + 5, K + 8, dtype=torch.bfloat16)
+    kw = dict(A=XA[:, 5:], B=rnd(g, 70, K, dtype=torch.bfloat16), D=torch.zeros(Bn * Mb, 72), M=Bn * Mb, N=70, K=K, a_op=OP_K, b_op=OP_K,
+              a_dtype=BF16, b_dtype=BF16, d_dtype=F32, prec=0, lda=K + 8, ldb=K, ldd=72, a_mb=Mb, a_bs=(Mb + 5) * (K + 8),
+              batch=1, batch_inner=1, alpha=1.0, colshift=rnd(g, 70), act=1, n_store=72)
+    cases.append(("gemm_fast_rowgroups", "gemm", kw, TOL_BF))
+    Z, M, N, K = 4, 150, 40, 192
+    kw = dict(A=rnd(g, Z, M, K, dtype=torch.bfloat16), B=rnd(g, Z, N, K, dtype=torch.bfloat16), D=torch.full((2, M, 2 * 40), 3.0, dtype=torch.bfloat16),
+              M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=80, batch=Z, batch_inner=2,
+              a_zo=2 * M * K, a_zi=M * K, b_zo=2 * N * K, b_zi=N * K, d_zo=M * 80, d_zi=40, alpha=1.0, n_store=40)
+    cases.append(("gemm_fast_batched2", "gemm", kw, TOL_BF))
     # 2. asymmetric identity check (A = I) catches transposed C layout
     kw = base(128, 128, 128, F32, F32, F32, 1)
     kw["A"] = torch.eye(128, 136)
