@@ -192,12 +192,15 @@ MTT_DEV void stager_init_b(S& s, const GemmP& p, const void* base, int row0) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Shared epilogue of the 128 x 128 / 4-wave kernels (acc[a][b][r] = D[wm*64 + a*16 + lg*4 + r][wn*64 + b*16 + li]).
+// Shared epilogue.  Block tile TBN columns wide, WAVES_M x WAVES_N waves, each wave MT x NTL tiles of 16 x 16:
+//   acc[a][b][r] = D[(wm*MT + a)*16 + lg*4 + r][(wn*NTL + b)*16 + li]
 // ---------------------------------------------------------------------------------------------
-MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4], unsigned char* smem, int m0, int n0, int zo, int zi) {
+template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  constexpr int NTHREADS = 64 * WAVES_M * WAVES_N, CHUNKS = TBN / 8, RPP = NTHREADS / CHUNKS, NSLAB = WAVES_M * MT / 4;
   // ------------------------------- epilogue --------------------------------------------------
   // Accumulators go through LDS (two 64-row halves, [64][132] fp32) so that every thread owns 8 consecutive
   // columns of a row: column constants are loaded once, row addressing once per 8 outputs, and D / resid / aux
@@ -208,10 +211,10 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4], unsigned char* sm
   const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi;
   const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi;
   const int n_store = d.n_store > d.N ? d.n_store : d.N;
-  constexpr int EP_LD = 132;
+  constexpr int EP_LD = TBN + 4;
   float* const ep = (float*)smem;
 
-  const int c8 = threadIdx.x & 15;                 // this thread's 8-column chunk of the 128-wide tile
+  const int c8 = threadIdx.x % CHUNKS;             // this thread's 8-column chunk of the tile
   const int ncol0 = n0 + c8 * 8;
   float cs[8], sh[8];
 #pragma unroll
@@ -224,21 +227,22 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4], unsigned char* sm
   const bool full_chunk = ncol0 + 8 <= d.N && d.store_mode == MTT_STORE_ROWS;
 
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
+  for (int half = 0; half < NSLAB; ++half) {          // 64-row slabs of the block tile
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MT; ++a) {
+      const int gt = wm * MT + a;                      // m-tile index inside the block tile
+      if ((gt >> 2) != half) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NTL; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            ep[(a * 16 + lg * 4 + r) * EP_LD + wn * 64 + b * 16 + li] = acc[a][b][r];
+        for (int r = 0; r < 4; ++r)
+          ep[((gt & 3) * 16 + lg * 4 + r) * EP_LD + (wn * NTL + b) * 16 + li] = acc[a][b][r];
     }
     __syncthreads();
     if (ncol0 < n_store || (d.store_mode == MTT_STORE_PIXSHUF2 && ncol0 < d.N)) {
 #pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int rl = (threadIdx.x >> 4) + 16 * i;
+      for (int i = 0; i < 64 / RPP; ++i) {
+        const int rl = threadIdx.x / CHUNKS + RPP * i;
         const int m = m0 + half * 64 + rl;
         if (m >= d.M) continue;
         float v[8];
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     __syncthreads();
   }
 
-  gemm_epilogue(p, acc, smem, m0, n0, zo, zi);
+  gemm_epilogue<BN, 2, 2, 4, 4>(p, acc, smem, m0, n0, zo, zi);
 }
 
 
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void gemm_fast_kernel(const GemmP p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[kh][a], fb[kh][b], acc[a][b]);
   }
   __syncthreads();                          // all waves done with the last stage before LDS is reused by the epilogue
-  gemm_epilogue(p, acc, smem, m0, n0, zo, zi);
+  gemm_epilogue<BN, 2, 2, 4, 4>(p, acc, smem, m0, n0, zo, zi);
 }
 
 int launch_fast(const GemmP& p, hipStream_t stream) {
@@ -543,6 +547,97 @@ int launch_fast(const GemmP& p, hipStream_t stream) {
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.d.batch);
   hipLaunchKernelGGL(gemm_fast_kernel, grid, dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4, each 128 x 64 = 8 x 4 MFMA tiles, 128 fp32 accumulators per lane), operands
+// streamed HBM -> LDS by global_load_lds into 2 stages of 64 KiB.  Twice the arithmetic intensity of the 128 x 128
+// tile (128 FLOP per staged byte): the 128-tile kernels need ~64 B/clk/CU from L2 to keep the MFMA pipe busy,
+// which L2 cannot deliver; this one needs 32.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM2 = 256, BN2 = 256, TILE2 = BM2 * BK * 2;     // 32 KiB per operand tile
+
+__global__ __launch_bounds__(512, 1) void gemm_fast256_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int STAGE = TILE2 * 2;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + BN2 - 1) / BN2;
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM2, n0 = tile_n * BN2;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  const bf16_t* Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
+  const bf16_t* Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);          // wave w streams rows [32w, 32w + 32)
+    const int c = (lane & 7) ^ lds_swz(row);
+    int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;
+    int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
+    pa[i] = Abase + row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + c * 8;
+    pb[i] = Bbase + (int64_t)rb * p.d.ldb + c * 8;
+  }
+  auto issue = [&](int stage, int kt) {
+    unsigned char* sA = smem + stage * STAGE + wave * 4096;
+    unsigned char* sB = sA + TILE2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(pa[i] + kt * BK, sA + i * 1024);
+      glds16(pb[i] + kt * BK, sB + i * 1024);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.d.K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile kt has landed
+    __builtin_amdgcn_s_barrier();                           // ... everyone's has, and everyone finished reading stage (kt+1)&1
+    if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+    const unsigned char* Ah = smem + (kt & 1) * STAGE;
+    const unsigned char* Bh = Ah + TILE2;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      u32x4 fa[8], fb[4];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * 128 + t * 16 + li, kh * 4 + lg));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+    }
+  }
+  __syncthreads();
+  gemm_epilogue<BN2, 2, 4, 8, 4>(p, acc, smem, m0, n0, zo, zi);
+}
+
+int launch_fast256(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = TILE2 * 2 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_fast256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + BN2 - 1) / BN2;
+  dim3 grid(tm * tn, 1, p.d.batch);
+  hipLaunchKernelGGL(gemm_fast256_kernel, grid, dim3(512), smem, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -631,8 +726,13 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   else if (d.b_dtype != MTT_BF16) return MTT_E_UNSUPPORTED;      /* bf16 mode: B must be bf16 (A may be f32) */
   else mode = d.a_dtype == MTT_F32 ? 1 : 0;
   static const bool fast_ok = []() { const char* e = getenv("MTT_GEMM_FAST"); return !(e && e[0] == '0'); }();
-  if (fast_ok && mode == 0 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16)
-    return launch_fast(p, s);
+  static const int fast_mode = []() { const char* e = getenv("MTT_GEMM_FAST"); return e ? atoi(e) : 2; }();   // 0 off, 1 = 128 tile, 2 = auto
+  if (fast_ok && fast_mode && mode == 0 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16) {
+    // the 256 x 256 tile pays off once it still fills the chip (>= ~1 block per CU); small / skinny outputs keep the 128 tile
+    const int64_t blocks256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch;
+    if (fast_mode == 2 && blocks256 >= 200 && d.M >= 256 && d.N >= 256) return launch_fast256(p, s);
+    if (fast_mode == 1) return launch_fast(p, s);
+  }
 #define MTT_CASE(AO, BO) \
   if (d.a_op == AO && d.b_op == BO) \
     return mode == 2 ? launch<AO, BO, 2>(p, s) : (mode == 1 ? launch<AO, BO, 1>(p, s) : launch<AO, BO, 0>(p, s));

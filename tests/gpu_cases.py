@@ -111,6 +111,20 @@ def gemm_cases():
               M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=80, batch=Z, batch_inner=2,
               a_zo=2 * M * K, a_zi=M * K, b_zo=2 * N * K, b_zi=N * K, d_zo=M * 80, d_zi=40, alpha=1.0, n_store=40)
     cases.append(("gemm_fast_batched2", "gemm", kw, TOL_BF))
+    # 1c. 256 x 256 / 8-wave direct-to-LDS kernel (chosen when >= 200 such tiles): ragged edges, batch, epilogue, row groups
+    Z, M, N, K = 4, 2096, 2088, 192
+    kw = dict(A=rnd(g, Z, M, K, dtype=torch.bfloat16), B=rnd(g, Z, N, K, dtype=torch.bfloat16), D=torch.zeros(Z, M, 2088, dtype=torch.bfloat16),
+              M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=2088, batch=Z, batch_inner=1,
+              a_zo=M * K, b_zo=N * K, d_zo=M * 2088, alpha=1.0, colshift=rnd(g, Z, N), col_zo=N, act=1, n_store=N)
+    cases.append(("gemm_fast256_batched_gelu", "gemm", kw, TOL_BF))
+    Bn, Mb, K, N = 16, 517, 128, 1030
+    XA = rnd(g, Bn, Mb + 3, K, dtype=torch.bfloat16)
+    XT = rnd(g, Bn, Mb + 3, 1032)
+    kw = dict(A=XA[:, 3:], B=rnd(g, N, K, dtype=torch.bfloat16), D=XT[:, 3:], M=Bn * Mb, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16,
+              d_dtype=F32, prec=0, lda=K, ldb=K, ldd=1032, a_mb=Mb, a_bs=(Mb + 3) * K, d_mb=Mb, d_bs=(Mb + 3) * 1032, batch=1, batch_inner=1,
+              alpha=1.0, colshift=rnd(g, N), resid=XT[:, 3:], ldr=1032, r_mb=Mb, r_bs=(Mb + 3) * 1032,
+              rowscale=torch.rand(Bn, 2, generator=g), n_prompt=5, n_store=1032)
+    cases.append(("gemm_fast256_rowgroups_resid", "gemm", kw, TOL_BF))
     # 2. asymmetric identity check (A = I) catches transposed C layout
     kw = base(128, 128, 128, F32, F32, F32, 1)
     kw["A"] = torch.eye(128, 136)
