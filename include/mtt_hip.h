@@ -99,6 +99,8 @@ int mtt_abi_version(void);
  * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
+/* benchmarking aid: force a GEMM kernel variant (0 register-staged 128, 1 LDS-DMA 128, 2 default policy, 3 LDS-DMA 256; -1 = default) */
+void mtt_debug_gemm_variant(int v);
 
 /*
  * Fused global attention over [T prompts || hw patches] with the prompt-row logit side channel.

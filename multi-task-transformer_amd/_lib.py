@@ -147,7 +147,7 @@ DESC_EXTRA = {
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),
 }
-EXPORTS = ["mtt_abi_version", "mtt_desc_size"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 

@@ -665,6 +665,10 @@ int launch(const GemmP& p, hipStream_t stream) {
 
 }  // namespace
 
+static int g_fast_override = -1;
+/* debug / benchmarking only: select the GEMM variant at run time (-1 = default policy) */
+extern "C" void mtt_debug_gemm_variant(int v) { g_fast_override = v; }
+
 extern "C" int mtt_abi_version(void) { return MTT_ABI_VERSION; }
 
 // sizeof() of each descriptor, so a foreign-language binding can verify its struct mirror at load time
@@ -726,11 +730,12 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   else if (d.b_dtype != MTT_BF16) return MTT_E_UNSUPPORTED;      /* bf16 mode: B must be bf16 (A may be f32) */
   else mode = d.a_dtype == MTT_F32 ? 1 : 0;
   static const bool fast_ok = []() { const char* e = getenv("MTT_GEMM_FAST"); return !(e && e[0] == '0'); }();
-  static const int fast_mode = []() { const char* e = getenv("MTT_GEMM_FAST"); return e ? atoi(e) : 2; }();   // 0 off, 1 = 128 tile, 2 = auto
+  static const int fast_env = []() { const char* e = getenv("MTT_GEMM_FAST"); return e ? atoi(e) : 2; }();   // 0 off, 1 = 128 tile, 2 = auto, 3 = force 256
+  const int fast_mode = g_fast_override >= 0 ? g_fast_override : fast_env;
   if (fast_ok && fast_mode && mode == 0 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16) {
     // the 256 x 256 tile pays off once it still fills the chip (>= ~1 block per CU); small / skinny outputs keep the 128 tile
     const int64_t blocks256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch;
-    if (fast_mode == 2 && blocks256 >= 200 && d.M >= 256 && d.N >= 256) return launch_fast256(p, s);
+    if ((fast_mode == 2 && blocks256 >= 96 && d.M >= 512 && d.N >= 512) || fast_mode == 3) return launch_fast256(p, s);
     if (fast_mode == 1) return launch_fast(p, s);
   }
 #define MTT_CASE(AO, BO) \
