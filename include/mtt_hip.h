@@ -206,6 +206,9 @@ int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t l
 /* dst[r,:] = rowscale[(r/mb)*2 + ((r%mb) >= n_prompt)] * src[r,:] with dtype cast (DropPath scale of a branch gradient) */
 int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
                       const float* rowscale, int32_t mb, int32_t n_prompt, void* stream);
+/* dst[c, r] = src[r, c] for r < rows, c < cols; dst is [cols, ldd] with columns rows..ldd-1 written as zeros (ldd >= rows). */
+int mtt_transpose_pad(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
+                      void* stream);
 int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream);
 int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype,
                  float alpha, void* stream);

@@ -140,6 +140,7 @@ POSITIONAL = {
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
+    "transpose_pad": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, ptr],
 }
 # descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)
 DESC_EXTRA = {

@@ -37,7 +37,7 @@ def _colsum(x2d, cols):
 
 def _scaled(g, rowscale, mb, n_prompt, prec):
     """g * per-row DropPath scale, cast to the activation dtype (identity when no DropPath)."""
-    if rowscale is None:
+    if rowscale is None and (g.dtype == prec.adt or not FAST_BWD):
         return g
     out = torch.empty(g.shape, dtype=prec.adt, device=g.device)
     ops.call("rowscale_cast", args=[g, out, g.shape[0], g.shape[1], g.stride(0), out.stride(0), dtype_code(g), dtype_code(out),
@@ -66,6 +66,57 @@ def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
         return slabs.sum(0)
     dW = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
     return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
+
+
+def _transposed(x2d, cols, dtype=torch.bfloat16):
+    """[rows, ld] -> [cols, pad64(rows)] (zero padded): reduction-contiguous operand for the fast weight-gradient GEMM."""
+    rows = x2d.shape[0]
+    Mp = (rows + 63) // 64 * 64
+    out = torch.empty(cols, Mp, dtype=dtype, device=x2d.device)
+    ops.call("transpose_pad", args=[x2d, out, rows, cols, x2d.stride(0), Mp, dtype_code(x2d), dtype_code(out)])
+    return out
+
+
+def _wgrad_fast(dy, x, N, Kp, prec):
+    """bf16 mode: dW = (dy^T) (x^T)^T with both operands transposed to reduction-contiguous form, so the weight gradient
+    runs on the direct-to-LDS GEMM kernels instead of the transposing stagers."""
+    dyT, xT = _transposed(dy, N), _transposed(x, Kp)
+    Mp = dyT.shape[1]
+    tiles = -(-N // 256) * -(-Kp // 256)
+    if tiles < 64 and Mp >= 4096:                                   # split the token reduction over the batch dimension
+        Z = max(2, min(32, 256 // tiles))
+        c = (Mp // Z) // 64 * 64
+        if c >= 512:
+            nz = Mp // c
+            rem = Mp - nz * c
+            slabs = torch.empty(nz + (1 if rem else 0), N, Kp, dtype=torch.float32, device=dy.device)
+            _gemm(dyT, xT, slabs, N, Kp, c, prec, lda=Mp, ldb=Mp, ldd=Kp, batch=nz, a_zo=c, b_zo=c, d_zo=N * Kp)
+            if rem:
+                _gemm(dyT[:, nz * c:], xT[:, nz * c:], slabs[nz], N, Kp, rem, prec, lda=Mp, ldb=Mp, ldd=Kp)
+            return slabs.sum(0)
+    dW = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
+    return _gemm(dyT, xT, dW, N, Kp, Mp, prec, lda=Mp, ldb=Mp, ldd=Kp)
+
+
+def _enc_wgrad(dy, x, N, Kp, prec):
+    if prec.name == "bf16" and FAST_BWD and N >= FAST_MIN_DIM and Kp >= FAST_MIN_DIM and dy.shape[0] >= FAST_MIN_ROWS:
+        return _wgrad_fast(dy, x, N, Kp, prec)
+    return _wgrad(dy, x, N, Kp, prec)
+
+
+def _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, **epi):
+    """dx = dy @ W.  bf16 mode: uses a cached transposed pack W^T [N_in, K_out] so that both operands are
+    reduction-contiguous (fast GEMM path); otherwise the transposing B stager."""
+    if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and K_out % 64 == 0 and N_in >= FAST_MIN_DIM:
+        wT = ops._cached((tag, 'wT', id(weight)), [weight],
+                         lambda: weight.detach().reshape(weight.shape[0], -1).t().contiguous().to(torch.bfloat16))
+        dx = torch.empty(M, N_in, dtype=out_dtype, device=dy.device)
+        return _gemm(dy, wT, dx, M, N_in, K_out, prec, lda=dy.stride(0), ldb=wT.stride(0), ldd=N_in, n_store=N_in, **epi)
+    return _dgrad(dy, wpack2d, M, N_in, K_out, prec, out_dtype, **epi)
+
+
+FAST_BWD = True
+FAST_MIN_DIM, FAST_MIN_ROWS = 256, 1024      # below these the general (transposing-stager) kernels are used
 
 
 def _dgrad(dy, wpack2d, M, N_in, K_out, prec, out_dtype, **epi):
@@ -135,6 +186,7 @@ class AttnBlockFn(Function):
                    M=B * N)
         ctx.save_for_backward(xn, qkv, ao, wq, wp, rowscale)
         ctx.geo, ctx.prec = geo, prec
+        ctx.params = (Wqkv, Wproj)
         if rawlog is None:
             rawlog = torch.zeros(0, device=xn.device)
         return XT2, rawlog
@@ -142,18 +194,19 @@ class AttnBlockFn(Function):
     @staticmethod
     def backward(ctx, dXT2, drawlog):
         xn, qkv, ao, wq, wp, rowscale = ctx.saved_tensors
+        Wqkv_, Wproj_ = ctx.params
         B, N, nH, T = ctx.geo
         prec, C, M = ctx.prec, nH * 64, B * N
         dXT2 = dXT2.contiguous()
         g = _scaled(dXT2, rowscale, N, T, prec)
-        dWproj = _wgrad(g, ao, C, C, prec)
+        dWproj = _enc_wgrad(g, ao, C, C, prec)
         dbproj = _colsum(g, C)
-        dao = _dgrad(g, wp[0], M, C, C, prec, prec.adt)
+        dao = _enc_dgrad(g, Wproj_, wp[0], M, C, C, prec, prec.adt, 'proj')
         dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
         dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
-        dWqkv = _wgrad(dqkv, xn, 3 * C, C, prec)
+        dWqkv = _enc_wgrad(dqkv, xn, 3 * C, C, prec)
         dbqkv = _colsum(dqkv, 3 * C)
-        dxn = _dgrad(dqkv, wq[0], M, C, 3 * C, prec, torch.float32)
+        dxn = _enc_dgrad(dqkv, Wqkv_, wq[0], M, C, 3 * C, prec, torch.float32, 'qkv')
         return dxn, dXT2, dWqkv, dbqkv, dWproj, dbproj, None, None, None, None
 
 
@@ -221,6 +274,7 @@ class MlpFn(Function):
                    M=B * N)
         ctx.save_for_backward(xn2, z, hmid, w1, w2, rowscale)
         ctx.geo, ctx.prec = geo, prec
+        ctx.params = (W1, W2)
         return XT3
 
     @staticmethod
@@ -231,12 +285,13 @@ class MlpFn(Function):
         C, Hd = xn2.shape[1], z.shape[1]
         dXT3 = dXT3.contiguous()
         g = _scaled(dXT3, rowscale, N, T, prec)
-        dW2 = _wgrad(g, hmid, C, Hd, prec)
+        W1_, W2_ = ctx.params
+        dW2 = _enc_wgrad(g, hmid, C, Hd, prec)
         db2 = _colsum(g, C)
-        dz = _dgrad(g, w2[0], M, Hd, C, prec, prec.adt, act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
-        dW1 = _wgrad(dz, xn2, Hd, C, prec)
+        dz = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
+        dW1 = _enc_wgrad(dz, xn2, Hd, C, prec)
         db1 = _colsum(dz, Hd)
-        dxn2 = _dgrad(dz, w1[0], M, C, Hd, prec, prec.adt)
+        dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
         return dxn2, dXT3, dW1, db1, dW2, db2, None, None, None, None
 
 

@@ -771,6 +771,29 @@ __global__ __launch_bounds__(256) void rowscale_cast_kernel(const void* src, voi
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// dst[c, r] = src[r, c] (r < rows, c < cols), dst rows zero-padded up to ldd columns: turns the token-contiguous
+// operands of a weight-gradient GEMM into reduction-contiguous ones for the fast GEMM path.  64 x 64 tiles through LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd,
+                                                            int sdt, int ddt) {
+  __shared__ float tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t r = r0 + ty * 16 + i, c = c0 + tx;
+    tile[ty * 16 + i][tx] = (r < rows && c < cols) ? ld_elem(src, r * lds_ + c, sdt) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t c = c0 + ty * 16 + i, r = r0 + tx;
+    if (c < cols && r < ldd) st_elem(dst, c * ldd + r, ddt, tile[tx][ty * 16 + i]);
+  }
+}
+
 int grid_for(int64_t work_items) {
   int64_t g = (work_items + 255) / 256;
   if (g > 256 * 8) g = 256 * 8;
@@ -952,5 +975,13 @@ extern "C" int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32
   if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;
   hipLaunchKernelGGL(rowscale_cast_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype,
                      dst_dtype, rowscale, mb, n_prompt);
+  return LAUNCH_OK();
+}
+
+extern "C" int mtt_transpose_pad(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, int src_dtype,
+                                 int dst_dtype, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || ldd < rows) return MTT_E_BADARG;
+  dim3 grid((unsigned)((ldd + 63) / 64), (unsigned)((cols + 63) / 64));
+  hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype, dst_dtype);
   return LAUNCH_OK();
 }

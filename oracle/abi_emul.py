@@ -563,6 +563,15 @@ def convt3x3s2_gather(**kw):
     _wr(kw["out"], torch.arange(out.numel()), out.reshape(-1))
 
 
+def transpose_pad(args):
+    src, dst, rows, cols, lds, ldd, sdt, ddt = args[:8]
+    r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+    v = _rd(src, r * lds + c)                                   # [rows, cols]
+    full = torch.zeros(cols, ldd, dtype=torch.float64)
+    full[:, :rows] = v.t()
+    _wr(dst, torch.arange(cols)[:, None] * ldd + torch.arange(ldd)[None, :], full)
+
+
 _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
@@ -570,7 +579,7 @@ _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd
               modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw,
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
               convt3x3s2_gather=convt3x3s2_gather)
-_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast)
+_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad)
 
 
 def call(name, **kw):

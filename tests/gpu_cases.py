@@ -280,6 +280,8 @@ def row_cases():
         kw = dict(fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rpb, ld=ld, C=C, fea_dtype=dt, accumulate=0,
                   xargs=[rnd(g, T, B * rpb, ld), torch.zeros(B, T, T)])
         cases.append((f"ctr_dw_{dt}", "ctr_dw", kw, dict(f32=2e-5, bf16=5e-3)))
+        cases.append((f"transpose_pad_{dt}", "transpose_pad",
+                      dict(args=[rnd(g, 203, 80, dtype=DT[dt]), torch.full((72, 256), 5.0, dtype=torch.bfloat16), 203, 72, 80, 256, dt, BF16]), TOL_ROW))
         cases.append((f"rowscale_cast_{dt}", "rowscale_cast",
                       dict(args=[rnd(g, 2 * 13, 24), torch.zeros(26, 32, dtype=DT[dt]), 26, 20, 24, 32, F32, dt,
                                  torch.tensor([[0.5, 2.0], [0.0, 1.5]]), 13, 3]), TOL_ROW))
