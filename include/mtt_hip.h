@@ -101,6 +101,8 @@ size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
 /* benchmarking aid: force a GEMM kernel variant (0 register-staged 128, 1 LDS-DMA 128, 2 default policy, 3 LDS-DMA 256; -1 = default) */
 void mtt_debug_gemm_variant(int v);
+/* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128, 1 LDS-DMA 128x128, 3 LDS-DMA 256x256 */
+int mtt_gemm_variant(const mtt_gemm_desc* d);
 
 /*
  * Fused global attention over [T prompts || hw patches] with the prompt-row logit side channel.

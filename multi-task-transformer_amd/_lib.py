@@ -148,7 +148,7 @@ DESC_EXTRA = {
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),
 }
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant", "mtt_gemm_variant"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 
@@ -205,6 +205,23 @@ def _addr(t):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def gemm_variant(**kw):
+    """Kernel variant mtt_gemm would dispatch these descriptor fields to (0 general, 1 LDS-DMA 128, 3 LDS-DMA 256)."""
+    lib = load()
+    desc = GemmDesc()
+    for k, v in kw.items():
+        if k == "conv":
+            for ck, cv in v.items():
+                setattr(desc.conv, ck, int(cv))
+        elif isinstance(v, torch.Tensor):
+            setattr(desc, k, v.data_ptr())
+        elif v is not None:
+            setattr(desc, k, v)
+    lib.mtt_gemm_variant.restype = C.c_int
+    lib.mtt_gemm_variant.argtypes = [C.POINTER(GemmDesc)]
+    return lib.mtt_gemm_variant(C.byref(desc))
 
 
 def call(name, **kw):

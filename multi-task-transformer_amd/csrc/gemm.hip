@@ -613,14 +613,16 @@ __global__ __launch_bounds__(512, 1) void gemm_fast256_kernel(const GemmP p) {
     for (int kh = 0; kh < 2; ++kh) {
       u32x4 fa[8], fb[4];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * 128 + t * 16 + li, kh * 4 + lg));
-#pragma unroll
       for (int t = 0; t < 4; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * 128 + t * 16 + li, kh * 4 + lg));
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
   __syncthreads();
@@ -693,6 +695,21 @@ extern "C" size_t mtt_desc_size(int which) {
   }
 }
 
+// 0 = register-staged 128 tile (general), 1 = LDS-DMA 128 tile, 3 = LDS-DMA 256 tile
+static int gemm_variant_for(const mtt_gemm_desc& d) {
+  static const int fast_env = []() { const char* e = getenv("MTT_GEMM_FAST"); return e ? atoi(e) : 2; }();
+  const int fast_mode = g_fast_override >= 0 ? g_fast_override : fast_env;
+  const bool plain = d.prec == MTT_PREC_BF16 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16 &&
+                     d.b_dtype == MTT_BF16;
+  if (!plain || fast_mode == 0) return 0;
+  const int batch = d.batch < 1 ? 1 : d.batch;
+  const int64_t blocks256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * batch;
+  if ((fast_mode == 2 && blocks256 >= 96 && d.M >= 512 && d.N >= 512) || fast_mode == 3) return 3;
+  if (fast_mode == 1) return 1;
+  return 0;
+}
+extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }
+
 extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (!dd || !dd->A || !dd->B || !dd->D) return MTT_E_BADARG;
   GemmP p; p.d = *dd;
@@ -729,14 +746,10 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (d.prec == MTT_PREC_X3) mode = 2;
   else if (d.b_dtype != MTT_BF16) return MTT_E_UNSUPPORTED;      /* bf16 mode: B must be bf16 (A may be f32) */
   else mode = d.a_dtype == MTT_F32 ? 1 : 0;
-  static const bool fast_ok = []() { const char* e = getenv("MTT_GEMM_FAST"); return !(e && e[0] == '0'); }();
-  static const int fast_env = []() { const char* e = getenv("MTT_GEMM_FAST"); return e ? atoi(e) : 2; }();   // 0 off, 1 = 128 tile, 2 = auto, 3 = force 256
-  const int fast_mode = g_fast_override >= 0 ? g_fast_override : fast_env;
-  if (fast_ok && fast_mode && mode == 0 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16) {
-    // the 256 x 256 tile pays off once it still fills the chip (>= ~1 block per CU); small / skinny outputs keep the 128 tile
-    const int64_t blocks256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch;
-    if ((fast_mode == 2 && blocks256 >= 96 && d.M >= 512 && d.N >= 512) || fast_mode == 3) return launch_fast256(p, s);
-    if (fast_mode == 1) return launch_fast(p, s);
+  if (mode == 0) {
+    const int v = gemm_variant_for(d);
+    if (v == 3) return launch_fast256(p, s);
+    if (v == 1) return launch_fast(p, s);
   }
 #define MTT_CASE(AO, BO) \
   if (d.a_op == AO && d.b_op == BO) \
