@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--prec", default="bf16", choices=["bf16", "x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
     return ap.parse_args()
 
