@@ -21,6 +21,7 @@ struct GemmP {
   FastDiv divAmb, divDmb, divRmb;    // row-group mappings
   FastDiv divPsW, divPsH, divPsCo;   // pixel-shuffle store
   int tiles_m, tiles_n;
+  int group_m;
 };
 
 MTT_DEV int64_t row_off(uint32_t m, int mb, int64_t bs, int64_t ld, FastDiv f) {
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int STAGE = TILE_BYTES * 2 * NPL;   // A planes then B planes
 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  grouped_tile(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
   const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
@@ -462,7 +464,8 @@ __global__ __launch_bounds__(256, 1) void gemm_fast_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = TILE_BYTES * 2;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  grouped_tile(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
   const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
@@ -562,8 +565,9 @@ __global__ __launch_bounds__(512, 1) void gemm_fast256_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = TILE2 * 2;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles_n = (p.d.N + BN2 - 1) / BN2;
-  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int tiles_n = (p.d.N + BN2 - 1) / BN2, tiles_m = (p.d.M + BM2 - 1) / BM2;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
   const int m0 = tile_m * BM2, n0 = tile_n * BN2;
   const int z = blockIdx.z;
   const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
@@ -741,6 +745,8 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   p.divPsW = make_div(d.ps_W > 0 ? d.ps_W : 1); p.divPsH = make_div(d.ps_H > 0 ? d.ps_H : 1);
   p.divPsCo = make_div(d.ps_Co > 0 ? d.ps_Co : 1);
   p.tiles_m = (d.M + BM - 1) / BM; p.tiles_n = (d.N + BN - 1) / BN;
+  static const int gm_env = []() { const char* e = getenv("MTT_GEMM_GROUP_M"); return e ? atoi(e) : 4; }();
+  p.group_m = gm_env < 1 ? 1 : gm_env;
   hipStream_t s = (hipStream_t)stream;
   int mode;
   if (d.prec == MTT_PREC_X3) mode = 2;

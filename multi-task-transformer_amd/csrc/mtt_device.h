@@ -123,6 +123,19 @@ MTT_DEV int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
 }
 
+// Grouped tile order (GROUP_M rows of tiles are swept together): the ~32 workgroups an XCD runs concurrently then cover a
+// GROUP_M x (32 / GROUP_M) patch of output tiles and share both operands' panels in that XCD's L2, instead of one row of
+// tiles that re-streams all of B per row (PMC: 5x algorithmic FETCH_SIZE with the row-major order).
+MTT_DEV void grouped_tile(int wg, int tiles_m, int tiles_n, int gm, int& tile_m, int& tile_n) {
+  const int per_group = gm * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * gm;
+  const int rows = tiles_m - first_m < gm ? tiles_m - first_m : gm;
+  const int in = wg - group * per_group;
+  tile_m = first_m + in % rows;
+  tile_n = in / rows;
+}
+
 MTT_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
