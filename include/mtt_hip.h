@@ -227,10 +227,13 @@ typedef struct {
   int32_t Z, B, H, W; int64_t ld; int32_t dtype;
 } mtt_dwconv_desc;
 int mtt_dwconv3x3s2(const mtt_dwconv_desc* d, void* stream);
+/* backward (scale/shift ignored: apply BN backward first): dx [Z, B*H*W, ld] (same dtype, optional), dw fp32 [Z, 9, ld] (optional) */
+int mtt_dwconv3x3s2_bwd(const mtt_dwconv_desc* d, const void* dy, void* dx, float* dw, void* stream);
 
 /* nn.AvgPool2d(kernel=stride=k, padding=0, ceil_mode=True) on NHWC (keys/values, invpt.py:139-149). */
 typedef struct { const void* x; void* y; int32_t B, H, W, k; int64_t ld; int32_t dtype; } mtt_pool_desc;
 int mtt_avgpool_ceil(const mtt_pool_desc* d, void* stream);
+int mtt_avgpool_ceil_bwd(const mtt_pool_desc* d, const void* dy, void* dx, void* stream);
 
 /* LayerNorm over the concatenated channels of all T tasks (norm_mts, invpt.py:482,526): x fp32 [T, rows, ldx],
  * gamma/beta fp32 [T*D] -> y [T, rows, ldy] (channels >= D written as zeros). */
@@ -255,6 +258,8 @@ typedef struct {
   const void* yall; void* out; const float* bias; int32_t B, H, W, Cop; int32_t dtype, out_dtype;
 } mtt_convt_desc;
 int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream);
+/* backward: dyall [B*H*W, 9*Cop] (d->dtype) gathered from dout [B*2H*2W, Cop] (d->out_dtype) */
+int mtt_convt3x3s2_gather_bwd(const mtt_convt_desc* d, const void* dout, void* dyall, void* stream);
 
 #ifdef __cplusplus
 }

@@ -142,12 +142,17 @@ POSITIONAL = {
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
     "transpose_pad": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, ptr],
 }
+
 # descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)
 DESC_EXTRA = {
     "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr]),
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),
+    "dwconv3x3s2_bwd": (DwconvDesc, [ptr, ptr, ptr]),
+    "avgpool_ceil_bwd": (PoolDesc, [ptr, ptr]),
+    "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
+
 EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant", "mtt_gemm_variant"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None

@@ -191,6 +191,110 @@ __global__ __launch_bounds__(256) void convt3s2_gather_kernel(const mtt_convt_de
   }
 }
 
+
+// ---- backward kernels ------------------------------------------------------------------------------------
+// depthwise 3x3 s2: dx[z,b,iy,ix,c] = sum over taps with iy = 2*oy - 1 + ky of w[z,tap,c] * dy[z,b,oy,ox,c]
+__global__ __launch_bounds__(256) void dwconv3s2_bwd_dx_kernel(const mtt_dwconv_desc d, const void* dy, void* dx) {
+  const int C8 = d.ld >> 3;
+  const int Ho = (d.H - 1) / 2 + 1, Wo = (d.W - 1) / 2 + 1;
+  const int64_t total = (int64_t)d.Z * d.B * d.H * d.W * C8;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    int64_t r = t / C8;
+    const int ix = (int)(r % d.W); r /= d.W;
+    const int iy = (int)(r % d.H); r /= d.H;
+    const int b = (int)(r % d.B);
+    const int z = (int)(r / d.B);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = iy + 1 - ky;
+      if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = ix + 1 - kx;
+        if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+        float g[8], wv[8];
+        ld8(dy, ((((int64_t)z * d.B + b) * Ho + (ty >> 1)) * Wo + (tx >> 1)) * d.ld + c8 * 8, d.dtype, g);
+        ld8(d.w, ((int64_t)z * 9 + ky * 3 + kx) * d.ld + c8 * 8, MTT_F32, wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += g[j] * wv[j];
+      }
+    }
+    st8(dx, ((((int64_t)z * d.B + b) * d.H + iy) * d.W + ix) * d.ld + c8 * 8, d.dtype, acc);
+  }
+}
+// dw[z,tap,c] = sum_{b,oy,ox} x[z,b,2oy-1+ky,2ox-1+kx,c] * dy[z,b,oy,ox,c]     (one thread per (z, tap, 8 channels))
+__global__ __launch_bounds__(256) void dwconv3s2_bwd_dw_kernel(const mtt_dwconv_desc d, const void* dy, float* dw) {
+  const int C8 = d.ld >> 3;
+  const int Ho = (d.H - 1) / 2 + 1, Wo = (d.W - 1) / 2 + 1;
+  const int64_t total = (int64_t)d.Z * 9 * C8;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c8 = (int)(t % C8), tap = (int)((t / C8) % 9), z = (int)(t / (9 * C8));
+  const int ky = tap / 3, kx = tap % 3;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int b = 0; b < d.B; ++b)
+    for (int oy = 0; oy < Ho; ++oy) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= d.H) continue;
+      for (int ox = 0; ox < Wo; ++ox) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= d.W) continue;
+        float xv[8], g[8];
+        ld8(d.x, ((((int64_t)z * d.B + b) * d.H + iy) * d.W + ix) * d.ld + c8 * 8, d.dtype, xv);
+        ld8(dy, ((((int64_t)z * d.B + b) * Ho + oy) * Wo + ox) * d.ld + c8 * 8, d.dtype, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += xv[j] * g[j];
+      }
+    }
+  st8(dw, ((int64_t)z * 9 + tap) * d.ld + c8 * 8, MTT_F32, acc);
+}
+// average-pool backward: dx[b,y,x,c] = dy[b, y/k, x/k, c] / (#in-bounds elements of that window)
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const mtt_pool_desc d, const void* dy, void* dx) {
+  const int C8 = d.ld >> 3;
+  const int Ho = (d.H + d.k - 1) / d.k, Wo = (d.W + d.k - 1) / d.k;
+  const int64_t total = (int64_t)d.B * d.H * d.W * C8;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    int64_t r = t / C8;
+    const int x = (int)(r % d.W); r /= d.W;
+    const int y = (int)(r % d.H);
+    const int b = (int)(r / d.H);
+    const int oy = y / d.k, ox = x / d.k;
+    const int hh = (oy + 1) * d.k < d.H ? d.k : d.H - oy * d.k, ww = (ox + 1) * d.k < d.W ? d.k : d.W - ox * d.k;
+    float g[8];
+    ld8(dy, (((int64_t)b * Ho + oy) * Wo + ox) * d.ld + c8 * 8, d.dtype, g);
+    const float inv = 1.0f / (float)(hh * ww);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= inv;
+    st8(dx, (((int64_t)b * d.H + y) * d.W + x) * d.ld + c8 * 8, d.dtype, g);
+  }
+}
+// ConvTranspose gather backward: dyall[b,iy,ix,tap,co] = dout[b, 2iy-1+ky, 2ix-1+kx, co] (0 outside)
+__global__ __launch_bounds__(256) void convt3s2_gather_bwd_kernel(const mtt_convt_desc d, const void* dout, void* dyall) {
+  const int C8 = d.Cop >> 3, Ho = 2 * d.H, Wo = 2 * d.W;
+  const int64_t total = (int64_t)d.B * d.H * d.W * 9 * C8;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(t % C8);
+    int64_t r = t / C8;
+    const int tap = (int)(r % 9); r /= 9;
+    const int ix = (int)(r % d.W); r /= d.W;
+    const int iy = (int)(r % d.H);
+    const int b = (int)(r / d.H);
+    const int oy = 2 * iy - 1 + tap / 3, ox = 2 * ix - 1 + tap % 3;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) ld8(dout, (((int64_t)b * Ho + oy) * Wo + ox) * d.Cop + c8 * 8, d.out_dtype, g);
+    st8(dyall, (((int64_t)b * d.H + iy) * d.W + ix) * (9 * d.Cop) + tap * d.Cop + c8 * 8, d.dtype, g);
+  }
+}
+
 int grid_for(int64_t work_items) {
   int64_t g = (work_items + 255) / 256;
   if (g > 256 * 8) g = 256 * 8;
@@ -227,5 +331,22 @@ extern "C" int mtt_attn_msg(const mtt_attnmsg_desc* d, void* stream) {
 extern "C" int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream) {
   if (!d || !d->yall || !d->out || !d->bias || d->B <= 0 || (d->Cop % 8)) return MTT_E_BADARG;
   hipLaunchKernelGGL(convt3s2_gather_kernel, dim3(grid_for((int64_t)d->B * 4 * d->H * d->W * (d->Cop / 8))), dim3(256), 0, S_, *d);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_dwconv3x3s2_bwd(const mtt_dwconv_desc* d, const void* dy, void* dx, float* dw, void* stream) {
+  if (!d || !d->x || !d->w || !dy || d->Z <= 0 || d->B <= 0 || (d->ld % 8)) return MTT_E_BADARG;
+  if (dx) hipLaunchKernelGGL(dwconv3s2_bwd_dx_kernel, dim3(grid_for((int64_t)d->Z * d->B * d->H * d->W * (d->ld / 8))), dim3(256), 0, S_, *d, dy, dx);
+  if (dw) hipLaunchKernelGGL(dwconv3s2_bwd_dw_kernel, dim3((unsigned)(((int64_t)d->Z * 9 * (d->ld / 8) + 255) / 256)), dim3(256), 0, S_, *d, dy, dw);
+  return (int)hipGetLastError();
+}
+extern "C" int mtt_avgpool_ceil_bwd(const mtt_pool_desc* d, const void* dy, void* dx, void* stream) {
+  if (!d || !dy || !dx || d->B <= 0 || d->k <= 0 || (d->ld % 8)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)d->B * d->H * d->W * (d->ld / 8))), dim3(256), 0, S_, *d, dy, dx);
+  return (int)hipGetLastError();
+}
+extern "C" int mtt_convt3x3s2_gather_bwd(const mtt_convt_desc* d, const void* dout, void* dyall, void* stream) {
+  if (!d || !dout || !dyall || d->B <= 0 || (d->Cop % 8)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(convt3s2_gather_bwd_kernel, dim3(grid_for((int64_t)d->B * d->H * d->W * 9 * (d->Cop / 8))), dim3(256), 0, S_, *d, dout, dyall);
   return (int)hipGetLastError();
 }

@@ -572,18 +572,70 @@ def transpose_pad(args):
     _wr(dst, torch.arange(cols)[:, None] * ldd + torch.arange(ldd)[None, :], full)
 
 
+
+def dwconv3x3s2_bwd(**kw):
+    dy, dx, dw = kw["xargs"]
+    Z, B, H, W, ld = kw["Z"], kw["B"], kw["H"], kw["W"], kw["ld"]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = _rd(kw["x"], torch.arange(Z * B * H * W * ld)).view(Z, B, H, W, ld).permute(0, 1, 4, 2, 3)
+    w = _rd(kw["w"], torch.arange(Z * 9 * ld)).view(Z, 3, 3, ld).permute(0, 3, 1, 2)
+    g = _rd(dy, torch.arange(Z * B * Ho * Wo * ld)).view(Z, B, Ho, Wo, ld).permute(0, 1, 4, 2, 3)
+    dxs, dws = [], []
+    for z in range(Z):
+        xi = x[z].clone().requires_grad_(True); wi = w[z][:, None].clone().requires_grad_(True)
+        y = torch.nn.functional.conv2d(xi, wi, None, stride=2, padding=1, groups=ld)
+        with torch.enable_grad():
+            pass
+        gx, gw = torch.autograd.grad(y, (xi, wi), g[z])
+        dxs.append(gx.permute(0, 2, 3, 1).reshape(-1)); dws.append(gw[:, 0].permute(1, 2, 0).reshape(-1))
+    if dx is not None:
+        v = torch.cat(dxs); _wr(dx, torch.arange(v.numel()), v)
+    if dw is not None:
+        v = torch.cat(dws); _wr(dw, torch.arange(v.numel()), v)
+
+
+def avgpool_ceil_bwd(**kw):
+    dy, dx = kw["xargs"]
+    B, H, W, k, ld = kw["B"], kw["H"], kw["W"], kw["k"], kw["ld"]
+    Ho, Wo = -(-H // k), -(-W // k)
+    xi = torch.zeros(B, ld, H, W, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.avg_pool2d(xi, k, k, 0, ceil_mode=True)
+    g = _rd(dy, torch.arange(B * Ho * Wo * ld)).view(B, Ho, Wo, ld).permute(0, 3, 1, 2)
+    (gx,) = torch.autograd.grad(y, xi, g)
+    _wr(dx, torch.arange(B * H * W * ld), gx.permute(0, 2, 3, 1).reshape(-1))
+
+
+def convt3x3s2_gather_bwd(**kw):
+    dout, dyall = kw["xargs"]
+    B, H, W, Cop = kw["B"], kw["H"], kw["W"], kw["Cop"]
+    g = _rd(dout, torch.arange(B * 4 * H * W * Cop)).view(B, 2 * H, 2 * W, Cop)
+    out = torch.zeros(B, H, W, 3, 3, Cop, dtype=torch.float64)
+    for ky in range(3):
+        for kx in range(3):
+            for iy in range(H):
+                oy = 2 * iy - 1 + ky
+                if not 0 <= oy < 2 * H:
+                    continue
+                for ix in range(W):
+                    ox = 2 * ix - 1 + kx
+                    if 0 <= ox < 2 * W:
+                        out[:, iy, ix, ky, kx] = g[:, oy, ox]
+    _wr(dyall, torch.arange(out.numel()), out.reshape(-1))
+
+
 _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
               bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply,
               modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw,
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
-              convt3x3s2_gather=convt3x3s2_gather)
+              convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
+              convt3x3s2_gather_bwd=convt3x3s2_gather_bwd)
 _POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad)
 
 
 def call(name, **kw):
-    with torch.no_grad():
+    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd") else torch.no_grad():
         if name in _POS:
             return _POS[name](kw["args"])
         return _TABLE[name](**kw)

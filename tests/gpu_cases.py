@@ -353,6 +353,16 @@ def invpt_cases():
         kw = dict(yall=rnd(g, B * H * W, 9 * Cop, dtype=DT[dt]), out=torch.zeros(B * 4 * H * W, Cop, dtype=DT[dt]), bias=rnd(g, Cop),
                   B=B, H=H, W=W, Cop=Cop, dtype=dt, out_dtype=dt)
         cases.append((f"convt_gather_{dt}", "convt3x3s2_gather", kw, TOL_ROW))
+    for dt in (F32, BF16):
+        Z, B, H, W, ld = 2, 2, 6, 4, 24
+        kw = dict(x=rnd(g, Z, B * H * W, ld, dtype=DT[dt]), w=rnd(g, Z, 9, ld), y=None, scale=None, shift=None, Z=Z, B=B, H=H, W=W, ld=ld, dtype=dt,
+                  xargs=[rnd(g, Z, B * 3 * 2, ld, dtype=DT[dt]), torch.zeros(Z, B * H * W, ld, dtype=DT[dt]), torch.zeros(Z, 9, ld)])
+        cases.append((f"dwconv_bwd_{dt}", "dwconv3x3s2_bwd", kw, dict(f32=2e-5, bf16=6e-3)))
+        kw = dict(x=None, y=None, B=2, H=5, W=7, k=4, ld=16, dtype=dt, xargs=[rnd(g, 2 * 2 * 2, 16, dtype=DT[dt]), torch.zeros(2 * 35, 16, dtype=DT[dt])])
+        cases.append((f"avgpool_bwd_{dt}", "avgpool_ceil_bwd", kw, TOL_ROW))
+        kw = dict(yall=None, out=None, bias=None, B=2, H=3, W=4, Cop=16, dtype=dt, out_dtype=dt,
+                  xargs=[rnd(g, 2 * 4 * 12, 16, dtype=DT[dt]), torch.zeros(2 * 12, 9 * 16, dtype=DT[dt])])
+        cases.append((f"convt_gather_bwd_{dt}", "convt3x3s2_gather_bwd", kw, TOL_ROW))
     B, heads, T, qh, qw, K = 2, 2, 3, 4, 2, 9
     Q = T * qh * qw
     kw = dict(cur=rnd(g, B, heads, Q, 16), prev=rnd(g, B, heads, Q // 4, 16), out=torch.zeros(B, heads, Q, 16), w=rnd(g, heads, 2 * heads),
