@@ -417,7 +417,7 @@ class BLinearFn(Function):
             if kmap is None:
                 dws.append(dW[z][:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
             else:
-                g = torch.empty(N, math.prod(wshapes[z][1:]), dtype=torch.float32, device=x.device)
+                g = torch.zeros(N, math.prod(wshapes[z][1:]), dtype=torch.float32, device=x.device)
                 for (d0, s0, ln) in kmap[1]:
                     g[:, s0:s0 + ln] = dW[z][:, d0:d0 + ln]
                 dws.append(g.reshape(wshapes[z]))
@@ -430,32 +430,35 @@ class BLinearFn(Function):
 
 class Conv3x3Fn(Function):
     """Task-batched 3x3 conv (+bias) as implicit GEMM; dgrad = same kernel with mirrored taps on the
-    transposed pack; wgrad = MTT_OP_CONV_R (taskprompter.py:362 fea_fuse[1], :692/:706 head convs)."""
+    transposed pack; wgrad = MTT_OP_CONV_R (taskprompter.py:362 fea_fuse[1], :692/:706 head convs).
+    geo = (B, H, W, Co, Ci[, dilation]); the Z biases may all be None (bias-free convs of the InvPT decoder)."""
 
     @staticmethod
     def forward(ctx, x, geo, prec, tag, *wb):
-        B, H, W, Co, Ci = geo
+        B, H, W, Co, Ci = geo[:5]
+        dil = geo[5] if len(geo) > 5 else 1
         Z = len(wb) // 2
         ws, bs = wb[:Z], wb[Z:]
+        has_bias = bs[0] is not None
         wpack = ops.pack_conv3(list(ws), prec, tag)
-        y = ops.conv3x3(x, wpack, Co, Ci, B, H, W, prec, bias=ops.stack_vec(list(bs), (tag, 'b')))
+        y = ops.conv3x3(x, wpack, Co, Ci, B, H, W, prec, dil=dil, bias=ops.stack_vec(list(bs), (tag, 'b')) if has_bias else None)
         ctx.save_for_backward(x, *ws)
-        ctx.meta = (geo, prec, tag, Z)
+        ctx.meta = ((B, H, W, Co, Ci, dil), prec, tag, Z, has_bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        (B, H, W, Co, Ci), prec, tag, Z = ctx.meta
+        (B, H, W, Co, Ci, dil), prec, tag, Z, has_bias = ctx.meta
         dy = dy.contiguous()
         rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
         wd = ops.pack_conv3(list(ws), prec, tag, transpose=True)                     # [Z, Ci, 9*Cop]
-        dx = ops.conv3x3(dy, wd, Ci, Co, B, H, W, prec, flip=1, out_dtype=x.dtype)
+        dx = ops.conv3x3(dy, wd, Ci, Co, B, H, W, prec, flip=1, dil=dil, out_dtype=x.dtype)
         dW = torch.empty(Z, Co, 9 * Cip, dtype=torch.float32, device=x.device)
         _gemm(dy, x, dW, Co, 9 * Cip, rows, prec, a_op=OP_R, b_op=OP_CONV_R, lda=Cop, ldb=Cip, ldd=9 * Cip, batch=Z,
-              a_zo=rows * Cop, b_zo=rows * Cip, d_zo=Co * 9 * Cip, conv=dict(H=H, W=W, C=Ci, Cp=Cip, dil=1, flip=0))
+              a_zo=rows * Cop, b_zo=rows * Cip, d_zo=Co * 9 * Cip, conv=dict(H=H, W=W, C=Ci, Cp=Cip, dil=dil, flip=0))
         dws = [dW[z].view(Co, 3, 3, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous() for z in range(Z)]
-        dbs = [_colsum(dy[z], Co) for z in range(Z)]
+        dbs = [_colsum(dy[z], Co) if has_bias else None for z in range(Z)]
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 

@@ -13,8 +13,8 @@ Schedule (differs from the reference's op graph):
   * Dead reference compute is skipped (scale_embed[2], norm_mt, stage-0 fuse_attn, redu_chan[0]); their parameters
     exist (strict state_dict) and — as in the reference — receive no gradient.
 
-Round 1: inference / no-grad forward (eval and train-mode BatchNorm statistics); the autograd path of the InvPT
-decoder is not wired yet (TaskPrompter's is) — calling it with grad enabled raises.
+This file is the no-grad forward (eval and train-mode BatchNorm statistics); with gradients enabled the same
+modules route to invpt_autograd.py (autograd Functions with hand-written backward on the same kernels).
 """
 import math
 from collections import OrderedDict
@@ -85,8 +85,9 @@ class VisionTransformer(nn.Module):
 
     def forward_taps(self, img):
         """-> 4 contiguous [B*hw, C] activation-dtype token maps (cls dropped), vit.py:340-349."""
-        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
-            raise NotImplementedError("InvPT training path is not wired in round 1 (inference only); use torch.no_grad()")
+        if torch.is_grad_enabled() and (img.requires_grad or any(q.requires_grad for q in self.parameters())):
+            from . import invpt_autograd
+            return invpt_autograd.vit_taps(self, img)
         prec = self.prec
         B = img.shape[0]
         C, nH = self.embed_dim, self.num_heads
@@ -308,6 +309,10 @@ class TransformerDecoder(nn.Module):
 
     def forward_nhwc(self, taps, B):
         """taps: 4 contiguous [B*hw, C] maps.  -> (features [T, B*8mh*8mw, pad8(E)], {task: inter_pred [B*mh*mw, pad8(n)] fp32})."""
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in taps) or any(q.requires_grad for q in self.parameters())):
+            from . import invpt_autograd
+            f, inter = invpt_autograd.decoder_forward(self, taps, B)
+            return f, {t: v[0] for t, v in inter.items()}
         p, prec = self.p, self.prec
         names = p.TASKS.NAMES
         T = len(names)
@@ -581,6 +586,9 @@ class TransformerNet(nn.Module):
         self.p = p
 
     def forward(self, x):
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            from . import invpt_autograd
+            return invpt_autograd.net_forward(self, x)
         img_size = tuple(x.shape[-2:])
         B = x.shape[0]
         dec = self.multi_task_decoder

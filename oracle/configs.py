@@ -58,6 +58,8 @@ def invpt(name):
         # BASELINE.json configs[0]: ViT-S built through the parametric constructor
         "cfg1": dict(backbone="small", img_size=(256, 256), tasks=NYUD2, embed_dim=512, pred_const=64, mtt_down=2),
         "mini": dict(backbone="tiny", img_size=(128, 64), tasks=NYUD2, embed_dim=32, pred_const=8, mtt_down=2),
+        # every channel / head dim a multiple of 8 (64/32/16, heads 32/16/8) like the published configs: training-path tests
+        "mini8": dict(backbone="tiny", img_size=(128, 64), tasks=NYUD2, embed_dim=56, pred_const=8, mtt_down=2),
     }[name]
     return dict(t, name=name, model="TransformerNet")
 

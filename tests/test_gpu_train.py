@@ -35,3 +35,16 @@ def test_gradients_with_droppath_masks():
     fwd, errs = train_check.grad_errors("mini_ctr", "x3", "cuda", drop=drop)
     worst, med = train_check.summarize(errs)
     assert max(fwd.values()) < 1e-3 and med < 1e-3, (worst, med)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,ftol,mtol", [("x3", 1e-3, 1e-3), ("bf16", 4e-2, 8e-2)])
+def test_invpt_gradients(prec, ftol, mtol):
+    """InvPT (ViT + InvPT decoder + MLP heads) training forward + backward through the C ABI vs the oracle's autograd."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fwd, errs, dead = train_check.invpt_grad_errors("mini8", prec, "cuda")
+    assert max(fwd.values()) < ftol, fwd
+    worst, med = train_check.summarize(errs, floor=1e-6 if prec == "x3" else 1e-4)
+    assert med < mtol and (prec != "x3" or worst[0] < 1e-2), (worst, med)
+    assert len(dead) == 10

@@ -126,6 +126,16 @@ def test_invpt_contract_and_wiring_on_emulator(emulated, prec, tol):
     _invpt_outputs_vs_golden(model, cfg, meta, gold, tol)
 
 
+def test_invpt_training_gradients_on_emulator(emulated):
+    """InvPT training path (invpt_autograd.py): outputs and every parameter gradient vs the oracle's autograd."""
+    import train_check
+    fwd, errs, dead = train_check.invpt_grad_errors("mini8", "x3", "cpu")
+    assert max(fwd.values()) < 5e-5, fwd
+    worst, med = train_check.summarize(errs)
+    assert worst[0] < 1e-3, worst
+    assert any("scale_embed.2" in k for k in dead) and any("norm_mt." in k for k in dead)
+
+
 def test_training_gradients_with_forced_split_k(emulated, monkeypatch):
     """Same gradient check with the split-K weight-gradient path forced on (production uses it for >= 4096-row reductions)."""
     import mtt_amd

@@ -30,6 +30,37 @@ def grad_errors(name, prec, device, drop=None, seed=0):
     return fwd, errs
 
 
+def invpt_grad_errors(name, prec, device, seed=0):
+    """InvPT: product training forward + backward vs the oracle's autograd (dead reference parameters must get no gradient)."""
+    from oracle import invpt_oracle as ipo
+    cfg = configs.invpt(name)
+    model = conftest.build_product_model(cfg, prec, device)
+    contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+    sd = weights.synth_state_dict(contract, seed)
+    model.load_state_dict({k: v.to(device) for k, v in sd.items()}, strict=True)
+    model.train()
+    x = weights.synth_images(2, cfg["img_size"], 2)
+    out = model(x.to(device))
+    cpu = {k: v.cpu() for k, v in out.items() if k != "inter_preds"}
+    cpu["inter_preds"] = {k: v.cpu() for k, v in out["inter_preds"].items()}
+    loss_of(cpu).backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    ref_out = ipo.forward(dict(sd, **params), cfg, x, training=True)
+    loss_of(ref_out).backward()
+    fwd = {t: float((cpu[t].detach() - ref_out[t].detach()).norm() / ref_out[t].detach().norm()) for t in cpu if t != "inter_preds"}
+    fwd.update({"inter/" + t: float((cpu["inter_preds"][t].detach() - v.detach()).norm() / v.detach().norm())
+                for t, v in ref_out["inter_preds"].items()})
+    errs, dead = {}, []
+    for k, prm in model.named_parameters():
+        if params[k].grad is None:
+            dead.append(k)
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, f"{k}: dead in the reference but got a gradient"
+            continue
+        assert prm.grad is not None, f"{k}: no gradient"
+        errs[k] = (float((prm.grad.cpu() - params[k].grad).norm()), float(params[k].grad.norm()))
+    return fwd, errs, dead
+
+
 def summarize(errs, floor=1e-6):
     rel = sorted(((e / n, k) for k, (e, n) in errs.items() if n > floor), reverse=True)
     med = rel[len(rel) // 2][0]
