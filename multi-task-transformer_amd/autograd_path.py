@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import ops
-from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code
+from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code  # noqa: F401
 
 pad8 = ops.pad8
 SPLITK_MIN_ROWS = 4096      # reduction length from which few-tile weight gradients are split over the batch dimension
@@ -543,6 +543,35 @@ class CtrMixFn(Function):
         return dfea, dw, (dout if had_acc else None), None, None
 
 
+class Deconv2x2Fn(Function):
+    """ConvTranspose2d(k=2, s=2) = GEMM with a pixel-shuffle store (taskprompter.py:705).  x [B*H*W, Cip] -> [B*2H*2W, pad8(Co)]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geo, prec, tag):
+        B, H, W = geo
+        Ci, Co = weight.shape[0], weight.shape[1]
+        Wd = ops._cached((tag, prec.name, id(weight)), [weight],
+                         lambda: ops.pack_matrix(weight.detach().permute(2, 3, 1, 0).reshape(4 * Co, Ci), prec)[None])
+        y = ops.deconv2x2(x, Wd, Co, Ci, B, H, W, prec, bias4=bias.detach().repeat(4).contiguous())
+        ctx.save_for_backward(x, Wd)
+        ctx.meta = (geo, prec, Ci, Co)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wd = ctx.saved_tensors
+        (B, H, W), prec, Ci, Co = ctx.meta
+        N4, N4p = 4 * Co, pad8(4 * Co)
+        # pixel-unshuffle of the gradient (pure re-indexing): g4[(b,y,x), (dy*2+dx)*Co + co] = dy[b, 2y+dy, 2x+dx, co]
+        g4 = torch.zeros(B * H * W, N4p, dtype=dy.dtype, device=dy.device)
+        g4[:, :N4] = dy.view(B, H, 2, W, 2, -1)[..., :Co].permute(0, 1, 3, 2, 4, 5).reshape(B * H * W, N4)
+        dW4 = _wgrad(g4, x, N4, x.shape[1], prec)                                       # [4*Co, Cip]
+        dweight = dW4[:, :Ci].reshape(2, 2, Co, Ci).permute(3, 2, 0, 1).contiguous()
+        dbias = _colsum(g4, N4).view(4, Co).sum(0)
+        dx = _dgrad(g4, Wd[0], B * H * W, x.shape[1], N4, prec, x.dtype)
+        return dx, dweight, dbias, None, None, None
+
+
 class BilinearFn(Function):
     """F.interpolate(mode='bilinear', align_corners=False) on NHWC maps; nchw=True -> fp32 [B, C, Ho, Wo]."""
 
@@ -666,4 +695,15 @@ def wrapper_forward(wrapper, x, target):
                                    hd.linear_pred.bias)
             out[t] = BilinearFn.apply(pred, (B, n_out, h4, w4, target[0], target[1]), torch.float32, True)
         return out
-    raise NotImplementedError('training path: ConvHead heads only in round 1 (DEConvHead inference is supported)')
+    if all(isinstance(hd, DEConvHead) for hd in heads):
+        F2 = F // 2
+        for i, (t, hd) in enumerate(zip(wrapper.tasks, heads)):
+            y = Deconv2x2Fn.apply(fea[i], hd.mt_proj[0].weight, hd.mt_proj[0].bias, (B, h4, w4), prec, ('hd0', t))
+            y = BnActFn.apply(y, hd.mt_proj[1].weight, hd.mt_proj[1].bias, hd.mt_proj[1], F2, ACT_GELU, wrapper.training)[None]
+            y = Conv3x3Fn.apply(y, (B, 2 * h4, 2 * w4, F2, F2), prec, ('hd3', t), hd.mt_proj[3].weight, hd.mt_proj[3].bias)
+            y = BnActFn.apply(y[0], hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, wrapper.training)[None]
+            n_out = hd.linear_pred.weight.shape[0]
+            pred = BLinearFn.apply(y, n_out, 'plain', None, torch.float32, prec, ('hp', t), hd.linear_pred.weight, hd.linear_pred.bias)
+            out[t] = BilinearFn.apply(pred, (B, n_out, 2 * h4, 2 * w4, target[0], target[1]), torch.float32, True)
+        return out
+    raise NotImplementedError('heads must all be ConvHead or all DEConvHead (the 3ddet FCOS3D head is out of scope)')

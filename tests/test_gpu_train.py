@@ -6,7 +6,7 @@ import train_check
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mini_ctr", "mini_win"])
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv"])
 def test_gradients_x3(name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

@@ -78,7 +78,7 @@ def test_wiring_train_mode_batchnorm(emulated, name):
             assert float((sd[k] - torch.from_numpy(gold[f"bn/{k}"])).abs().max()) < 1e-4, k
 
 
-@pytest.mark.parametrize("name", ["mini_ctr", "mini_win"])
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv"])
 def test_training_gradients_on_emulator(emulated, name):
     """Every backward descriptor (dgrad/wgrad views, conv wgrad, attention bwd, modulation bwd, BN bwd, ...) on the
     ABI emulator vs the oracle's autograd: all parameter gradients within 1e-3 relative."""
