@@ -38,7 +38,7 @@ def test_gradients_with_droppath_masks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,ftol,mtol", [("x3", 1e-3, 1e-3), ("bf16", 4e-2, 8e-2)])
+@pytest.mark.parametrize("prec,ftol,mtol", [("x3", 1e-3, 1e-3), ("bf16", 4e-2, 2e-1)])
 def test_invpt_gradients(prec, ftol, mtol):
     """InvPT (ViT + InvPT decoder + MLP heads) training forward + backward through the C ABI vs the oracle's autograd."""
     if not torch.cuda.is_available():
