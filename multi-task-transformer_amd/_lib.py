@@ -148,6 +148,7 @@ DESC_EXTRA = {
     "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr]),
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),
+    "attn_bwd": (AttnDesc, [ptr, ptr, ptr, ptr]),
     "dwconv3x3s2_bwd": (DwconvDesc, [ptr, ptr, ptr]),
     "avgpool_ceil_bwd": (PoolDesc, [ptr, ptr]),
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),

@@ -8,6 +8,7 @@ attention backward materialises P per (batch, head) with the batched GEMM + row-
 (no N x N tensor ever leaves the backward), see DESIGN.md.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -170,6 +171,18 @@ def attention_bwd(qkv, dao, drawlog, B, N, nH, T, prec):
     return dqkv
 
 
+FLASH_BWD = os.environ.get("MTT_FLASH_BWD", "1") != "0"
+
+
+def attention_bwd_flash(qkv, ao, lse, dao, drawlog, B, N, nH, T, prec):
+    """bf16 mode: mtt_attn_bwd (recomputes P tile by tile from q, k and the forward's log-sum-exp; no N x N buffer)."""
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty(B, nH, N, dtype=torch.float32, device=qkv.device)
+    ops.call("attn_bwd", qkv=qkv, out=ao, rawlog=None, lse=lse, B=B, N=N, nH=nH, T=T, dtype=dtype_code(qkv), prec=prec.code,
+             scale=64 ** -0.5, xargs=[dao, drawlog, dqkv, dsum])
+    return dqkv
+
+
 class AttnBlockFn(Function):
     """xn -> qkv GEMM -> flash attention (+ prompt-row logits) -> proj GEMM + residual (taskprompter.py:199-214, :273)."""
 
@@ -180,11 +193,12 @@ class AttnBlockFn(Function):
         wq = ops.pack_linear([Wqkv], prec, tag + ('qkv',))
         wp = ops.pack_linear([Wproj], prec, tag + ('proj',))
         qkv = ops.linear(xn, wq, 3 * C, prec, bias=bqkv[None])[0]
-        ao, rawlog, _ = ops.attention(qkv, B, N, nH, T, prec)
+        flash = FLASH_BWD and prec.name == "bf16" and qkv.dtype == torch.bfloat16
+        ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=flash)
         XT2 = torch.empty_like(XT)
         ops.linear(ao, wp, C, prec, bias=bproj[None], out=XT2, resid=XT, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
                    M=B * N)
-        ctx.save_for_backward(xn, qkv, ao, wq, wp, rowscale)
+        ctx.save_for_backward(xn, qkv, ao, wq, wp, rowscale, lse)
         ctx.geo, ctx.prec = geo, prec
         ctx.params = (Wqkv, Wproj)
         if rawlog is None:
@@ -193,7 +207,7 @@ class AttnBlockFn(Function):
 
     @staticmethod
     def backward(ctx, dXT2, drawlog):
-        xn, qkv, ao, wq, wp, rowscale = ctx.saved_tensors
+        xn, qkv, ao, wq, wp, rowscale, lse = ctx.saved_tensors
         Wqkv_, Wproj_ = ctx.params
         B, N, nH, T = ctx.geo
         prec, C, M = ctx.prec, nH * 64, B * N
@@ -203,7 +217,10 @@ class AttnBlockFn(Function):
         dbproj = _colsum(g, C)
         dao = _enc_dgrad(g, Wproj_, wp[0], M, C, C, prec, prec.adt, 'proj')
         dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
-        dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
+        if lse is not None:
+            dqkv = attention_bwd_flash(qkv, ao, lse, dao, dl, B, N, nH, T, prec)
+        else:
+            dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
         dWqkv = _enc_wgrad(dqkv, xn, 3 * C, C, prec)
         dbqkv = _colsum(dqkv, 3 * C)
         dxn = _enc_dgrad(dqkv, Wqkv_, wq[0], M, C, 3 * C, prec, torch.float32, 'qkv')

@@ -205,12 +205,16 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* img, void* c
 // grid (C/8/32 column groups, pixel splits, B*nwin); block = 32 column chunks x 8 pixel lanes.
 // ------------------------------------------------------------------------------------------------
 constexpr int CL_MAXT = 8;
+// grid (C/64 column groups, pixel splits, B*nwin); block = 8 column chunks (64 channels, 128 B per pixel) x 32 pixel lanes.
+// Pixel lanes are reduced with wave shuffles, the 4 waves through LDS; gridDim.y == 1 -> plain store, else one atomic per
+// (t, channel) per split (destination zero-initialised by the caller).
 __global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc d, int tbase) {
   const int nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw, P = wh * ww;
   const int b = blockIdx.z / nwin, win = blockIdx.z % nwin;
   const int wy = win / d.nw, wx = win % d.nw;
-  const int cchunk = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int plane = threadIdx.x >> 5;                 // 0..7
+  const int cl = threadIdx.x & 7;
+  const int cchunk = blockIdx.x * 8 + cl;
+  const int plane = threadIdx.x >> 3;                 // 0..31
   const int nT = d.T - tbase < CL_MAXT ? d.T - tbase : CL_MAXT;
   float acc[CL_MAXT][8];
 #pragma unroll
@@ -221,7 +225,8 @@ __global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc
   const int per = (P + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * per, p1 = p0 + per < P ? p0 + per : P;
   if (cok) {
-    for (int pi = p0 + plane; pi < p1; pi += 8) {
+#pragma unroll 2
+    for (int pi = p0 + plane; pi < p1; pi += 32) {
       const int y = wy * wh + pi / ww, x = wx * ww + pi % ww;
       const int pix = y * d.w + x;
       float xv[8];
@@ -236,22 +241,27 @@ __global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc
       }
     }
   }
-  // reduce the 8 pixel lanes through LDS, then one atomic per (t, channel)
-  __shared__ float red[8][32][8];
-  for (int t = 0; t < nT; ++t) {
+  __shared__ float red[4][CL_MAXT][64];
+  const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[plane][threadIdx.x & 31][j] = acc[t][j];
-    __syncthreads();
-    if (plane == 0 && cok) {
+  for (int t = 0; t < CL_MAXT; ++t) {
+    if (t < nT) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += red[q][threadIdx.x & 31][j];
-        atomicAdd(&d.rawchan[(((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + cchunk * 8 + j], s);
+        float v = acc[t][j];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if ((threadIdx.x & 63) < 8) red[wave][t][cl * 8 + j] = v;
       }
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nT * 64; i += 256) {
+    const int t = i >> 6, c = i & 63;
+    const int col = blockIdx.x * 64 + c;
+    if (col >= d.C) continue;
+    const float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
+    float* dst = &d.rawchan[(((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + col];
+    if (gridDim.y == 1) *dst = v; else atomicAdd(dst, v);
   }
 }
 
@@ -685,18 +695,35 @@ __global__ __launch_bounds__(256) void chanlogit_bwd_kernel(const mtt_chanlogit_
   const int y = p / d.w, x = p % d.w;
   const int win = (y / wh) * d.nw + (x / ww);
   const int64_t xrow = ((int64_t)b * d.N + d.T + p) * d.C;
-  for (int t = 0; t < d.T; ++t) {
-    const float* g = drawchan + (((int64_t)b * d.T + t) * nwin + win) * d.C;
-    float s = 0.f;
-    for (int c = lane; c < d.C; c += 64) s += g[c] * ld_elem(d.xn, xrow + c, d.dtype);
-    s = wave_sum(s);
-    if (lane == 0) st_elem(dq, ((int64_t)b * d.T + t) * d.ldq + p, dq_dtype, s);
+  const int C8 = d.C >> 3;
+  float qv[CL_MAXT * 2], sq[CL_MAXT * 2];
+  const int nT = d.T < CL_MAXT * 2 ? d.T : CL_MAXT * 2;
+#pragma unroll
+  for (int t = 0; t < CL_MAXT * 2; ++t) {
+    sq[t] = 0.f;
+    qv[t] = t < nT ? ld_elem(d.q, ((int64_t)b * d.T + t) * d.ldq + p, d.dtype) : 0.f;
   }
-  for (int c = lane; c < d.C; c += 64) {
-    float s = 0.f;
-    for (int t = 0; t < d.T; ++t)
-      s += drawchan[(((int64_t)b * d.T + t) * nwin + win) * d.C + c] * ld_elem(d.q, ((int64_t)b * d.T + t) * d.ldq + p, d.dtype);
-    dxn[xrow + c] += s;
+  for (int c8 = lane; c8 < C8; c8 += 64) {
+    float xv[8], da[8];
+    ld8(d.xn, xrow + c8 * 8, d.dtype, xv);
+    ld8(dxn, xrow + c8 * 8, MTT_F32, da);
+#pragma unroll
+    for (int t = 0; t < CL_MAXT * 2; ++t) {
+      if (t < nT) {
+        float g[8];
+        ld8(drawchan, (((int64_t)b * d.T + t) * nwin + win) * d.C + c8 * 8, MTT_F32, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sq[t] += g[j] * xv[j]; da[j] += g[j] * qv[t]; }
+      }
+    }
+    st8(dxn, xrow + c8 * 8, MTT_F32, da);
+  }
+#pragma unroll
+  for (int t = 0; t < CL_MAXT * 2; ++t) {
+    if (t < nT) {
+      const float s = wave_sum(sq[t]);
+      if (lane == 0) st_elem(dq, ((int64_t)b * d.T + t) * d.ldq + p, dq_dtype, s);
+    }
   }
 }
 
@@ -850,8 +877,9 @@ extern "C" int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream) {
   if (!d || !d->q || !d->xn || !d->rawchan) return MTT_E_BADARG;
   if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
   const int P = (d->h / d->nh) * (d->w / d->nw);
-  int splits = P / 64; if (splits < 1) splits = 1; if (splits > 32) splits = 32;
-  dim3 grid((d->C / 8 + 31) / 32, splits, d->B * d->nh * d->nw);
+  const int base = ((d->C + 63) / 64) * d->B * d->nh * d->nw;
+  int splits = (1024 + base - 1) / base; if (splits > P / 32) splits = P / 32; if (splits < 1) splits = 1; if (splits > 64) splits = 64;
+  dim3 grid((d->C + 63) / 64, splits, d->B * d->nh * d->nw);
   for (int tb = 0; tb < d->T; tb += CL_MAXT) hipLaunchKernelGGL(chanlogit_kernel, grid, dim3(256), 0, S_, *d, tb);
   return LAUNCH_OK();
 }
@@ -955,7 +983,8 @@ extern "C" int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, fl
 
 extern "C" int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* drawchan, void* dq, int dq_dtype, float* dxn, void* stream) {
   if (!d || !d->q || !d->xn || !drawchan || !dq || !dxn) return MTT_E_BADARG;
-  if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw)) return MTT_E_BADARG;
+  if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
+  if (d->T > 2 * CL_MAXT) return MTT_E_UNSUPPORTED;
   const int64_t toks = (int64_t)d->B * d->h * d->w;
   hipLaunchKernelGGL(chanlogit_bwd_kernel, dim3((unsigned)((toks + 3) / 4)), dim3(256), 0, S_, *d, drawchan, dq, dq_dtype, dxn);
   return LAUNCH_OK();

@@ -180,6 +180,28 @@ def attn_fwd(**kw):
     _wr(out, torch.arange(B * N * C), y)
 
 
+def attn_bwd(**kw):
+    """xargs = [dout, drawlog | None, dqkv, dsum]; forward recomputed in fp64 from (bf16-rounded) qkv."""
+    dout, drawlog, dqkv, dsum = kw["xargs"]
+    B, N, nH, T = kw["B"], kw["N"], kw["nH"], kw["T"]
+    C = nH * 64
+    x = _rd(kw["qkv"], torch.arange(B * N * 3 * C)).view(B, N, 3, nH, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))                      # [B, nH, N, 64]
+    g = _rd(dout, torch.arange(B * N * C)).view(B, N, nH, 64).transpose(1, 2)
+    raw = q @ k.transpose(-1, -2)
+    P = torch.softmax(raw * kw["scale"], dim=-1)
+    dV = P.transpose(-1, -2) @ g
+    dP = g @ v.transpose(-1, -2)
+    D = (dP * P).sum(-1, keepdim=True)
+    dS = kw["scale"] * P * (dP - D)
+    if drawlog is not None and T > 0:
+        dS[:, :, :T] += _rd(drawlog, torch.arange(B * nH * T * N)).view(B, nH, T, N)
+    dQ, dK = dS @ k, dS.transpose(-1, -2) @ q
+    out = torch.stack([dQ, dK, dV], 0).permute(1, 3, 0, 2, 4).reshape(-1)      # [B, N, 3, nH, 64]
+    _wr(dqkv, torch.arange(B * N * 3 * C), out)
+    _wr(dsum, torch.arange(B * nH * N), D.reshape(-1))
+
+
 def softmax_fwd(**kw):
     rows, cols, ld = kw["rows"], kw["cols"], kw["ld"]
     idx = torch.arange(rows)[:, None] * ld + torch.arange(cols)[None, :]
@@ -630,7 +652,7 @@ _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd
               modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw,
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
-              convt3x3s2_gather_bwd=convt3x3s2_gather_bwd)
+              convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd)
 _POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad)
 
 

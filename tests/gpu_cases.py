@@ -211,6 +211,17 @@ def attn_cases():
                       B=B, N=N, nH=nH, T=T, dtype=adt, prec=prec, scale=0.125)
             cases.append((f"attn_B{B}N{N}T{T}_{'x3' if prec else 'bf16'}", "attn_fwd", kw,
                           dict(f32=3e-5 if prec else 2e-3, bf16=6e-3)))
+    # flash backward (bf16 mode): out / lse inputs come from the fp64 emulator of the forward
+    for (B, N, nH, T) in ((2, 150, 2, 6), (1, 257, 1, 0), (1, 64, 1, 3)):
+        C = nH * 64
+        qkv = rnd(g, B * N, 3 * C, dtype=DT[BF16])
+        fw = dict(qkv=qkv, out=torch.zeros(B * N, C, dtype=DT[BF16]), rawlog=None, lse=torch.zeros(B, nH, N), B=B, N=N, nH=nH, T=0,
+                  dtype=BF16, prec=0, scale=0.125)
+        abi_emul.call("attn_fwd", **fw)
+        kw = dict(qkv=qkv, out=fw["out"], rawlog=None, lse=fw["lse"], B=B, N=N, nH=nH, T=T, dtype=BF16, prec=0, scale=0.125,
+                  xargs=[rnd(g, B * N, C, dtype=DT[BF16]), rnd(g, B, nH, T, N) * 0.05 if T else None,
+                         torch.zeros(B * N, 3 * C, dtype=DT[BF16]), torch.zeros(B, nH, N)])
+        cases.append((f"attn_bwd_B{B}N{N}T{T}", "attn_bwd", kw, dict(f32=5e-3, bf16=1.5e-2)))
     # softmax spike (forces large running-max jumps across tiles)
     B, N, nH, T = 1, 200, 1, 2
     q = rnd(g, B * N, 3 * 64)

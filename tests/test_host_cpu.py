@@ -89,6 +89,19 @@ def test_training_gradients_on_emulator(emulated, name):
     assert worst[0] < 1e-3, worst
 
 
+def test_bf16_training_uses_flash_attention_backward(emulated, monkeypatch):
+    """bf16 mode routes the attention backward to mtt_attn_bwd (flash, no N x N buffer); gradients stay bf16-accurate."""
+    import mtt_amd
+    import train_check
+    seen = []
+    inner = mtt_amd.ops.call
+    monkeypatch.setattr(mtt_amd.ops, "call", lambda name, **kw: (seen.append(name), inner(name, **kw))[1])
+    fwd, errs = train_check.grad_errors("mini_ctr", "bf16", "cpu")
+    assert "attn_bwd" in seen and "softmax_bwd" not in seen
+    worst, med = train_check.summarize(errs, floor=1e-4)
+    assert max(fwd.values()) < 4e-2 and med < 6e-2, (worst, med)
+
+
 def test_training_with_injected_droppath_masks(emulated):
     import train_check
     g = torch.Generator().manual_seed(3)
