@@ -520,45 +520,51 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const mtt_bn_desc d, int
   for (int c = threadIdx.x; c < d.C; c += 256) { atomicAdd(&o0[c], lsm[c]); if (MODE != 1) atomicAdd(&o1[c], lsm[Cp + c]); }
 }
 
-// y = act((x - mean) * rstd * gamma + beta); channels >= C are written as zeros (padding)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const mtt_bn_desc d) {
+// y = act((x - mean) * rstd * gamma + beta); channels >= C are written as zeros (padding).
+// Block = a range of rows; thread = one fixed 8-channel chunk (per-channel parameters live in registers, no
+// division in the loop), 256 / C8 rows in flight per block.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, int rows_per_block) {
   const int C8 = (d.C + 7) >> 3;
-  const int64_t total = d.rows * C8;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int c8 = (int)(t % C8);
-    const int64_t r = t / C8;
-    float x[8], o[8];
-    ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c8 * 8 + j;
-      o[j] = c < d.C ? act_fwd((x[j] - d.mean[c]) * d.rstd[c] * d.gamma[c] + d.beta[c], d.act) : 0.f;
-    }
-    st8(d.y, r * d.ld + c8 * 8, d.dtype, o);
-  }
-}
-
-// dx = gamma*rstd * (du - dsum/rows - xhat * dsumxh/rows), du = dy * act'(u)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const mtt_bn_desc d) {
-  const int C8 = (d.C + 7) >> 3;
-  const int64_t total = d.rows * C8;
+  const int lanes = C8 >= 256 ? 1 : 256 / C8;
+  const int c8_0 = C8 >= 256 ? threadIdx.x : threadIdx.x % C8;
+  const int rl = C8 >= 256 ? 0 : threadIdx.x / C8;
+  if (rl >= lanes) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
   const float invn = 1.0f / (float)d.rows;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int c8 = (int)(t % C8);
-    const int64_t r = t / C8;
-    float x[8], g[8], o[8];
-    ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
-    ld8(d.dy, r * d.ld + c8 * 8, d.dtype, g);
+  for (int c8 = c8_0; c8 < C8; c8 += 256) {
+    float mu[8], rs[8], ga[8], be[8], s0[8], s1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c8 * 8 + j;
-      if (c < d.C) {
-        const float xh = (x[j] - d.mean[c]) * d.rstd[c];
-        const float du = g[j] * act_bwd(xh * d.gamma[c] + d.beta[c], d.act);
-        o[j] = d.gamma[c] * d.rstd[c] * (du - d.dsum[c] * invn - xh * d.dsumxh[c] * invn);
-      } else o[j] = 0.f;
+      const bool ok = c < d.C;
+      mu[j] = ok ? d.mean[c] : 0.f; rs[j] = ok ? d.rstd[c] : 0.f; ga[j] = ok ? d.gamma[c] : 0.f; be[j] = ok ? d.beta[c] : 0.f;
+      if (BWD) { s0[j] = ok ? d.dsum[c] * invn : 0.f; s1[j] = ok ? d.dsumxh[c] * invn : 0.f; }
     }
-    st8(d.dx, r * d.ld + c8 * 8, d.dtype, o);
+    const bool tail = c8 * 8 + 8 > d.C;
+    for (int64_t r = r0 + rl; r < r1; r += lanes) {
+      float x[8], o[8];
+      ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
+      if (BWD) {
+        float g[8];
+        ld8(d.dy, r * d.ld + c8 * 8, d.dtype, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (x[j] - mu[j]) * rs[j];
+          const float du = g[j] * act_bwd(xh * ga[j] + be[j], d.act);
+          o[j] = ga[j] * rs[j] * (du - s0[j] - xh * s1[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd((x[j] - mu[j]) * rs[j] * ga[j] + be[j], d.act);
+      }
+      if (tail) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (c8 * 8 + j >= d.C) o[j] = 0.f;
+      }
+      st8(BWD ? d.dx : d.y, r * d.ld + c8 * 8, d.dtype, o);
+    }
   }
 }
 
@@ -921,6 +927,13 @@ static int colreduce_cfg(const mtt_bn_desc* d, int& nblk, int& rpb) {
   nblk = (int)((d->rows + rpb - 1) / rpb);
   return 0;
 }
+static void bn_rowwise_cfg(const mtt_bn_desc* d, int& nblk, int& rpb) {
+  const int C8 = (d->C + 7) / 8;
+  const int lanes = C8 >= 256 ? 1 : 256 / C8;
+  int64_t nb = (d->rows + 4 * lanes - 1) / (4 * lanes); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;   // >= 4 rows per lane
+  rpb = (int)((d->rows + nb - 1) / nb);
+  nblk = (int)((d->rows + rpb - 1) / rpb);
+}
 extern "C" int mtt_bn_stats(const mtt_bn_desc* d, void* stream) {
   int nblk, rpb; int e = colreduce_cfg(d, nblk, rpb); if (e) return e;
   if (!d->x || !d->sum || !d->sumsq) return MTT_E_BADARG;
@@ -947,12 +960,14 @@ extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, void* stream) {
 }
 extern "C" int mtt_bn_apply(const mtt_bn_desc* d, void* stream) {
   if (!d || !d->x || !d->y || !d->mean || !d->rstd || !d->gamma || !d->beta || (d->ld % 8)) return MTT_E_BADARG;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(d->rows * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
+  int nblk, rpb; bn_rowwise_cfg(d, nblk, rpb);
+  hipLaunchKernelGGL(bn_rowwise_kernel<false>, dim3(nblk), dim3(256), 0, S_, *d, rpb);
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream) {
   if (!d || !d->x || !d->dy || !d->dx || !d->mean || !d->rstd || !d->gamma || !d->beta || !d->dsum || !d->dsumxh || (d->ld % 8)) return MTT_E_BADARG;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(d->rows * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
+  int nblk, rpb; bn_rowwise_cfg(d, nblk, rpb);
+  hipLaunchKernelGGL(bn_rowwise_kernel<true>, dim3(nblk), dim3(256), 0, S_, *d, rpb);
   return LAUNCH_OK();
 }
 

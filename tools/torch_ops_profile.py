@@ -1,0 +1,37 @@
+"""Which torch (non-libmtt) ops run inside one training step, with input shapes: finds glue that should be fused or removed.
+Usage (GPU box): python tools/torch_ops_profile.py [batch]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+import mtt_amd  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device("cuda")
+p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (512, 512), backbone="TaskPrompter_vitL", head="conv", embed_dim=300,
+                           final_embed_dim=350, chan_nheads=1, use_ctr=True, prec="bf16")
+model = mtt_amd.factory.get_model(p).to(dev).train()
+crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES).to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=2e-5, fused=True)
+x = torch.randn(B, 3, 512, 512, device=dev)
+gt = mtt_amd.losses.synthetic_targets(p, B, 512, 512, dev)
+
+
+def step():
+    loss = crit(model(x), gt)["total"]
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+    opt.step()
+
+
+step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    step()
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=40,
+                                                         max_shapes_column_width=70))
