@@ -216,6 +216,10 @@ int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, in
 /* dst[c, r] = src[r, c] for r < rows, c < cols; dst is [cols, ldd] with columns rows..ldd-1 written as zeros (ldd >= rows). */
 int mtt_transpose_pad(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
                       void* stream);
+/* same, and colsum[c] += sum_r src[r, c] (fp32 atomics; bf16 destination, 8-aligned shapes only): the bias gradient comes for
+ * free with the transposing copy the fast weight-gradient GEMM needs anyway. */
+int mtt_transpose_pad_sum(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int src_dtype,
+                          int dst_dtype, float* colsum, void* stream);
 int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream);
 int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype,
                  float alpha, void* stream);

@@ -141,6 +141,7 @@ POSITIONAL = {
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
     "transpose_pad": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, ptr],
+    "transpose_pad_sum": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, ptr, ptr],
 }
 
 # descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)

@@ -69,19 +69,23 @@ def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
     return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
 
 
-def _transposed(x2d, cols, dtype=torch.bfloat16):
-    """[rows, ld] -> [cols, pad64(rows)] (zero padded): reduction-contiguous operand for the fast weight-gradient GEMM."""
+def _transposed(x2d, cols, dtype=torch.bfloat16, colsum=None):
+    """[rows, ld] -> [cols, pad64(rows)] (zero padded): reduction-contiguous operand for the fast weight-gradient GEMM.
+    colsum (fp32 [cols], zero-initialised): also receives the column sums of x2d (the bias gradient) from the same pass."""
     rows = x2d.shape[0]
     Mp = (rows + 63) // 64 * 64
     out = torch.empty(cols, Mp, dtype=dtype, device=x2d.device)
-    ops.call("transpose_pad", args=[x2d, out, rows, cols, x2d.stride(0), Mp, dtype_code(x2d), dtype_code(out)])
+    if colsum is not None:
+        ops.call("transpose_pad_sum", args=[x2d, out, rows, cols, x2d.stride(0), Mp, dtype_code(x2d), dtype_code(out), colsum])
+    else:
+        ops.call("transpose_pad", args=[x2d, out, rows, cols, x2d.stride(0), Mp, dtype_code(x2d), dtype_code(out)])
     return out
 
 
-def _wgrad_fast(dy, x, N, Kp, prec):
+def _wgrad_fast(dy, x, N, Kp, prec, colsum=None):
     """bf16 mode: dW = (dy^T) (x^T)^T with both operands transposed to reduction-contiguous form, so the weight gradient
     runs on the direct-to-LDS GEMM kernels instead of the transposing stagers."""
-    dyT, xT = _transposed(dy, N), _transposed(x, Kp)
+    dyT, xT = _transposed(dy, N, colsum=colsum), _transposed(x, Kp)
     Mp = dyT.shape[1]
     tiles = -(-N // 256) * -(-Kp // 256)
     if tiles < 64 and Mp >= 4096:                                   # split the token reduction over the batch dimension
@@ -100,9 +104,12 @@ def _wgrad_fast(dy, x, N, Kp, prec):
 
 
 def _enc_wgrad(dy, x, N, Kp, prec):
-    if prec.name == "bf16" and FAST_BWD and N >= FAST_MIN_DIM and Kp >= FAST_MIN_DIM and dy.shape[0] >= FAST_MIN_ROWS:
-        return _wgrad_fast(dy, x, N, Kp, prec)
-    return _wgrad(dy, x, N, Kp, prec)
+    """-> (dW [N, Kp], dbias [N]) of y = x W^T + b given dy."""
+    if (prec.name == "bf16" and FAST_BWD and N >= FAST_MIN_DIM and Kp >= FAST_MIN_DIM and dy.shape[0] >= FAST_MIN_ROWS
+            and N % 8 == 0 and dy.stride(0) % 8 == 0):
+        db = torch.zeros(N, dtype=torch.float32, device=dy.device)
+        return _wgrad_fast(dy, x, N, Kp, prec, colsum=db), db
+    return _wgrad(dy, x, N, Kp, prec), _colsum(dy, N)
 
 
 def _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, **epi):
@@ -213,16 +220,14 @@ class AttnBlockFn(Function):
         prec, C, M = ctx.prec, nH * 64, B * N
         dXT2 = dXT2.contiguous()
         g = _scaled(dXT2, rowscale, N, T, prec)
-        dWproj = _enc_wgrad(g, ao, C, C, prec)
-        dbproj = _colsum(g, C)
+        dWproj, dbproj = _enc_wgrad(g, ao, C, C, prec)
         dao = _enc_dgrad(g, Wproj_, wp[0], M, C, C, prec, prec.adt, 'proj')
         dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
         if lse is not None:
             dqkv = attention_bwd_flash(qkv, ao, lse, dao, dl, B, N, nH, T, prec)
         else:
             dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
-        dWqkv = _enc_wgrad(dqkv, xn, 3 * C, C, prec)
-        dbqkv = _colsum(dqkv, 3 * C)
+        dWqkv, dbqkv = _enc_wgrad(dqkv, xn, 3 * C, C, prec)
         dxn = _enc_dgrad(dqkv, Wqkv_, wq[0], M, C, 3 * C, prec, torch.float32, 'qkv')
         return dxn, dXT2, dWqkv, dbqkv, dWproj, dbproj, None, None, None, None
 
@@ -303,13 +308,138 @@ class MlpFn(Function):
         dXT3 = dXT3.contiguous()
         g = _scaled(dXT3, rowscale, N, T, prec)
         W1_, W2_ = ctx.params
-        dW2 = _enc_wgrad(g, hmid, C, Hd, prec)
-        db2 = _colsum(g, C)
+        dW2, db2 = _enc_wgrad(g, hmid, C, Hd, prec)
         dz = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
-        dW1 = _enc_wgrad(dz, xn2, Hd, C, prec)
-        db1 = _colsum(dz, Hd)
+        dW1, db1 = _enc_wgrad(dz, xn2, Hd, C, prec)
         dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
         return dxn2, dXT3, dW1, db1, dW2, db2, None, None, None, None
+
+
+def _ln_bwd_into(dres, x, dy, gamma, mean, rstd, eps):
+    """dres += LayerNorm backward of dy (the kernel accumulates into dx): residual-stream gradient updated in place.
+    Returns (dgamma, dbeta)."""
+    dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+    ops.call("layernorm_bwd", x=x, dy=dy, gamma=gamma, mean=mean, rstd=rstd, dx=dres, dgamma=dg, dbeta=db,
+             rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=eps)
+    return dg, db
+
+
+class AttnHalfFn(Function):
+    """First half of a ViT block in ONE autograd node: norm1 -> qkv GEMM -> flash attention (+ prompt-row logits) -> proj GEMM +
+    residual [-> channel attention on the prompt rows] (taskprompter.py:195-254, :273-276; vit.py:199-202 without prompts).
+    Fusing the node removes three [tokens, C] fp32 passes per block that autograd would add: the sum of the two gradients of
+    the normalised tokens, the zero-initialised LayerNorm-backward buffer and its sum with the residual gradient — here the
+    channel-attention backward accumulates onto the qkv dgrad output, and the LayerNorm backward accumulates straight into
+    the incoming residual gradient."""
+
+    @staticmethod
+    def forward(ctx, XT, g1, b1, eps, Wqkv, bqkv, Wproj, bproj, Wtt, btt, Wtt1, btt1, rowscale, geo, prec, tag):
+        B, N, nH, T, h, w, nwin = geo
+        C, hw = nH * 64, h * w
+        chan = Wtt is not None
+        xn, mean, rstd = ops.layernorm(XT, g1, b1, eps, prec, save_stats=True)
+        wq = ops.pack_linear([Wqkv], prec, tag + ('qkv',))
+        wp = ops.pack_linear([Wproj], prec, tag + ('proj',))
+        qkv = ops.linear(xn, wq, 3 * C, prec, bias=bqkv[None])[0]
+        flash = FLASH_BWD and prec.name == "bf16" and qkv.dtype == torch.bfloat16
+        ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=flash)
+        XT2 = torch.empty_like(XT)
+        ops.linear(ao, wp, C, prec, bias=bproj[None], out=XT2, resid=XT, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
+                   M=B * N)
+        cq = wt = wt1 = rawchan = None
+        if chan:
+            wt = ops.pack_linear([Wtt], prec, tag + ('tt',))
+            wt1 = ops.pack_linear([Wtt1], prec, tag + ('tt1',))
+            cq = ops.linear(xn, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
+            rawchan = ops.chan_logits(cq, xn, B, T, N, C, (h, w), (nwin, nwin))
+            pr = XT2.view(B, N, C)[:, :T]
+            ops.linear(cq, wt1, C, prec, bias=btt1[None], out=pr, d_rows=(T, N * C, C), resid=pr, rowscale=rowscale, n_prompt=T,
+                       M=B * T)
+        ctx.save_for_backward(XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1)
+        ctx.geo, ctx.prec, ctx.eps, ctx.chan = geo, prec, eps, chan
+        ctx.params = (Wqkv, Wproj)
+        z = torch.zeros(0, device=XT.device)
+        return XT2, (rawlog if rawlog is not None else z), (rawchan if rawchan is not None else z)
+
+    @staticmethod
+    def backward(ctx, dXT2, drawlog, drawchan):
+        XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1 = ctx.saved_tensors
+        Wqkv_, Wproj_ = ctx.params
+        B, N, nH, T, h, w, nwin = ctx.geo
+        prec, C, M, hw = ctx.prec, nH * 64, B * N, h * w
+        dXT2 = dXT2.contiguous()
+        # ---- spatial attention ---------------------------------------------------------------------------------
+        g = _scaled(dXT2, rowscale, N, T, prec)
+        dWproj, dbproj = _enc_wgrad(g, ao, C, C, prec)
+        dao = _enc_dgrad(g, Wproj_, wp[0], M, C, C, prec, prec.adt, 'proj')
+        dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
+        if lse is not None:
+            dqkv = attention_bwd_flash(qkv, ao, lse, dao, dl, B, N, nH, T, prec)
+        else:
+            dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
+        dWqkv, dbqkv = _enc_wgrad(dqkv, xn, 3 * C, C, prec)
+        dxn = _enc_dgrad(dqkv, Wqkv_, wq[0], M, C, 3 * C, prec, torch.float32, 'qkv')
+        # ---- channel attention: accumulates onto dxn -------------------------------------------------------------
+        dWtt = dbtt = dWtt1 = dbtt1 = None
+        if ctx.chan:
+            hwp = cq.shape[-1]
+            gp = dXT2.view(B, N, C)[:, :T].reshape(B * T, C)                  # tiny copy (B*T rows)
+            if rowscale is not None:
+                gp = gp * rowscale[:, 0].repeat_interleave(T)[:, None]
+            dWtt1 = _wgrad(gp, cq, C, hwp, prec)[:, :hw]
+            dbtt1 = _colsum(gp, C)
+            dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
+            if drawchan is not None and drawchan.numel():
+                dq2 = torch.zeros(B * T, hwp, dtype=torch.float32, device=xn.device)
+                ops.call("chan_logits_bwd", q=cq, xn=xn, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
+                         dtype=dtype_code(xn), ldq=hwp, xargs=[drawchan.contiguous(), dq2, F32, dxn])
+                dcq = dcq + dq2                                                # [B*T, hwp] fp32 (tiny)
+            xnp = xn.view(B, N, C)[:, :T].reshape(B * T, C)
+            dWtt = _wgrad(dcq, xnp, hw, C, prec)[:, :C]
+            dbtt = _colsum(dcq, hw)
+            dp = dxn.view(B, N, C)[:, :T]
+            _gemm(dcq, wt[0], dp, B * T, C, hw, prec, b_op=OP_R, lda=hwp, ldb=wt.shape[-1], ldd=C, d_mb=T, d_bs=N * C,
+                  resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
+        # ---- norm1 backward accumulated into the residual gradient ------------------------------------------------
+        dg1, db1 = _ln_bwd_into(dXT2, XT, dxn, g1, mean, rstd, ctx.eps)
+        return (dXT2, dg1, db1, None, dWqkv, dbqkv, dWproj, dbproj, dWtt, dbtt, dWtt1, dbtt1, None, None, None, None)
+
+
+class MlpHalfFn(Function):
+    """Second half of a ViT block in one autograd node: norm2 -> fc1 + GELU -> fc2 + residual (taskprompter.py:277; vit.py:203)."""
+
+    @staticmethod
+    def forward(ctx, XT2, g2, b2n, eps, W1, b1, W2, b2, rowscale, geo, prec, tag):
+        B, N, T = geo
+        C, Hd = W1.shape[1], W1.shape[0]
+        xn2, mean, rstd = ops.layernorm(XT2, g2, b2n, eps, prec, save_stats=True)
+        w1 = ops.pack_linear([W1], prec, tag + ('fc1',))
+        w2 = ops.pack_linear([W2], prec, tag + ('fc2',))
+        z = torch.empty(B * N, Hd, dtype=prec.adt, device=XT2.device)
+        hmid = ops.linear(xn2, w1, Hd, prec, bias=b1[None], act=ACT_GELU, aux_out=z)[0]
+        XT3 = torch.empty_like(XT2)
+        ops.linear(hmid, w2, C, prec, bias=b2[None], out=XT3, resid=XT2, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
+                   M=B * N)
+        ctx.save_for_backward(XT2, g2, mean, rstd, xn2, z, hmid, w1, w2, rowscale)
+        ctx.geo, ctx.prec, ctx.eps = geo, prec, eps
+        ctx.params = (W1, W2)
+        return XT3
+
+    @staticmethod
+    def backward(ctx, dXT3):
+        XT2, g2, mean, rstd, xn2, z, hmid, w1, w2, rowscale = ctx.saved_tensors
+        B, N, T = ctx.geo
+        prec, M = ctx.prec, B * N
+        C, Hd = xn2.shape[1], z.shape[1]
+        dXT3 = dXT3.contiguous()
+        g = _scaled(dXT3, rowscale, N, T, prec)
+        W1_, W2_ = ctx.params
+        dW2, db2 = _enc_wgrad(g, hmid, C, Hd, prec)
+        dz = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
+        dW1, db1 = _enc_wgrad(dz, xn2, Hd, C, prec)
+        dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
+        dg2, dbn2 = _ln_bwd_into(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps)
+        return dXT3, dg2, dbn2, None, dW1, db1, dW2, db2, None, None, None, None
 
 
 class PatchEmbedFn(Function):
@@ -534,6 +664,101 @@ class BnActFn(Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
+class BnActStackFn(Function):
+    """BnActFn over a task stack [Z, rows, ld] (one BatchNorm per task): same kernels per task on slices of ONE input and ONE
+    output tensor, so autograd never slices / re-stacks the multi-GB head maps (select-backward costs a zero fill + copy + add
+    of the whole stack per task)."""
+
+    @staticmethod
+    def forward(ctx, x, C, act, training, bns, *gb):
+        Z, rows, ld = x.shape
+        gammas, betas = gb[:Z], gb[Z:]
+        y = torch.empty_like(x)
+        means, rstds, ns = [], [], []
+        for z, bn in enumerate(bns):
+            if training:
+                s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+                ops.call("bn_stats", x=x[z], sum=s[0], sumsq=s[1], rows=rows, C=C, ld=ld, dtype=dtype_code(x))
+                world = _sync_stats(s, bn)
+                n = rows * world
+                mean = s[0] / n
+                var = torch.clamp_min(s[1] / n - mean * mean, 0.0)
+                with torch.no_grad():
+                    m = bn.momentum if bn.momentum is not None else 0.1
+                    bn.running_mean.mul_(1 - m).add_(mean * m)
+                    bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)) * m)
+                    bn.num_batches_tracked += 1
+            else:
+                mean, var, n = bn.running_mean, bn.running_var, rows
+            rstd = torch.rsqrt(var + bn.eps)
+            ops.bn_apply(x[z], C, mean, rstd, gammas[z], betas[z], act, out=y[z])
+            means.append(mean); rstds.append(rstd); ns.append(n)
+        ctx.save_for_backward(x, torch.stack(means), torch.stack(rstds), *gb)
+        ctx.meta = (C, act, training, ns, bns)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, means, rstds = ctx.saved_tensors[:3]
+        gb = ctx.saved_tensors[3:]
+        C, act, training, ns, bns = ctx.meta
+        Z, rows, ld = x.shape
+        gammas, betas = gb[:Z], gb[Z:]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgs, dbs = [], []
+        for z, bn in enumerate(bns):
+            s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+            kw = dict(x=x[z], dy=dy[z], mean=means[z], rstd=rstds[z], gamma=gammas[z], beta=betas[z], rows=rows, C=C, ld=ld,
+                      dtype=dtype_code(x), act=act)
+            ops.call("bn_bwd_reduce", dsum=s[0], dsumxh=s[1], **kw)
+            dgs.append(s[1].clone()); dbs.append(s[0].clone())
+            if training:
+                _sync_stats(s, bn)
+                red = s * (rows / float(ns[z]))        # kernel divides by its local row count
+            else:
+                red = torch.zeros_like(s)
+            ops.call("bn_bwd_apply", dx=dx[z], dsum=red[0], dsumxh=red[1], **kw)
+        return (dx, None, None, None, None) + tuple(dgs) + tuple(dbs)
+
+
+class TaskHeadsFn(Function):
+    """The per-task 1x1 prediction convs (different output widths) on a task stack y [Z, rows, ld]: returns Z fp32 maps
+    [1, rows, pad8(n_z)].  One Function so that the backward writes each task's input gradient straight into its slice of a
+    single dy buffer (taskprompter.py:694 linear_pred / transformer_decoder.py:130)."""
+
+    @staticmethod
+    def forward(ctx, y, prec, tag, *wb):
+        Z = y.shape[0]
+        ws, bs = wb[:Z], wb[Z:]
+        outs, packs = [], []
+        for z in range(Z):
+            n = ws[z].shape[0]
+            wp = ops.pack_linear([ws[z]], prec, (tag, z))
+            outs.append(ops.linear(y[z], wp, n, prec, bias=bs[z][None], out_dtype=torch.float32))
+            packs.append(wp)
+        ctx.save_for_backward(y, *packs)
+        ctx.meta = (prec, [tuple(w.shape) for w in ws])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dps):
+        y, packs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        prec, wshapes = ctx.meta
+        Z, rows, ld = y.shape
+        dy = torch.empty_like(y)
+        dws, dbs = [], []
+        for z in range(Z):
+            n = wshapes[z][0]
+            g = dps[z].contiguous().view(rows, -1)
+            Kp = packs[z].shape[-1]
+            _gemm(g, packs[z][0], dy[z], rows, ld, n, prec, b_op=OP_R, lda=g.shape[1], ldb=Kp, ldd=ld, n_store=ld)
+            dW = _wgrad(g, y[z], n, Kp, prec)
+            dws.append(dW[:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
+            dbs.append(_colsum(g, n))
+        return (dy, None, None) + tuple(dws) + tuple(dbs)
+
+
 class CtrMixFn(Function):
     """acc (+)= sum_s wmix[b,t,s] * fea[s]  — cross-task reweighting fused with the 4-tap sum (taskprompter.py:411,484)."""
 
@@ -632,8 +857,7 @@ def _drop_scales(model, blk, i, B, device):
 
 
 def _bn_act(y, bns, C, act, training):
-    outs = [BnActFn.apply(y[t], bn.weight, bn.bias, bn, C, act, training) for t, bn in enumerate(bns)]
-    return torch.stack(outs, 0)
+    return BnActStackFn.apply(y, C, act, training, list(bns), *[bn.weight for bn in bns], *[bn.bias for bn in bns])
 
 
 def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
@@ -677,14 +901,12 @@ def backbone_forward(model, img):
     for i, blk in enumerate(model.blocks):
         a = blk.attn
         rs_attn, rs_mlp = _drop_scales(model, blk, i, B, img.device)
-        xn = LayerNormFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, prec, None)
-        XT2, rawlog = AttnBlockFn.apply(xn, XT, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, rs_attn,
-                                        (B, N, nH, T), prec, ('blk', i))
-        XT2, rawchan = ChanAttnFn.apply(xn, XT2, a.token_trans.weight, a.token_trans.bias, a.token_trans1.weight,
-                                        a.token_trans1.bias, rs_attn, (B, N, nH, T, h, w, nwin), prec, ('blk', i))
-        xn2 = LayerNormFn.apply(XT2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, prec, None)
-        XT = MlpFn.apply(xn2, XT2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp,
-                         (B, N, T), prec, ('blk', i))
+        XT2, rawlog, rawchan = AttnHalfFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, a.qkv.weight, a.qkv.bias,
+                                                a.proj.weight, a.proj.bias, a.token_trans.weight, a.token_trans.bias,
+                                                a.token_trans1.weight, a.token_trans1.bias, rs_attn, (B, N, nH, T, h, w, nwin), prec,
+                                                ('blk', i))
+        XT = MlpHalfFn.apply(XT2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp, (B, N, T), prec, ('blk', i))
         if (i + 1) in model.select_list:
             acc = _task_features(model, XT, rawlog, rawchan, model._tap_index(i), B, acc)
     xf = LayerNormFn.apply(XT, model.norm.weight, model.norm.bias, model.norm.eps, prec, torch.float32)
@@ -706,10 +928,9 @@ def wrapper_forward(wrapper, x, target):
         y = Conv3x3Fn.apply(fea, (B, h4, w4, F, F), prec, 'hc', *[hd.mt_proj[0].weight for hd in heads],
                             *[hd.mt_proj[0].bias for hd in heads])
         y = _bn_act(y, [hd.mt_proj[1] for hd in heads], F, ACT_GELU, wrapper.training)
-        for i, (t, hd) in enumerate(zip(wrapper.tasks, heads)):
+        preds = TaskHeadsFn.apply(y, prec, 'hp', *[hd.linear_pred.weight for hd in heads], *[hd.linear_pred.bias for hd in heads])
+        for t, hd, pred in zip(wrapper.tasks, heads, preds):
             n_out = hd.linear_pred.weight.shape[0]
-            pred = BLinearFn.apply(y[i][None], n_out, 'plain', None, torch.float32, prec, ('hp', t), hd.linear_pred.weight,
-                                   hd.linear_pred.bias)
             out[t] = BilinearFn.apply(pred, (B, n_out, h4, w4, target[0], target[1]), torch.float32, True)
         return out
     if all(isinstance(hd, DEConvHead) for hd in heads):

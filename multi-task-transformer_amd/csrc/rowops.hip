@@ -827,6 +827,50 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const void* src, voi
   }
 }
 
+// Vectorised variant for a bf16 destination: 16-byte global loads / stores on both sides, bf16 tile [64][66] in LDS.
+// Optionally accumulates the column sums of src (= row sums of dst: the bias gradient of the same weight-gradient GEMM)
+// so that no separate reduction pass over the gradient is needed.
+template <bool SRC_F32>
+__global__ __launch_bounds__(256) void transpose_pad_vec_kernel(const void* src, bf16_t* dst, int64_t rows, int64_t cols, int64_t lds_,
+                                                                int64_t ldd, float* colsum) {
+  __shared__ bf16_t tile[64][66];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  {
+    const int r = threadIdx.x >> 2, cs = (threadIdx.x & 3) * 16;
+    const int64_t rr = r0 + r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t c = c0 + cs + h * 8;
+      float v[8];
+      if (rr < rows && c < cols) ld8(src, rr * lds_ + c, SRC_F32 ? MTT_F32 : MTT_BF16, v);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) *(unsigned*)&tile[r][cs + h * 8 + j] = pack2(v[j], v[j + 1]);
+    }
+  }
+  __syncthreads();
+  const int c = threadIdx.x >> 2, rs = (threadIdx.x & 3) * 16;
+  float sum = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t a = tile[rs + h * 8 + 2 * j][c], b = tile[rs + h * 8 + 2 * j + 1][c];
+      sum += bf2f(a) + bf2f(b);
+      o[j] = (unsigned)a | ((unsigned)b << 16);
+    }
+    if (c0 + c < cols && r0 + rs + h * 8 < ldd) *(u32x4*)(dst + (c0 + c) * ldd + r0 + rs + h * 8) = o;
+  }
+  if (colsum) {
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+    if ((threadIdx.x & 3) == 0 && c0 + c < cols) atomicAdd(&colsum[c0 + c], sum);
+  }
+}
+
 int grid_for(int64_t work_items) {
   int64_t g = (work_items + 255) / 256;
   if (g > 256 * 8) g = 256 * 8;
@@ -1022,10 +1066,25 @@ extern "C" int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32
   return LAUNCH_OK();
 }
 
+extern "C" int mtt_transpose_pad_sum(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, int src_dtype,
+                                     int dst_dtype, float* colsum, void* stream);
 extern "C" int mtt_transpose_pad(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, int src_dtype,
                                  int dst_dtype, void* stream) {
+  return mtt_transpose_pad_sum(src, dst, rows, cols, lds_, ldd, src_dtype, dst_dtype, nullptr, stream);
+}
+
+extern "C" int mtt_transpose_pad_sum(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, int src_dtype,
+                                     int dst_dtype, float* colsum, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0 || ldd < rows) return MTT_E_BADARG;
   dim3 grid((unsigned)((ldd + 63) / 64), (unsigned)((cols + 63) / 64));
-  hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype, dst_dtype);
+  const bool vec = dst_dtype == MTT_BF16 && (cols % 8) == 0 && (lds_ % 8) == 0 && (ldd % 8) == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
+  if (!vec) {
+    if (colsum) return MTT_E_UNSUPPORTED;
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype, dst_dtype);
+  } else if (src_dtype == MTT_F32) {
+    hipLaunchKernelGGL(transpose_pad_vec_kernel<true>, grid, dim3(256), 0, S_, src, (bf16_t*)dst, rows, cols, lds_, ldd, colsum);
+  } else {
+    hipLaunchKernelGGL(transpose_pad_vec_kernel<false>, grid, dim3(256), 0, S_, src, (bf16_t*)dst, rows, cols, lds_, ldd, colsum);
+  }
   return LAUNCH_OK();
 }

@@ -16,8 +16,8 @@ from torch.autograd import Function
 
 from . import ops
 from ._lib import ACT_NONE, ACT_RELU, F32, OP_K, OP_R, dtype_code
-from .autograd_path import (AttnBlockFn, BLinearFn, BilinearFn, BnActFn, Conv3x3Fn, LayerNormFn, MlpFn, _bn_act, _colsum,
-                            _dgrad, _gemm, _wgrad)
+from .autograd_path import (AttnBlockFn, AttnHalfFn, MlpHalfFn, BLinearFn, BilinearFn, BnActFn, Conv3x3Fn, LayerNormFn, MlpFn, TaskHeadsFn, _bn_act,  # noqa: F401
+                            _colsum, _dgrad, _gemm, _wgrad)
 
 pad8 = ops.pad8
 
@@ -250,11 +250,10 @@ def vit_taps(vit, img):
     taps = []
     for i, blk in enumerate(vit.blocks):
         a = blk.attn
-        xn = LayerNormFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, prec, None)
-        XT2, _ = AttnBlockFn.apply(xn, XT, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, None, (B, N, nH, 0), prec, ('vblk', i))
-        xn2 = LayerNormFn.apply(XT2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, prec, None)
-        XT = MlpFn.apply(xn2, XT2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, None, (B, N, 0), prec,
-                         ('vblk', i))
+        XT2, _, _ = AttnHalfFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                                     a.proj.bias, None, None, None, None, None, (B, N, nH, 0, 0, 0, 1), prec, ('vblk', i))
+        XT = MlpHalfFn.apply(XT2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, None, (B, N, 0), prec, ('vblk', i))
         if (i + 1) in vit.select_list:
             taps.append(XT.view(B, N, C)[:, 1:].to(prec.adt).reshape(B * hw, C))
     xf = LayerNormFn.apply(XT, vit.norm.weight, vit.norm.bias, vit.norm.eps, prec, None)
@@ -336,6 +335,7 @@ def decoder_forward(dec, taps, B):
     y = Conv3x3Fn.apply(y, (B, mh, mw, Ed, C), prec, 'pd1', *[m[1].conv.weight for m in pd], *([None] * T))
     y = _bn_act(y, [m[1].bn1 for m in pd], Ed, ACT_RELU, training)
     inter, xs = {}, []
+    y = y.unbind(0)                                                                        # backward = one stack (no per-slice zero fill + add)
     for i, t in enumerate(names):
         n_out = p.TASKS.NUM_OUTPUT[t]
         ih = dec.intermediate_head[t]
@@ -394,12 +394,10 @@ def net_forward(net, x):
     mh, mw = net.p.mtt_resolution
     th, tw = 8 * mh, 8 * mw
     out = {}
-    for i, t in enumerate(net.tasks):
-        hd = net.heads[t]
-        n_out = hd.linear_pred.weight.shape[0]
-        pred = BLinearFn.apply(feats[i][None], n_out, 'plain', None, torch.float32, prec, ('iph', t), hd.linear_pred.weight,
-                               hd.linear_pred.bias)
-        out[t] = BilinearFn.apply(pred, (B, n_out, th, tw, img_size[0], img_size[1]), torch.float32, True)
+    hds = [net.heads[t] for t in net.tasks]
+    preds = TaskHeadsFn.apply(feats, prec, 'iph', *[hd.linear_pred.weight for hd in hds], *[hd.linear_pred.bias for hd in hds])
+    for t, hd, pred in zip(net.tasks, hds, preds):
+        out[t] = BilinearFn.apply(pred, (B, hd.linear_pred.weight.shape[0], th, tw, img_size[0], img_size[1]), torch.float32, True)
     out['inter_preds'] = {t: BilinearFn.apply(inter[t], (B, net.p.TASKS.NUM_OUTPUT[t], mh, mw, img_size[0], img_size[1]),
                                               torch.float32, True) for t in net.tasks}
     return out

@@ -294,9 +294,9 @@ def bn_batch_stats(x, C):
     return mean, var
 
 
-def bn_apply(x, C, mean, rstd, gamma, beta, act):
+def bn_apply(x, C, mean, rstd, gamma, beta, act, out=None):
     rows, ld = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     call("bn_apply", x=x, y=y, mean=mean, rstd=rstd, gamma=gamma, beta=beta, rows=rows, C=C, ld=ld,
          dtype=dtype_code(x), act=act)
     return y

@@ -595,6 +595,17 @@ def transpose_pad(args):
 
 
 
+def transpose_pad_sum(args):
+    transpose_pad(args[:8])
+    src, dst, rows, cols, lds, ldd, sdt, ddt, colsum = args[:9]
+    if colsum is not None:
+        r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+        v = _rd(src, r * lds + c)
+        if ddt == 1:                                             # sums are taken over the bf16-rounded values that are written
+            v = v.float().to(torch.bfloat16).double()
+        _wr(colsum, torch.arange(cols), _rd(colsum, torch.arange(cols)) + v.sum(0))
+
+
 def dwconv3x3s2_bwd(**kw):
     dy, dx, dw = kw["xargs"]
     Z, B, H, W, ld = kw["Z"], kw["B"], kw["H"], kw["W"], kw["ld"]
@@ -653,7 +664,8 @@ _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd)
-_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad)
+_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
+            transpose_pad_sum=transpose_pad_sum)
 
 
 def call(name, **kw):

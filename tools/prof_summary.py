@@ -35,6 +35,17 @@ def main():
     print(f"# {'total_ms':>10} {'%':>6} {'calls':>7} {'avg_us':>10}  vgpr agpr   lds  kernel")
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"  {a[1] / 1e6:10.3f} {100 * a[1] / tot:6.2f} {a[0]:7d} {a[1] / a[0] / 1e3:10.1f}  {a[2]:4d} {a[3]:4d} {a[4]:6d}  {name[:120]}")
+    # per launch shape (workgroups x, grid z) of the GEMM-family kernels: which call sites the time belongs to
+    shp = {}
+    for name, dur, gx, gz, vg, ag, lds in rows:
+        if "gemm" in name:
+            key = (name.replace("(anonymous namespace)::", "").replace("void ", "")[:34], gx, gz)
+            a = shp.setdefault(key, [0, 0])
+            a[0] += 1
+            a[1] += dur
+    print("# GEMM-family kernels by launch shape:   total_ms  calls  avg_us  workgroups  grid_z  kernel")
+    for (name, gx, gz), a in sorted(shp.items(), key=lambda kv: -kv[1][1])[:36]:
+        print(f"  {a[1] / 1e6:10.3f} {a[0]:6d} {a[1] / a[0] / 1e3:9.1f} {gx:8d} {gz:5d}  {name}")
 
 
 if __name__ == "__main__":
