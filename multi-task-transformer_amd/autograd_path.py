@@ -88,8 +88,8 @@ def _wgrad_fast(dy, x, N, Kp, prec, colsum=None):
     dyT, xT = _transposed(dy, N, colsum=colsum), _transposed(x, Kp)
     Mp = dyT.shape[1]
     tiles = -(-N // 256) * -(-Kp // 256)
-    if tiles < 64 and Mp >= 4096:                                   # split the token reduction over the batch dimension
-        Z = max(2, min(32, 256 // tiles))
+    if tiles < 192 and Mp >= 4096:                                  # split the token reduction over the batch dimension
+        Z = max(2, min(32, -(-256 // tiles)))                       # >= one 256x256 tile per CU
         c = (Mp // Z) // 64 * 64
         if c >= 512:
             nz = Mp // c

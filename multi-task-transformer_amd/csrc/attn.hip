@@ -8,6 +8,7 @@
 // are 4 xor-shuffles inside a 16-lane group); P goes through a wave-private LDS tile to turn the
 // MFMA C layout into an A fragment.  The N x N matrix never reaches HBM; the only extra output is
 // rawlog[B, nH, T, N] (unscaled q.k of the T prompt rows) that cal_task_feature consumes.
+#include <cstdlib>
 #include "mtt_device.h"
 
 namespace {
@@ -27,7 +28,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   unsigned char* const Pbase = smem + 2 * STAGE;
 
   const mtt_attn_desc& d = p.d;
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int nqb = (d.N + QB - 1) / QB;                       // XCD-aware 1-D grid: one head's query blocks share an XCD's L2
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = wi % nqb, bh = wi / nqb;
+  const int h = bh % d.nH, b = bh / d.nH;
   const int N = d.N, C = d.nH * HD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -243,18 +247,23 @@ int launch_attn(const AttnP& p, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid((p.d.N + QB - 1) / QB, p.d.nH, p.d.B);
+  dim3 grid((unsigned)(((p.d.N + QB - 1) / QB) * p.d.nH * p.d.B));
   hipLaunchKernelGGL((attn_fwd_kernel<X3, F32>), grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
+int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s);     // attn_fast.hip
+
 extern "C" int mtt_attn_fwd(const mtt_attn_desc* dd, void* stream) {
   if (!dd || !dd->qkv || !dd->out) return MTT_E_BADARG;
   if (dd->B <= 0 || dd->N <= 0 || dd->nH <= 0 || dd->T < 0 || dd->T > 16) return MTT_E_BADARG;
   if (dd->prec == MTT_PREC_X3 && dd->dtype != MTT_F32) return MTT_E_UNSUPPORTED;
   if ((uintptr_t)dd->qkv & 15) return MTT_E_ALIGN;
+  static const bool fast = []() { const char* e = getenv("MTT_ATTN_FAST"); return !(e && e[0] == '0'); }();
+  if (fast && dd->prec == MTT_PREC_BF16 && dd->dtype == MTT_BF16 && !((uintptr_t)dd->out & 15))
+    return mtt_attn_fwd_fast(dd, (hipStream_t)stream);
   AttnP p; p.d = *dd;
   if (dd->prec == MTT_PREC_X3) return launch_attn<true, true>(p, (hipStream_t)stream);
   return dd->dtype == MTT_F32 ? launch_attn<false, true>(p, (hipStream_t)stream) : launch_attn<false, false>(p, (hipStream_t)stream);

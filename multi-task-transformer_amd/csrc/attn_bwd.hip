@@ -54,7 +54,10 @@ MTT_DEV void store_tile_elem(unsigned char* Pw, int row, int col, float v) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const BwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 3 * KTILE;                  // K, K^T, V
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int nqb = (p.N + 63) / 64;                            // XCD-aware 1-D grid: one head's blocks share an XCD's L2
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = wi % nqb, bh_ = wi / nqb;
+  const int h = bh_ % p.nH, b = bh_ / p.nH;
   const int N = p.N, C = p.nH * HD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -189,7 +192,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const BwdP p) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const BwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 4 * KTILE;                  // Q, Q^T, dO, dO^T
-  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int nkb = (p.N + 63) / 64;
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int kb = wi % nkb, bh_ = wi / nkb;
+  const int h = bh_ % p.nH, b = bh_ / p.nH;
   const int N = p.N, C = p.nH * HD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -366,7 +372,7 @@ extern "C" int mtt_attn_bwd(const mtt_attn_desc* d, const void* dout, const floa
                      dsum, d->B, d->N, d->nH);
   BwdP p{(const bf16_t*)d->qkv, (const bf16_t*)dout, d->lse, dsum, d->T > 0 ? drawlog : nullptr, (bf16_t*)dqkv, d->B, d->N, d->nH, d->T,
          d->scale};
-  dim3 grid((d->N + 63) / 64, d->nH, d->B);
+  dim3 grid((unsigned)(((d->N + 63) / 64) * d->nH * d->B));
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), smem_dq, s, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), smem_dkv, s, p);
   return (int)hipGetLastError();
