@@ -121,8 +121,9 @@ int mtt_attn_fwd(const mtt_attn_desc* d, void* stream);
 /* Flash backward of mtt_attn_fwd (autograd of taskprompter.py:201-210 / vit.py:184-191), bf16 storage + MTT_PREC_BF16 only
  * (the x3 parity mode uses the materialised batched-GEMM backward).  Inputs: d->qkv, d->out (forward output), d->lse (forward
  * log-sum-exp), dout [B*N, nH*64] bf16, drawlog fp32 [B,nH,T,N] = gradient of the rawlog side channel (NULL if T == 0).
- * Outputs: dqkv [B*N, 3*nH*64] bf16 (every row written); dsum fp32 [B,nH,N] scratch (rowsum(dO*O)).  No N x N tensor, no atomics. */
-int mtt_attn_bwd(const mtt_attn_desc* d, const void* dout, const float* drawlog, void* dqkv, float* dsum, void* stream);
+ * Outputs: dqkv [B*N, 3*nH*64] bf16 (every row written); stat fp32 [B,nH,2,pad4(N)] scratch (row 0: rowsum(dO*O), row 1:
+ * lse*log2(e); pads zero).  No N x N tensor, no atomics. */
+int mtt_attn_bwd(const mtt_attn_desc* d, const void* dout, const float* drawlog, void* dqkv, float* stat, void* stream);
 
 /* Row softmax (+ its backward) on a materialised score matrix: used by the InvPT decoder attention
  * (invpt.py:232) and by the round-1 attention backward.  rows x cols, ld in elements.

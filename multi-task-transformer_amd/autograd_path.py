@@ -184,7 +184,7 @@ FLASH_BWD = os.environ.get("MTT_FLASH_BWD", "1") != "0"
 def attention_bwd_flash(qkv, ao, lse, dao, drawlog, B, N, nH, T, prec):
     """bf16 mode: mtt_attn_bwd (recomputes P tile by tile from q, k and the forward's log-sum-exp; no N x N buffer)."""
     dqkv = torch.empty_like(qkv)
-    dsum = torch.empty(B, nH, N, dtype=torch.float32, device=qkv.device)
+    dsum = torch.empty(B, nH, 2, (N + 3) // 4 * 4, dtype=torch.float32, device=qkv.device)      # rowsum(dO*O) and lse*log2e
     ops.call("attn_bwd", qkv=qkv, out=ao, rawlog=None, lse=lse, B=B, N=N, nH=nH, T=T, dtype=dtype_code(qkv), prec=prec.code,
              scale=64 ** -0.5, xargs=[dao, drawlog, dqkv, dsum])
     return dqkv

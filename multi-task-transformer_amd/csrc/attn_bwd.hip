@@ -1,33 +1,31 @@
-// mtt_attn_bwd: flash-style backward of mtt_attn_fwd (bf16 storage, head_dim 64).  The N x N probabilities are
-// recomputed tile by tile from q, k and the forward's log-sum-exp; nothing of size N x N reaches HBM and no atomics
-// are used: two kernels own disjoint outputs.
+// mtt_attn_bwd: flash-style backward of mtt_attn_fwd (bf16 storage, head_dim 64).  The N x N probabilities are recomputed
+// tile by tile from q, k and the forward's log-sum-exp; nothing of size N x N reaches HBM and no atomics are used: two
+// kernels own disjoint outputs.  Both use the "swapped product" form of attn_fast.hip: a score tile comes out of the MFMA
+// in the C layout that IS the B fragment of the next product (reduction index permuted consistently on the A side, whose
+// fragments are two 8-byte reads of a transposed LDS tile), so P and dS never go through LDS.
 //
-//   dsum[b,h,i] = sum_d dO[i,d] * O[i,d]                                   (attn_dsum_kernel)
-//   dQ kernel : block = 64 query rows of one (b, h); loops over key tiles:
-//                 S = Q K^T, P = exp(scale*S - lse), dP = dO V^T, dS = scale * P * (dP - dsum) (+ drawlog on prompt rows),
-//                 dQ += dS K
-//   dKV kernel: block = 64 keys of one (b, h); loops over query tiles, everything transposed so that the key rows are
-//                 the MFMA A operand held in registers:
-//                 S^T = K Q^T, P^T, dP^T = V dO^T, dV += P^T dO, dK += dS^T Q
-// Tiles are staged like the forward: 128 threads load 4-row x 8-column units and store them row-major AND transposed
-// (in-register 4x8 transposes), the other 128 threads stage the second operand.  P^T / dS tiles go through a wave-private
-// LDS tile to turn the MFMA C layout into an A fragment.  drawlog is the gradient of the forward's UNSCALED prompt-row
-// logits side channel (rawlog), added to dS of the first T query rows.
+//   stat[b,h,0,i] = sum_d dO[i,d] * O[i,d],  stat[b,h,1,i] = lse[i] * log2(e)                (attn_stat_kernel)
+//   dQ kernel : workgroup = 128 query rows (32 per wave, B fragments of Q and dO in registers); per 64-key tile
+//                 S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - D),   dQ^T += K^T dS^T
+//   dKV kernel: workgroup = 128 keys (32 per wave, B fragments of K and V in registers); per 64-query tile
+//                 S = Q K^T, dP = dO V^T,   dV^T += dO^T P,   dK^T += Q^T dS
+// The softmax scale is applied once to the dQ / dK accumulators; drawlog (gradient of the forward's UNSCALED prompt-row
+// logits) is therefore added to dS divided by the scale.
 #include "mtt_device.h"
 
 namespace {
 
-constexpr int KV = 64, HD = 64;
-constexpr int KTILE = KV * HD * 2;   // 8 KiB per bf16 tile
-constexpr int PT = 16 * 64 * 2;      // wave-private 16 x 64 bf16 tile
+constexpr int HD = 64;
+constexpr int KTILE = 64 * HD * 2;   // 8 KiB per bf16 tile
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct BwdP {
-  const bf16_t* qkv; const bf16_t* dout; const float* lse; const float* dsum; const float* drawlog; bf16_t* dqkv;
-  int B, N, nH, T; float scale;
+  const bf16_t* qkv; const bf16_t* dout; const float* stat; const float* drawlog; bf16_t* dqkv;
+  int B, N, nH, T, Np; float scale;
 };
 
-__global__ __launch_bounds__(256) void attn_dsum_kernel(const bf16_t* out, const bf16_t* dout, float* dsum, int B, int N, int nH) {
+__global__ __launch_bounds__(256) void attn_stat_kernel(const bf16_t* out, const bf16_t* dout, const float* lse, float* stat, int B, int N,
+                                                        int nH, int Np) {
   const int C8 = nH * 8;
   const int64_t total = (int64_t)B * N * C8;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -42,19 +40,39 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(const bf16_t* out, const
     const int64_t tok = t / C8;
     const int h = (int)(t % C8) >> 3;
     const int b = (int)(tok / N), n = (int)(tok % N);
-    dsum[((int64_t)b * nH + h) * N + n] = s;
+    float* row = stat + ((int64_t)b * nH + h) * 2 * Np;
+    row[n] = s;
+    row[Np + n] = lse[((int64_t)b * nH + h) * N + n] * LOG2E;
+    if (n == N - 1)
+      for (int k = N; k < Np; ++k) { row[k] = 0.f; row[Np + k] = 0.f; }
   }
 }
 
-MTT_DEV void store_tile_elem(unsigned char* Pw, int row, int col, float v) {
-  *(bf16_t*)(Pw + lds_off(row, col >> 3) + (col & 7) * 2) = f2bf(v);
+// A fragment whose reduction index follows the C-layout permutation of a 32-wide k step (see attn_fast.hip)
+MTT_DEV u32x4 perm_frag(const unsigned char* tile, int row, int ks, int lg) {
+  const u32x2 lo = *(const u32x2*)(tile + lds_off(row, 4 * ks + (lg >> 1)) + (lg & 1) * 8);
+  const u32x2 hi = *(const u32x2*)(tile + lds_off(row, 4 * ks + 2 + (lg >> 1)) + (lg & 1) * 8);
+  return (u32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
+// 4-row x 8-column units of a 64-row tile: 128 threads stage one operand row-major (and transposed when TR)
+template <bool TR>
+MTT_DEV void store_units(unsigned char* rowmajor, unsigned char* transposed, const u32x4 (&sh)[4], int kq, int rb) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *(u32x4*)(rowmajor + lds_off(kq * 4 + i, rb)) = sh[i];
+  if (TR) {
+    u32x2 piece[8];
+    transpose4x8(sh, piece);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(u32x2*)(transposed + lds_off(rb * 8 + j, kq >> 1) + (kq & 1) * 8) = piece[j];
+  }
 }
 
 // --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const BwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 3 * KTILE;                  // K, K^T, V
-  const int nqb = (p.N + 63) / 64;                            // XCD-aware 1-D grid: one head's blocks share an XCD's L2
+  const int nqb = (p.N + 127) / 128;                // XCD-aware 1-D grid: one head's blocks share an XCD's L2
   const int wi = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = wi % nqb, bh_ = wi / nqb;
   const int h = bh_ % p.nH, b = bh_ / p.nH;
@@ -63,28 +81,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const BwdP p) {
   const int li = lane & 15, lg = lane >> 4;
   const int64_t tok0 = (int64_t)b * N;
   const int64_t bh = (int64_t)b * p.nH + h;
-  unsigned char* const Pw = smem + 2 * STAGE + wave * PT;
+  const int q0 = qb * 128 + wave * 32;
+  const bool active = q0 < N;
 
-  u32x4 qf[2], gf[2], dummy;
-  {
-    const int qrow = qb * 64 + wave * 16 + li;
+  u32x4 qf[2][2], gf[2][2], dummy;
+  float lse2[2], Dq[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int qrow = q0 + sub * 16 + li;
     const bool ok = qrow < N;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       Raw8<false> r;
       load8_raw<false>(p.qkv, (tok0 + qrow) * 3 * C + h * HD + kh * 32 + lg * 8, ok, r);
-      cvt8<false, false>(ok, r, qf[kh], dummy);
+      cvt8<false, false>(ok, r, qf[sub][kh], dummy);
       load8_raw<false>(p.dout, (tok0 + qrow) * C + h * HD + kh * 32 + lg * 8, ok, r);
-      cvt8<false, false>(ok, r, gf[kh], dummy);
+      cvt8<false, false>(ok, r, gf[sub][kh], dummy);
     }
-  }
-  float lse2[4], Dr[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = qb * 64 + wave * 16 + lg * 4 + r;
-    const bool ok = row < N;
-    lse2[r] = ok ? p.lse[bh * N + row] * LOG2E : 0.f;
-    Dr[r] = ok ? p.dsum[bh * N + row] : 0.f;
+    Dq[sub] = ok ? p.stat[bh * 2 * p.Np + qrow] : 0.f;
+    lse2[sub] = ok ? p.stat[bh * 2 * p.Np + p.Np + qrow] : 0.f;
   }
 
   const bool isK = tid < 128;
@@ -105,86 +120,104 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const BwdP p) {
     u32x4 sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cvt8<false, false>((okm >> i) & 1u, raw[i], sh[i], dummy);
-    unsigned char* rowmajor = isK ? st : st + 2 * KTILE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(rowmajor + lds_off(kq * 4 + i, rb)) = sh[i];
-    if (isK) {
-      u32x2 piece[8];
-      transpose4x8(sh, piece);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) *(u32x2*)(st + KTILE + lds_off(rb * 8 + j, kq >> 1) + (kq & 1) * 8) = piece[j];
-    }
+    if (isK) store_units<true>(st, st + KTILE, sh, kq, rb);
+    else store_units<false>(st + 2 * KTILE, nullptr, sh, kq, rb);
   };
 
-  f32x4 dq[4];
+  f32x4 dq[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) dq[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float sc2 = p.scale * LOG2E;
-  const bool add_raw = p.drawlog != nullptr && p.T > 0 && qb == 0 && wave == 0;
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dq[sub][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float sc2 = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
+  const bool add_raw = p.drawlog != nullptr && p.T > 0 && qb == 0 && wave == 0 && li < p.T;
 
-  const int nkv = (N + KV - 1) / KV;
+  const int nkv = (N + 63) / 64;
   stage_load(0);
   stage_store(smem);
   __syncthreads();
 
   for (int j = 0; j < nkv; ++j) {
     const bool more = j + 1 < nkv;
-    if (more) stage_load((j + 1) * KV);
-    const unsigned char* st = smem + (j & 1) * STAGE;
-    const unsigned char* Kh = st;
-    const unsigned char* Kt = st + KTILE;
-    const unsigned char* Vh = st + 2 * KTILE;
-    const int kv0 = j * KV;
-
-    f32x4 s[4], dp[4];
+    if (more) stage_load((j + 1) * 64);
+    const unsigned char* Kh = smem + (j & 1) * STAGE;
+    const unsigned char* Kt = Kh + KTILE;
+    const unsigned char* Vh = Kh + 2 * KTILE;
+    const int kv0 = j * 64;
+    if (active) {
+      const bool full = kv0 + 64 <= N;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dp[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < 2; ++ks) {                 // two 32-key halves: keeps the live score registers at 2 x [2][2] tiles
+        if (kv0 + 32 * ks >= N) continue;              // (block-uniform) nothing valid in this half of the last tile
+        f32x4 s[2][2], dp[2][2];
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        const u32x4 kf = *(const u32x4*)(Kh + lds_off(nt * 16 + li, kh * 4 + lg));
-        const u32x4 vf = *(const u32x4*)(Vh + lds_off(nt * 16 + li, kh * 4 + lg));
-        s[nt] = mfma16(qf[kh], kf, s[nt]);
-        dp[nt] = mfma16(gf[kh], vf, dp[nt]);
-      }
-    }
-    const bool full_tile = kv0 + KV <= N;
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int kt = 2 * ks + k2;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int key = kv0 + nt * 16 + li;
-      const bool kok = full_tile || key < N;
+          for (int sub = 0; sub < 2; ++sub) { s[sub][k2] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[sub][k2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = kok ? __builtin_amdgcn_exp2f(s[nt][r] * sc2 - lse2[r]) : 0.f;
-        float ds = pv * (dp[nt][r] - Dr[r]) * p.scale;
-        if (add_raw) {
-          const int row = lg * 4 + r;
-          if (row < p.T && key < N) ds += p.drawlog[(bh * p.T + row) * N + key];
+          for (int kh = 0; kh < 2; ++kh) {
+            const u32x4 kf = *(const u32x4*)(Kh + lds_off(kt * 16 + li, kh * 4 + lg));
+            const u32x4 vf = *(const u32x4*)(Vh + lds_off(kt * 16 + li, kh * 4 + lg));
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+              s[sub][k2] = mfma16(kf, qf[sub][kh], s[sub][k2]);
+              dp[sub][k2] = mfma16(vf, gf[sub][kh], dp[sub][k2]);
+            }
+          }
         }
-        store_tile_elem(Pw, lg * 4 + r, nt * 16 + li, ds);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+        // s[sub][k2][r] = S[q = li][key = kv0 + 16 (2ks + k2) + 4 lg + r]
+        u32x4 dsb[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const u32x4 df = *(const u32x4*)(Pw + lds_off(li, ks * 4 + lg));
+        for (int sub = 0; sub < 2; ++sub) {
+          float ds[2][4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const u32x4 kt = *(const u32x4*)(Kt + lds_off(dt * 16 + li, ks * 4 + lg));
-        dq[dt] = mfma16(df, kt, dq[dt]);
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][k2][r], sc2, -lse2[sub]));
+              ds[k2][r] = pv * (dp[sub][k2][r] - Dq[sub]);
+            }
+          if (!full) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (kv0 + (2 * ks + k2) * 16 + lg * 4 + r >= N) ds[k2][r] = 0.f;
+          }
+          if (sub == 0 && add_raw) {
+            const float* rl = p.drawlog + (bh * p.T + li) * N;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int key = kv0 + (2 * ks + k2) * 16 + lg * 4 + r;
+                if (key < N) ds[k2][r] += rl[key] * inv_scale;
+              }
+          }
+          dsb[sub] = (u32x4){pack2(ds[0][0], ds[0][1]), pack2(ds[0][2], ds[0][3]), pack2(ds[1][0], ds[1][1]), pack2(ds[1][2], ds[1][3])};
+        }
+        // dQ^T[d][q] += K^T[d][keys of this half] dS^T
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const u32x4 ka = perm_frag(Kt, dt * 16 + li, ks, lg);
+          dq[0][dt] = mfma16(ka, dsb[0], dq[0][dt]);
+          dq[1][dt] = mfma16(ka, dsb[1], dq[1][dt]);
+        }
       }
     }
     if (more) stage_store(smem + ((j + 1) & 1) * STAGE);
     __syncthreads();
   }
+  // dq[sub][dt][r] = dQ[q = li][d = 16 dt + 4 lg + r] / scale
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qrow = qb * 64 + wave * 16 + lg * 4 + r;
+  for (int sub = 0; sub < 2; ++sub) {
+    const int qrow = q0 + sub * 16 + li;
     if (qrow >= N) continue;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) p.dqkv[(tok0 + qrow) * 3 * C + h * HD + dt * 16 + li] = f2bf(dq[dt][r]);
+    for (int dt = 0; dt < 4; ++dt)
+      *(u32x2*)(p.dqkv + (tok0 + qrow) * 3 * C + h * HD + dt * 16 + lg * 4) =
+          (u32x2){pack2(dq[sub][dt][0] * p.scale, dq[sub][dt][1] * p.scale), pack2(dq[sub][dt][2] * p.scale, dq[sub][dt][3] * p.scale)};
   }
 }
 
@@ -192,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const BwdP p) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const BwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 4 * KTILE;                  // Q, Q^T, dO, dO^T
-  const int nkb = (p.N + 63) / 64;
+  const int nkb = (p.N + 127) / 128;
   const int wi = xcd_remap(blockIdx.x, gridDim.x);
   const int kb = wi % nkb, bh_ = wi / nkb;
   const int h = bh_ % p.nH, b = bh_ / p.nH;
@@ -201,19 +234,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const BwdP p) {
   const int li = lane & 15, lg = lane >> 4;
   const int64_t tok0 = (int64_t)b * N;
   const int64_t bh = (int64_t)b * p.nH + h;
-  unsigned char* const Pw = smem + 2 * STAGE + wave * PT;
+  const int key0 = kb * 128 + wave * 32;
+  const bool active = key0 < N;
 
-  u32x4 kf[2], vf[2], dummy;
-  {
-    const int krow = kb * 64 + wave * 16 + li;
+  u32x4 kf[2][2], vf[2][2], dummy;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int krow = key0 + kt * 16 + li;
     const bool ok = krow < N;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       Raw8<false> r;
       load8_raw<false>(p.qkv, (tok0 + krow) * 3 * C + C + h * HD + kh * 32 + lg * 8, ok, r);
-      cvt8<false, false>(ok, r, kf[kh], dummy);
+      cvt8<false, false>(ok, r, kf[kt][kh], dummy);
       load8_raw<false>(p.qkv, (tok0 + krow) * 3 * C + 2 * C + h * HD + kh * 32 + lg * 8, ok, r);
-      cvt8<false, false>(ok, r, vf[kh], dummy);
+      cvt8<false, false>(ok, r, vf[kt][kh], dummy);
     }
   }
 
@@ -237,19 +272,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const BwdP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) cvt8<false, false>((okm >> i) & 1u, raw[i], sh[i], dummy);
     unsigned char* base = isQ ? st : st + 2 * KTILE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(base + lds_off(kq * 4 + i, rb)) = sh[i];
-    u32x2 piece[8];
-    transpose4x8(sh, piece);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *(u32x2*)(base + KTILE + lds_off(rb * 8 + j, kq >> 1) + (kq & 1) * 8) = piece[j];
+    store_units<true>(base, base + KTILE, sh, kq, rb);
   };
 
-  f32x4 dk[4], dv[4];
+  f32x4 dk[2][4], dv[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { dk[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  const float sc2 = p.scale * LOG2E;
-  const int key0 = kb * 64 + wave * 16 + lg * 4;     // this lane's 4 key rows (C layout): key0 + r
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dk[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const float sc2 = p.scale * LOG2E, inv_scale = 1.0f / p.scale;
+  const float* Drow = p.stat + bh * 2 * p.Np;
+  const float* Lrow = Drow + p.Np;
 
   const int nq = (N + 63) / 64;
   stage_load(0);
@@ -259,106 +292,104 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const BwdP p) {
   for (int j = 0; j < nq; ++j) {
     const bool more = j + 1 < nq;
     if (more) stage_load((j + 1) * 64);
-    const unsigned char* st = smem + (j & 1) * STAGE;
-    const unsigned char* Qh = st;
-    const unsigned char* Qt = st + KTILE;
-    const unsigned char* Gh = st + 2 * KTILE;
-    const unsigned char* Gt = st + 3 * KTILE;
+    const unsigned char* Qh = smem + (j & 1) * STAGE;
+    const unsigned char* Qt = Qh + KTILE;
+    const unsigned char* Gh = Qh + 2 * KTILE;
+    const unsigned char* Gt = Qh + 3 * KTILE;
     const int q0 = j * 64;
-
-    float lse2c[4], Dc[4];
+    if (active) {
+      const bool full = q0 + 64 <= N;
+      const bool add_raw = p.drawlog != nullptr && j == 0 && p.T > 0;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int qc = q0 + nt * 16 + li;
-      const bool ok = qc < N;
-      lse2c[nt] = ok ? p.lse[bh * N + qc] * LOG2E : 0.f;
-      Dc[nt] = ok ? p.dsum[bh * N + qc] : 0.f;
-    }
-    f32x4 s[4], dp[4];
+      for (int ks = 0; ks < 2; ++ks) {                 // two 32-query halves
+        if (q0 + 32 * ks >= N) continue;               // (block-uniform) nothing valid in this half of the last tile
+        f32x4 s[2][2], dp[2][2];                       // [q sub of the half][key tile]
+        float4 D4[2], L4[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dp[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const int qs = 2 * ks + q2;
+          const int qr = q0 + qs * 16 + lg * 4;        // stat rows are padded to a multiple of 4 (zeros)
+          D4[q2] = qr < p.Np ? *(const float4*)(Drow + qr) : make_float4(0.f, 0.f, 0.f, 0.f);
+          L4[q2] = qr < p.Np ? *(const float4*)(Lrow + qr) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        const u32x4 qfr = *(const u32x4*)(Qh + lds_off(nt * 16 + li, kh * 4 + lg));
-        const u32x4 gfr = *(const u32x4*)(Gh + lds_off(nt * 16 + li, kh * 4 + lg));
-        s[nt] = mfma16(kf[kh], qfr, s[nt]);
-        dp[nt] = mfma16(vf[kh], gfr, dp[nt]);
-      }
-    }
-    // P^T -> wave tile, dV += P^T dO
-    const bool full_tile = q0 + 64 <= N;
+          for (int kt = 0; kt < 2; ++kt) { s[q2][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[q2][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const bool qok = full_tile || (q0 + nt * 16 + li) < N;
+          for (int kh = 0; kh < 2; ++kh) {
+            const u32x4 qa = *(const u32x4*)(Qh + lds_off(qs * 16 + li, kh * 4 + lg));
+            const u32x4 ga = *(const u32x4*)(Gh + lds_off(qs * 16 + li, kh * 4 + lg));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = qok ? __builtin_amdgcn_exp2f(s[nt][r] * sc2 - lse2c[nt]) : 0.f;
-        s[nt][r] = pv;
-        store_tile_elem(Pw, lg * 4 + r, nt * 16 + li, pv);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+            for (int kt = 0; kt < 2; ++kt) {
+              s[q2][kt] = mfma16(qa, kf[kt][kh], s[q2][kt]);
+              dp[q2][kt] = mfma16(ga, vf[kt][kh], dp[q2][kt]);
+            }
+          }
+        }
+        // s[q2][kt][r] = S[q = q0 + 16 (2ks + q2) + 4 lg + r][key = key0 + 16 kt + li]
+        u32x4 pb[2], dsb[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const u32x4 pf = *(const u32x4*)(Pw + lds_off(li, ks * 4 + lg));
+        for (int kt = 0; kt < 2; ++kt) {
+          float pv[2][4], ds[2][4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const u32x4 gt = *(const u32x4*)(Gt + lds_off(dt * 16 + li, ks * 4 + lg));
-        dv[dt] = mfma16(pf, gt, dv[dt]);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // dS^T -> wave tile, dK += dS^T Q
-    const bool add_raw = p.drawlog != nullptr && j == 0 && p.T > 0;
+          for (int q2 = 0; q2 < 2; ++q2) {
+            const float lr[4] = {L4[q2].x, L4[q2].y, L4[q2].z, L4[q2].w};
+            const float dr[4] = {D4[q2].x, D4[q2].y, D4[q2].z, D4[q2].w};
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int qc = q0 + nt * 16 + li;
+            for (int r = 0; r < 4; ++r) {
+              pv[q2][r] = __builtin_amdgcn_exp2f(fmaf(s[q2][kt][r], sc2, -lr[r]));
+              if (!full && q0 + (2 * ks + q2) * 16 + lg * 4 + r >= N) pv[q2][r] = 0.f;
+              ds[q2][r] = pv[q2][r] * (dp[q2][kt][r] - dr[r]);
+            }
+          }
+          if (add_raw && ks == 0) {
+            const int key = key0 + kt * 16 + li;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float ds = s[nt][r] * (dp[nt][r] - Dc[nt]) * p.scale;
-        if (add_raw && qc < p.T && key0 + r < N) ds += p.drawlog[(bh * p.T + qc) * N + key0 + r];
-        store_tile_elem(Pw, lg * 4 + r, nt * 16 + li, ds);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 4; ++r) {
+              const int q = lg * 4 + r;                  // query sub 0 of the first tile
+              if (q < p.T && key < N) ds[0][r] += p.drawlog[(bh * p.T + q) * N + key] * inv_scale;
+            }
+          }
+          pb[kt] = (u32x4){pack2(pv[0][0], pv[0][1]), pack2(pv[0][2], pv[0][3]), pack2(pv[1][0], pv[1][1]), pack2(pv[1][2], pv[1][3])};
+          dsb[kt] = (u32x4){pack2(ds[0][0], ds[0][1]), pack2(ds[0][2], ds[0][3]), pack2(ds[1][0], ds[1][1]), pack2(ds[1][2], ds[1][3])};
+        }
+        // dV^T[d][key] += dO^T[d][q half] P ;  dK^T[d][key] += Q^T[d][q half] dS
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const u32x4 df = *(const u32x4*)(Pw + lds_off(li, ks * 4 + lg));
+        for (int dt = 0; dt < 4; ++dt) {
+          const u32x4 ga = perm_frag(Gt, dt * 16 + li, ks, lg);
+          const u32x4 qa = perm_frag(Qt, dt * 16 + li, ks, lg);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const u32x4 qt = *(const u32x4*)(Qt + lds_off(dt * 16 + li, ks * 4 + lg));
-        dk[dt] = mfma16(df, qt, dk[dt]);
+          for (int kt = 0; kt < 2; ++kt) {
+            dv[kt][dt] = mfma16(ga, pb[kt], dv[kt][dt]);
+            dk[kt][dt] = mfma16(qa, dsb[kt], dk[kt][dt]);
+          }
+        }
       }
     }
     if (more) stage_store(smem + ((j + 1) & 1) * STAGE);
     __syncthreads();
   }
+  // dk[kt][dt][r] = dK[key = key0 + 16 kt + li][d = 16 dt + 4 lg + r] / scale
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int krow = key0 + r;
+  for (int kt = 0; kt < 2; ++kt) {
+    const int krow = key0 + kt * 16 + li;
     if (krow >= N) continue;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      p.dqkv[(tok0 + krow) * 3 * C + C + h * HD + dt * 16 + li] = f2bf(dk[dt][r]);
-      p.dqkv[(tok0 + krow) * 3 * C + 2 * C + h * HD + dt * 16 + li] = f2bf(dv[dt][r]);
+      bf16_t* dst = p.dqkv + (tok0 + krow) * 3 * C + C + h * HD + dt * 16 + lg * 4;
+      *(u32x2*)dst = (u32x2){pack2(dk[kt][dt][0] * p.scale, dk[kt][dt][1] * p.scale), pack2(dk[kt][dt][2] * p.scale, dk[kt][dt][3] * p.scale)};
+      *(u32x2*)(dst + C) = (u32x2){pack2(dv[kt][dt][0], dv[kt][dt][1]), pack2(dv[kt][dt][2], dv[kt][dt][3])};
     }
   }
 }
 
 }  // namespace
 
-extern "C" int mtt_attn_bwd(const mtt_attn_desc* d, const void* dout, const float* drawlog, void* dqkv, float* dsum, void* stream) {
-  if (!d || !d->qkv || !d->out || !d->lse || !dout || !dqkv || !dsum) return MTT_E_BADARG;
+extern "C" int mtt_attn_bwd(const mtt_attn_desc* d, const void* dout, const float* drawlog, void* dqkv, float* stat, void* stream) {
+  if (!d || !d->qkv || !d->out || !d->lse || !dout || !dqkv || !stat) return MTT_E_BADARG;
   if (d->B <= 0 || d->N <= 0 || d->nH <= 0 || d->T < 0 || d->T > 16) return MTT_E_BADARG;
   if (d->dtype != MTT_BF16 || d->prec != MTT_PREC_BF16) return MTT_E_UNSUPPORTED;
-  if (((uintptr_t)d->qkv | (uintptr_t)dout | (uintptr_t)d->out) & 15) return MTT_E_ALIGN;
+  if (((uintptr_t)d->qkv | (uintptr_t)dout | (uintptr_t)d->out | (uintptr_t)stat | (uintptr_t)dqkv) & 15) return MTT_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int smem_dq = 2 * 3 * KTILE + 4 * PT, smem_dkv = 2 * 4 * KTILE + 4 * PT;
+  constexpr int smem_dq = 2 * 3 * KTILE, smem_dkv = 2 * 4 * KTILE;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
@@ -367,12 +398,12 @@ extern "C" int mtt_attn_bwd(const mtt_attn_desc* d, const void* dout, const floa
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  const int Np = (d->N + 3) & ~3;
   const int64_t chunks = (int64_t)d->B * d->N * d->nH * 8;
-  hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const bf16_t*)d->out, (const bf16_t*)dout,
-                     dsum, d->B, d->N, d->nH);
-  BwdP p{(const bf16_t*)d->qkv, (const bf16_t*)dout, d->lse, dsum, d->T > 0 ? drawlog : nullptr, (bf16_t*)dqkv, d->B, d->N, d->nH, d->T,
-         d->scale};
-  dim3 grid((unsigned)(((d->N + 63) / 64) * d->nH * d->B));
+  hipLaunchKernelGGL(attn_stat_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const bf16_t*)d->out, (const bf16_t*)dout,
+                     d->lse, stat, d->B, d->N, d->nH, Np);
+  BwdP p{(const bf16_t*)d->qkv, (const bf16_t*)dout, stat, d->T > 0 ? drawlog : nullptr, (bf16_t*)dqkv, d->B, d->N, d->nH, d->T, Np, d->scale};
+  dim3 grid((unsigned)(((d->N + 127) / 128) * d->nH * d->B));
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), smem_dq, s, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), smem_dkv, s, p);
   return (int)hipGetLastError();

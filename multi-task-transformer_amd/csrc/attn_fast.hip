@@ -143,39 +143,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
             if (key < N) rl[key] = s[0][kt][r];
           }
       }
+      // softmax in the log2 domain on the RAW scores: p = 2^(s*sc2 - m) is one fma + one v_exp per element; masking only in
+      // the (wave-uniform) last slice; O^T is rescaled only when some lane's running max moved (alpha == 1 otherwise).
       const bool full = kbase + 32 <= N;
+      if (!full) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if ((kbase + kt * 16 + lg * 4 + r) >= N) s[sub][kt][r] = -INFINITY;
+      }
       u32x4 pb[4];
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = s[sub][kt][r] * sc2;
-            if (!full) t = (kbase + kt * 16 + lg * 4 + r) < N ? t : -INFINITY;
-            s[sub][kt][r] = t;
-            mx = fmaxf(mx, t);
-          }
+        float mx = fmaxf(fmaxf(fmaxf(s[sub][0][0], s[sub][0][1]), fmaxf(s[sub][0][2], s[sub][0][3])),
+                         fmaxf(fmaxf(s[sub][1][0], s[sub][1][1]), fmaxf(s[sub][1][2], s[sub][1][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[sub], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new);
+        const float m_new = fmaxf(m_run[sub], mx * sc2);
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[sub]) != 0) {      // wave-uniform: rescale only when a max moved
+          const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new);
+          l_part[sub] *= alpha;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[sub][t][r] *= alpha;
+          m_run[sub] = m_new;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[sub][kt][r] - m_new);
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sc2, -m_new));
             s[sub][kt][r] = pv;
             rs += pv;
           }
-        l_part[sub] = l_part[sub] * alpha + rs;
-        m_run[sub] = m_new;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[sub][t][r] *= alpha;
+        l_part[sub] += rs;
         pb[sub] = (u32x4){pack2(s[sub][0][0], s[sub][0][1]), pack2(s[sub][0][2], s[sub][0][3]),
                           pack2(s[sub][1][0], s[sub][1][1]), pack2(s[sub][1][2], s[sub][1][3])};
       }
@@ -192,8 +198,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   }
 
   // ---- merge the four key-slice partials: O = sum_w e_w O_w / sum_w e_w l_w, e_w = 2^(m_w - m) -----------------------
-  float* stat = (float*)(smem + 2 * STAGE);            // [2][4 waves][64 q]: m, l
-  float* part = (float*)smem;                          // [4 waves][64 q][64 d] fp32 (reuses the staging buffers)
+  constexpr int PSTR = 68;                             // fp32 row pitch of the partials (64 + 4: rows start on different banks)
+  float* stat = (float*)(smem + 4 * 64 * PSTR * 4);    // [2][4 waves][64 q]: m, l
+  float* part = (float*)smem;                          // [4 waves][64 q][PSTR] fp32 (reuses the staging buffers)
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
     float l = l_part[sub];
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
     const float f = __builtin_amdgcn_exp2f(m_run[sub] - m) / l;        // m_run = -inf (no key seen) -> 0
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *(float4*)(part + ((wave * 64 + q) * 64 + dt * 16 + lg * 4)) =
+      *(float4*)(part + ((wave * 64 + q) * PSTR + dt * 16 + lg * 4)) =
           make_float4(o[sub][dt][0] * f, o[sub][dt][1] * f, o[sub][dt][2] * f, o[sub][dt][3] * f);
   }
   __syncthreads();
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
       for (int w = 0; w < 4; ++w)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float4 v = *(const float4*)(part + ((w * 64 + q) * 64 + ds + c * 4));
+          const float4 v = *(const float4*)(part + ((w * 64 + q) * PSTR + ds + c * 4));
           acc[c * 4] += v.x; acc[c * 4 + 1] += v.y; acc[c * 4 + 2] += v.z; acc[c * 4 + 3] += v.w;
         }
       bf16_t* out = (bf16_t*)d.out + (tok0 + qrow) * C + h * HD + ds;
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
 
 // called by mtt_attn_fwd (attn.hip) for bf16 storage + MTT_PREC_BF16
 int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s) {
-  constexpr int smem = 2 * 4 * KTILE + 2 * 4 * 64 * 4;
+  constexpr int smem = 4 * 64 * 68 * 4 + 2 * 4 * 64 * 4;      // merge buffers (69.6 KB) >= 2 staging stages (64 KB)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

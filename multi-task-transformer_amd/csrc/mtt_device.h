@@ -22,7 +22,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 MTT_DEV float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((unsigned)h) << 16); }
 MTT_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
-MTT_DEV unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | (((unsigned)f2bf(b)) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> packed bf16 pair (one v_cvt_pk_bf16_f32)
+MTT_DEV unsigned pack2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
 MTT_DEV float lo_of(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 MTT_DEV float hi_of(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 

@@ -181,7 +181,7 @@ def attn_fwd(**kw):
 
 
 def attn_bwd(**kw):
-    """xargs = [dout, drawlog | None, dqkv, dsum]; forward recomputed in fp64 from (bf16-rounded) qkv."""
+    """xargs = [dout, drawlog | None, dqkv, stat [B,nH,2,pad4(N)]]; forward recomputed in fp64 from (bf16-rounded) qkv."""
     dout, drawlog, dqkv, dsum = kw["xargs"]
     B, N, nH, T = kw["B"], kw["N"], kw["nH"], kw["T"]
     C = nH * 64
@@ -199,7 +199,11 @@ def attn_bwd(**kw):
     dQ, dK = dS @ k, dS.transpose(-1, -2) @ q
     out = torch.stack([dQ, dK, dV], 0).permute(1, 3, 0, 2, 4).reshape(-1)      # [B, N, 3, nH, 64]
     _wr(dqkv, torch.arange(B * N * 3 * C), out)
-    _wr(dsum, torch.arange(B * nH * N), D.reshape(-1))
+    Np = (N + 3) // 4 * 4
+    stat = torch.zeros(B, nH, 2, Np, dtype=torch.float64)
+    stat[:, :, 0, :N] = D[..., 0]
+    stat[:, :, 1, :N] = _rd(kw["lse"], torch.arange(B * nH * N)).view(B, nH, N) * 1.4426950408889634
+    _wr(dsum, torch.arange(stat.numel()), stat.reshape(-1))
 
 
 def softmax_fwd(**kw):

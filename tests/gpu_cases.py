@@ -220,7 +220,7 @@ def attn_cases():
         abi_emul.call("attn_fwd", **fw)
         kw = dict(qkv=qkv, out=fw["out"], rawlog=None, lse=fw["lse"], B=B, N=N, nH=nH, T=T, dtype=BF16, prec=0, scale=0.125,
                   xargs=[rnd(g, B * N, C, dtype=DT[BF16]), rnd(g, B, nH, T, N) * 0.05 if T else None,
-                         torch.zeros(B * N, 3 * C, dtype=DT[BF16]), torch.zeros(B, nH, N)])
+                         torch.zeros(B * N, 3 * C, dtype=DT[BF16]), torch.zeros(B, nH, 2, (N + 3) // 4 * 4)])
         cases.append((f"attn_bwd_B{B}N{N}T{T}", "attn_bwd", kw, dict(f32=5e-3, bf16=1.5e-2)))
     # softmax spike (forces large running-max jumps across tiles)
     B, N, nH, T = 1, 200, 1, 2

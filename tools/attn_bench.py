@@ -1,0 +1,48 @@
+"""Micro-benchmark of the attention kernels through the C ABI (HIP-event timed).  Usage: python tools/attn_bench.py [B] [N] [nH] [T]
+Set MTT_ATTN_FAST=0 for the straightforward forward kernel."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import mtt_amd  # noqa: E402
+from mtt_amd import ops  # noqa: E402
+
+B, N, nH, T = [int(a) for a in sys.argv[1:5]] + [40, 1030, 16, 6][len(sys.argv) - 1:]
+C = nH * 64
+prec = ops.Prec("bf16")
+dev = torch.device("cuda")
+qkv = (torch.randn(B * N, 3 * C, device=dev) * 1.0).to(torch.bfloat16)
+dao = torch.randn(B * N, C, device=dev).to(torch.bfloat16)
+drawlog = torch.randn(B, nH, T, N, device=dev) * 0.01 if T else None
+
+
+def timed(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
+t_f = timed(lambda: ops.attention(qkv, B, N, nH, T, prec, want_lse=True))
+dqkv = torch.empty_like(qkv)
+dsum = torch.empty(B, nH, 2, (N + 3) // 4 * 4, device=dev)
+
+
+def bwd():
+    ops.call("attn_bwd", qkv=qkv, out=ao, rawlog=None, lse=lse, B=B, N=N, nH=nH, T=T, dtype=1, prec=0, scale=0.125,
+             xargs=[dao, drawlog, dqkv, dsum])
+
+
+t_b = timed(bwd)
+gf = 4.0 * N * N * 64 * nH * B / 1e9
+print(f"attention B={B} N={N} nH={nH} T={T} fast={os.environ.get('MTT_ATTN_FAST', '1')}: fwd {t_f * 1e3:.0f} us = {gf / t_f:.0f} TFLOP/s (2 GEMMs);"
+      f"  bwd {t_b * 1e3:.0f} us = {2.5 * gf / t_b:.0f} TFLOP/s (5 GEMMs algorithmic)")
