@@ -33,7 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=40, help="per-GPU batch (weak scaling); 40*1030 tokens fills 161 row tiles of 256 to 99.8%%")
+    ap.add_argument("--batch", type=int, default=63,
+                    help="per-GPU batch (weak scaling).  63*1030 token rows = 254 row tiles of 256, so the N=1024/3072/4096 encoder GEMMs launch "
+                         "1016/3048/4064 workgroups = 3.97/11.9/15.9 full rounds of the 256 CUs (batch 40 left the last round half empty); 93 GB of HBM")
     ap.add_argument("--prec", default="bf16", choices=["bf16", "x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -206,7 +208,7 @@ def main():
                                          "512x512, ConvHead, embed 300/350, ctr; random-init weights",
                                 per_gpu_batch=a.batch, global_batch=a.batch * world, parallelism=f"dp{world}",
                                 optimizer="Adam(fused) + clip_grad_norm 10", loss=float(loss.detach())),
-                    fwd_ms_per_img=round(fwd_ms_img, 3),
+                    fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                       fwd=round(GFLOP_FWD_PER_IMG / fwd_ms_img, 1)),
                     roofline=roof, cpu_baseline=cpu)

@@ -26,19 +26,15 @@ MTT_DEV u32x4 perm_frag(const unsigned char* tile, int row, int ks, int lg) {
   return (u32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
-// Workgroup = 64 query rows (all 4 waves carry all 64 rows: 4 B fragments per K / V^T fragment read); the 128 keys of a
-// staged tile are split over the waves (wave w owns keys 32w .. 32w+31): each wave runs an independent online softmax over
-// its key subset (own running max / sum / O^T partial, like split-KV decoding) and the four partials are merged once, in
-// LDS, at the end.  Compared with splitting the query rows over the waves this divides the LDS fragment traffic per MFMA by
-// 3 (that variant was LDS-bandwidth bound: 24 KB of fragment reads per 32 MFMAs per wave).
+// Workgroup = 128 query rows, 32 per wave (two B fragments of Q per K / V^T fragment read); 64-key tiles.
+// (A key-split variant — all waves share 64 query rows, each wave owns 32 keys of a 128-key tile, partials merged in LDS —
+// measured 5 % slower on MI355X: the kernel is bound by VALU issue (softmax, staging address math), not by LDS traffic.)
 __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = 4 * KTILE;                  // K [128 keys][64 d] (2 tiles), V^T 2 x [64 d][64 keys]
+  constexpr int STAGE = 2 * KTILE;                  // K, V^T
   const mtt_attn_desc& d = p.d;
-  // 1-D grid, XCD-aware: the query blocks of one (batch, head) are consecutive work items of ONE XCD, so its K / V are fetched
-  // into that XCD's L2 once and re-used by all of them (round-robin placement gave every query block a different L2: the
-  // kernel was bound by the latency of L2-missing tile loads)
-  const int nqb = (d.N + 63) / 64;
+  // 1-D grid, XCD-aware: the query blocks of one (batch, head) are consecutive work items of one XCD (shared L2)
+  const int nqb = (d.N + 127) / 128;
   const int wi = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = wi % nqb, bh = wi / nqb;
   const int h = bh % d.nH, b = bh / d.nH;
@@ -47,11 +43,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   const int li = lane & 15, lg = lane >> 4;
   const int64_t tok0 = (int64_t)b * N;
   const bf16_t* qkv = (const bf16_t*)d.qkv;
-  const int q0 = qb * 64;
+  const int q0 = qb * 128 + wave * 32;
+  const bool active = q0 < N;
 
-  u32x4 qf[4][2], dummy;
+  u32x4 qf[2][2], dummy;
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
+  for (int sub = 0; sub < 2; ++sub) {
     const int qrow = q0 + sub * 16 + li;
     const bool ok = qrow < N;
 #pragma unroll
@@ -62,104 +59,105 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
     }
   }
 
-  // staging: every thread copies 4 K chunks and transposes one 4-key x 8-d unit of V
-  Raw8<false> rawk[4], rawv[4];
-  unsigned okk = 0, okv = 0;
-  const int vq = tid & 31, vb = tid >> 5;            // V unit: keys 4 vq .. 4 vq + 3, d chunk vb
+  // staging roles: waves 0,1 transpose V (4 keys x 8 d units), waves 2,3 copy K
+  const bool isV = tid < 128;
+  Raw8<false> raw[4];
+  unsigned okm = 0;
+  const int kq = tid & 15, rb = (tid >> 4) & 7;
+  const int kt_ = tid - 128;
   auto stage_load = [&](int kv0) {
-    okk = okv = 0;
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;                  // K chunk: key idx >> 3, d chunk idx & 7
-      const int key = kv0 + (idx >> 3);
+      const int idx = kt_ + 128 * i;
+      const int key = isV ? kv0 + kq * 4 + i : kv0 + (idx >> 3);
+      const int col = isV ? 2 * C + rb * 8 : C + (idx & 7) * 8;
       const bool ok = key < N;
-      okk |= (ok ? 1u : 0u) << i;
-      load8_raw<false>(qkv, (tok0 + key) * 3 * C + C + h * HD + (idx & 7) * 8, ok, rawk[i]);
-      const int vkey = kv0 + vq * 4 + i;
-      const bool okv_ = vkey < N;
-      okv |= (okv_ ? 1u : 0u) << i;
-      load8_raw<false>(qkv, (tok0 + vkey) * 3 * C + 2 * C + h * HD + vb * 8, okv_, rawv[i]);
+      okm |= (ok ? 1u : 0u) << i;
+      load8_raw<false>(qkv, (tok0 + key) * 3 * C + col + h * HD, ok, raw[i]);
     }
   };
   auto stage_store = [&](unsigned char* st) {
     u32x4 sh[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      u32x4 kk;
-      cvt8<false, false>((okk >> i) & 1u, rawk[i], kk, dummy);
-      *(u32x4*)(st + lds_off(idx >> 3, idx & 7)) = kk;                 // rows 0..127: two consecutive 8 KiB tiles
-      cvt8<false, false>((okv >> i) & 1u, rawv[i], sh[i], dummy);
-    }
-    u32x2 piece[8];
-    transpose4x8(sh, piece);
-    unsigned char* vt = st + 2 * KTILE + (vq >> 4) * KTILE;           // keys 0..63 -> first V^T tile, 64..127 -> second
-    const int kq = vq & 15;
+    for (int i = 0; i < 4; ++i) cvt8<false, false>((okm >> i) & 1u, raw[i], sh[i], dummy);
+    if (isV) {
+      u32x2 piece[8];
+      transpose4x8(sh, piece);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *(u32x2*)(vt + lds_off(vb * 8 + j, kq >> 1) + (kq & 1) * 8) = piece[j];
+      for (int j = 0; j < 8; ++j) *(u32x2*)(st + KTILE + lds_off(rb * 8 + j, kq >> 1) + (kq & 1) * 8) = piece[j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = kt_ + 128 * i;
+        *(u32x4*)(st + lds_off(idx >> 3, idx & 7)) = sh[i];
+      }
+    }
   };
 
-  f32x4 o[4][4];
+  f32x4 o[2][4];
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub)
+  for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[sub][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_part[4] = {0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
   const float sc2 = d.scale * LOG2E;
-  const bool write_raw = d.rawlog != nullptr && d.T > 0 && qb == 0 && li < d.T;
+  const bool write_raw = d.rawlog != nullptr && d.T > 0 && qb == 0 && wave == 0 && li < d.T;
 
-  const int nkv = (N + 127) / 128;
+  const int nkv = (N + KV - 1) / KV;
   stage_load(0);
   stage_store(smem);
   __syncthreads();
 
   for (int j = 0; j < nkv; ++j) {
     const bool more = j + 1 < nkv;
-    if (more) stage_load((j + 1) * 128);
+    if (more) stage_load((j + 1) * KV);
     const unsigned char* Kh = smem + (j & 1) * STAGE;
-    const unsigned char* Vt = Kh + 2 * KTILE + (wave >> 1) * KTILE;
-    const int kbase = j * 128 + wave * 32;            // first key of this wave's 32-key slice
-    if (kbase < N) {
-      // ---- S^T = K Q^T : s[sub][kt][r] = S[q = 16 sub + li][key = kbase + 16 kt + 4 lg + r] ---------------------
-      f32x4 s[4][2];
+    const unsigned char* Vt = Kh + KTILE;
+    const int kv0 = j * KV;
+    if (active) {
+      // ---- S^T = K Q^T : s[sub][kt][r] = S[q = li][key = kv0 + 16 kt + 4 lg + r] ------------------------------
+      f32x4 s[2][4];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) s[sub][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kt = 0; kt < 4; ++kt) {
+        s[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-          const u32x4 kf = *(const u32x4*)(Kh + lds_off(wave * 32 + kt * 16 + li, kh * 4 + lg));
-#pragma unroll
-          for (int sub = 0; sub < 4; ++sub) s[sub][kt] = mfma16(kf, qf[sub][kh], s[sub][kt]);
+          const u32x4 kf = *(const u32x4*)(Kh + lds_off(kt * 16 + li, kh * 4 + lg));
+          s[0][kt] = mfma16(kf, qf[0][kh], s[0][kt]);
+          s[1][kt] = mfma16(kf, qf[1][kh], s[1][kt]);
         }
       }
       if (write_raw) {
         float* rl = d.rawlog + (((int64_t)b * d.nH + h) * d.T + li) * N;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = kbase + kt * 16 + lg * 4 + r;
+            const int key = kv0 + kt * 16 + lg * 4 + r;
             if (key < N) rl[key] = s[0][kt][r];
           }
       }
       // softmax in the log2 domain on the RAW scores: p = 2^(s*sc2 - m) is one fma + one v_exp per element; masking only in
-      // the (wave-uniform) last slice; O^T is rescaled only when some lane's running max moved (alpha == 1 otherwise).
-      const bool full = kbase + 32 <= N;
-      if (!full) {
+      // the (block-uniform) last tile; O^T is rescaled only when some lane's running max moved (alpha == 1 otherwise).
+      if (kv0 + KV > N) {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
+          for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if ((kbase + kt * 16 + lg * 4 + r) >= N) s[sub][kt][r] = -INFINITY;
+              if ((kv0 + kt * 16 + lg * 4 + r) >= N) s[sub][kt][r] = -INFINITY;
       }
-      u32x4 pb[4];
+      u32x4 pb[2][2];
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        float mx = fmaxf(fmaxf(fmaxf(s[sub][0][0], s[sub][0][1]), fmaxf(s[sub][0][2], s[sub][0][3])),
-                         fmaxf(fmaxf(s[sub][1][0], s[sub][1][1]), fmaxf(s[sub][1][2], s[sub][1][3])));
+      for (int sub = 0; sub < 2; ++sub) {
+        float mx = s[sub][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run[sub], mx * sc2);
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
         }
         float rs = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sc2, -m_new));
@@ -182,73 +180,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
             rs += pv;
           }
         l_part[sub] += rs;
-        pb[sub] = (u32x4){pack2(s[sub][0][0], s[sub][0][1]), pack2(s[sub][0][2], s[sub][0][3]),
-                          pack2(s[sub][1][0], s[sub][1][1]), pack2(s[sub][1][2], s[sub][1][3])};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          pb[sub][ks] = (u32x4){pack2(s[sub][2 * ks][0], s[sub][2 * ks][1]), pack2(s[sub][2 * ks][2], s[sub][2 * ks][3]),
+                                pack2(s[sub][2 * ks + 1][0], s[sub][2 * ks + 1][1]), pack2(s[sub][2 * ks + 1][2], s[sub][2 * ks + 1][3])};
       }
-      // ---- O^T += V^T P^T over this wave's 32 keys -----------------------------------------------------------------
+      // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const u32x4 vf = perm_frag(Vt, dt * 16 + li, wave & 1, lg);
+      for (int ks = 0; ks < 2; ++ks) {
+        if (kv0 + 32 * ks >= N) continue;              // block-uniform: nothing valid in this half of the last tile (P = 0)
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) o[sub][dt] = mfma16(vf, pb[sub], o[sub][dt]);
+        for (int dt = 0; dt < 4; ++dt) {
+          const u32x4 vf = perm_frag(Vt, dt * 16 + li, ks, lg);
+          o[0][dt] = mfma16(vf, pb[0][ks], o[0][dt]);
+          o[1][dt] = mfma16(vf, pb[1][ks], o[1][dt]);
+        }
       }
     }
     if (more) stage_store(smem + ((j + 1) & 1) * STAGE);
     __syncthreads();
   }
 
-  // ---- merge the four key-slice partials: O = sum_w e_w O_w / sum_w e_w l_w, e_w = 2^(m_w - m) -----------------------
-  constexpr int PSTR = 68;                             // fp32 row pitch of the partials (64 + 4: rows start on different banks)
-  float* stat = (float*)(smem + 4 * 64 * PSTR * 4);    // [2][4 waves][64 q]: m, l
-  float* part = (float*)smem;                          // [4 waves][64 q][PSTR] fp32 (reuses the staging buffers)
+  // ---- epilogue: o[sub][dt][r] = O[q = li][d = 16 dt + 4 lg + r] ---------------------------------------------------
+  bf16_t* out = (bf16_t*)d.out;
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
+  for (int sub = 0; sub < 2; ++sub) {
     float l = l_part[sub];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    l_part[sub] = l;
-    if (lg == 0) { stat[wave * 64 + sub * 16 + li] = m_run[sub]; stat[256 + wave * 64 + sub * 16 + li] = l; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
-    const int q = sub * 16 + li;
-    float m = fmaxf(fmaxf(stat[q], stat[64 + q]), fmaxf(stat[128 + q], stat[192 + q]));
-    float l = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) l += __builtin_amdgcn_exp2f(stat[w * 64 + q] - m) * stat[256 + w * 64 + q];
-    const float f = __builtin_amdgcn_exp2f(m_run[sub] - m) / l;        // m_run = -inf (no key seen) -> 0
+    const int qrow = q0 + sub * 16 + li;
+    if (qrow >= N) continue;
+    const float inv = 1.0f / l;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *(float4*)(part + ((wave * 64 + q) * PSTR + dt * 16 + lg * 4)) =
-          make_float4(o[sub][dt][0] * f, o[sub][dt][1] * f, o[sub][dt][2] * f, o[sub][dt][3] * f);
-  }
-  __syncthreads();
-  {
-    const int q = tid >> 2, ds = (tid & 3) * 16;
-    const int qrow = q0 + q;
-    if (qrow < N) {
-      float acc[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 v = *(const float4*)(part + ((w * 64 + q) * PSTR + ds + c * 4));
-          acc[c * 4] += v.x; acc[c * 4 + 1] += v.y; acc[c * 4 + 2] += v.z; acc[c * 4 + 3] += v.w;
-        }
-      bf16_t* out = (bf16_t*)d.out + (tok0 + qrow) * C + h * HD + ds;
-      *(u32x4*)out = (u32x4){pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
-      *(u32x4*)(out + 8) = (u32x4){pack2(acc[8], acc[9]), pack2(acc[10], acc[11]), pack2(acc[12], acc[13]), pack2(acc[14], acc[15])};
-      if (d.lse && (tid & 3) == 0) {
-        const float m = fmaxf(fmaxf(stat[q], stat[64 + q]), fmaxf(stat[128 + q], stat[192 + q]));
-        float l = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) l += __builtin_amdgcn_exp2f(stat[w * 64 + q] - m) * stat[256 + w * 64 + q];
-        d.lse[((int64_t)b * d.nH + h) * N + qrow] = (m + log2f(l)) * 0.6931471805599453f;
-      }
-    }
+      *(u32x2*)(out + (tok0 + qrow) * C + h * HD + dt * 16 + lg * 4) =
+          (u32x2){pack2(o[sub][dt][0] * inv, o[sub][dt][1] * inv), pack2(o[sub][dt][2] * inv, o[sub][dt][3] * inv)};
+    if (d.lse && lg == 0) d.lse[((int64_t)b * d.nH + h) * N + qrow] = (m_run[sub] + log2f(l)) * 0.6931471805599453f;
   }
 }
 
@@ -256,15 +223,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
 
 // called by mtt_attn_fwd (attn.hip) for bf16 storage + MTT_PREC_BF16
 int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s) {
-  constexpr int smem = 4 * 64 * 68 * 4 + 2 * 4 * 64 * 4;      // merge buffers (69.6 KB) >= 2 staging stages (64 KB)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  constexpr int smem = 2 * 2 * KTILE;
   AttnP p; p.d = *dd;
-  dim3 grid((unsigned)(((dd->N + 63) / 64) * dd->nH * dd->B));
+  dim3 grid((unsigned)(((dd->N + 127) / 128) * dd->nH * dd->B));
   hipLaunchKernelGGL(attn_fwd_fast_kernel, grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }
