@@ -34,16 +34,25 @@ MTT_DEV int64_t row_off(uint32_t m, int mb, int64_t bs, int64_t ld, FastDiv f) {
 // Stagers: global -> registers (load) -> LDS tile (store).  All 256 threads take part.
 // ---------------------------------------------------------------------------------------------
 
+// 32 zero bytes: invalid chunks (row / k out of range, conv halo) are READ from here instead of being masked after the
+// load — the register stagers are VALU-issue bound (every VALU instruction costs 4 SIMD cycles), and a pointer select is 2
+// v_cndmask where masking the 16 loaded bytes (+ keeping the address in range) was 6.
+__device__ __attribute__((aligned(32))) const unsigned g_zero_page[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+
 // reduction index contiguous in memory.  4 chunks of 8 elements per thread.
 template <bool X3, bool CONV, bool F32>
 struct StagerK {
   const void* base; int dtype; int K; int c;
   int64_t roff[4]; bool rok[4];
-  int py[4], px[4];                 // CONV: pixel coordinates of each row
-  Raw8<F32> raw[4]; unsigned okm;
+  uint64_t zpage;                   // address of g_zero_page, kept opaque in SGPRs (otherwise re-materialised per load)
+  unsigned tapmask[4];              // CONV: bit t set <=> tap t of this row reads inside the image
+  int tap, ci, knext;               // CONV: incremental (tap, channel) of this thread's chunk; k the next load() expects
+  Raw8<F32> raw[4];
 
   MTT_DEV void init(const GemmP& p, const void* b, int dt, int row0, int rows, int64_t ld, int mb, int64_t bs, FastDiv fmb) {
     base = b; dtype = dt; K = p.d.K; c = threadIdx.x & 7;
+    zpage = (uint64_t)(uintptr_t)g_zero_page;
+    asm volatile("" : "+s"(zpage));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = row0 + (threadIdx.x >> 3) + 32 * i;
@@ -51,15 +60,29 @@ struct StagerK {
       const uint32_t rr = rok[i] ? (uint32_t)r : 0u;
       if (CONV) {
         const uint32_t t = fdiv(rr, p.divW);
-        px[i] = (int)(rr - t * (uint32_t)p.d.conv.W);
+        const int px = (int)(rr - t * (uint32_t)p.d.conv.W);
         const uint32_t bb = fdiv(t, p.divH);
-        py[i] = (int)(t - bb * (uint32_t)p.d.conv.H);
+        const int py = (int)(t - bb * (uint32_t)p.d.conv.H);
         roff[i] = (int64_t)rr * ld;
+        unsigned m = 0;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          int ty = tp / 3, tx = tp % 3;
+          if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+          const int yy = py + (ty - 1) * p.d.conv.dil, xx = px + (tx - 1) * p.d.conv.dil;
+          if (rok[i] && yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W) m |= 1u << tp;
+        }
+        tapmask[i] = m;
       } else {
         roff[i] = row_off(rr, mb, bs, ld, fmb);
+        tapmask[i] = rok[i] ? 1u : 0u;
       }
     }
     ldx = ld;
+    tap = 0; ci = c * 8; knext = 0;
+    if (CONV) {                       // normalise (Cp may be smaller than 64)
+      while (ci >= p.d.conv.Cp) { ci -= p.d.conv.Cp; ++tap; }
+    }
   }
   int64_t ldx;
 
@@ -67,26 +90,33 @@ struct StagerK {
     const int k = k0 + c * 8;
     bool kok = k < K;
     int64_t koff = k;
-    int dy = 0, dx = 0;
+    unsigned bit = 0;
     if (CONV) {
-      const uint32_t tap = fdiv((uint32_t)(kok ? k : 0), p.divCp);
-      const int ci = k - (int)tap * p.d.conv.Cp;
+      if (k0 != knext) {              // (never taken by the k loop: steps are consecutive)
+        const uint32_t t = fdiv((uint32_t)(kok ? k : 0), p.divCp);
+        tap = (int)t; ci = k - (int)t * p.d.conv.Cp;
+      }
       kok = kok && ci < p.d.conv.C;
-      int ty = (int)fdiv(tap, p.div3), tx = (int)tap - 3 * ty;
+      int ty = (int)fdiv((uint32_t)tap, p.div3), tx = tap - 3 * ty;
       if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
-      dy = (ty - 1) * p.d.conv.dil; dx = (tx - 1) * p.d.conv.dil;
-      koff = (int64_t)(dy * p.d.conv.W + dx) * ldx + ci;
+      koff = (int64_t)((ty - 1) * p.d.conv.dil * p.d.conv.W + (tx - 1) * p.d.conv.dil) * ldx + ci;
+      bit = (unsigned)tap;
+      // advance to the next 64-wide step
+      ci += 64; knext = k0 + 64;
+      while (ci >= p.d.conv.Cp) { ci -= p.d.conv.Cp; ++tap; }
     }
-    okm = 0;
+    const int es = F32 ? 4 : 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bool ok = rok[i] && kok;
-      if (CONV) {
-        const int yy = py[i] + dy, xx = px[i] + dx;
-        ok = ok && yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W;
+      const bool ok = kok && ((tapmask[i] >> bit) & 1u);
+      const uint64_t real = (uint64_t)(uintptr_t)base + (uint64_t)((roff[i] + koff) * es);
+      const unsigned char* ptr = (const unsigned char*)(uintptr_t)(ok ? real : zpage);
+      if constexpr (F32) {
+        raw[i].v0 = *(const float4*)ptr;
+        raw[i].v1 = *(const float4*)(ptr + 16);
+      } else {
+        raw[i].r0 = *(const u32x4*)ptr;
       }
-      okm |= (ok ? 1u : 0u) << i;
-      load8_raw<F32>(base, roff[i] + koff, ok, raw[i]);
     }
   }
 
@@ -95,7 +125,7 @@ struct StagerK {
     for (int i = 0; i < 4; ++i) {
       const int row = (threadIdx.x >> 3) + 32 * i;
       u32x4 hi, lo;
-      cvt8<X3, F32>((okm >> i) & 1u, raw[i], hi, lo);
+      cvt8<X3, F32>(true, raw[i], hi, lo);
       *(u32x4*)(t_hi + lds_off(row, c)) = hi;
       if (X3) *(u32x4*)(t_lo + lds_off(row, c)) = lo;
     }
