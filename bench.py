@@ -137,7 +137,8 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=100)
     crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=2e-5, weight_decay=1e-6, fused=True)  # pascal_vitLp16_taskprompter.yml:19-22
+    # pascal_vitLp16_taskprompter.yml:19-24: Adam(lr 2e-5, wd 1e-6) + clip_grad_norm_(10), fused into two multi-tensor HIP launches
+    opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=2e-5, weight_decay=1e-6, max_norm=10.0)
     g = torch.Generator().manual_seed(1 + rank)
     x = torch.randn(a.batch, 3, 512, 512, generator=g).to(dev)
     gt = mtt_amd.losses.synthetic_targets(p, a.batch, 512, 512, dev, seed=rank)
@@ -147,8 +148,7 @@ def main():
         loss = crit(out, gt)["total"]
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, norm_type=2)   # yml:24
-        opt.step()
+        opt.step()                                        # global-norm clip (yml:24) + Adam
         return loss
 
     for _ in range(a.warmup):
@@ -207,7 +207,7 @@ def main():
                     config=dict(workload="TaskPrompter ViT-L/16 (taskprompter_vit_large_patch16_384), PASCAL-Context 5 tasks + depth = 6 tasks, "
                                          "512x512, ConvHead, embed 300/350, ctr; random-init weights",
                                 per_gpu_batch=a.batch, global_batch=a.batch * world, parallelism=f"dp{world}",
-                                optimizer="Adam(fused) + clip_grad_norm 10", loss=float(loss.detach())),
+                                optimizer="clip_grad_norm 10 + Adam (mtt_grad_sqnorm / mtt_adam_step)", loss=float(loss.detach())),
                     fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                       fwd=round(GFLOP_FWD_PER_IMG / fwd_ms_img, 1)),

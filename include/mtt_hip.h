@@ -95,7 +95,7 @@ typedef struct {
 } mtt_gemm_desc;
 
 int mtt_abi_version(void);
-/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom,
+/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom, (15 adam)
  * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
@@ -270,6 +270,23 @@ typedef struct {
 int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream);
 /* backward: dyall [B*H*W, 9*Cop] (d->dtype) gathered from dout [B*2H*2W, Cop] (d->out_dtype) */
 int mtt_convt3x3s2_gather_bwd(const mtt_convt_desc* d, const void* dout, void* dyall, void* stream);
+
+/* Fused multi-tensor clip_grad_norm_ + Adam (TaskPrompter/utils/train_utils.py:47-51, torch.optim.Adam semantics: L2 weight decay
+ * added to the gradient, bias-corrected moments).  All n tensors are fp32; grads/params/exp_avg/exp_avg_sq/numel are DEVICE arrays
+ * of n pointers / element counts; work is cut into chunks of mtt_adam_chunk() elements: chunk c covers elements
+ * [chunk_off[c], chunk_off[c] + chunk) of tensor chunk_tensor[c] (device arrays of n_chunks entries, built once by the host).
+ *   mtt_grad_sqnorm: *out_sq += sum of squares of all gradients (out_sq zeroed by the caller)
+ *   mtt_adam_step  : g = grad * min(1, max_norm / (sqrt(*total_sq) + 1e-6))  (no clipping if max_norm <= 0 or total_sq NULL);
+ *                    g += weight_decay * p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *                    p -= step_size * m / (sqrt(v) * inv_sqrt_bc2 + eps)   with step_size = lr / (1 - b1^t), inv_sqrt_bc2 = 1/sqrt(1 - b2^t) */
+typedef struct {
+  const void* const* grads; float* const* params; float* const* exp_avg; float* const* exp_avg_sq; const int64_t* numel;
+  const int32_t* chunk_tensor; const int64_t* chunk_off; int32_t n_chunks;
+  float max_norm, step_size, beta1, beta2, eps, weight_decay, inv_sqrt_bc2;
+} mtt_adam_desc;
+int mtt_adam_chunk(void);
+int mtt_grad_sqnorm(const mtt_adam_desc* d, float* out_sq, void* stream);
+int mtt_adam_step(const mtt_adam_desc* d, const float* total_sq, void* stream);
 
 #ifdef __cplusplus
 }

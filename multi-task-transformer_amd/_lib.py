@@ -123,6 +123,13 @@ class ConvtDesc(C.Structure):
                 ("dtype", i32), ("out_dtype", i32)]
 
 
+class AdamDesc(C.Structure):
+    _fields_ = [("grads", ptr), ("params", ptr), ("exp_avg", ptr), ("exp_avg_sq", ptr), ("numel", ptr),
+                ("chunk_tensor", ptr), ("chunk_off", ptr), ("n_chunks", i32),
+                ("max_norm", f32), ("step_size", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32),
+                ("inv_sqrt_bc2", f32)]
+
+
 # entry point -> (descriptor struct, size index in mtt_desc_size) ; None = positional-argument entry
 DESCS = {
     "gemm": GemmDesc, "attn_fwd": AttnDesc, "softmax_fwd": SoftmaxDesc, "softmax_bwd": SoftmaxDesc,
@@ -133,7 +140,7 @@ DESCS = {
     "convt3x3s2_gather": ConvtDesc,
 }
 _SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom,
-               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc]
+               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc]
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
@@ -150,12 +157,14 @@ DESC_EXTRA = {
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),
     "attn_bwd": (AttnDesc, [ptr, ptr, ptr, ptr]),
+    "grad_sqnorm": (AdamDesc, [ptr]),
+    "adam_step": (AdamDesc, [ptr]),
     "dwconv3x3s2_bwd": (DwconvDesc, [ptr, ptr, ptr]),
     "avgpool_ceil_bwd": (PoolDesc, [ptr, ptr]),
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
 
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant", "mtt_gemm_variant"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant", "mtt_gemm_variant", "mtt_adam_chunk"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 

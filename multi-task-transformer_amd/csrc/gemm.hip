@@ -725,6 +725,7 @@ extern "C" size_t mtt_desc_size(int which) {
     case 12: return sizeof(mtt_lnmt_desc);
     case 13: return sizeof(mtt_attnmsg_desc);
     case 14: return sizeof(mtt_convt_desc);
+    case 15: return sizeof(mtt_adam_desc);
     default: return 0;
   }
 }

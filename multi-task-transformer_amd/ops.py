@@ -37,6 +37,10 @@ def call(name, **kw):          # single indirection point (tests monkeypatch thi
     return _lib.call(name, **kw)
 
 
+def adam_chunk():
+    return int(_lib.load().mtt_adam_chunk())
+
+
 # ---------------------------------------------------------------------------------------------
 # parameter packing (cached per parameter version)
 # ---------------------------------------------------------------------------------------------

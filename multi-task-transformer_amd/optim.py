@@ -1,0 +1,102 @@
+"""Optimizer step of the reference training loop (TaskPrompter/utils/train_utils.py:47-51 and :139-150) on the HIP kernels:
+`clip_grad_norm_(params, max_norm)` + `torch.optim.Adam.step()` fused into two multi-tensor launches (mtt_grad_sqnorm,
+mtt_adam_step), and the reference's polynomial learning-rate schedule.
+
+`FusedClipAdam` keeps torch.optim.Adam's state layout (`step`, `exp_avg`, `exp_avg_sq` per parameter), so a reference
+checkpoint's optimizer state loads with `load_state_dict` and vice versa.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    """Adam (torch.optim.Adam semantics: L2 weight decay added to the gradient, bias-corrected moments, no amsgrad) preceded by
+    global-norm gradient clipping.  `step()` returns the total gradient norm before clipping (like clip_grad_norm_)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_norm = float(max_norm)
+        self._tables = {}
+
+    def _group_tables(self, gi, plist):
+        key = (gi, tuple(p.data_ptr() for p in plist))
+        tab = self._tables.get(gi)
+        if tab is not None and tab["key"] == key:
+            return tab
+        dev = plist[0].device
+        chunk = ops.adam_chunk()
+        numel = [p.numel() for p in plist]
+        ct, co = [], []
+        for t, n in enumerate(numel):
+            for off in range(0, n, chunk):
+                ct.append(t)
+                co.append(off)
+        st = [self.state[p] for p in plist]
+
+        def ptrs(ts):
+            return torch.from_numpy(np.array([t.data_ptr() for t in ts], dtype=np.int64)).to(dev)
+        tab = dict(key=key, params=ptrs(plist), exp_avg=ptrs([s["exp_avg"] for s in st]), exp_avg_sq=ptrs([s["exp_avg_sq"] for s in st]),
+                   numel=torch.tensor(numel, dtype=torch.int64, device=dev), chunk_tensor=torch.tensor(ct, dtype=torch.int32, device=dev),
+                   chunk_off=torch.tensor(co, dtype=torch.int64, device=dev), n_chunks=len(ct))
+        self._tables[gi] = tab
+        return tab
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        work = []
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedClipAdam: fp32 contiguous parameters and gradients only")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+            tab = self._group_tables(gi, plist)
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
+            gp = torch.from_numpy(np.array([g.data_ptr() for g in grads], dtype=np.int64)).to(plist[0].device, non_blocking=True)
+            work.append((group, plist, tab, grads, gp))
+        if not work:
+            return loss
+        dev = work[0][1][0].device
+        total_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        base = dict(max_norm=0.0, step_size=0.0, beta1=0.0, beta2=0.0, eps=0.0, weight_decay=0.0, inv_sqrt_bc2=0.0)
+        for group, plist, tab, grads, gp in work:
+            ops.call("grad_sqnorm", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
+                     chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], xargs=[total_sq], **base)
+        for group, plist, tab, grads, gp in work:
+            st0 = self.state[plist[0]]
+            for p in plist:
+                self.state[p]["step"] += 1
+            t = float(st0["step"])
+            b1, b2 = group["betas"]
+            ops.call("adam_step", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
+                     chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], max_norm=self.max_norm,
+                     step_size=group["lr"] / (1.0 - b1 ** t), beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
+                     inv_sqrt_bc2=1.0 / math.sqrt(1.0 - b2 ** t), xargs=[total_sq if self.max_norm > 0 else None])
+        self.last_grad_norm = total_sq.sqrt()
+        return loss if loss is not None else self.last_grad_norm
+
+
+class PolynomialLR(torch.optim.lr_scheduler._LRScheduler):
+    """TaskPrompter/utils/train_utils.py:139-150: lr = base_lr * (1 - iter / max_iterations) ** gamma, floored at min_lr."""
+
+    def __init__(self, optimizer, max_iterations, gamma=0.9, min_lr=0.0, last_epoch=-1):
+        self.max_iterations, self.gamma, self.min_lr = max_iterations, gamma, min_lr
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        factor = (1 - self.last_epoch / float(self.max_iterations)) ** self.gamma
+        return [(base_lr - self.min_lr) * factor + self.min_lr for base_lr in self.base_lrs]

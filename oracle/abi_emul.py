@@ -610,6 +610,43 @@ def transpose_pad_sum(args):
         _wr(colsum, torch.arange(cols), _rd(colsum, torch.arange(cols)) + v.sum(0))
 
 
+def _raw_f32(addr, n):
+    """fp32 view of host memory at a raw address (the optimizer entry points take arrays of tensor pointers)."""
+    import ctypes
+    import numpy as np
+    return np.ctypeslib.as_array((ctypes.c_float * int(n)).from_address(int(addr)))
+
+
+def _adam_tables(kw):
+    return [t.tolist() if t is not None else None for t in (kw["grads"], kw["params"], kw["exp_avg"], kw["exp_avg_sq"], kw["numel"])]
+
+
+def grad_sqnorm(**kw):
+    grads, _, _, _, numel = _adam_tables(kw)
+    tot = 0.0
+    for g, n in zip(grads, numel):
+        tot += float((_raw_f32(g, n).astype("float64") ** 2).sum())
+    out = kw["xargs"][0]
+    _wr(out, torch.arange(1), _rd(out, torch.arange(1)) + tot)
+
+
+def adam_step(**kw):
+    import numpy as np
+    grads, params, ms, vs, numel = _adam_tables(kw)
+    total = kw["xargs"][0]
+    coef = 1.0
+    if kw["max_norm"] > 0 and total is not None:
+        coef = min(1.0, kw["max_norm"] / (float(_rd(total, torch.arange(1))[0]) ** 0.5 + 1e-6))
+    for g, p, m, v, n in zip(grads, params, ms, vs, numel):
+        ga, pa, ma, va = (_raw_f32(a, n) for a in (g, p, m, v))
+        gg = ga.astype("float64") * coef + kw["weight_decay"] * pa.astype("float64")
+        mm = kw["beta1"] * ma.astype("float64") + (1 - kw["beta1"]) * gg
+        vv = kw["beta2"] * va.astype("float64") + (1 - kw["beta2"]) * gg * gg
+        pa[:] = (pa.astype("float64") - kw["step_size"] * mm / (np.sqrt(vv) * kw["inv_sqrt_bc2"] + kw["eps"])).astype("float32")
+        ma[:] = mm.astype("float32")
+        va[:] = vv.astype("float32")
+
+
 def dwconv3x3s2_bwd(**kw):
     dy, dx, dw = kw["xargs"]
     Z, B, H, W, ld = kw["Z"], kw["B"], kw["H"], kw["W"], kw["ld"]
@@ -667,7 +704,7 @@ _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd
               modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw,
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
-              convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd)
+              convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step)
 _POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
             transpose_pad_sum=transpose_pad_sum)
 

@@ -51,3 +51,31 @@ def test_invpt_gradients(prec, ftol, mtol):
     worst, med = train_check.summarize(errs, floor=1e-6 if prec == "x3" else 1e-4)
     assert med < mtol and (prec != "x3" or worst[0] < 3e-2), (worst, med)
     assert len(dead) == 10
+
+
+@pytest.mark.gpu
+def test_fused_clip_adam_matches_torch_on_gpu():
+    """mtt_grad_sqnorm + mtt_adam_step vs clip_grad_norm_ + torch.optim.Adam (4 steps; chunk-spanning, tiny and 4-byte-aligned tensors)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mtt_amd
+    torch.manual_seed(0)
+    flat = torch.randn(200001, device="cuda")
+    shapes = [(300000,), (1024, 1024), (7,), (350, 350, 3, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    mine = [torch.nn.Parameter(q.detach().clone()) for q in ref]
+    o_ref = torch.optim.Adam(ref, lr=2e-3, weight_decay=1e-6)
+    o_mine = mtt_amd.optim.FusedClipAdam(mine, lr=2e-3, weight_decay=1e-6, max_norm=10.0)
+    for it in range(4):
+        for i, (q, r, s) in enumerate(zip(mine, ref, shapes)):
+            g = torch.randn(s, device="cuda") * (1.0 if it % 2 == 0 else 1e-3)
+            if i == 0:                                   # a gradient that is only 4-byte aligned (DDP bucket views can be)
+                flat[1:1 + 200000].normal_()
+                g = torch.cat([flat[1:200001], g[200000:]])
+            q.grad, r.grad = g.clone(), g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 10.0)
+        o_ref.step()
+        n_mine = o_mine.step()
+        assert abs(float(n_ref) - float(n_mine)) < 1e-4 * float(n_ref)
+        for q, r in zip(mine, ref):
+            assert float((q.detach() - r.detach()).abs().max()) < 5e-6, it

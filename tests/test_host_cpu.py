@@ -176,3 +176,32 @@ def test_fast_backward_gemm_routing_matches_general_path(emulated, monkeypatch):
     for k in ref:
         if "blocks" in k and k.endswith("weight") and ref[k][1] > 1e-4:
             assert abs(got[k][0] - ref[k][0]) <= 0.5 * ref[k][0] + 1e-3 * ref[k][1], (k, got[k], ref[k])
+
+
+def test_fused_clip_adam_matches_torch_adam_with_clipping(emulated, monkeypatch):
+    """optim.FusedClipAdam (mtt_grad_sqnorm + mtt_adam_step on the emulator) vs clip_grad_norm_ + torch.optim.Adam, 3 steps, with a
+    learning-rate schedule; state_dict layouts are interchangeable."""
+    import mtt_amd
+    monkeypatch.setattr(mtt_amd.ops, "adam_chunk", lambda: 65536)
+    torch.manual_seed(0)
+    shapes = [(70000,), (33, 17), (5,), (128, 64, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    mine = [torch.nn.Parameter(q.detach().clone()) for q in ref]
+    o_ref = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    o_mine = mtt_amd.optim.FusedClipAdam(mine, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, max_norm=2.0)
+    s_ref = mtt_amd.optim.PolynomialLR(o_ref, max_iterations=10, gamma=0.9)
+    s_mine = mtt_amd.optim.PolynomialLR(o_mine, max_iterations=10, gamma=0.9)
+    for it in range(3):
+        gs = [torch.randn(s) * (3.0 if it == 0 else 0.05) for s in shapes]      # first step clips, later ones do not
+        for q, r, g in zip(mine, ref, gs):
+            q.grad, r.grad = g.clone(), g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 2.0)
+        o_ref.step()
+        n_mine = o_mine.step()
+        s_ref.step(), s_mine.step()
+        assert abs(float(n_ref) - float(n_mine)) < 1e-4 * float(n_ref)
+        for q, r in zip(mine, ref):
+            assert float((q.detach() - r.detach()).abs().max()) < 2e-6, it
+    sd = o_mine.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    o_ref.load_state_dict(sd)                                                     # layouts are interchangeable
