@@ -136,7 +136,7 @@ def main():
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=100)
-    crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES).to(dev)
+    crit = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES).to(dev)      # HIP loss kernels (the CPU baseline uses the torch restatement)
     # pascal_vitLp16_taskprompter.yml:19-24: Adam(lr 2e-5, wd 1e-6) + clip_grad_norm_(10), fused into two multi-tensor HIP launches
     opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=2e-5, weight_decay=1e-6, max_norm=10.0)
     g = torch.Generator().manual_seed(1 + rank)

@@ -95,7 +95,7 @@ typedef struct {
 } mtt_gemm_desc;
 
 int mtt_abi_version(void);
-/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom, (15 adam)
+/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom, (15 adam, 16 loss)
  * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
@@ -287,6 +287,21 @@ typedef struct {
 int mtt_adam_chunk(void);
 int mtt_grad_sqnorm(const mtt_adam_desc* d, float* out_sq, void* stream);
 int mtt_adam_step(const mtt_adam_desc* d, const float* total_sq, void* stream);
+
+/* Per-task training losses from the full-resolution logits (TaskPrompter/losses/loss_functions.py:15-177; MultiTaskLoss,
+ * loss_schemes.py:9-39, sums them with the task weights on the host side).  kind: 0 CrossEntropy(ignore) | 1 CrossEntropy with
+ * 2-class label-frequency weights (`balanced`) | 2 balanced BCE-with-logits (pos_weight) | 3 L1(ignore) | 4 L1 on L2-normalised pred.
+ * pred fp32 [B, C, HW] (NCHW), label fp32 [B, Cl, HW]; a pixel is valid when all its Cl label channels != ignore.
+ *   mtt_loss_label_stats: stats[0] += number of valid pixels, stats[1] += sum of valid labels (channel 0)   (stats zeroed by caller)
+ *   mtt_loss_fwd        : loss[0] += task loss (mean over valid pixels; normalisation read from `stats` on the device)
+ *   mtt_loss_bwd        : dpred [B, C, HW] = gout[0] * d loss / d pred */
+typedef struct {
+  const float* pred; const float* label; float* dpred; float* loss; const float* stats;
+  int64_t B, HW; int32_t C, Cl, kind; float ignore, pos_weight;
+} mtt_loss_desc;
+int mtt_loss_label_stats(const mtt_loss_desc* d, float* stats, void* stream);
+int mtt_loss_fwd(const mtt_loss_desc* d, void* stream);
+int mtt_loss_bwd(const mtt_loss_desc* d, const float* gout, void* stream);
 
 #ifdef __cplusplus
 }

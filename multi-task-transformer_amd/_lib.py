@@ -130,8 +130,14 @@ class AdamDesc(C.Structure):
                 ("inv_sqrt_bc2", f32)]
 
 
+class LossDesc(C.Structure):
+    _fields_ = [("pred", ptr), ("label", ptr), ("dpred", ptr), ("loss", ptr), ("stats", ptr), ("B", i64), ("HW", i64),
+                ("C", i32), ("Cl", i32), ("kind", i32), ("ignore", f32), ("pos_weight", f32)]
+
+
 # entry point -> (descriptor struct, size index in mtt_desc_size) ; None = positional-argument entry
 DESCS = {
+    "loss_fwd": LossDesc,
     "gemm": GemmDesc, "attn_fwd": AttnDesc, "softmax_fwd": SoftmaxDesc, "softmax_bwd": SoftmaxDesc,
     "layernorm_fwd": LnDesc, "layernorm_bwd": LnDesc, "chan_logits": ChanLogitDesc, "modulate": ModulateDesc,
     "ctr_mix": CtrDesc, "bilinear_fwd": ResizeDesc, "bilinear_bwd": ResizeDesc,
@@ -140,7 +146,7 @@ DESCS = {
     "convt3x3s2_gather": ConvtDesc,
 }
 _SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom,
-               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc]
+               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc, LossDesc]
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
@@ -159,6 +165,8 @@ DESC_EXTRA = {
     "attn_bwd": (AttnDesc, [ptr, ptr, ptr, ptr]),
     "grad_sqnorm": (AdamDesc, [ptr]),
     "adam_step": (AdamDesc, [ptr]),
+    "loss_label_stats": (LossDesc, [ptr]),
+    "loss_bwd": (LossDesc, [ptr]),
     "dwconv3x3s2_bwd": (DwconvDesc, [ptr, ptr, ptr]),
     "avgpool_ceil_bwd": (PoolDesc, [ptr, ptr]),
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),

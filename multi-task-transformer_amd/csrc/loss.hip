@@ -1,0 +1,161 @@
+// Per-task training losses straight from the full-resolution logits (TaskPrompter/losses/loss_functions.py:15-177):
+//   kind 0  CrossEntropy with ignore index                     (semseg, human_parts)
+//   kind 1  2-class CrossEntropy re-weighted by label frequency (sal, `balanced=True`)
+//   kind 2  HED-style balanced binary cross entropy             (edge)
+//   kind 3  L1 with ignore value                                 (depth)
+//   kind 4  L1 on L2-normalised predictions                      (normals)
+// pred fp32 NCHW [B, C, HW], label fp32 [B, Cl, HW] (Cl = 1, or = C for kinds 3/4).  Three entry points:
+//   mtt_loss_label_stats: stats[0] += #valid pixels, stats[1] += sum of the valid labels (class-frequency weights of kind 1)
+//   mtt_loss_fwd        : loss[0] += task loss (normalised with stats, read on the device: no host synchronisation)
+//   mtt_loss_bwd        : dpred = gout[0] * d(task loss)/d(pred)
+// One thread per pixel: the C logits of a pixel are strided by HW, so a wave reads C coalesced 256-byte rows.
+#include "mtt_device.h"
+
+namespace {
+
+constexpr int MAXC = 32;
+
+MTT_DEV float block_sum256(float v) {
+  __shared__ float red[4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+MTT_DEV bool pixel_valid(const mtt_loss_desc& d, const float* lab, int64_t b, int64_t hw) {
+  bool ok = true;
+  for (int c = 0; c < d.Cl; ++c) ok = ok && lab[(b * d.Cl + c) * d.HW + hw] != d.ignore;
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void label_stats_kernel(const mtt_loss_desc d, float* stats) {
+  float cnt = 0.f, pos = 0.f;
+  const int64_t total = d.B * d.HW;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t b = t / d.HW, hw = t - b * d.HW;
+    if (pixel_valid(d, d.label, b, hw)) { cnt += 1.f; pos += d.label[b * d.Cl * d.HW + hw]; }
+  }
+  cnt = block_sum256(cnt); pos = block_sum256(pos);
+  if (threadIdx.x == 0) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[1], pos); }
+}
+
+// softplus(-x) = -log(sigmoid(x)), stable
+MTT_DEV float softplus_neg(float x) { return fmaxf(-x, 0.f) + log1pf(__expf(-fabsf(x))); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void loss_kernel(const mtt_loss_desc d, const float* gout) {
+  const float nvalid = fmaxf(d.stats[0], 1.f);
+  const float inv = 1.0f / nvalid;
+  float w0 = 1.f, w1 = 1.f;
+  if (d.kind == 1) {                                   // class weights (1 - w_pos, w_pos), w_pos = fraction of zeros among the valid
+    const float wpos = (nvalid - d.stats[1]) * inv;
+    w0 = 1.f - wpos; w1 = wpos;
+  }
+  const float factor = 1.0f / (1.0f - d.pos_weight), pw = d.pos_weight * factor;    // kind 2
+  const float go = BWD ? gout[0] : 0.f;
+  float acc = 0.f;
+  const int64_t total = d.B * d.HW;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t b = t / d.HW, hw = t - b * d.HW;
+    const float* x = d.pred + b * d.C * d.HW + hw;
+    float* g = BWD ? d.dpred + b * d.C * d.HW + hw : nullptr;
+    const bool ok = pixel_valid(d, d.label, b, hw);
+    if (d.kind <= 1) {
+      float v[MAXC];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < d.C) { v[c] = x[(int64_t)c * d.HW]; mx = fmaxf(mx, v[c]); }
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < d.C) se += __expf(v[c] - mx);
+      const int y = ok ? (int)d.label[b * d.HW + hw] : 0;
+      const float wy = d.kind == 1 ? (y == 1 ? w1 : w0) : 1.f;
+      if (!BWD) {
+        float xy = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < d.C && c == y) xy = v[c];
+        if (ok) acc += wy * (mx + __logf(se) - xy);
+      } else {
+        const float s = ok ? go * wy * inv : 0.f, rse = 1.0f / se;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < d.C) g[(int64_t)c * d.HW] = s * (__expf(v[c] - mx) * rse - (c == y ? 1.f : 0.f));
+      }
+    } else if (d.kind == 2) {
+      const float xv = x[0], y = d.label[b * d.HW + hw];
+      if (!BWD) {
+        if (ok) acc += pw * y * softplus_neg(xv) + (1.f - y) * softplus_neg(-xv);
+      } else {
+        const float sg = 1.0f / (1.0f + __expf(-xv));
+        g[0] = ok ? go * inv / factor * ((1.f - y) * sg - pw * y * (1.f - sg)) : 0.f;
+      }
+    } else {
+      float v[3], yv[3];
+      float nrm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c < d.C) { v[c] = x[(int64_t)c * d.HW]; yv[c] = d.label[(b * d.Cl + c) * d.HW + hw]; nrm += v[c] * v[c]; }
+      nrm = fmaxf(sqrtf(nrm), 1e-12f);
+      const float rn = d.kind == 4 ? 1.0f / nrm : 1.f;
+      float sgn[3], dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c < d.C) {
+          const float o = v[c] * rn, df = o - yv[c];
+          if (!BWD && ok) acc += fabsf(df);
+          sgn[c] = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+          dot += o * sgn[c];
+        }
+      if (BWD) {
+        const float s = ok ? go * inv : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (c < d.C) g[(int64_t)c * d.HW] = d.kind == 4 ? s * (sgn[c] - v[c] * rn * dot) * rn : s * sgn[c];
+      }
+    }
+  }
+  if (!BWD) {
+    acc = block_sum256(acc);
+    if (threadIdx.x == 0) atomicAdd(d.loss, acc * inv * (d.kind == 2 ? 1.0f / factor : 1.f));
+  }
+}
+
+int loss_grid(const mtt_loss_desc* d) {
+  int64_t g = (d->B * d->HW + 255) / 256;
+  if (g > 4096) g = 4096;
+  return (int)(g < 1 ? 1 : g);
+}
+
+int loss_check(const mtt_loss_desc* d) {
+  if (!d || !d->pred || !d->label || d->B <= 0 || d->HW <= 0 || d->C <= 0 || d->kind < 0 || d->kind > 4) return MTT_E_BADARG;
+  if ((d->kind <= 1 && (d->C > MAXC || d->Cl != 1)) || (d->kind == 1 && d->C != 2) || (d->kind == 2 && (d->C != 1 || d->Cl != 1)) ||
+      (d->kind >= 3 && (d->C > 3 || d->Cl != d->C)))
+    return MTT_E_UNSUPPORTED;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mtt_loss_label_stats(const mtt_loss_desc* d, float* stats, void* stream) {
+  if (!d || !d->label || !stats || d->B <= 0 || d->HW <= 0 || d->Cl <= 0) return MTT_E_BADARG;
+  hipLaunchKernelGGL(label_stats_kernel, dim3(loss_grid(d)), dim3(256), 0, (hipStream_t)stream, *d, stats);
+  return (int)hipGetLastError();
+}
+extern "C" int mtt_loss_fwd(const mtt_loss_desc* d, void* stream) {
+  if (int e = loss_check(d)) return e;
+  if (!d->stats || !d->loss) return MTT_E_BADARG;
+  hipLaunchKernelGGL(loss_kernel<false>, dim3(loss_grid(d)), dim3(256), 0, (hipStream_t)stream, *d, (const float*)nullptr);
+  return (int)hipGetLastError();
+}
+extern "C" int mtt_loss_bwd(const mtt_loss_desc* d, const float* gout, void* stream) {
+  if (int e = loss_check(d)) return e;
+  if (!d->stats || !d->dpred || !gout) return MTT_E_BADARG;
+  hipLaunchKernelGGL(loss_kernel<true>, dim3(loss_grid(d)), dim3(256), 0, (hipStream_t)stream, *d, gout);
+  return (int)hipGetLastError();
+}

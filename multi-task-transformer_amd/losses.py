@@ -1,8 +1,12 @@
 """Host-side mirror of the reference's training criterion (TaskPrompter/losses/loss_functions.py,
 loss_schemes.py:9-39, utils/common_config.py:200-236): per-task losses + weighted sum.
 
-Row (f) rank 1 of SURVEY.md §8 ("next": fused loss-from-logits kernels).  In round 1 these are restated with
-torch ops on the full-resolution fp32 logits the HIP path produces; they are part of the timed training step.
+Two implementations with the same constructor / call signatures:
+  * `MultiTaskLoss` — restatement with torch ops (verified bit-identical to the reference's criterion): the CPU oracle of the
+    tests and of bench.py's cpu_baseline leg;
+  * `FusedMultiTaskLoss` — the product path (SURVEY.md §8 f rank 1): every task loss is computed straight from the full-resolution
+    fp32 logits by the HIP kernels mtt_loss_label_stats / mtt_loss_fwd / mtt_loss_bwd (one pass for the loss, one for the gradient,
+    normalisation constants stay on the device).  Raises on CPU tensors.
 """
 import torch
 import torch.nn as nn
@@ -89,6 +93,76 @@ class MultiTaskLoss(nn.Module):
     def forward(self, pred, gt, tasks=None):
         tasks = tasks or self.tasks
         out = {t: self.loss_ft[t](pred[t], gt[t]) for t in tasks}
+        out['total'] = torch.sum(torch.stack([self.loss_weights[t] * out[t] for t in tasks]))
+        return out
+
+
+_KIND = dict(ce=0, ce_balanced=1, bce=2, l1=3, l1_norm=4)
+
+
+class _TaskLossFn(torch.autograd.Function):
+    """One task's loss on the HIP kernels; backward = mtt_loss_bwd scaled by the incoming scalar gradient (read on the device)."""
+
+    @staticmethod
+    def forward(ctx, pred, label, kind, ignore, pos_weight):
+        from . import ops
+        pred = pred.contiguous()
+        label = label.contiguous().float()
+        if pred.dtype != torch.float32:
+            raise RuntimeError("fused losses take the fp32 logits the HIP path produces")
+        B, C = pred.shape[0], pred.shape[1]
+        HW = pred[0, 0].numel()
+        Cl = label.shape[1]
+        stats = torch.zeros(2, dtype=torch.float32, device=pred.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        kw = dict(pred=pred, label=label, dpred=None, loss=loss, stats=stats, B=B, HW=HW, C=C, Cl=Cl, kind=kind, ignore=float(ignore),
+                  pos_weight=float(pos_weight))
+        ops.call("loss_label_stats", xargs=[stats], **kw)
+        ops.call("loss_fwd", **kw)
+        ctx.save_for_backward(pred, label, stats)
+        ctx.meta = (kind, float(ignore), float(pos_weight))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+        pred, label, stats = ctx.saved_tensors
+        kind, ignore, pos_weight = ctx.meta
+        dpred = torch.empty_like(pred)
+        g = gout.reshape(1).float().contiguous()
+        ops.call("loss_bwd", pred=pred, label=label, dpred=dpred, loss=None, stats=stats, B=pred.shape[0], HW=pred[0, 0].numel(),
+                 C=pred.shape[1], Cl=label.shape[1], kind=kind, ignore=ignore, pos_weight=pos_weight, xargs=[g])
+        return dpred, None, None, None, None
+
+
+def _fused_spec(p, task):
+    ign = p.get('ignore_index', 255)
+    if task == 'edge':
+        return _KIND['bce'], ign, p.get('edge_w', 0.95)
+    if task in ('semseg', 'human_parts'):
+        return _KIND['ce'], ign, 0.0
+    if task == 'normals':
+        return _KIND['l1_norm'], ign, 0.0
+    if task == 'sal':
+        return _KIND['ce_balanced'], ign, 0.0
+    if task == 'depth':
+        return _KIND['l1'], -1, 0.0
+    raise NotImplementedError(task)
+
+
+class FusedMultiTaskLoss(nn.Module):
+    """loss_schemes.py:9-39 with the per-task losses of utils/common_config.py:200-228 on the HIP kernels (same call signature and
+    result dict as MultiTaskLoss)."""
+
+    def __init__(self, p, tasks, loss_weights=None):
+        super().__init__()
+        self.tasks = list(tasks)
+        self.spec = {t: _fused_spec(p, t) for t in self.tasks}
+        self.loss_weights = dict(loss_weights or {t: DEFAULT_WEIGHTS[t] for t in self.tasks})
+
+    def forward(self, pred, gt, tasks=None):
+        tasks = tasks or self.tasks
+        out = {t: _TaskLossFn.apply(pred[t], gt[t], *self.spec[t]) for t in tasks}
         out['total'] = torch.sum(torch.stack([self.loss_weights[t] * out[t] for t in tasks]))
         return out
 

@@ -647,6 +647,59 @@ def adam_step(**kw):
         va[:] = vv.astype("float32")
 
 
+def _loss_views(kw):
+    B, HW, C, Cl = kw["B"], kw["HW"], kw["C"], kw["Cl"]
+    x = _rd(kw["pred"], torch.arange(B * C * HW)).view(B, C, HW) if kw.get("pred") is not None else None
+    y = _rd(kw["label"], torch.arange(B * Cl * HW)).view(B, Cl, HW)
+    valid = (y != kw["ignore"]).all(1)                                  # [B, HW]
+    return x, y, valid
+
+
+def loss_label_stats(**kw):
+    _, y, valid = _loss_views(kw)
+    st = kw["xargs"][0]
+    _wr(st, torch.arange(2), _rd(st, torch.arange(2)) + torch.stack([valid.sum().double(), y[:, 0][valid].sum()]))
+
+
+def _loss_value(x, y, valid, kw, stats):
+    """Task loss as a differentiable fp64 torch expression (same algebra as losses.py / the reference)."""
+    kind = kw["kind"]
+    n = stats[0].clamp_min(1)
+    if kind <= 1:
+        lab = torch.where(valid, y[:, 0], torch.zeros_like(y[:, 0])).long()
+        w = None
+        if kind == 1:
+            wpos = (n - stats[1]) / n
+            w = torch.stack([1 - wpos, wpos])
+        per = torch.nn.functional.cross_entropy(x, lab, weight=w, reduction="none")
+        return (per * valid).sum() / n
+    if kind == 2:
+        pwt = kw["pos_weight"]
+        factor = 1.0 / (1.0 - pwt)
+        yy = y[:, 0]
+        per = torch.nn.functional.binary_cross_entropy_with_logits(x[:, 0], yy, pos_weight=torch.tensor(pwt * factor, dtype=x.dtype), reduction="none")
+        return (per * valid).sum() / n / factor
+    o = torch.nn.functional.normalize(x, p=2, dim=1) if kind == 4 else x
+    return ((o - y).abs() * valid[:, None]).sum() / n
+
+
+def loss_fwd(**kw):
+    x, y, valid = _loss_views(kw)
+    stats = _rd(kw["stats"], torch.arange(2))
+    v = _loss_value(x, y, valid, kw, stats)
+    _wr(kw["loss"], torch.arange(1), _rd(kw["loss"], torch.arange(1)) + v.reshape(1))
+
+
+def loss_bwd(**kw):
+    x, y, valid = _loss_views(kw)
+    stats = _rd(kw["stats"], torch.arange(2))
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        (g,) = torch.autograd.grad(_loss_value(xr, y, valid, kw, stats), xr)
+    g = g * float(_rd(kw["xargs"][0], torch.arange(1))[0])
+    _wr(kw["dpred"], torch.arange(g.numel()), g.reshape(-1))
+
+
 def dwconv3x3s2_bwd(**kw):
     dy, dx, dw = kw["xargs"]
     Z, B, H, W, ld = kw["Z"], kw["B"], kw["H"], kw["W"], kw["ld"]
@@ -704,13 +757,14 @@ _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd
               modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw,
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
-              convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step)
+              convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
+              loss_fwd=loss_fwd, loss_bwd=loss_bwd)
 _POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
             transpose_pad_sum=transpose_pad_sum)
 
 
 def call(name, **kw):
-    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd") else torch.no_grad():
+    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd") else torch.no_grad():
         if name in _POS:
             return _POS[name](kw["args"])
         return _TABLE[name](**kw)

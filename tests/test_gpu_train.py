@@ -79,3 +79,12 @@ def test_fused_clip_adam_matches_torch_on_gpu():
         assert abs(float(n_ref) - float(n_mine)) < 1e-4 * float(n_ref)
         for q, r in zip(mine, ref):
             assert float((q.detach() - r.detach()).abs().max()) < 5e-6, it
+
+
+@pytest.mark.gpu
+def test_fused_losses_on_gpu():
+    """mtt_loss_label_stats / mtt_loss_fwd / mtt_loss_bwd vs the torch restatement of the reference criterion (CPU, fp32)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from test_host_cpu import check_fused_losses
+    check_fused_losses("cuda", 2e-5)

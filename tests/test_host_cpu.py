@@ -205,3 +205,34 @@ def test_fused_clip_adam_matches_torch_adam_with_clipping(emulated, monkeypatch)
     sd = o_mine.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
     o_ref.load_state_dict(sd)                                                     # layouts are interchangeable
+
+
+def _loss_case(device, B=2, H=12, W=10):
+    import mtt_amd
+    p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (H, W))
+    g = torch.Generator().manual_seed(4)
+    pred = {t: (torch.randn(B, p.TASKS.NUM_OUTPUT[t], H, W, generator=g) * 2).to(device).requires_grad_(True) for t in p.TASKS.NAMES}
+    gt = mtt_amd.losses.synthetic_targets(p, B, H, W, device, seed=5)
+    return p, pred, gt
+
+
+def check_fused_losses(device, tol):
+    import mtt_amd
+    p, pred, gt = _loss_case(device)
+    ref_pred = {t: v.detach().cpu().clone().requires_grad_(True) for t, v in pred.items()}
+    ref = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)(ref_pred, {t: v.cpu() for t, v in gt.items()})
+    out = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES)(pred, gt)
+    ref["total"].backward()
+    out["total"].backward()
+    for t in p.TASKS.NAMES + ["total"]:
+        a, b = float(out[t].detach()), float(ref[t].detach())
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (t, a, b)
+    for t in p.TASKS.NAMES:
+        a, b = pred[t].grad.cpu(), ref_pred[t].grad
+        assert float((a - b).norm()) <= tol * 10 * float(b.norm()) + 1e-12, t
+
+
+def test_fused_losses_match_the_restated_criterion_on_emulator(emulated):
+    """FusedMultiTaskLoss (mtt_loss_* through the emulator) vs the torch restatement of the reference criterion: values and
+    gradients w.r.t. the logits for all six PASCAL task losses (ignore labels, class-frequency weights, pos_weight, normalisation)."""
+    check_fused_losses("cpu", 1e-6)
