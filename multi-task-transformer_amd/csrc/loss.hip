@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int MAXC = 32;
+constexpr int MAXC = 1 << 20;   // classes are looped at run time
 
 MTT_DEV float block_sum256(float v) {
   __shared__ float red[4];
@@ -25,18 +25,16 @@ MTT_DEV float block_sum256(float v) {
   return r;
 }
 
-MTT_DEV bool pixel_valid(const mtt_loss_desc& d, const float* lab, int64_t b, int64_t hw) {
-  bool ok = true;
-  for (int c = 0; c < d.Cl; ++c) ok = ok && lab[(b * d.Cl + c) * d.HW + hw] != d.ignore;
-  return ok;
-}
-
+// grid (pixel blocks, B): no per-pixel division; the class loop runs over the C coalesced rows of a pixel block (the second
+// read of the backward hits L2: a block touches 256 px x C x 4 B).
 __global__ __launch_bounds__(256) void label_stats_kernel(const mtt_loss_desc d, float* stats) {
   float cnt = 0.f, pos = 0.f;
-  const int64_t total = d.B * d.HW;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int64_t b = t / d.HW, hw = t - b * d.HW;
-    if (pixel_valid(d, d.label, b, hw)) { cnt += 1.f; pos += d.label[b * d.Cl * d.HW + hw]; }
+  const int64_t b = blockIdx.y;
+  const float* lab = d.label + b * d.Cl * d.HW;
+  for (int64_t hw = (int64_t)blockIdx.x * 256 + threadIdx.x; hw < d.HW; hw += (int64_t)gridDim.x * 256) {
+    bool ok = true;
+    for (int c = 0; c < d.Cl; ++c) ok = ok && lab[(int64_t)c * d.HW + hw] != d.ignore;
+    if (ok) { cnt += 1.f; pos += lab[hw]; }
   }
   cnt = block_sum256(cnt); pos = block_sum256(pos);
   if (threadIdx.x == 0) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[1], pos); }
@@ -57,50 +55,55 @@ __global__ __launch_bounds__(256) void loss_kernel(const mtt_loss_desc d, const 
   const float factor = 1.0f / (1.0f - d.pos_weight), pw = d.pos_weight * factor;    // kind 2
   const float go = BWD ? gout[0] : 0.f;
   float acc = 0.f;
-  const int64_t total = d.B * d.HW;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int64_t b = t / d.HW, hw = t - b * d.HW;
-    const float* x = d.pred + b * d.C * d.HW + hw;
-    float* g = BWD ? d.dpred + b * d.C * d.HW + hw : nullptr;
-    const bool ok = pixel_valid(d, d.label, b, hw);
+  const int64_t b = blockIdx.y;
+  const float* xb = d.pred + b * d.C * d.HW;
+  const float* lab = d.label + b * d.Cl * d.HW;
+  float* gb = BWD ? d.dpred + b * d.C * d.HW : nullptr;
+  for (int64_t hw = (int64_t)blockIdx.x * 256 + threadIdx.x; hw < d.HW; hw += (int64_t)gridDim.x * 256) {
+    const float* x = xb + hw;
     if (d.kind <= 1) {
-      float v[MAXC];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c)
-        if (c < d.C) { v[c] = x[(int64_t)c * d.HW]; mx = fmaxf(mx, v[c]); }
-      float se = 0.f;
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c)
-        if (c < d.C) se += __expf(v[c] - mx);
-      const int y = ok ? (int)d.label[b * d.HW + hw] : 0;
+      const float yl = lab[hw];
+      const bool ok = yl != d.ignore;
+      const int y = ok ? (int)yl : -1;
+      float mx = -INFINITY, se = 0.f, xy = 0.f;      // online log-sum-exp over the classes
+#pragma unroll 4
+      for (int c = 0; c < d.C; ++c) {
+        const float v = x[(int64_t)c * d.HW];
+        const float m2 = fmaxf(mx, v);
+        se = se * __expf(mx - m2) + __expf(v - m2);
+        mx = m2;
+        xy = c == y ? v : xy;
+      }
       const float wy = d.kind == 1 ? (y == 1 ? w1 : w0) : 1.f;
       if (!BWD) {
-        float xy = 0.f;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-          if (c < d.C && c == y) xy = v[c];
         if (ok) acc += wy * (mx + __logf(se) - xy);
       } else {
         const float s = ok ? go * wy * inv : 0.f, rse = 1.0f / se;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-          if (c < d.C) g[(int64_t)c * d.HW] = s * (__expf(v[c] - mx) * rse - (c == y ? 1.f : 0.f));
+        float* g = gb + hw;
+#pragma unroll 4
+        for (int c = 0; c < d.C; ++c)
+          g[(int64_t)c * d.HW] = s * (__expf(x[(int64_t)c * d.HW] - mx) * rse - (c == y ? 1.f : 0.f));
       }
     } else if (d.kind == 2) {
-      const float xv = x[0], y = d.label[b * d.HW + hw];
+      const float xv = x[0], y = lab[hw];
+      const bool ok = y != d.ignore;
       if (!BWD) {
         if (ok) acc += pw * y * softplus_neg(xv) + (1.f - y) * softplus_neg(-xv);
       } else {
         const float sg = 1.0f / (1.0f + __expf(-xv));
-        g[0] = ok ? go * inv / factor * ((1.f - y) * sg - pw * y * (1.f - sg)) : 0.f;
+        gb[hw] = ok ? go * inv / factor * ((1.f - y) * sg - pw * y * (1.f - sg)) : 0.f;
       }
     } else {
       float v[3], yv[3];
       float nrm = 0.f;
+      bool ok = true;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        if (c < d.C) { v[c] = x[(int64_t)c * d.HW]; yv[c] = d.label[(b * d.Cl + c) * d.HW + hw]; nrm += v[c] * v[c]; }
+        if (c < d.C) {
+          v[c] = x[(int64_t)c * d.HW]; yv[c] = lab[(int64_t)c * d.HW + hw];
+          nrm += v[c] * v[c];
+          ok = ok && yv[c] != d.ignore;
+        }
       nrm = fmaxf(sqrtf(nrm), 1e-12f);
       const float rn = d.kind == 4 ? 1.0f / nrm : 1.f;
       float sgn[3], dot = 0.f;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const mtt_loss_desc d, const 
         const float s = ok ? go * inv : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          if (c < d.C) g[(int64_t)c * d.HW] = d.kind == 4 ? s * (sgn[c] - v[c] * rn * dot) * rn : s * sgn[c];
+          if (c < d.C) gb[(int64_t)c * d.HW + hw] = d.kind == 4 ? s * (sgn[c] - v[c] * rn * dot) * rn : s * sgn[c];
       }
     }
   }
@@ -126,10 +129,11 @@ __global__ __launch_bounds__(256) void loss_kernel(const mtt_loss_desc d, const 
   }
 }
 
-int loss_grid(const mtt_loss_desc* d) {
-  int64_t g = (d->B * d->HW + 255) / 256;
-  if (g > 4096) g = 4096;
-  return (int)(g < 1 ? 1 : g);
+dim3 loss_grid(const mtt_loss_desc* d) {
+  int64_t g = (d->HW + 255) / 256;
+  const int64_t cap = (8192 + d->B - 1) / d->B;
+  if (g > cap) g = cap;
+  return dim3((unsigned)(g < 1 ? 1 : g), (unsigned)d->B);
 }
 
 int loss_check(const mtt_loss_desc* d) {
@@ -144,18 +148,18 @@ int loss_check(const mtt_loss_desc* d) {
 
 extern "C" int mtt_loss_label_stats(const mtt_loss_desc* d, float* stats, void* stream) {
   if (!d || !d->label || !stats || d->B <= 0 || d->HW <= 0 || d->Cl <= 0) return MTT_E_BADARG;
-  hipLaunchKernelGGL(label_stats_kernel, dim3(loss_grid(d)), dim3(256), 0, (hipStream_t)stream, *d, stats);
+  hipLaunchKernelGGL(label_stats_kernel, loss_grid(d), dim3(256), 0, (hipStream_t)stream, *d, stats);
   return (int)hipGetLastError();
 }
 extern "C" int mtt_loss_fwd(const mtt_loss_desc* d, void* stream) {
   if (int e = loss_check(d)) return e;
   if (!d->stats || !d->loss) return MTT_E_BADARG;
-  hipLaunchKernelGGL(loss_kernel<false>, dim3(loss_grid(d)), dim3(256), 0, (hipStream_t)stream, *d, (const float*)nullptr);
+  hipLaunchKernelGGL(loss_kernel<false>, loss_grid(d), dim3(256), 0, (hipStream_t)stream, *d, (const float*)nullptr);
   return (int)hipGetLastError();
 }
 extern "C" int mtt_loss_bwd(const mtt_loss_desc* d, const float* gout, void* stream) {
   if (int e = loss_check(d)) return e;
   if (!d->stats || !d->dpred || !gout) return MTT_E_BADARG;
-  hipLaunchKernelGGL(loss_kernel<true>, dim3(loss_grid(d)), dim3(256), 0, (hipStream_t)stream, *d, gout);
+  hipLaunchKernelGGL(loss_kernel<true>, loss_grid(d), dim3(256), 0, (hipStream_t)stream, *d, gout);
   return (int)hipGetLastError();
 }

@@ -21,6 +21,22 @@ class FusedClipAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_norm = float(max_norm)
         self._tables = {}
+        self._pinned = {}          # (group, slot) -> pinned int64 staging buffer of gradient pointers (rotated: copies are asynchronous)
+        self._slot = 0
+
+    def _grad_ptrs(self, gi, grads, dev):
+        """Device array of the gradients' addresses.  The table is staged through a ring of pinned host buffers and copied with
+        non_blocking=True: a pageable copy would block the host until the stream drains and cost the CPU its run-ahead."""
+        n = len(grads)
+        if dev.type != "cuda":
+            return torch.from_numpy(np.array([g.data_ptr() for g in grads], dtype=np.int64))
+        key = (gi, self._slot % 4)
+        buf = self._pinned.get(key)
+        if buf is None or buf.numel() != n:
+            buf = torch.empty(n, dtype=torch.int64).pin_memory()
+            self._pinned[key] = buf
+        buf.numpy()[:] = [g.data_ptr() for g in grads]
+        return buf.to(dev, non_blocking=True)
 
     def _group_tables(self, gi, plist):
         key = (gi, tuple(p.data_ptr() for p in plist))
@@ -66,10 +82,11 @@ class FusedClipAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
             tab = self._group_tables(gi, plist)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
-            gp = torch.from_numpy(np.array([g.data_ptr() for g in grads], dtype=np.int64)).to(plist[0].device, non_blocking=True)
+            gp = self._grad_ptrs(gi, grads, plist[0].device)
             work.append((group, plist, tab, grads, gp))
         if not work:
             return loss
+        self._slot += 1
         dev = work[0][1][0].device
         total_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         base = dict(max_norm=0.0, step_size=0.0, beta1=0.0, beta2=0.0, eps=0.0, weight_decay=0.0, inv_sqrt_bc2=0.0)
@@ -78,8 +95,7 @@ class FusedClipAdam(torch.optim.Optimizer):
                      chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], xargs=[total_sq], **base)
         for group, plist, tab, grads, gp in work:
             st0 = self.state[plist[0]]
-            for p in plist:
-                self.state[p]["step"] += 1
+            torch._foreach_add_([self.state[p]["step"] for p in plist], 1)
             t = float(st0["step"])
             b1, b2 = group["betas"]
             ops.call("adam_step", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
