@@ -190,131 +190,6 @@ def attention_bwd_flash(qkv, ao, lse, dao, drawlog, B, N, nH, T, prec):
     return dqkv
 
 
-class AttnBlockFn(Function):
-    """xn -> qkv GEMM -> flash attention (+ prompt-row logits) -> proj GEMM + residual (taskprompter.py:199-214, :273)."""
-
-    @staticmethod
-    def forward(ctx, xn, XT, Wqkv, bqkv, Wproj, bproj, rowscale, geo, prec, tag):
-        B, N, nH, T = geo
-        C = nH * 64
-        wq = ops.pack_linear([Wqkv], prec, tag + ('qkv',))
-        wp = ops.pack_linear([Wproj], prec, tag + ('proj',))
-        qkv = ops.linear(xn, wq, 3 * C, prec, bias=bqkv[None])[0]
-        flash = FLASH_BWD and prec.name == "bf16" and qkv.dtype == torch.bfloat16
-        ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=flash)
-        XT2 = torch.empty_like(XT)
-        ops.linear(ao, wp, C, prec, bias=bproj[None], out=XT2, resid=XT, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
-                   M=B * N)
-        ctx.save_for_backward(xn, qkv, ao, wq, wp, rowscale, lse)
-        ctx.geo, ctx.prec = geo, prec
-        ctx.params = (Wqkv, Wproj)
-        if rawlog is None:
-            rawlog = torch.zeros(0, device=xn.device)
-        return XT2, rawlog
-
-    @staticmethod
-    def backward(ctx, dXT2, drawlog):
-        xn, qkv, ao, wq, wp, rowscale, lse = ctx.saved_tensors
-        Wqkv_, Wproj_ = ctx.params
-        B, N, nH, T = ctx.geo
-        prec, C, M = ctx.prec, nH * 64, B * N
-        dXT2 = dXT2.contiguous()
-        g = _scaled(dXT2, rowscale, N, T, prec)
-        dWproj, dbproj = _enc_wgrad(g, ao, C, C, prec)
-        dao = _enc_dgrad(g, Wproj_, wp[0], M, C, C, prec, prec.adt, 'proj')
-        dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
-        if lse is not None:
-            dqkv = attention_bwd_flash(qkv, ao, lse, dao, dl, B, N, nH, T, prec)
-        else:
-            dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
-        dWqkv, dbqkv = _enc_wgrad(dqkv, xn, 3 * C, C, prec)
-        dxn = _enc_dgrad(dqkv, Wqkv_, wq[0], M, C, 3 * C, prec, torch.float32, 'qkv')
-        return dxn, dXT2, dWqkv, dbqkv, dWproj, dbproj, None, None, None, None
-
-
-class ChanAttnFn(Function):
-    """Channel attention (taskprompter.py:216-250): token_trans GEMM on the prompt rows, windowed logits,
-    token_trans1 GEMM accumulated into the prompt rows of XT2 (in place)."""
-
-    @staticmethod
-    def forward(ctx, xn, XT2, Wtt, btt, Wtt1, btt1, rowscale, geo, prec, tag):
-        B, N, nH, T, h, w, nwin = geo
-        C, hw = nH * 64, h * w
-        wt = ops.pack_linear([Wtt], prec, tag + ('tt',))
-        wt1 = ops.pack_linear([Wtt1], prec, tag + ('tt1',))
-        cq = ops.linear(xn, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
-        rawchan = ops.chan_logits(cq, xn, B, T, N, C, (h, w), (nwin, nwin))
-        pr = XT2.view(B, N, C)[:, :T]
-        ops.linear(cq, wt1, C, prec, bias=btt1[None], out=pr, d_rows=(T, N * C, C), resid=pr, rowscale=rowscale, n_prompt=T,
-                   M=B * T)
-        ctx.mark_dirty(XT2)
-        ctx.save_for_backward(xn, cq, wt, wt1, rowscale)
-        ctx.geo, ctx.prec = geo, prec
-        return XT2, rawchan
-
-    @staticmethod
-    def backward(ctx, dXT2, drawchan):
-        xn, cq, wt, wt1, rowscale = ctx.saved_tensors
-        B, N, nH, T, h, w, nwin = ctx.geo
-        prec, C, hw = ctx.prec, nH * 64, h * w
-        hwp = cq.shape[-1]
-        dXT2 = dXT2.contiguous()
-        gp = dXT2.view(B, N, C)[:, :T].reshape(B * T, C)                  # tiny copy (B*T rows)
-        if rowscale is not None:
-            gp = gp * rowscale[:, 0].repeat_interleave(T)[:, None]
-        dWtt1 = _wgrad(gp, cq, C, hwp, prec)
-        dbtt1 = _colsum(gp, C)
-        dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
-        dxn = torch.zeros(B * N, C, dtype=torch.float32, device=xn.device)
-        dq2 = torch.zeros(B * T, hwp, dtype=torch.float32, device=xn.device)
-        if drawchan is not None:
-            ops.call("chan_logits_bwd", q=cq, xn=xn, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
-                     dtype=dtype_code(xn), ldq=hwp, xargs=[drawchan.contiguous(), dq2, F32, dxn])
-        dcq = dcq + dq2                                                    # [B*T, hwp] fp32 (tiny)
-        xnp = xn.view(B, N, C)[:, :T].reshape(B * T, C)
-        dWtt = _wgrad(dcq, xnp, hw, C, prec)
-        dbtt = _colsum(dcq, hw)
-        dp = dxn.view(B, N, C)[:, :T]
-        _gemm(dcq, wt[0], dp, B * T, C, hw, prec, b_op=OP_R, lda=hwp, ldb=wt.shape[-1], ldd=C, d_mb=T, d_bs=N * C,
-              resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
-        return dxn, dXT2, dWtt[:, :C], dbtt, dWtt1[:, :hw], dbtt1, None, None, None, None
-
-
-class MlpFn(Function):
-    """fc1 + GELU + fc2 + residual over prompts and patches at once (timm Mlp at taskprompter.py:274,277)."""
-
-    @staticmethod
-    def forward(ctx, xn2, XT2, W1, b1, W2, b2, rowscale, geo, prec, tag):
-        B, N, T = geo
-        C, Hd = W1.shape[1], W1.shape[0]
-        w1 = ops.pack_linear([W1], prec, tag + ('fc1',))
-        w2 = ops.pack_linear([W2], prec, tag + ('fc2',))
-        z = torch.empty(B * N, Hd, dtype=prec.adt, device=xn2.device)
-        hmid = ops.linear(xn2, w1, Hd, prec, bias=b1[None], act=ACT_GELU, aux_out=z)[0]
-        XT3 = torch.empty_like(XT2)
-        ops.linear(hmid, w2, C, prec, bias=b2[None], out=XT3, resid=XT2, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
-                   M=B * N)
-        ctx.save_for_backward(xn2, z, hmid, w1, w2, rowscale)
-        ctx.geo, ctx.prec = geo, prec
-        ctx.params = (W1, W2)
-        return XT3
-
-    @staticmethod
-    def backward(ctx, dXT3):
-        xn2, z, hmid, w1, w2, rowscale = ctx.saved_tensors
-        B, N, T = ctx.geo
-        prec, M = ctx.prec, B * N
-        C, Hd = xn2.shape[1], z.shape[1]
-        dXT3 = dXT3.contiguous()
-        g = _scaled(dXT3, rowscale, N, T, prec)
-        W1_, W2_ = ctx.params
-        dW2, db2 = _enc_wgrad(g, hmid, C, Hd, prec)
-        dz = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
-        dW1, db1 = _enc_wgrad(dz, xn2, Hd, C, prec)
-        dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
-        return dxn2, dXT3, dW1, db1, dW2, db2, None, None, None, None
-
-
 def _ln_bwd_into(dres, x, dy, gamma, mean, rstd, eps):
     """dres += LayerNorm backward of dy (the kernel accumulates into dx): residual-stream gradient updated in place.
     Returns (dgamma, dbeta)."""

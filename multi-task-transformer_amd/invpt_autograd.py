@@ -2,8 +2,8 @@
 InvPT/models/transformer_net.py): the schedule of invpt.py's no-grad forward rebuilt from
 torch.autograd.Functions whose forward AND backward run on the libmtt_hip.so kernels.
 
-Shared with the TaskPrompter training path (autograd_path.py): LayerNormFn, AttnBlockFn (no prompt rows),
-MlpFn, BLinearFn, Conv3x3Fn (dilated, bias-free), BnActFn, BilinearFn.  New here: the ViT patch embed with a
+Shared with the TaskPrompter training path (autograd_path.py): LayerNormFn, AttnHalfFn (no prompt rows),
+MlpHalfFn, BLinearFn, Conv3x3Fn (dilated, bias-free), BnActFn, BilinearFn.  New here: the ViT patch embed with a
 class token, ConvTranspose2d(3, s2) = GEMM + gather, depthwise stride-2 conv, ceil-mode average pooling and the
 materialised (2-head, head dim D/2) cross-task attention: scores / softmax / P.V with hand-written backward GEMMs.
 
@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from . import ops
 from ._lib import ACT_NONE, ACT_RELU, F32, OP_K, OP_R, dtype_code
-from .autograd_path import (AttnBlockFn, AttnHalfFn, MlpHalfFn, BLinearFn, BilinearFn, BnActFn, Conv3x3Fn, LayerNormFn, MlpFn, TaskHeadsFn, _bn_act,  # noqa: F401
+from .autograd_path import (AttnHalfFn, MlpHalfFn, BLinearFn, BilinearFn, Conv3x3Fn, LayerNormFn, TaskHeadsFn, _bn_act,
                             _colsum, _dgrad, _gemm, _wgrad)
 
 pad8 = ops.pad8
@@ -305,9 +305,8 @@ def _block(dec, blk, si, Xf, B, T, D, gh, gw, prev_score):
     o_tm = o.view(B, T, nq, D).permute(1, 0, 2, 3).reshape(1, T * B * nq, D)
     om = BLinearFn.apply(o_tm, D, 'plain', None, None, prec, tag + ('po',), at.proj.weight, at.proj.bias).view(T, B * nq, D)
     X2 = Xf + BilinearFn.apply(om, (B, D, qh, qw, gh, gw), torch.float32, False)
-    xn2 = LayerNormFn.apply(X2.view(T * rows, D), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, prec, None)
-    X3 = MlpFn.apply(xn2, X2.view(T * rows, D), blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, None,
-                     (1, T * rows, 0), prec, tag)
+    X3 = MlpHalfFn.apply(X2.view(T * rows, D), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                         blk.mlp.fc2.weight, blk.mlp.fc2.bias, None, (1, T * rows, 0), prec, tag)
     return X3.view(T, rows, D), S
 
 
