@@ -78,6 +78,11 @@ class VisionTransformer(nn.Module):
         self.apply(_init_vit_weights)
         self.prec = ops.Prec(prec)
 
+    def load_pretrained(self, checkpoint_path, prefix=''):
+        """vit.py:320-321: import a Google/Flax ViT .npz (class token, resized position embedding)."""
+        from .checkpoints import load_flax_vit_npz
+        return load_flax_vit_npz(self, checkpoint_path, prefix)
+
     def forward(self, img):
         taps = self.forward_taps(img)
         B = img.shape[0]

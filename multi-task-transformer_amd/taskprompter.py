@@ -172,6 +172,11 @@ class TaskPrompter(nn.Module):
     def _tap_index(self, idx):
         return self.select_list.index(idx + 1)
 
+    def load_pretrained(self, checkpoint_path, prefix=''):
+        """taskprompter.py:385-386: import a Google/Flax ViT .npz into the encoder (prompts / decoders keep their initialisation)."""
+        from .checkpoints import load_flax_vit_npz
+        return load_flax_vit_npz(self, checkpoint_path, prefix)
+
     def forward(self, x):
         """-> ({task: [B, F, 4h, 4w]} (channels-last views of the NHWC buffers), info) as taskprompter.py:392-422."""
         fea = self.forward_nhwc(x)

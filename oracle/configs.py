@@ -13,6 +13,7 @@ NYUD2 = (("semseg", 40), ("depth", 1))
 CS2 = (("semseg", 19), ("depth", 1))
 
 VIT = {  # (embed_dim, depth, heads, select_list)
+    "nano": (64, 4, 1, (1, 2, 3)),       # test-only: checkpoint-import fixtures
     "tiny": (128, 4, 2, (1, 2, 3)),      # test-only miniature, same code path
     "small": (384, 12, 6, (3, 6, 9)),
     "base": (768, 12, 12, (3, 6, 9)),    # taskprompter.py:683

@@ -236,3 +236,28 @@ def test_fused_losses_match_the_restated_criterion_on_emulator(emulated):
     """FusedMultiTaskLoss (mtt_loss_* through the emulator) vs the torch restatement of the reference criterion: values and
     gradients w.r.t. the logits for all six PASCAL task losses (ignore labels, class-frequency weights, pos_weight, normalisation)."""
     check_fused_losses("cpu", 1e-6)
+
+
+def test_flax_vit_checkpoint_import_matches_reference_loader():
+    """checkpoints.load_flax_vit_npz / filter_state_dict vs tensors produced by the unmodified reference loaders
+    (tests/golden/make_ckpt_golden.py): layout rules, q/k/v packing, bicubic position-embedding resize, class token handling."""
+    import numpy as np
+    import mtt_amd
+    from tests.golden.make_ckpt_golden import STRIDE, fake_flax_vit
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ckpt_import.npz"))
+    for kind, name, seed in (("TP", "mini_ctr", 1), ("IP", "mini", 2)):
+        cfg = dict(configs.taskprompter(name) if kind == "TP" else configs.invpt(name), backbone="nano")
+        model = conftest.build_product_model(cfg, "x3")
+        C, depth, heads, _ = configs.VIT["nano"]
+        loaded = mtt_amd.checkpoints.load_flax_vit_npz(model.backbone, fake_flax_vit(C, depth, heads, 3, seed=seed))
+        sd = model.backbone.state_dict()
+        expect = [k[len(kind) + 8:] for k in gold.files if k.startswith(f"{kind}/expect/")]
+        assert sorted(expect) == sorted(loaded)
+        for k in expect:
+            got = sd[k].numpy() if k == "pos_embed" else sd[k].numpy().reshape(-1)[::STRIDE]
+            assert np.abs(got - gold[f"{kind}/expect/{k}"]).max() < 1e-5, (kind, k)
+        if kind == "TP":
+            raw = {"model": {k[len("TP/filter_in/"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("TP/filter_in/")}}
+            filt = mtt_amd.checkpoints.filter_state_dict(raw, model.backbone)
+            for k, v in filt.items():
+                assert np.abs(v.numpy() - gold[f"TP/filter_out/{k}"]).max() < 1e-5, k
