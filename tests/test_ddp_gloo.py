@@ -44,6 +44,13 @@ def _worker(rank, world, port, q):
         tot = tot + (out[k] * r).sum() / (2 * out[k][0].numel()) * world      # mean over the global batch, undo DDP's 1/world
     tot.backward()
     grads = {k: v.grad.clone() for k, v in model.named_parameters()}
+    # the fused clip + Adam step consumes DDP's (bucket-view) gradients: parameters must stay identical on every rank
+    opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-6, max_norm=0.5)
+    norm = opt.step()
+    chk = torch.stack([p_.detach().double().sum() for p_ in model.parameters()]).sum() + norm.double().sum()
+    seen = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(seen, chk)
+    assert all(bool(torch.equal(seen[0], s_)) for s_ in seen), seen
     if rank == 0:
         q.put({k: v.numpy() for k, v in grads.items()})
     dist.barrier()
