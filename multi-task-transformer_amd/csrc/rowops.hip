@@ -81,6 +81,72 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const mtt_ln_desc d) {
   }
 }
 
+// backward, fused (C <= 1024): one read of x and dy per row.  A wave owns a row at a time (4 float4 chunks per lane kept in
+// registers between the statistics pass and the dx pass) and keeps per-column partial sums of dgamma / dbeta for all its rows;
+// the 4 waves are combined through LDS and the block issues one atomic per column.
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, int rows_per_block) {
+  __shared__ float part[4][2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = d.C >> 2;
+  float4 ga[4], ag[4], ab[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c4 = lane + 64 * k;
+    ga[k] = c4 < C4 ? ((const float4*)d.gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
+  const float invC = 1.0f / (float)d.C;
+  for (int64_t row = r0 + wave; row < r1; row += 4) {
+    const float mean = d.mean[row], rstd = d.rstd[row];
+    float4 xh[4], g[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = lane + 64 * k;
+      xh[k] = make_float4(0.f, 0.f, 0.f, 0.f); g[k] = xh[k];
+      if (c4 < C4) {
+        const float4 xv = *(const float4*)(d.x + row * d.ldx + c4 * 4);
+        float4 dy;
+        if (d.y_dtype == MTT_F32) dy = *(const float4*)((const float*)d.dy + row * d.ldy + c4 * 4);
+        else {
+          const u32x2 r = *(const u32x2*)((const bf16_t*)d.dy + row * d.ldy + c4 * 4);
+          dy = make_float4(lo_of(r[0]), hi_of(r[0]), lo_of(r[1]), hi_of(r[1]));
+        }
+        xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        ag[k].x += dy.x * xh[k].x; ag[k].y += dy.y * xh[k].y; ag[k].z += dy.z * xh[k].z; ag[k].w += dy.w * xh[k].w;
+        ab[k].x += dy.x; ab[k].y += dy.y; ab[k].z += dy.z; ab[k].w += dy.w;
+        g[k] = make_float4(dy.x * ga[k].x, dy.y * ga[k].y, dy.z * ga[k].z, dy.w * ga[k].w);
+        s1 += g[k].x + g[k].y + g[k].z + g[k].w;
+        s2 += g[k].x * xh[k].x + g[k].y * xh[k].y + g[k].z * xh[k].z + g[k].w * xh[k].w;
+      }
+    }
+    s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = lane + 64 * k;
+      if (c4 < C4) {
+        float4* dx = (float4*)(d.dx + row * d.ldx + c4 * 4);
+        float4 o = *dx;
+        o.x += rstd * (g[k].x - s1 - xh[k].x * s2); o.y += rstd * (g[k].y - s1 - xh[k].y * s2);
+        o.z += rstd * (g[k].z - s1 - xh[k].z * s2); o.w += rstd * (g[k].w - s1 - xh[k].w * s2);
+        *dx = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c4 = lane + 64 * k;
+    if (c4 < C4) { *(float4*)&part[wave][0][c4 * 4] = ag[k]; *(float4*)&part[wave][1][c4 * 4] = ab[k]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d.C; c += 256) {
+    atomicAdd(&d.dgamma[c], part[0][0][c] + part[1][0][c] + part[2][0][c] + part[3][0][c]);
+    atomicAdd(&d.dbeta[c], part[0][1][c] + part[1][1][c] + part[2][1][c] + part[3][1][c]);
+  }
+}
+
 // backward, part 2 (column-parallel): dgamma += sum_rows dy*xhat, dbeta += sum_rows dy.  Thread = one column group of 4,
 // row slices across blockIdx.y-style chunks; partials combined through LDS then one atomic per column per block.
 __global__ __launch_bounds__(256) void ln_bwd_dgb_kernel(const mtt_ln_desc d, int rows_per_block) {
@@ -893,6 +959,13 @@ extern "C" int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream) {
 extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
   if (!d || !d->x || !d->dy || !d->gamma || !d->mean || !d->rstd || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
   if (d->C > 8192 || (d->C % 4) || (d->ldx % 4)) return MTT_E_UNSUPPORTED;
+  if (d->dx && d->dgamma && d->dbeta && d->C <= 1024 && (d->ldy % 4) == 0 && !(((uintptr_t)d->x | (uintptr_t)d->dx | (uintptr_t)d->dy) & 15)) {
+    int64_t nblk = (d->rows + 63) / 64; if (nblk > 2048) nblk = 2048;
+    const int rpb = (int)((d->rows + nblk - 1) / nblk);
+    nblk = (d->rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)nblk), dim3(256), 0, S_, *d, rpb);
+    return LAUNCH_OK();
+  }
   if (d->dx) hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
   if (d->dgamma) {
     if (!d->dbeta) return MTT_E_BADARG;
