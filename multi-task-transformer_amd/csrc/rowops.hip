@@ -855,6 +855,25 @@ __global__ __launch_bounds__(256) void ctr_dw_kernel(const mtt_ctr_desc d, const
   }
 }
 
+// vectorised form (8-column chunks, 32-bit index math): cols, both pitches multiples of 8 and rows * cols / 8 < 2^31
+__global__ __launch_bounds__(256) void rowscale_cast_vec_kernel(const void* src, void* dst, int rows, int C8, int64_t lds_, int64_t ldd, int sdt,
+                                                                int ddt, const float* rowscale, int mb, int n_prompt) {
+  const unsigned total = (unsigned)rows * (unsigned)C8;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+    const unsigned r = t / (unsigned)C8, c8 = t - r * (unsigned)C8;
+    float rs = 1.0f;
+    if (rowscale) {
+      const unsigned q = mb > 0 ? r / (unsigned)mb : 0u, rem = mb > 0 ? r - q * (unsigned)mb : r;
+      rs = rowscale[q * 2 + (rem >= (unsigned)n_prompt ? 1 : 0)];
+    }
+    float v[8];
+    ld8(src, (int64_t)r * lds_ + c8 * 8, sdt, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= rs;
+    st8(dst, (int64_t)r * ldd + c8 * 8, ddt, v);
+  }
+}
+
 // dst[r, :] = rowscale(r) * src[r, :]  (dtype cast; DropPath scale of the branch gradient)
 __global__ __launch_bounds__(256) void rowscale_cast_kernel(const void* src, void* dst, int64_t rows, int cols, int64_t lds_, int64_t ldd,
                                                             int sdt, int ddt, const float* rowscale, int mb, int n_prompt) {
@@ -1134,6 +1153,11 @@ extern "C" int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dw, v
 extern "C" int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds_, int64_t ldd, int src_dtype,
                                  int dst_dtype, const float* rowscale, int32_t mb, int32_t n_prompt, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;
+  if ((cols % 8) == 0 && (lds_ % 8) == 0 && (ldd % 8) == 0 && rows * (cols / 8) < (1ll << 31) && !(((uintptr_t)src | (uintptr_t)dst) & 15)) {
+    hipLaunchKernelGGL(rowscale_cast_vec_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, S_, src, dst, (int)rows, cols / 8, lds_, ldd,
+                       src_dtype, dst_dtype, rowscale, mb, n_prompt);
+    return LAUNCH_OK();
+  }
   hipLaunchKernelGGL(rowscale_cast_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype,
                      dst_dtype, rowscale, mb, n_prompt);
   return LAUNCH_OK();

@@ -304,6 +304,9 @@ def row_cases():
                                  rnd(g, 72)]), dict(f32=2e-5, bf16=5e-3)))
         cases.append((f"transpose_pad_vec_{dt}", "transpose_pad",
                       dict(args=[rnd(g, 130, 136, dtype=DT[dt]), torch.full((136, 192), 5.0, dtype=torch.bfloat16), 130, 136, 136, 192, dt, BF16]), TOL_ROW))
+        cases.append((f"rowscale_cast_vec_{dt}", "rowscale_cast",
+                      dict(args=[rnd(g, 2 * 13, 24), torch.zeros(26, 32, dtype=DT[dt]), 26, 24, 24, 32, F32, dt,
+                                 torch.tensor([[0.5, 2.0], [0.0, 1.5]]), 13, 3]), TOL_ROW))
         cases.append((f"rowscale_cast_{dt}", "rowscale_cast",
                       dict(args=[rnd(g, 2 * 13, 24), torch.zeros(26, 32, dtype=DT[dt]), 26, 20, 24, 32, F32, dt,
                                  torch.tensor([[0.5, 2.0], [0.0, 1.5]]), 13, 3]), TOL_ROW))
