@@ -412,23 +412,27 @@ MTT_DEV void src_index(int o, int in, int out, int& i0, int& i1, float& w1) {
   w1 = s - (float)i0;
 }
 
+// grid (column blocks, output row, batch): the row / batch come from the block indices and the column index is split with one
+// 32-bit division — the flat 64-bit div/mod chain per 16-byte output chunk cost more than the interpolation itself.
 __global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const mtt_resize_desc d) {
-  const int C8 = (d.C + 7) >> 3;
-  const int64_t total = (int64_t)d.B * d.Hout * d.Wout * C8;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int c8 = (int)(t % C8);
-    const int64_t pix = t / C8;
-    const int ox = (int)(pix % d.Wout), oy = (int)((pix / d.Wout) % d.Hout), b = (int)(pix / ((int64_t)d.Wout * d.Hout));
-    int y0, y1, x0, x1; float wy, wx;
-    src_index(oy, d.Hin, d.Hout, y0, y1, wy);
-    src_index(ox, d.Win, d.Wout, x0, x1, wx);
-    const int64_t ib = (int64_t)b * d.Hin * d.Win;
+  const unsigned C8 = (unsigned)((d.C + 7) >> 3);
+  const int oy = blockIdx.y, b = blockIdx.z;
+  int y0, y1; float wy;
+  src_index(oy, d.Hin, d.Hout, y0, y1, wy);
+  const int64_t ib = (int64_t)b * d.Hin * d.Win;
+  const int64_t r0 = (ib + (int64_t)y0 * d.Win) * d.ld_in, r1 = (ib + (int64_t)y1 * d.Win) * d.ld_in;
+  const int64_t orow = ((int64_t)b * d.Hout + oy) * d.Wout;
+  const unsigned total = (unsigned)d.Wout * C8;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+    const unsigned ox = t / C8, c8 = t - ox * C8;
+    int x0, x1; float wx;
+    src_index((int)ox, d.Win, d.Wout, x0, x1, wx);
     float v00[8], v01[8], v10[8], v11[8], o[8];
-    ld8(d.in, (ib + (int64_t)y0 * d.Win + x0) * d.ld_in + c8 * 8, d.in_dtype, v00);
-    ld8(d.in, (ib + (int64_t)y0 * d.Win + x1) * d.ld_in + c8 * 8, d.in_dtype, v01);
-    ld8(d.in, (ib + (int64_t)y1 * d.Win + x0) * d.ld_in + c8 * 8, d.in_dtype, v10);
-    ld8(d.in, (ib + (int64_t)y1 * d.Win + x1) * d.ld_in + c8 * 8, d.in_dtype, v11);
-    const int64_t oi = pix * d.ld_out + c8 * 8;
+    ld8(d.in, r0 + (int64_t)x0 * d.ld_in + c8 * 8, d.in_dtype, v00);
+    ld8(d.in, r0 + (int64_t)x1 * d.ld_in + c8 * 8, d.in_dtype, v01);
+    ld8(d.in, r1 + (int64_t)x0 * d.ld_in + c8 * 8, d.in_dtype, v10);
+    ld8(d.in, r1 + (int64_t)x1 * d.ld_in + c8 * 8, d.in_dtype, v11);
+    const int64_t oi = (orow + ox) * d.ld_out + c8 * 8;
     if (d.accumulate) ld8(d.out, oi, d.out_dtype, o);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -440,21 +444,22 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const mtt_resize
   }
 }
 
-// NHWC in -> NCHW fp32 out (the module's output contract, taskprompter_wrapper.py:36)
+// NHWC in -> NCHW fp32 out (the module's output contract, taskprompter_wrapper.py:36); grid (column blocks, output row, batch)
 __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const mtt_resize_desc d) {
-  const int64_t total = (int64_t)d.B * d.Hout * d.Wout;
-  for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * 256) {
-    const int ox = (int)(pix % d.Wout), oy = (int)((pix / d.Wout) % d.Hout), b = (int)(pix / ((int64_t)d.Wout * d.Hout));
-    int y0, y1, x0, x1; float wy, wx;
-    src_index(oy, d.Hin, d.Hout, y0, y1, wy);
+  const int oy = blockIdx.y, b = blockIdx.z;
+  int y0, y1; float wy;
+  src_index(oy, d.Hin, d.Hout, y0, y1, wy);
+  const int64_t ib = (int64_t)b * d.Hin * d.Win;
+  for (int ox = blockIdx.x * 256 + threadIdx.x; ox < d.Wout; ox += gridDim.x * 256) {
+    int x0, x1; float wx;
     src_index(ox, d.Win, d.Wout, x0, x1, wx);
-    const int64_t ib = (int64_t)b * d.Hin * d.Win;
     const int64_t a00 = (ib + (int64_t)y0 * d.Win + x0) * d.ld_in, a01 = (ib + (int64_t)y0 * d.Win + x1) * d.ld_in;
     const int64_t a10 = (ib + (int64_t)y1 * d.Win + x0) * d.ld_in, a11 = (ib + (int64_t)y1 * d.Win + x1) * d.ld_in;
+    float* out = (float*)d.out + ((int64_t)b * d.C * d.Hout + oy) * d.Wout + ox;
     for (int c = 0; c < d.C; ++c) {
       const float top = ld_elem(d.in, a00 + c, d.in_dtype) * (1.f - wx) + ld_elem(d.in, a01 + c, d.in_dtype) * wx;
       const float bot = ld_elem(d.in, a10 + c, d.in_dtype) * (1.f - wx) + ld_elem(d.in, a11 + c, d.in_dtype) * wx;
-      ((float*)d.out)[(((int64_t)b * d.C + c) * d.Hout + oy) * d.Wout + ox] = top * (1.f - wy) + bot * wy;
+      out[(int64_t)c * d.Hout * d.Wout] = top * (1.f - wy) + bot * wy;
     }
   }
 }
@@ -479,48 +484,45 @@ MTT_DEV float tap_weight(int o, int i, int in, int out) {
   return w;
 }
 
+// grid (column blocks, input row, batch)
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const mtt_resize_desc d) {
   float* din = (float*)d.out;
+  const int iy = blockIdx.y, b = blockIdx.z;
+  int ylo, yhi;
+  gather_range(iy, d.Hin, d.Hout, ylo, yhi);
   if (d.out_nchw) {
-    // one thread per (input pixel, channel): reads a small window of the NCHW gradient plane
-    const int64_t total = (int64_t)d.B * d.Hin * d.Win * d.C;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-      const int ix = (int)(t % d.Win);
-      int64_t r = t / d.Win;
-      const int iy = (int)(r % d.Hin); r /= d.Hin;
-      const int c = (int)(r % d.C);
-      const int b = (int)(r / d.C);
-      int ylo, yhi, xlo, xhi;
-      gather_range(iy, d.Hin, d.Hout, ylo, yhi);
-      gather_range(ix, d.Win, d.Wout, xlo, xhi);
+    // one thread per (channel, input column): reads a small window of the NCHW gradient plane
+    const unsigned total = (unsigned)d.C * (unsigned)d.Win;
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+      const unsigned c = t / (unsigned)d.Win, ix = t - c * (unsigned)d.Win;
+      int xlo, xhi;
+      gather_range((int)ix, d.Win, d.Wout, xlo, xhi);
       const float* g = (const float*)d.in + ((int64_t)b * d.C + c) * d.Hout * d.Wout;
       float acc = 0.f;
       for (int oy = ylo; oy <= yhi; ++oy) {
         const float wy = tap_weight(oy, iy, d.Hin, d.Hout);
         if (wy == 0.f) continue;
         float rowacc = 0.f;
-        for (int ox = xlo; ox <= xhi; ++ox) rowacc += tap_weight(ox, ix, d.Win, d.Wout) * g[(int64_t)oy * d.Wout + ox];
+        for (int ox = xlo; ox <= xhi; ++ox) rowacc += tap_weight(ox, (int)ix, d.Win, d.Wout) * g[(int64_t)oy * d.Wout + ox];
         acc += wy * rowacc;
       }
       din[(((int64_t)b * d.Hin + iy) * d.Win + ix) * d.ld_in + c] += acc;
     }
   } else {
-    const int C8 = (d.C + 7) >> 3;
-    const int64_t total = (int64_t)d.B * d.Hin * d.Win * C8;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-      const int c8 = (int)(t % C8);
-      const int64_t pix = t / C8;
-      const int ix = (int)(pix % d.Win), iy = (int)((pix / d.Win) % d.Hin), b = (int)(pix / ((int64_t)d.Win * d.Hin));
-      int ylo, yhi, xlo, xhi;
-      gather_range(iy, d.Hin, d.Hout, ylo, yhi);
-      gather_range(ix, d.Win, d.Wout, xlo, xhi);
+    const unsigned C8 = (unsigned)((d.C + 7) >> 3);
+    const unsigned total = (unsigned)d.Win * C8;
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+      const unsigned ix = t / C8, c8 = t - ix * C8;
+      const int64_t pix = ((int64_t)b * d.Hin + iy) * d.Win + ix;
+      int xlo, xhi;
+      gather_range((int)ix, d.Win, d.Wout, xlo, xhi);
       float acc[8];
       ld8(din, pix * d.ld_in + c8 * 8, MTT_F32, acc);
       for (int oy = ylo; oy <= yhi; ++oy) {
         const float wy = tap_weight(oy, iy, d.Hin, d.Hout);
         if (wy == 0.f) continue;
         for (int ox = xlo; ox <= xhi; ++ox) {
-          const float w = wy * tap_weight(ox, ix, d.Win, d.Wout);
+          const float w = wy * tap_weight(ox, (int)ix, d.Win, d.Wout);
           if (w == 0.f) continue;
           float g[8];
           ld8(d.in, (((int64_t)b * d.Hout + oy) * d.Wout + ox) * d.ld_out + c8 * 8, d.in_dtype, g);
@@ -1040,19 +1042,22 @@ extern "C" int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream) {
 
 extern "C" int mtt_bilinear_fwd(const mtt_resize_desc* d, void* stream) {
   if (!d || !d->in || !d->out || d->B <= 0 || d->C <= 0) return MTT_E_BADARG;
+  if (d->Hout > 65535 || d->B > 65535) return MTT_E_UNSUPPORTED;
   if (d->out_nchw) {
-    hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3(grid_for((int64_t)d->B * d->Hout * d->Wout)), dim3(256), 0, S_, *d);
+    hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3((unsigned)((d->Wout + 255) / 256), d->Hout, d->B), dim3(256), 0, S_, *d);
   } else {
     if ((d->ld_in % 8) || (d->ld_out % 8)) return MTT_E_ALIGN;
-    hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel, dim3(grid_for((int64_t)d->B * d->Hout * d->Wout * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
+    const int64_t cols = (int64_t)d->Wout * ((d->C + 7) / 8);
+    hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel, dim3((unsigned)((cols + 255) / 256), d->Hout, d->B), dim3(256), 0, S_, *d);
   }
   return LAUNCH_OK();
 }
 extern "C" int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream) {
   if (!d || !d->in || !d->out || d->B <= 0 || d->C <= 0) return MTT_E_BADARG;
-  const int64_t work = d->out_nchw ? (int64_t)d->B * d->Hin * d->Win * d->C : (int64_t)d->B * d->Hin * d->Win * ((d->C + 7) / 8);
+  if (d->Hin > 65535 || d->B > 65535) return MTT_E_UNSUPPORTED;
+  const int64_t cols = d->out_nchw ? (int64_t)d->Win * d->C : (int64_t)d->Win * ((d->C + 7) / 8);
   if (!d->out_nchw && (d->ld_in % 8)) return MTT_E_ALIGN;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(work)), dim3(256), 0, S_, *d);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((cols + 255) / 256), d->Hin, d->B), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }
 
