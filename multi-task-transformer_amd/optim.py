@@ -107,12 +107,14 @@ class FusedClipAdam(torch.optim.Optimizer):
 
 
 class PolynomialLR(torch.optim.lr_scheduler._LRScheduler):
-    """TaskPrompter/utils/train_utils.py:139-150: lr = base_lr * (1 - iter / max_iterations) ** gamma, floored at min_lr."""
+    """The reference's per-iteration schedule (TaskPrompter/utils/train_utils.py:139-150): the distance of every group's learning rate
+    above `min_lr` decays as (1 - iteration / max_iterations) ** gamma.  `scheduler.step()` is called once per training iteration."""
 
     def __init__(self, optimizer, max_iterations, gamma=0.9, min_lr=0.0, last_epoch=-1):
-        self.max_iterations, self.gamma, self.min_lr = max_iterations, gamma, min_lr
+        self.max_iterations, self.gamma, self.min_lr = int(max_iterations), float(gamma), float(min_lr)
         super().__init__(optimizer, last_epoch)
 
     def get_lr(self):
-        factor = (1 - self.last_epoch / float(self.max_iterations)) ** self.gamma
-        return [(base_lr - self.min_lr) * factor + self.min_lr for base_lr in self.base_lrs]
+        progress = min(self.last_epoch, self.max_iterations) / float(self.max_iterations)     # clamped: never a negative base
+        decay = (1.0 - progress) ** self.gamma
+        return [self.min_lr + (base - self.min_lr) * decay for base in self.base_lrs]
