@@ -9,6 +9,8 @@ all gradients of parameters are fp32 in both modes.
 Nothing here falls back to torch math: every function launches a HIP kernel through `_lib.call`.
 torch is used for allocation, views and the (tiny) parameter re-packing.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -45,15 +47,28 @@ def adam_chunk():
 # parameter packing (cached per parameter version)
 # ---------------------------------------------------------------------------------------------
 _pack_cache = {}
+_param_epoch = 0
+
+
+def bump_param_epoch():
+    """Invalidate every cached pack: called by optimizers that write parameters through raw device pointers (optim.FusedClipAdam),
+    where torch's own `_version` counter cannot see the update.  (FusedClipAdam also bumps `_version`; the epoch is the second,
+    independent line of defence so that a stale pack can never be served after a step.)"""
+    global _param_epoch
+    _param_epoch += 1
 
 
 def _cached(key, params, build):
-    ver = tuple((p.data_ptr(), p._version) for p in params)
+    """Pack cache keyed by `key`, valid while every source tensor is the same object with the same storage and version."""
+    ver = (_param_epoch, tuple((p.data_ptr(), p._version) for p in params))
     hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     val = build()
-    _pack_cache[key] = (ver, val)
+    if len(_pack_cache) > 4096:                       # drop packs of parameters that no longer exist (models built and discarded)
+        for k in [k for k, v in _pack_cache.items() if any(r() is None for r in v[2])]:
+            del _pack_cache[k]
+    _pack_cache[key] = (ver, val, [weakref.ref(p) for p in params])
     return val
 
 

@@ -38,9 +38,14 @@ class FusedClipAdam(torch.optim.Optimizer):
         buf.numpy()[:] = [g.data_ptr() for g in grads]
         return buf.to(dev, non_blocking=True)
 
-    def _group_tables(self, gi, plist):
-        key = (gi, tuple(p.data_ptr() for p in plist))
-        tab = self._tables.get(gi)
+    def _group_tables(self, gi, part, plist):
+        """Device pointer / chunk tables of one launch group.  The key covers the parameter AND the moment tensors' addresses:
+        `load_state_dict`, `add_param_group` or a state reset replace the moment tensors, and a table built before that would
+        make the kernel update freed memory.  The table holds references to the tensors whose addresses it caches."""
+        st = [self.state[p] for p in plist]
+        key = (tuple(p.data_ptr() for p in plist), tuple(s["exp_avg"].data_ptr() for s in st),
+               tuple(s["exp_avg_sq"].data_ptr() for s in st))
+        tab = self._tables.get((gi, part))
         if tab is not None and tab["key"] == key:
             return tab
         dev = plist[0].device
@@ -51,15 +56,20 @@ class FusedClipAdam(torch.optim.Optimizer):
             for off in range(0, n, chunk):
                 ct.append(t)
                 co.append(off)
-        st = [self.state[p] for p in plist]
 
         def ptrs(ts):
             return torch.from_numpy(np.array([t.data_ptr() for t in ts], dtype=np.int64)).to(dev)
-        tab = dict(key=key, params=ptrs(plist), exp_avg=ptrs([s["exp_avg"] for s in st]), exp_avg_sq=ptrs([s["exp_avg_sq"] for s in st]),
+        keep = [s["exp_avg"] for s in st] + [s["exp_avg_sq"] for s in st]
+        tab = dict(key=key, keep=keep, params=ptrs(plist), exp_avg=ptrs([s["exp_avg"] for s in st]),
+                   exp_avg_sq=ptrs([s["exp_avg_sq"] for s in st]),
                    numel=torch.tensor(numel, dtype=torch.int64, device=dev), chunk_tensor=torch.tensor(ct, dtype=torch.int32, device=dev),
                    chunk_off=torch.tensor(co, dtype=torch.int64, device=dev), n_chunks=len(ct))
-        self._tables[gi] = tab
+        self._tables[(gi, part)] = tab
         return tab
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables.clear()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -69,10 +79,10 @@ class FusedClipAdam(torch.optim.Optimizer):
                 loss = closure()
         work = []
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group["params"] if p.grad is not None]
-            if not plist:
-                continue
-            for p in plist:
+            parts = {}                                    # step count -> parameters (torch.optim.Adam keeps one `step` per parameter)
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedClipAdam: fp32 contiguous parameters and gradients only")
                 st = self.state[p]
@@ -80,28 +90,32 @@ class FusedClipAdam(torch.optim.Optimizer):
                     st["step"] = torch.zeros((), dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-            tab = self._group_tables(gi, plist)
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
-            gp = self._grad_ptrs(gi, grads, plist[0].device)
-            work.append((group, plist, tab, grads, gp))
+                parts.setdefault(float(st["step"]), []).append(p)
+            for part, (t0, plist) in enumerate(sorted(parts.items())):
+                tab = self._group_tables(gi, part, plist)
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
+                gp = self._grad_ptrs((gi, part), grads, plist[0].device)
+                work.append((group, plist, tab, grads, gp, t0 + 1.0))
         if not work:
             return loss
         self._slot += 1
         dev = work[0][1][0].device
         total_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         base = dict(max_norm=0.0, step_size=0.0, beta1=0.0, beta2=0.0, eps=0.0, weight_decay=0.0, inv_sqrt_bc2=0.0)
-        for group, plist, tab, grads, gp in work:
+        for group, plist, tab, grads, gp, t in work:
             ops.call("grad_sqnorm", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
                      chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], xargs=[total_sq], **base)
-        for group, plist, tab, grads, gp in work:
-            st0 = self.state[plist[0]]
+        for group, plist, tab, grads, gp, t in work:
             torch._foreach_add_([self.state[p]["step"] for p in plist], 1)
-            t = float(st0["step"])
             b1, b2 = group["betas"]
             ops.call("adam_step", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
                      chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], max_norm=self.max_norm,
                      step_size=group["lr"] / (1.0 - b1 ** t), beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
                      inv_sqrt_bc2=1.0 / math.sqrt(1.0 - b2 ** t), xargs=[total_sq if self.max_norm > 0 else None])
+            # the kernel wrote the parameters through raw pointers: tell torch (autograd's saved-tensor checks, any cache keyed
+            # on `_version`) and the pack cache of ops.py that they changed
+            torch.autograd.graph.increment_version(plist)
+        ops.bump_param_epoch()
         self.last_grad_norm = total_sq.sqrt()
         return loss if loss is not None else self.last_grad_norm
 

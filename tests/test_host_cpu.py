@@ -261,3 +261,38 @@ def test_flax_vit_checkpoint_import_matches_reference_loader():
             filt = mtt_amd.checkpoints.filter_state_dict(raw, model.backbone)
             for k, v in filt.items():
                 assert np.abs(v.numpy() - gold[f"TP/filter_out/{k}"]).max() < 1e-5, k
+
+
+def test_multi_step_training_rebuilds_weight_packs(emulated):
+    """Three optimizer steps: FusedClipAdam writes the parameters through raw pointers, so every cached weight pack (bf16 / padded /
+    transposed / BN-folded) must be invalidated — the product's losses and final parameters track clip_grad_norm_ + torch.optim.Adam
+    on the oracle.  (A stale pack cache makes every step after the first reuse step-0 weights: the loss would not move.)"""
+    import train_check
+    losses, worst = train_check.multi_step_check("mini_ctr", "x3", "cpu", steps=3)
+    for lp, lo in losses:
+        assert abs(lp - lo) <= 2e-4 * max(1.0, abs(lo)), losses
+    assert abs(losses[0][0] - losses[2][0]) > 1e-3, losses          # the objective actually moves
+    assert worst < 2e-3, worst
+
+
+def test_pack_cache_sees_raw_pointer_updates(emulated):
+    import mtt_amd
+    w = torch.nn.Parameter(torch.randn(16, 24))
+    prec = mtt_amd.ops.Prec("bf16")
+    a = mtt_amd.ops.pack_linear([w], prec, "t").clone()
+    opt = mtt_amd.optim.FusedClipAdam([w], lr=0.1)
+    w.grad = torch.ones_like(w)
+    v0 = w._version
+    opt.step()
+    assert w._version > v0
+    b = mtt_amd.ops.pack_linear([w], prec, "t")
+    assert float((a.float() - b.float()).abs().max()) > 0.05
+    # load_state_dict replaces the moment tensors: the pointer tables must follow them
+    sd = opt.state_dict()
+    opt2 = mtt_amd.optim.FusedClipAdam([w], lr=0.1)
+    w.grad = torch.ones_like(w)
+    opt2.step()
+    opt2.load_state_dict(sd)
+    m_before = opt2.state[w]["exp_avg"].clone()
+    opt2.step()
+    assert not torch.equal(opt2.state[w]["exp_avg"], m_before)

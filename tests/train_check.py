@@ -65,3 +65,43 @@ def summarize(errs, floor=1e-6):
     rel = sorted(((e / n, k) for k, (e, n) in errs.items() if n > floor), reverse=True)
     med = rel[len(rel) // 2][0]
     return rel[0], med
+
+
+def multi_step_check(name, prec, device, steps=3, lr=5e-3, seed=0):
+    """`steps` optimizer steps of the product (FusedClipAdam writes the parameters through raw pointers -> every cached weight pack
+    must be rebuilt) vs the oracle driven by clip_grad_norm_ + torch.optim.Adam.  Returns per-step (loss_product, loss_oracle) and
+    the final worst relative parameter difference."""
+    import mtt_amd
+    cfg = configs.taskprompter(name)
+    meta, _ = conftest.load_golden(name)
+    sd = weights.synth_state_dict(meta["contract"], seed)
+    model = conftest.build_product_model(cfg, prec, device)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=lr, weight_decay=1e-6, max_norm=1.0)
+    ref = {k: v.clone() for k, v in sd.items()}
+    params = {k: ref[k].requires_grad_(True) for k in ref if ref[k].dtype.is_floating_point and "running_" not in k}
+    ropt = torch.optim.Adam(list(params.values()), lr=lr, weight_decay=1e-6)
+    x = weights.synth_images(2, cfg["img_size"], 2)
+    losses = []
+    for it in range(steps):
+        out = model(x.to(device))
+        lp = loss_of({k: v.cpu() for k, v in out.items()})
+        opt.zero_grad(set_to_none=True)
+        lp.backward()
+        opt.step()
+        rout = tpo.forward(ref, cfg, x, training=True)
+        lr_ = loss_of(rout)
+        ropt.zero_grad(set_to_none=True)
+        lr_.backward()
+        for q in params.values():                      # the reference gives every TaskPrompter parameter a gradient
+            if q.grad is None:
+                q.grad = torch.zeros_like(q)
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        ropt.step()
+        losses.append((float(lp.detach()), float(lr_.detach())))
+    worst = 0.0
+    for k, prm in model.named_parameters():
+        d = float((prm.detach().cpu() - params[k].detach()).norm() / params[k].detach().norm().clamp_min(1e-12))
+        worst = max(worst, d)
+    return losses, worst
