@@ -2,8 +2,8 @@
 loss_schemes.py:9-39, utils/common_config.py:200-236): per-task losses + weighted sum.
 
 Two implementations with the same constructor / call signatures:
-  * `MultiTaskLoss` — restatement with torch ops (verified bit-identical to the reference's criterion): the CPU oracle of the
-    tests and of bench.py's cpu_baseline leg;
+  * `MultiTaskLoss` — restatement with torch ops, pinned against the unmodified reference criterion by the fixtures of
+    tests/golden/make_loss_golden.py (tests/test_losses_golden.py): the CPU oracle of the tests and of bench.py's cpu_baseline leg;
   * `FusedMultiTaskLoss` — the product path (SURVEY.md §8 f rank 1): every task loss is computed straight from the full-resolution
     fp32 logits by the HIP kernels mtt_loss_label_stats / mtt_loss_fwd / mtt_loss_bwd (one pass for the loss, one for the gradient,
     normalisation constants stay on the device).  Raises on CPU tensors.
@@ -81,20 +81,38 @@ def get_loss(p, task):
 DEFAULT_WEIGHTS = dict(semseg=1.0, human_parts=2.0, sal=5.0, edge=50.0, normals=10.0, depth=1.0)   # pascal yml:44-50
 
 
+def _intermediate(p):
+    return bool(p.get('intermediate_supervision', False)) if hasattr(p, 'get') else bool(getattr(p, 'intermediate_supervision', False))
+
+
+def _scheme(loss_of, tasks, all_tasks, weights, pred, gt, intermediate):
+    """TaskPrompter/losses/loss_schemes.py:27-39 and InvPT/losses/loss_schemes.py:20-33: weighted sum of the task losses, plus — with
+    `p.intermediate_supervision` (InvPT yml:14) — the same losses on the preliminary decoder's `inter_preds` for ALL of the
+    criterion's tasks, reported as `inter_<task>` and added to the total with the task weights."""
+    out = {t: loss_of(t, pred[t], gt[t]) for t in tasks}
+    out['total'] = torch.sum(torch.stack([weights[t] * out[t] for t in tasks]))
+    if intermediate:
+        inter = pred['inter_preds']
+        for t in all_tasks:
+            v = loss_of(t, inter[t], gt[t])
+            out['inter_%s' % t] = v
+            out['total'] = out['total'] + weights[t] * v
+    return out
+
+
 class MultiTaskLoss(nn.Module):
-    """loss_schemes.py:9-39 (dense tasks)."""
+    """loss_schemes.py:9-39 (dense tasks); InvPT's variant with intermediate supervision when `p.intermediate_supervision`."""
 
     def __init__(self, p, tasks, loss_weights=None):
         super().__init__()
         self.tasks = list(tasks)
         self.loss_ft = nn.ModuleDict({t: get_loss(p, t) for t in self.tasks})
         self.loss_weights = dict(loss_weights or {t: DEFAULT_WEIGHTS[t] for t in self.tasks})
+        self.intermediate_supervision = _intermediate(p)
 
     def forward(self, pred, gt, tasks=None):
-        tasks = tasks or self.tasks
-        out = {t: self.loss_ft[t](pred[t], gt[t]) for t in tasks}
-        out['total'] = torch.sum(torch.stack([self.loss_weights[t] * out[t] for t in tasks]))
-        return out
+        return _scheme(lambda t, a, b: self.loss_ft[t](a, b), tasks or self.tasks, self.tasks, self.loss_weights, pred, gt,
+                       self.intermediate_supervision)
 
 
 _KIND = dict(ce=0, ce_balanced=1, bce=2, l1=3, l1_norm=4)
@@ -159,12 +177,11 @@ class FusedMultiTaskLoss(nn.Module):
         self.tasks = list(tasks)
         self.spec = {t: _fused_spec(p, t) for t in self.tasks}
         self.loss_weights = dict(loss_weights or {t: DEFAULT_WEIGHTS[t] for t in self.tasks})
+        self.intermediate_supervision = _intermediate(p)
 
     def forward(self, pred, gt, tasks=None):
-        tasks = tasks or self.tasks
-        out = {t: _TaskLossFn.apply(pred[t], gt[t], *self.spec[t]) for t in tasks}
-        out['total'] = torch.sum(torch.stack([self.loss_weights[t] * out[t] for t in tasks]))
-        return out
+        return _scheme(lambda t, a, b: _TaskLossFn.apply(a, b, *self.spec[t]), tasks or self.tasks, self.tasks, self.loss_weights,
+                       pred, gt, self.intermediate_supervision)
 
 
 def synthetic_targets(p, B, H, W, device, seed=0):
