@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 1
+#define MTT_ABI_VERSION 2
 
 enum { MTT_F32 = 0, MTT_BF16 = 1 };
 enum { MTT_PREC_BF16 = 0, MTT_PREC_X3 = 1 };
@@ -194,18 +194,26 @@ typedef struct {
 int mtt_bilinear_fwd(const mtt_resize_desc* d, void* stream);
 int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream);   /* in = dout, out = din (fp32) */
 
-/* BatchNorm2d (+GELU/ReLU) on NHWC rows, training mode (batch statistics; nn.BatchNorm2d at
- * taskprompter.py:362,692,705; SyncBatchNorm invpt.py:14).  stats: sum/sumsq [C] fp32 (atomics, caller zeroes).
- * apply: y = act((x-mean)*rstd*gamma+beta).  bwd_reduce: sums of dz and dz*xhat; bwd_apply: dx. */
+/* BatchNorm2d (+GELU/ReLU) on Z stacked NHWC maps [Z][rows, ld] (one BatchNorm per map; Z <= 1 = a single map), training mode
+ * (batch statistics; nn.BatchNorm2d at taskprompter.py:362,692,705; SyncBatchNorm invpt.py:14).  Map z starts x_zs elements after
+ * map z-1; its per-channel vectors (mean, rstd, gamma, beta, outputs) start p_zs floats after the previous map's.
+ *   stats     : mean_out[z][c] = batch mean, m2_out[z][c] = sum_r (x - mean)^2 (centred; biased variance = m2 / rows).  Two-level
+ *               deterministic reduction through the caller's workspace `ws` (mtt_bn_reduce_ws_floats(rows, C, Z) floats); no atomics,
+ *               nothing to zero.  (mean, m2, rows) triplets of several ranks merge exactly (SyncBatchNorm) with Chan's update.
+ *   apply     : y = act((x-mean)*rstd*gamma+beta), channels C..pad8(C) written as zeros.
+ *   bwd_reduce: dsum[z][c] = sum_r du, dsumxh[z][c] = sum_r du*xhat with du = dy*act'(u)   (same workspace, written not accumulated)
+ *   bwd_apply : dx = gamma*rstd*(du - dsum/rows - xhat*dsumxh/rows)   (multi-rank: pass the all-reduced sums scaled by rows/rows_total) */
 typedef struct {
   const void* x; void* y; const void* dy; void* dx;
-  float* sum; float* sumsq; const float* mean; const float* rstd; const float* gamma; const float* beta;
+  float* mean_out; float* m2_out; const float* mean; const float* rstd; const float* gamma; const float* beta;
   float* dsum; float* dsumxh;
   int64_t rows; int32_t C; int64_t ld; int32_t dtype; int32_t act;
+  int32_t Z; int64_t x_zs; int64_t p_zs;
 } mtt_bn_desc;
-int mtt_bn_stats(const mtt_bn_desc* d, void* stream);
+size_t mtt_bn_reduce_ws_floats(int64_t rows, int32_t C, int32_t Z);
+int mtt_bn_stats(const mtt_bn_desc* d, float* ws, void* stream);
 int mtt_bn_apply(const mtt_bn_desc* d, void* stream);
-int mtt_bn_bwd_reduce(const mtt_bn_desc* d, void* stream);
+int mtt_bn_bwd_reduce(const mtt_bn_desc* d, float* ws, void* stream);
 int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream);
 
 /* Small utilities: dtype cast / strided 2-D copy, column sums (bias gradients), axpy-style accumulate. */

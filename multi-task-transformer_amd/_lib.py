@@ -16,6 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
+ABI_VERSION = 2
 F32, BF16 = 0, 1
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -94,9 +95,10 @@ class ResizeDesc(C.Structure):
 
 class BnDesc(C.Structure):
     _fields_ = [("x", ptr), ("y", ptr), ("dy", ptr), ("dx", ptr),
-                ("sum", ptr), ("sumsq", ptr), ("mean", ptr), ("rstd", ptr), ("gamma", ptr), ("beta", ptr),
+                ("mean_out", ptr), ("m2_out", ptr), ("mean", ptr), ("rstd", ptr), ("gamma", ptr), ("beta", ptr),
                 ("dsum", ptr), ("dsumxh", ptr),
-                ("rows", i64), ("C", i32), ("ld", i64), ("dtype", i32), ("act", i32)]
+                ("rows", i64), ("C", i32), ("ld", i64), ("dtype", i32), ("act", i32),
+                ("Z", i32), ("x_zs", i64), ("p_zs", i64)]
 
 
 class DwconvDesc(C.Structure):
@@ -141,7 +143,7 @@ DESCS = {
     "gemm": GemmDesc, "attn_fwd": AttnDesc, "softmax_fwd": SoftmaxDesc, "softmax_bwd": SoftmaxDesc,
     "layernorm_fwd": LnDesc, "layernorm_bwd": LnDesc, "chan_logits": ChanLogitDesc, "modulate": ModulateDesc,
     "ctr_mix": CtrDesc, "bilinear_fwd": ResizeDesc, "bilinear_bwd": ResizeDesc,
-    "bn_stats": BnDesc, "bn_apply": BnDesc, "bn_bwd_reduce": BnDesc, "bn_bwd_apply": BnDesc,
+    "bn_apply": BnDesc, "bn_bwd_apply": BnDesc,
     "dwconv3x3s2": DwconvDesc, "avgpool_ceil": PoolDesc, "layernorm_mt": LnMtDesc, "attn_msg": AttnMsgDesc,
     "convt3x3s2_gather": ConvtDesc,
 }
@@ -159,6 +161,7 @@ POSITIONAL = {
 
 # descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)
 DESC_EXTRA = {
+    "bn_stats": (BnDesc, [ptr]), "bn_bwd_reduce": (BnDesc, [ptr]),
     "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr]),
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),
@@ -172,7 +175,7 @@ DESC_EXTRA = {
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
 
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant", "mtt_gemm_variant", "mtt_adam_chunk"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 
@@ -190,7 +193,9 @@ def load():
     lib.mtt_abi_version.restype = C.c_int
     lib.mtt_desc_size.restype = C.c_size_t
     lib.mtt_desc_size.argtypes = [C.c_int]
-    if lib.mtt_abi_version() != 1:
+    lib.mtt_bn_reduce_ws_floats.restype = C.c_size_t
+    lib.mtt_bn_reduce_ws_floats.argtypes = [i64, i32, i32]
+    if lib.mtt_abi_version() != ABI_VERSION:
         raise RuntimeError("libmtt_hip.so ABI version mismatch")
     for idx, st in enumerate(_SIZE_INDEX):
         if lib.mtt_desc_size(idx) != C.sizeof(st):

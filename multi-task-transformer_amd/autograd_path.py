@@ -15,6 +15,7 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch.autograd import Function
 
+from . import bn as bn_mod
 from . import ops
 from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code  # noqa: F401
 
@@ -484,117 +485,44 @@ class Conv3x3Fn(Function):
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 
-def _sync_stats(t, bn):
-    sync = isinstance(bn, nn.SyncBatchNorm) or getattr(bn, "_mtt_sync", False)   # _mtt_sync: CPU/gloo tests (DDP rejects SyncBN on CPU)
-    if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t)
-        return dist.get_world_size()
-    return 1
-
-
-class BnActFn(Function):
-    """BatchNorm2d (+GELU) on one [rows, ld] map.  training: batch statistics (all-reduced across ranks when the
-    module is a SyncBatchNorm, main.py:92) + running-stat update; eval: running statistics."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, bn, C, act, training):
-        rows, ld = x.shape
-        if training:
-            s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
-            ops.call("bn_stats", x=x, sum=s[0], sumsq=s[1], rows=rows, C=C, ld=ld, dtype=dtype_code(x))
-            world = _sync_stats(s, bn)
-            n = rows * world
-            mean = s[0] / n
-            var = torch.clamp_min(s[1] / n - mean * mean, 0.0)
-            with torch.no_grad():
-                m = bn.momentum if bn.momentum is not None else 0.1
-                bn.running_mean.mul_(1 - m).add_(mean * m)
-                bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)) * m)
-                bn.num_batches_tracked += 1
-        else:
-            mean, var, n = bn.running_mean, bn.running_var, rows
-        rstd = torch.rsqrt(var + bn.eps)
-        y = ops.bn_apply(x, C, mean, rstd, gamma, beta, act)
-        ctx.save_for_backward(x, mean, rstd, gamma, beta)
-        ctx.meta = (C, act, training, n, bn)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, mean, rstd, gamma, beta = ctx.saved_tensors
-        C, act, training, n, bn = ctx.meta
-        rows, ld = x.shape
-        dy = dy.contiguous()
-        s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
-        kw = dict(x=x, dy=dy, mean=mean, rstd=rstd, gamma=gamma, beta=beta, rows=rows, C=C, ld=ld, dtype=dtype_code(x), act=act)
-        ops.call("bn_bwd_reduce", dsum=s[0], dsumxh=s[1], **kw)
-        dgamma, dbeta = s[1].clone(), s[0].clone()
-        if training:
-            world = _sync_stats(s, bn)
-            red = s * (rows / float(n))        # kernel divides by its local row count
-        else:
-            red = torch.zeros_like(s)
-        dx = torch.empty_like(x)
-        ops.call("bn_bwd_apply", dx=dx, dsum=red[0], dsumxh=red[1], **kw)
-        return dx, dgamma, dbeta, None, None, None, None
-
-
 class BnActStackFn(Function):
-    """BnActFn over a task stack [Z, rows, ld] (one BatchNorm per task): same kernels per task on slices of ONE input and ONE
-    output tensor, so autograd never slices / re-stacks the multi-GB head maps (select-backward costs a zero fill + copy + add
-    of the whole stack per task)."""
+    """BatchNorm2d (+GELU / ReLU) over a task stack [Z, rows, ld], one BatchNorm holder per task (taskprompter.py:362,692,705;
+    invpt.py:14).  training: centred batch statistics, merged across ranks in one collective when the holders are SyncBatchNorm
+    (main.py:92), + running-stat update; eval: running statistics.  Every step is ONE Z-batched launch on slices of one input and
+    one output tensor, so autograd never slices / re-stacks the multi-GB head maps."""
 
     @staticmethod
     def forward(ctx, x, C, act, training, bns, *gb):
-        Z, rows, ld = x.shape
-        gammas, betas = gb[:Z], gb[Z:]
-        y = torch.empty_like(x)
-        means, rstds, ns = [], [], []
-        for z, bn in enumerate(bns):
-            if training:
-                s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
-                ops.call("bn_stats", x=x[z], sum=s[0], sumsq=s[1], rows=rows, C=C, ld=ld, dtype=dtype_code(x))
-                world = _sync_stats(s, bn)
-                n = rows * world
-                mean = s[0] / n
-                var = torch.clamp_min(s[1] / n - mean * mean, 0.0)
-                with torch.no_grad():
-                    m = bn.momentum if bn.momentum is not None else 0.1
-                    bn.running_mean.mul_(1 - m).add_(mean * m)
-                    bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)) * m)
-                    bn.num_batches_tracked += 1
-            else:
-                mean, var, n = bn.running_mean, bn.running_var, rows
-            rstd = torch.rsqrt(var + bn.eps)
-            ops.bn_apply(x[z], C, mean, rstd, gammas[z], betas[z], act, out=y[z])
-            means.append(mean); rstds.append(rstd); ns.append(n)
-        ctx.save_for_backward(x, torch.stack(means), torch.stack(rstds), *gb)
-        ctx.meta = (C, act, training, ns, bns)
+        Z = x.shape[0]
+        gammas, betas = torch.stack([g.detach() for g in gb[:Z]]), torch.stack([b.detach() for b in gb[Z:]])
+        if training:
+            y, mean, rstd, scale = bn_mod.train_forward(x, C, bns, act, gammas, betas)
+        else:
+            mean = torch.stack([bn.running_mean for bn in bns])
+            rstd = torch.rsqrt(torch.stack([bn.running_var for bn in bns]) + bns[0].eps)
+            y, scale = ops.bn_apply(x, C, mean, rstd, gammas, betas, act), 1.0
+        ctx.save_for_backward(x, mean, rstd, gammas, betas)
+        ctx.meta = (C, act, training, scale, bns)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, means, rstds = ctx.saved_tensors[:3]
-        gb = ctx.saved_tensors[3:]
-        C, act, training, ns, bns = ctx.meta
-        Z, rows, ld = x.shape
-        gammas, betas = gb[:Z], gb[Z:]
+        x, mean, rstd, gammas, betas = ctx.saved_tensors
+        C, act, training, scale, bns = ctx.meta
+        Z = x.shape[0]
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        dgs, dbs = [], []
-        for z, bn in enumerate(bns):
-            s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
-            kw = dict(x=x[z], dy=dy[z], mean=means[z], rstd=rstds[z], gamma=gammas[z], beta=betas[z], rows=rows, C=C, ld=ld,
-                      dtype=dtype_code(x), act=act)
-            ops.call("bn_bwd_reduce", dsum=s[0], dsumxh=s[1], **kw)
-            dgs.append(s[1].clone()); dbs.append(s[0].clone())
-            if training:
-                _sync_stats(s, bn)
-                red = s * (rows / float(ns[z]))        # kernel divides by its local row count
-            else:
-                red = torch.zeros_like(s)
-            ops.call("bn_bwd_apply", dx=dx[z], dsum=red[0], dsumxh=red[1], **kw)
+        s = ops.bn_bwd_reduce(x, dy, C, mean, rstd, gammas, betas, act)
+        dgs, dbs = s[1].unbind(0), s[0].unbind(0)
+        if training:
+            red = bn_mod.sync_backward_sums(s.clone(), bns) * scale      # kernel divides by its local row count
+        else:
+            red = torch.zeros_like(s)
+        dx = ops.bn_bwd_apply(x, dy, C, mean, rstd, gammas, betas, act, red)
         return (dx, None, None, None, None) + tuple(dgs) + tuple(dbs)
+
+
+def bn_act_single(x, gamma, beta, bn, C, act, training):
+    return BnActStackFn.apply(x[None], C, act, training, [bn], gamma, beta)[0]
 
 
 class TaskHeadsFn(Function):
@@ -812,9 +740,9 @@ def wrapper_forward(wrapper, x, target):
         F2 = F // 2
         for i, (t, hd) in enumerate(zip(wrapper.tasks, heads)):
             y = Deconv2x2Fn.apply(fea[i], hd.mt_proj[0].weight, hd.mt_proj[0].bias, (B, h4, w4), prec, ('hd0', t))
-            y = BnActFn.apply(y, hd.mt_proj[1].weight, hd.mt_proj[1].bias, hd.mt_proj[1], F2, ACT_GELU, wrapper.training)[None]
+            y = bn_act_single(y, hd.mt_proj[1].weight, hd.mt_proj[1].bias, hd.mt_proj[1], F2, ACT_GELU, wrapper.training)[None]
             y = Conv3x3Fn.apply(y, (B, 2 * h4, 2 * w4, F2, F2), prec, ('hd3', t), hd.mt_proj[3].weight, hd.mt_proj[3].bias)
-            y = BnActFn.apply(y[0], hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, wrapper.training)[None]
+            y = bn_act_single(y[0], hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, wrapper.training)[None]
             n_out = hd.linear_pred.weight.shape[0]
             pred = BLinearFn.apply(y, n_out, 'plain', None, torch.float32, prec, ('hp', t), hd.linear_pred.weight, hd.linear_pred.bias)
             out[t] = BilinearFn.apply(pred, (B, n_out, 2 * h4, 2 * w4, target[0], target[1]), torch.float32, True)

@@ -542,50 +542,132 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const mtt_resize_desc
 MTT_DEV float act_fwd(float u, int act) { return act == MTT_ACT_GELU ? gelu_f(u) : (act == MTT_ACT_RELU ? fmaxf(u, 0.f) : u); }
 MTT_DEV float act_bwd(float u, int act) { return act == MTT_ACT_GELU ? gelu_grad_f(u) : (act == MTT_ACT_RELU ? (u > 0.f ? 1.f : 0.f) : 1.f); }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_kernel(const mtt_bn_desc d, int rows_per_block) {
-  extern __shared__ float lsm[];   // [2][C8*8]
+// MODE 1 (column sums for bias gradients): per-block LDS partials, one fp32 atomic per column per block (caller zeroes dst).
+__global__ __launch_bounds__(256) void colsum_kernel(const mtt_bn_desc d, int rows_per_block) {
+  extern __shared__ float lsm[];   // [C8*8]
   const int C8 = (d.C + 7) >> 3, Cp = C8 * 8;
-  for (int c = threadIdx.x; c < 2 * Cp; c += 256) lsm[c] = 0.f;
+  for (int c = threadIdx.x; c < Cp; c += 256) lsm[c] = 0.f;
   __syncthreads();
   const int lanes = 256 / C8 > 0 ? 256 / C8 : 1;     // row lanes per block
   const int c8 = threadIdx.x % C8, rl = threadIdx.x / C8;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
-  float a0[8], a1[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) a0[j] = a1[j] = 0.f;
-  float mu[8], rs[8], ga[8], be[8];
-  if (MODE == 2 && rl < lanes) {
-    ld8(d.mean, c8 * 8, MTT_F32, mu); ld8(d.rstd, c8 * 8, MTT_F32, rs);
-    ld8(d.gamma, c8 * 8, MTT_F32, ga); ld8(d.beta, c8 * 8, MTT_F32, be);
-  }
   if (rl < lanes) {
+    float a0[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = 0.f;
     for (int64_t r = r0 + rl; r < r1; r += lanes) {
       float v[8];
-      if (MODE == 2) {
-        float x[8];
-        ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
-        ld8(d.dy, r * d.ld + c8 * 8, d.dtype, v);
+      ld8(d.dy, r * d.ld + c8 * 8, d.dtype, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a0[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&lsm[c8 * 8 + j], a0[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d.C; c += 256) atomicAdd(&d.dsum[c], lsm[c]);
+}
+
+// BatchNorm reductions, deterministic (no atomics) and centred.  Grid (row blocks, Z maps).  Each block reduces its rows to one
+// partial per channel in `ws` [Z][nblk][2][Cp]; bn_final_kernel merges the partials in block order.
+//   MODE 0 (statistics): the block accumulates sums of (x - shift) and (x - shift)^2 with shift = the block's first row (a value
+//     within a few sigma of the mean, so nothing cancels even when |mean| >> std) and writes (mean_b, M2_b = sum (x - mean_b)^2);
+//     the merge is Chan's pairwise update — the result is the centred variance nn.BatchNorm2d computes, not E[x^2] - E[x]^2.
+//   MODE 2 (backward): sums of du and du * xhat with du = dy * act'(u).
+constexpr int BNR_LSM = 2 * 2048;     // lanes * Cp <= 256 * 8 floats per plane
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const mtt_bn_desc d, int rows_per_block, float* ws) {
+  __shared__ float lsm[BNR_LSM];
+  const int C8 = (d.C + 7) >> 3, Cp = C8 * 8;
+  const int lanes = 256 / C8 > 0 ? 256 / C8 : 1;
+  const int c8 = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int z = blockIdx.y;
+  const int es = d.dtype == MTT_F32 ? 4 : 2;
+  const unsigned char* xz = (const unsigned char*)d.x + (int64_t)z * d.x_zs * es;
+  const unsigned char* dyz = (const unsigned char*)d.dy + (int64_t)z * d.x_zs * es;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
+  float a0[8], a1[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a0[j] = a1[j] = sh[j] = 0.f;
+  if (rl < lanes) {
+    if (MODE == 0) {
+      ld8(xz, r0 * d.ld + c8 * 8, d.dtype, sh);
+      for (int64_t r = r0 + rl; r < r1; r += lanes) {
+        float v[8];
+        ld8(xz, r * d.ld + c8 * 8, d.dtype, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[j] - sh[j]; a0[j] += t; a1[j] = fmaf(t, t, a1[j]); }
+      }
+    } else {
+      float mu[8], rs[8], ga[8], be[8];
+      const int64_t pz = (int64_t)z * d.p_zs + c8 * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = c8 * 8 + j < d.C;
+        mu[j] = ok ? d.mean[pz + j] : 0.f; rs[j] = ok ? d.rstd[pz + j] : 0.f; ga[j] = ok ? d.gamma[pz + j] : 0.f; be[j] = ok ? d.beta[pz + j] : 0.f;
+      }
+      for (int64_t r = r0 + rl; r < r1; r += lanes) {
+        float x[8], v[8];
+        ld8(xz, r * d.ld + c8 * 8, d.dtype, x);
+        ld8(dyz, r * d.ld + c8 * 8, d.dtype, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = (x[j] - mu[j]) * rs[j];
           const float du = v[j] * act_bwd(xh * ga[j] + be[j], d.act);
-          a0[j] += du; a1[j] += du * xh;
+          a0[j] += du; a1[j] = fmaf(du, xh, a1[j]);
         }
-      } else {
-        ld8(MODE == 1 ? d.dy : d.x, r * d.ld + c8 * 8, d.dtype, v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { a0[j] += v[j]; if (MODE == 0) a1[j] += v[j] * v[j]; }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { atomicAdd(&lsm[c8 * 8 + j], a0[j]); if (MODE != 1) atomicAdd(&lsm[Cp + c8 * 8 + j], a1[j]); }
+    for (int j = 0; j < 8; ++j) { lsm[rl * Cp + c8 * 8 + j] = a0[j]; lsm[2048 + rl * Cp + c8 * 8 + j] = a1[j]; }
   }
   __syncthreads();
-  float* o0 = MODE == 0 ? d.sum : d.dsum;
-  float* o1 = MODE == 0 ? d.sumsq : d.dsumxh;
-  for (int c = threadIdx.x; c < d.C; c += 256) { atomicAdd(&o0[c], lsm[c]); if (MODE != 1) atomicAdd(&o1[c], lsm[Cp + c]); }
+  float* out = ws + ((int64_t)z * gridDim.x + blockIdx.x) * 2 * Cp;
+  for (int c = threadIdx.x; c < Cp; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int l = 0; l < lanes; ++l) { s0 += lsm[l * Cp + c]; s1 += lsm[2048 + l * Cp + c]; }      // fixed order
+    if (MODE == 0) {
+      const float n = (float)(r1 - r0);
+      const float shift = c < d.C ? ld_elem(xz, r0 * d.ld + c, d.dtype) : 0.f;
+      out[c] = shift + s0 / n;                    // block mean
+      out[Cp + c] = fmaxf(s1 - s0 * s0 / n, 0.f); // block M2 (about the block mean)
+    } else {
+      out[c] = s0; out[Cp + c] = s1;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_final_kernel(const mtt_bn_desc d, int rows_per_block, int nblk, const float* ws) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d.C) return;
+  const int z = blockIdx.y;
+  const int Cp = ((d.C + 7) >> 3) * 8;
+  const float* p = ws + (int64_t)z * nblk * 2 * Cp + c;
+  float o0, o1;
+  if (MODE == 0) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+      const int64_t r0 = (int64_t)b * rows_per_block;
+      const float nb = (float)((r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows) - r0);
+      const float mb = p[(int64_t)b * 2 * Cp], qb = p[(int64_t)b * 2 * Cp + Cp];
+      const float tot = n + nb, delta = mb - mean;
+      mean += delta * (nb / tot);
+      m2 += qb + delta * delta * (n * nb / tot);
+      n = tot;
+    }
+    o0 = mean; o1 = m2;
+  } else {
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = 0; b < nblk; ++b) { s0 += p[(int64_t)b * 2 * Cp]; s1 += p[(int64_t)b * 2 * Cp + Cp]; }
+    o0 = s0; o1 = s1;
+  }
+  float* const q0 = MODE == 0 ? d.mean_out : d.dsum;
+  float* const q1 = MODE == 0 ? d.m2_out : d.dsumxh;
+  q0[(int64_t)z * d.p_zs + c] = o0;
+  q1[(int64_t)z * d.p_zs + c] = o1;
 }
 
 // y = act((x - mean) * rstd * gamma + beta); channels >= C are written as zeros (padding).
@@ -598,6 +680,12 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
   const int c8_0 = C8 >= 256 ? threadIdx.x : threadIdx.x % C8;
   const int rl = C8 >= 256 ? 0 : threadIdx.x / C8;
   if (rl >= lanes) return;
+  const int z = blockIdx.y;
+  const int es = d.dtype == MTT_F32 ? 4 : 2;
+  const int64_t zoff = (int64_t)z * d.x_zs * es, pz = (int64_t)z * d.p_zs;
+  const unsigned char* xz = (const unsigned char*)d.x + zoff;
+  const unsigned char* dyz = (const unsigned char*)d.dy + zoff;
+  unsigned char* oz = (unsigned char*)(BWD ? d.dx : d.y) + zoff;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
   const float invn = 1.0f / (float)d.rows;
@@ -607,16 +695,16 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
     for (int j = 0; j < 8; ++j) {
       const int c = c8 * 8 + j;
       const bool ok = c < d.C;
-      mu[j] = ok ? d.mean[c] : 0.f; rs[j] = ok ? d.rstd[c] : 0.f; ga[j] = ok ? d.gamma[c] : 0.f; be[j] = ok ? d.beta[c] : 0.f;
-      if (BWD) { s0[j] = ok ? d.dsum[c] * invn : 0.f; s1[j] = ok ? d.dsumxh[c] * invn : 0.f; }
+      mu[j] = ok ? d.mean[pz + c] : 0.f; rs[j] = ok ? d.rstd[pz + c] : 0.f; ga[j] = ok ? d.gamma[pz + c] : 0.f; be[j] = ok ? d.beta[pz + c] : 0.f;
+      if (BWD) { s0[j] = ok ? d.dsum[pz + c] * invn : 0.f; s1[j] = ok ? d.dsumxh[pz + c] * invn : 0.f; }
     }
     const bool tail = c8 * 8 + 8 > d.C;
     for (int64_t r = r0 + rl; r < r1; r += lanes) {
       float x[8], o[8];
-      ld8(d.x, r * d.ld + c8 * 8, d.dtype, x);
+      ld8(xz, r * d.ld + c8 * 8, d.dtype, x);
       if (BWD) {
         float g[8];
-        ld8(d.dy, r * d.ld + c8 * 8, d.dtype, g);
+        ld8(dyz, r * d.ld + c8 * 8, d.dtype, g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = (x[j] - mu[j]) * rs[j];
@@ -631,7 +719,7 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (c8 * 8 + j >= d.C) o[j] = 0.f;
       }
-      st8(BWD ? d.dx : d.y, r * d.ld + c8 * 8, d.dtype, o);
+      st8(oz, r * d.ld + c8 * 8, d.dtype, o);
     }
   }
 }
@@ -1075,10 +1163,18 @@ static void bn_rowwise_cfg(const mtt_bn_desc* d, int& nblk, int& rpb) {
   rpb = (int)((d->rows + nb - 1) / nb);
   nblk = (int)((d->rows + rpb - 1) / rpb);
 }
-extern "C" int mtt_bn_stats(const mtt_bn_desc* d, void* stream) {
+static int bn_batch(const mtt_bn_desc* d) { return d->Z > 1 ? d->Z : 1; }
+extern "C" size_t mtt_bn_reduce_ws_floats(int64_t rows, int32_t C, int32_t Z) {
+  mtt_bn_desc d = {}; d.rows = rows; d.C = C; d.ld = 8;
+  int nblk, rpb; if (colreduce_cfg(&d, nblk, rpb)) return 0;
+  return (size_t)(Z > 1 ? Z : 1) * nblk * 2 * ((C + 7) / 8 * 8);
+}
+extern "C" int mtt_bn_stats(const mtt_bn_desc* d, float* ws, void* stream) {
   int nblk, rpb; int e = colreduce_cfg(d, nblk, rpb); if (e) return e;
-  if (!d->x || !d->sum || !d->sumsq) return MTT_E_BADARG;
-  hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nblk), dim3(256), 2 * ((d->C + 7) / 8) * 8 * sizeof(float), S_, *d, rpb);
+  if (!d->x || !d->mean_out || !d->m2_out || !ws) return MTT_E_BADARG;
+  const int Z = bn_batch(d);
+  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk, Z), dim3(256), 0, S_, *d, rpb, ws);
+  hipLaunchKernelGGL(bn_final_kernel<0>, dim3((d->C + 255) / 256, Z), dim3(256), 0, S_, *d, rpb, nblk, ws);
   return LAUNCH_OK();
 }
 extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream) {
@@ -1089,26 +1185,28 @@ extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t col
     d.dy = (const unsigned char*)src + (int64_t)c0 * es; d.dsum = dst + c0; d.rows = rows;
     d.C = cols - c0 < 2040 ? cols - c0 : 2040; d.ld = ld; d.dtype = src_dtype;
     int nblk, rpb; int e = colreduce_cfg(&d, nblk, rpb); if (e) return e;
-    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 2 * ((d.C + 7) / 8) * 8 * sizeof(float), S_, d, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), ((d.C + 7) / 8) * 8 * sizeof(float), S_, d, rpb);
   }
   return LAUNCH_OK();
 }
-extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, void* stream) {
+extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, float* ws, void* stream) {
   int nblk, rpb; int e = colreduce_cfg(d, nblk, rpb); if (e) return e;
-  if (!d->x || !d->dy || !d->dsum || !d->dsumxh || !d->mean || !d->rstd || !d->gamma || !d->beta) return MTT_E_BADARG;
-  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nblk), dim3(256), 2 * ((d->C + 7) / 8) * 8 * sizeof(float), S_, *d, rpb);
+  if (!d->x || !d->dy || !d->dsum || !d->dsumxh || !d->mean || !d->rstd || !d->gamma || !d->beta || !ws) return MTT_E_BADARG;
+  const int Z = bn_batch(d);
+  hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(nblk, Z), dim3(256), 0, S_, *d, rpb, ws);
+  hipLaunchKernelGGL(bn_final_kernel<2>, dim3((d->C + 255) / 256, Z), dim3(256), 0, S_, *d, rpb, nblk, ws);
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_apply(const mtt_bn_desc* d, void* stream) {
   if (!d || !d->x || !d->y || !d->mean || !d->rstd || !d->gamma || !d->beta || (d->ld % 8)) return MTT_E_BADARG;
   int nblk, rpb; bn_rowwise_cfg(d, nblk, rpb);
-  hipLaunchKernelGGL(bn_rowwise_kernel<false>, dim3(nblk), dim3(256), 0, S_, *d, rpb);
+  hipLaunchKernelGGL(bn_rowwise_kernel<false>, dim3(nblk, bn_batch(d)), dim3(256), 0, S_, *d, rpb);
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream) {
   if (!d || !d->x || !d->dy || !d->dx || !d->mean || !d->rstd || !d->gamma || !d->beta || !d->dsum || !d->dsumxh || (d->ld % 8)) return MTT_E_BADARG;
   int nblk, rpb; bn_rowwise_cfg(d, nblk, rpb);
-  hipLaunchKernelGGL(bn_rowwise_kernel<true>, dim3(nblk), dim3(256), 0, S_, *d, rpb);
+  hipLaunchKernelGGL(bn_rowwise_kernel<true>, dim3(nblk, bn_batch(d)), dim3(256), 0, S_, *d, rpb);
   return LAUNCH_OK();
 }
 

@@ -262,17 +262,8 @@ def _fold(bns, conv_biases, tag):
 
 def _bn_train(y, bns, C, act):
     """train-mode BatchNorm (+act) on [Z, rows, ld]; updates running statistics (momentum 0.1)."""
-    outs = []
-    rows = y.shape[1]
-    for z, bn in enumerate(bns):
-        mean, var = ops.bn_batch_stats(y[z], C)
-        with torch.no_grad():
-            m = bn.momentum if bn.momentum is not None else 0.1
-            bn.running_mean.mul_(1 - m).add_(mean * m)
-            bn.running_var.mul_(1 - m).add_(var * (rows / max(rows - 1, 1)) * m)
-            bn.num_batches_tracked += 1
-        outs.append(ops.bn_apply(y[z], C, mean, torch.rsqrt(var + bn.eps), bn.weight.detach(), bn.bias.detach(), act))
-    return torch.stack(outs, 0)
+    from . import bn as bn_mod
+    return bn_mod.train_forward(y, C, list(bns), act)[0]
 
 
 class TransformerDecoder(nn.Module):

@@ -3,7 +3,7 @@ InvPT/models/transformer_net.py): the schedule of invpt.py's no-grad forward reb
 torch.autograd.Functions whose forward AND backward run on the libmtt_hip.so kernels.
 
 Shared with the TaskPrompter training path (autograd_path.py): LayerNormFn, AttnHalfFn (no prompt rows),
-MlpHalfFn, BLinearFn, Conv3x3Fn (dilated, bias-free), BnActFn, BilinearFn.  New here: the ViT patch embed with a
+MlpHalfFn, BLinearFn, Conv3x3Fn (dilated, bias-free), BnActStackFn, BilinearFn.  New here: the ViT patch embed with a
 class token, ConvTranspose2d(3, s2) = GEMM + gather, depthwise stride-2 conv, ceil-mode average pooling and the
 materialised (2-head, head dim D/2) cross-task attention: scores / softmax / P.V with hand-written backward GEMMs.
 

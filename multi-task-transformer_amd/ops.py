@@ -303,19 +303,64 @@ def bilinear(x, B, C, Hin, Win, Hout, Wout, out_dtype, nchw=False):
     return out
 
 
-def bn_batch_stats(x, C):
-    """x [rows, ld] -> (mean, biased var) fp32 [C] from one pass of column sums."""
-    rows, ld = x.shape
-    s = torch.zeros(2, C, dtype=torch.float32, device=x.device)
-    call("bn_stats", x=x, sum=s[0], sumsq=s[1], rows=rows, C=C, ld=ld, dtype=dtype_code(x))
-    mean = s[0] / rows
-    var = torch.clamp_min(s[1] / rows - mean * mean, 0.0)
-    return mean, var
+_ws_cache = {}
+
+
+def workspace(nfloats, device):
+    """Grow-only fp32 scratch buffer per device for the kernels' workspaces (launches are stream-ordered, so one buffer serves all)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 18), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _bn_ws(rows, C, Z, device):
+    return workspace(_lib.load().mtt_bn_reduce_ws_floats(rows, C, Z), device)
+
+
+def _as3(x):
+    return x if x.dim() == 3 else x[None]
+
+
+def bn_stats(x, C):
+    """x [Z, rows, ld] (or [rows, ld]) -> (mean [Z, C], M2 [Z, C] = sum_r (x - mean)^2): centred, deterministic (mtt_bn_stats)."""
+    x = _as3(x)
+    Z, rows, ld = x.shape
+    out = torch.empty(2, Z, C, dtype=torch.float32, device=x.device)
+    call("bn_stats", x=x, mean_out=out[0], m2_out=out[1], rows=rows, C=C, ld=ld, dtype=dtype_code(x), Z=Z, x_zs=x.stride(0), p_zs=C,
+         xargs=[_bn_ws(rows, C, Z, x.device)])
+    return out[0], out[1]
 
 
 def bn_apply(x, C, mean, rstd, gamma, beta, act, out=None):
-    rows, ld = x.shape
+    """y[z] = act((x[z] - mean[z]) * rstd[z] * gamma[z] + beta[z]); x [Z, rows, ld] or [rows, ld]; vectors [Z, C] or [C]."""
+    x3 = _as3(x)
+    Z, rows, ld = x3.shape
     y = torch.empty_like(x) if out is None else out
-    call("bn_apply", x=x, y=y, mean=mean, rstd=rstd, gamma=gamma, beta=beta, rows=rows, C=C, ld=ld,
-         dtype=dtype_code(x), act=act)
+    vec = [v.reshape(Z, C) for v in (mean, rstd, gamma, beta)]
+    vec = [v if v.is_contiguous() else v.contiguous() for v in vec]
+    call("bn_apply", x=x3, y=y, mean=vec[0], rstd=vec[1], gamma=vec[2], beta=vec[3], rows=rows, C=C, ld=ld,
+         dtype=dtype_code(x3), act=act, Z=Z, x_zs=x3.stride(0), p_zs=C)
     return y
+
+
+def bn_bwd_reduce(x, dy, C, mean, rstd, gamma, beta, act):
+    """-> s [2, Z, C]: s[0] = sum_r du, s[1] = sum_r du * xhat (du = dy * act'(u)); deterministic (mtt_bn_bwd_reduce)."""
+    x, dy = _as3(x), _as3(dy)
+    Z, rows, ld = x.shape
+    s = torch.empty(2, Z, C, dtype=torch.float32, device=x.device)
+    call("bn_bwd_reduce", x=x, dy=dy, mean=mean, rstd=rstd, gamma=gamma, beta=beta, dsum=s[0], dsumxh=s[1], rows=rows, C=C, ld=ld,
+         dtype=dtype_code(x), act=act, Z=Z, x_zs=x.stride(0), p_zs=C, xargs=[_bn_ws(rows, C, Z, x.device)])
+    return s
+
+
+def bn_bwd_apply(x, dy, C, mean, rstd, gamma, beta, act, red):
+    """dx from the (rank-summed, pre-scaled to the local row count) sums `red` [2, Z, C]."""
+    x3, dy3 = _as3(x), _as3(dy)
+    Z, rows, ld = x3.shape
+    dx = torch.empty_like(x)
+    call("bn_bwd_apply", x=x3, dy=dy3, dx=dx, mean=mean, rstd=rstd, gamma=gamma, beta=beta, dsum=red[0], dsumxh=red[1], rows=rows, C=C,
+         ld=ld, dtype=dtype_code(x3), act=act, Z=Z, x_zs=x3.stride(0), p_zs=C)
+    return dx

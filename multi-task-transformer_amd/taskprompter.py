@@ -307,18 +307,8 @@ class TaskPrompter(nn.Module):
 
     def _bn_train(self, y, bns, C, act):
         """training-mode BatchNorm2d (+act) on [T, rows, ld] pre-activations; updates running stats like nn.BatchNorm2d."""
-        outs = []
-        rows = y.shape[1]
-        for t, bn in enumerate(bns):
-            mean, var = ops.bn_batch_stats(y[t], C)
-            with torch.no_grad():
-                m = bn.momentum if bn.momentum is not None else 0.1
-                bn.running_mean.mul_(1 - m).add_(mean * m)
-                bn.running_var.mul_(1 - m).add_(var * (rows / max(rows - 1, 1)) * m)
-                bn.num_batches_tracked += 1
-            rstd = torch.rsqrt(var + bn.eps)
-            outs.append(ops.bn_apply(y[t], C, mean, rstd, bn.weight.detach(), bn.bias.detach(), act))
-        return torch.stack(outs, 0)
+        from . import bn as bn_mod
+        return bn_mod.train_forward(y, C, list(bns), act)[0]
 
     def _task_features(self, xsrc, xview, rawlog, rawchan, il, B, acc):
         p, prec = self.p, self.prec
@@ -452,8 +442,8 @@ class TaskPrompterWrapper(nn.Module):
                 else:
                     # BN1 cannot fold into the pixel-shuffle GEMM's epilogue (rows differ per tap? no: per channel) -> apply kernel
                     bn1 = hd.mt_proj[1]
-                    y = ops.bn_apply(y[0], F2, bn1.running_mean, torch.rsqrt(bn1.running_var + bn1.eps), bn1.weight.detach(),
-                                     bn1.bias.detach(), ACT_GELU)[None]
+                    y = ops.bn_apply(y, F2, bn1.running_mean, torch.rsqrt(bn1.running_var + bn1.eps), bn1.weight.detach(),
+                                     bn1.bias.detach(), ACT_GELU)
                     sc, sh = bb._bn_fold([hd.mt_proj[4]], [hd.mt_proj[3].bias], ('hd4', t))
                     y = ops.conv3x3(y, Wc, F2, F2, B, 2 * h4, 2 * w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
                 n_out = hd.linear_pred.weight.shape[0]

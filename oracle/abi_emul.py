@@ -385,50 +385,56 @@ def _act_grad(u, act):
     return _gelu_grad(u) if act == ACT_GELU else ((u > 0).double() if act == ACT_RELU else torch.ones_like(u))
 
 
-def _bn_idx(kw):
-    return torch.arange(kw["rows"])[:, None] * kw["ld"] + torch.arange(kw["C"])[None, :]
+def _bn_maps(kw):
+    """(z, element index [rows, C] of map z, parameter index [C] of map z) for every map of a Z-batched BN descriptor."""
+    Z = max(1, kw.get("Z", 1) or 1)
+    base = torch.arange(kw["rows"])[:, None] * kw["ld"] + torch.arange(kw["C"])[None, :]
+    for z in range(Z):
+        yield z, base + z * (kw.get("x_zs", 0) or 0), torch.arange(kw["C"]) + z * (kw.get("p_zs", 0) or 0)
+
+
+def _bn_pad(kw, t, idx):
+    C8 = (kw["C"] + 7) // 8 * 8
+    if C8 > kw["C"]:
+        pad = idx[:, :1] + torch.arange(kw["C"], C8)[None, :]
+        _wr(t, pad, torch.zeros(kw["rows"], C8 - kw["C"], dtype=torch.float64))
 
 
 def bn_stats(**kw):
-    x = _rd(kw["x"], _bn_idx(kw))
-    c = torch.arange(kw["C"])
-    _wr(kw["sum"], c, _rd(kw["sum"], c) + x.sum(0))
-    _wr(kw["sumsq"], c, _rd(kw["sumsq"], c) + (x * x).sum(0))
+    for z, ix, pc in _bn_maps(kw):
+        x = _rd(kw["x"], ix)
+        mean = x.mean(0)
+        _wr(kw["mean_out"], pc, mean)
+        _wr(kw["m2_out"], pc, ((x - mean) ** 2).sum(0))
 
 
 def bn_apply(**kw):
-    c = torch.arange(kw["C"])
-    x = _rd(kw["x"], _bn_idx(kw))
-    u = (x - _rd(kw["mean"], c)) * _rd(kw["rstd"], c) * _rd(kw["gamma"], c) + _rd(kw["beta"], c)
-    _wr(kw["y"], _bn_idx(kw), _act(u, kw.get("act", 0)))
-    C8 = (kw["C"] + 7) // 8 * 8
-    if C8 > kw["C"]:
-        pad = torch.arange(kw["rows"])[:, None] * kw["ld"] + torch.arange(kw["C"], C8)[None, :]
-        _wr(kw["y"], pad, torch.zeros(kw["rows"], C8 - kw["C"], dtype=torch.float64))
+    for z, ix, pc in _bn_maps(kw):
+        x = _rd(kw["x"], ix)
+        u = (x - _rd(kw["mean"], pc)) * _rd(kw["rstd"], pc) * _rd(kw["gamma"], pc) + _rd(kw["beta"], pc)
+        _wr(kw["y"], ix, _act(u, kw.get("act", 0)))
+        _bn_pad(kw, kw["y"], ix)
 
 
 def bn_bwd_reduce(**kw):
-    c = torch.arange(kw["C"])
-    x, dy = _rd(kw["x"], _bn_idx(kw)), _rd(kw["dy"], _bn_idx(kw))
-    xh = (x - _rd(kw["mean"], c)) * _rd(kw["rstd"], c)
-    du = dy * _act_grad(xh * _rd(kw["gamma"], c) + _rd(kw["beta"], c), kw.get("act", 0))
-    _wr(kw["dsum"], c, _rd(kw["dsum"], c) + du.sum(0))
-    _wr(kw["dsumxh"], c, _rd(kw["dsumxh"], c) + (du * xh).sum(0))
+    for z, ix, pc in _bn_maps(kw):
+        x, dy = _rd(kw["x"], ix), _rd(kw["dy"], ix)
+        xh = (x - _rd(kw["mean"], pc)) * _rd(kw["rstd"], pc)
+        du = dy * _act_grad(xh * _rd(kw["gamma"], pc) + _rd(kw["beta"], pc), kw.get("act", 0))
+        _wr(kw["dsum"], pc, du.sum(0))
+        _wr(kw["dsumxh"], pc, (du * xh).sum(0))
 
 
 def bn_bwd_apply(**kw):
-    c = torch.arange(kw["C"])
-    x, dy = _rd(kw["x"], _bn_idx(kw)), _rd(kw["dy"], _bn_idx(kw))
-    rstd, gam = _rd(kw["rstd"], c), _rd(kw["gamma"], c)
-    xh = (x - _rd(kw["mean"], c)) * rstd
-    du = dy * _act_grad(xh * gam + _rd(kw["beta"], c), kw.get("act", 0))
     n = kw["rows"]
-    dx = gam * rstd * (du - _rd(kw["dsum"], c) / n - xh * _rd(kw["dsumxh"], c) / n)
-    _wr(kw["dx"], _bn_idx(kw), dx)
-    C8 = (kw["C"] + 7) // 8 * 8
-    if C8 > kw["C"]:
-        pad = torch.arange(kw["rows"])[:, None] * kw["ld"] + torch.arange(kw["C"], C8)[None, :]
-        _wr(kw["dx"], pad, torch.zeros(kw["rows"], C8 - kw["C"], dtype=torch.float64))
+    for z, ix, pc in _bn_maps(kw):
+        x, dy = _rd(kw["x"], ix), _rd(kw["dy"], ix)
+        rstd, gam = _rd(kw["rstd"], pc), _rd(kw["gamma"], pc)
+        xh = (x - _rd(kw["mean"], pc)) * rstd
+        du = dy * _act_grad(xh * gam + _rd(kw["beta"], pc), kw.get("act", 0))
+        dx = gam * rstd * (du - _rd(kw["dsum"], pc) / n - xh * _rd(kw["dsumxh"], pc) / n)
+        _wr(kw["dx"], ix, dx)
+        _bn_pad(kw, kw["dx"], ix)
 
 
 def cast2d(args):

@@ -28,6 +28,13 @@ def rnd(g, *shape, dtype=torch.float32, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(dtype)
 
 
+def scratch(n):
+    """A kernel workspace: contents are unspecified after the call, so its storage is excluded from the comparison."""
+    t = torch.zeros(n)
+    t._mtt_scratch = True
+    return t
+
+
 def run_case(name, kw, outputs, tol):
     """Run entry `name` with CPU emulator and on the GPU; compare the `outputs` tensors' whole storages.
     Returns dict(ok, errs={key: rel_err})."""
@@ -36,8 +43,12 @@ def run_case(name, kw, outputs, tol):
     # GPU copies sharing storage structure
     gpu_store, gpu_kw = {}, dict(kw)
 
+    skip = set()
+
     def to_gpu(t):
         key = t.untyped_storage().data_ptr()
+        if getattr(t, "_mtt_scratch", False):
+            skip.add(key)
         if key not in gpu_store:
             flat, _ = abi_emul.flat(t)
             gpu_store[key] = (flat.clone().cuda(), flat)
@@ -53,6 +64,8 @@ def run_case(name, kw, outputs, tol):
     abi_emul.call(name, **kw)
     errs, ok = {}, True
     for key, (gflat, cflat) in gpu_store.items():
+        if key in skip:
+            continue
         a, b = gflat.cpu().double(), cflat.double()
         if not torch.isfinite(a).all():
             errs[f"storage{len(errs)}"] = float("nan")
@@ -336,20 +349,41 @@ def row_cases():
     for dt in (F32, BF16):
         rows, C, ld = 300, 52, 56
         x = rnd(g, rows, ld, dtype=DT[dt]); x[:, C:] = 0
-        kw = dict(x=x, sum=torch.zeros(C), sumsq=torch.zeros(C), rows=rows, C=C, ld=ld, dtype=dt)
+        ws = scratch(1 << 16)
+        kw = dict(x=x, mean_out=torch.zeros(C), m2_out=torch.zeros(C), rows=rows, C=C, ld=ld, dtype=dt, Z=1, x_zs=0, p_zs=C, xargs=[ws])
         cases.append((f"bn_stats_{dt}", "bn_stats", kw, TOL_ROW))
         mean, rstd, gam, bet = rnd(g, C) * 0.1, rnd(g, C).abs() + 0.5, rnd(g, C), rnd(g, C)
         for act in (0, 1, 2):
             kw = dict(x=x, y=torch.full((rows, ld), 5.0, dtype=DT[dt]), mean=mean, rstd=rstd, gamma=gam, beta=bet,
-                      rows=rows, C=C, ld=ld, dtype=dt, act=act)
+                      rows=rows, C=C, ld=ld, dtype=dt, act=act, Z=1, x_zs=0, p_zs=C)
             cases.append((f"bn_apply_{dt}_act{act}", "bn_apply", kw, TOL_ROW))
         dy = rnd(g, rows, ld, dtype=DT[dt])
         kw = dict(x=x, dy=dy, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=torch.zeros(C), dsumxh=torch.zeros(C),
-                  rows=rows, C=C, ld=ld, dtype=dt, act=1)
+                  rows=rows, C=C, ld=ld, dtype=dt, act=1, Z=1, x_zs=0, p_zs=C, xargs=[ws])
         cases.append((f"bn_bwd_reduce_{dt}", "bn_bwd_reduce", kw, TOL_ROW))
         kw = dict(x=x, dy=dy, dx=torch.full((rows, ld), 5.0, dtype=DT[dt]), mean=mean, rstd=rstd, gamma=gam, beta=bet,
-                  dsum=rnd(g, C), dsumxh=rnd(g, C), rows=rows, C=C, ld=ld, dtype=dt, act=1)
+                  dsum=rnd(g, C), dsumxh=rnd(g, C), rows=rows, C=C, ld=ld, dtype=dt, act=1, Z=1, x_zs=0, p_zs=C)
         cases.append((f"bn_bwd_apply_{dt}", "bn_bwd_apply", kw, TOL_ROW))
+        # Z-batched stack (3 maps, 5000 rows -> several row blocks), channel means far from zero: the centred statistics must
+        # keep full accuracy where E[x^2] - E[x]^2 cancels (|mean| = 200 sigma)
+        Zs, rows2 = 3, 5000
+        xs = rnd(g, Zs, rows2, ld) * 0.05 + 10.0 * torch.arange(1, C + 1 + (ld - C))[None, None, :].float() / C
+        xs[..., C:] = 0
+        xs = xs.to(DT[dt])
+        kw = dict(x=xs, mean_out=torch.zeros(Zs, C), m2_out=torch.zeros(Zs, C), rows=rows2, C=C, ld=ld, dtype=dt, Z=Zs, x_zs=rows2 * ld, p_zs=C,
+                  xargs=[scratch(1 << 18)])
+        cases.append((f"bn_stats_stack_offset_{dt}", "bn_stats", kw, TOL_ROW))
+        means, rstds, gams, bets = rnd(g, Zs, C) * 0.1 + xs.float()[:, :, :C].mean(1), rnd(g, Zs, C).abs() + 0.5, rnd(g, Zs, C), rnd(g, Zs, C)
+        dys = rnd(g, Zs, rows2, ld, dtype=DT[dt])
+        kw = dict(x=xs, y=torch.full((Zs, rows2, ld), 5.0, dtype=DT[dt]), mean=means, rstd=rstds, gamma=gams, beta=bets,
+                  rows=rows2, C=C, ld=ld, dtype=dt, act=1, Z=Zs, x_zs=rows2 * ld, p_zs=C)
+        cases.append((f"bn_apply_stack_{dt}", "bn_apply", kw, TOL_ROW))
+        kw = dict(x=xs, dy=dys, mean=means, rstd=rstds, gamma=gams, beta=bets, dsum=torch.zeros(Zs, C), dsumxh=torch.zeros(Zs, C),
+                  rows=rows2, C=C, ld=ld, dtype=dt, act=2, Z=Zs, x_zs=rows2 * ld, p_zs=C, xargs=[scratch(1 << 18)])
+        cases.append((f"bn_bwd_reduce_stack_{dt}", "bn_bwd_reduce", kw, TOL_ROW))
+        kw = dict(x=xs, dy=dys, dx=torch.full((Zs, rows2, ld), 5.0, dtype=DT[dt]), mean=means, rstd=rstds, gamma=gams, beta=bets,
+                  dsum=rnd(g, Zs, C), dsumxh=rnd(g, Zs, C), rows=rows2, C=C, ld=ld, dtype=dt, act=2, Z=Zs, x_zs=rows2 * ld, p_zs=C)
+        cases.append((f"bn_bwd_apply_stack_{dt}", "bn_bwd_apply", kw, TOL_ROW))
         cases.append((f"cast2d_{dt}", "cast2d", dict(args=[rnd(g, 30, 20), torch.full((30, 24), 4.0, dtype=DT[dt]), 30, 18, 20, 24, F32, dt, 1]), TOL_ROW))
         cases.append((f"colsum_{dt}", "colsum", dict(args=[rnd(g, 300, 56, dtype=DT[dt]), torch.zeros(52), 300, 52, 56, dt]), TOL_ROW))
         cases.append((f"add_rows_{dt}", "add_rows", dict(args=[rnd(g, 30, 24, dtype=DT[dt]), rnd(g, 30, 32), 30, 20, 24, 32, dt, 0.5]), TOL_ROW))

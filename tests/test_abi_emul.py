@@ -126,15 +126,15 @@ def test_bn_train_fwd_bwd():
     dy = torch.randn(rows, C, generator=g)
     ref.backward(dy.reshape(rows, C, 1, 1))
     xp = torch.zeros(rows, 16); xp[:, :C] = x.detach()
-    s, ss = torch.zeros(C), torch.zeros(C)
-    E.call("bn_stats", x=xp, sum=s, sumsq=ss, rows=rows, C=C, ld=16)
-    mean = s / rows; var = ss / rows - mean * mean; rstd = torch.rsqrt(var + 1e-5)
+    mean, m2 = torch.zeros(C), torch.zeros(C)
+    E.call("bn_stats", x=xp, mean_out=mean, m2_out=m2, rows=rows, C=C, ld=16, xargs=[torch.zeros(1)])
+    var = m2 / rows; rstd = torch.rsqrt(var + 1e-5)
     y = torch.zeros(rows, 16)
     E.call("bn_apply", x=xp, y=y, mean=mean, rstd=rstd, gamma=gam, beta=bet, rows=rows, C=C, ld=16, act=1)
     assert torch.allclose(y[:, :C], ref.detach().reshape(rows, C), atol=1e-5)
     dyp = torch.zeros(rows, 16); dyp[:, :C] = dy
     ds, dsx = torch.zeros(C), torch.zeros(C)
-    E.call("bn_bwd_reduce", x=xp, dy=dyp, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=ds, dsumxh=dsx, rows=rows, C=C, ld=16, act=1)
+    E.call("bn_bwd_reduce", x=xp, dy=dyp, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=ds, dsumxh=dsx, rows=rows, C=C, ld=16, act=1, xargs=[torch.zeros(1)])
     dx = torch.zeros(rows, 16)
     E.call("bn_bwd_apply", x=xp, dy=dyp, dx=dx, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=ds, dsumxh=dsx, rows=rows, C=C, ld=16, act=1)
     assert torch.allclose(dx[:, :C], x.grad, atol=1e-4)
