@@ -5,8 +5,10 @@
  *
  * Conventions (all entry points):
  *   - return 0 on success, <0 = MTT_E_* argument error, >0 = hipError_t from the launch
- *   - asynchronous on the caller's stream; no allocation, no synchronisation, no global state
- *     (safe under hipGraph capture); every buffer is owned by the caller
+ *   - asynchronous on the caller's stream; no allocation, no synchronisation (safe under hipGraph capture); every buffer,
+ *     including kernel workspaces, is owned by the caller.  No environment variables and no process-global switches: which
+ *     kernel runs is a pure function of the descriptor.  The only process state is a per-device "already configured" bit per
+ *     kernel for the one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) opt-in (idempotent, thread-safe)
  *   - reduction-contiguous GEMM operands (MTT_OP_K) are read in 8-element chunks: when K is not a multiple
  *     of 8 the elements K..pad8(K)-1 of every row must exist and be zero (ld >= pad8(K))
  *   - activations are token-major / NHWC: a feature map is a row-major [rows = B*H*W, channels]
@@ -43,6 +45,11 @@ enum {
 };
 enum { MTT_ACT_NONE = 0, MTT_ACT_GELU = 1, MTT_ACT_RELU = 2, MTT_ACT_GELU_BWD = 3, MTT_ACT_RELU_BWD = 4 };
 enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
+/* kernel selection of mtt_gemm / mtt_attn_fwd: AUTO = the library's policy (a pure function of the descriptor); the other values
+ * force one kernel where it is applicable (benchmarks, A/B measurements).  There is no process-global switch and no environment
+ * variable: the library keeps no mutable state that affects results. */
+enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3 };
+enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1 };
 
 /* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */
 typedef struct {
@@ -92,6 +99,7 @@ typedef struct {
   int32_t n_store;               /* >= N, <= ldd; 0 means N */
   int32_t store_mode;            /* MTT_STORE_PIXSHUF2: n = (dy*2+dx)*Co + co, D is [B,2H,2W,ldd] (ConvTranspose2d k=s=2, taskprompter.py:705) */
   int32_t ps_H, ps_W, ps_Co;
+  int32_t variant;               /* MTT_GEMM_* (0 = AUTO) */
 } mtt_gemm_desc;
 
 int mtt_abi_version(void);
@@ -99,8 +107,6 @@ int mtt_abi_version(void);
  * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
-/* benchmarking aid: force a GEMM kernel variant (0 register-staged 128, 1 LDS-DMA 128, 2 default policy, 3 LDS-DMA 256; -1 = default) */
-void mtt_debug_gemm_variant(int v);
 /* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128, 1 LDS-DMA 128x128, 3 LDS-DMA 256x256 */
 int mtt_gemm_variant(const mtt_gemm_desc* d);
 
@@ -116,6 +122,7 @@ typedef struct {
   int32_t B, N, nH, T;
   int32_t dtype, prec;
   float scale;
+  int32_t variant;   /* MTT_ATTN_* (0 = AUTO: the swapped-product flash kernel for bf16 storage, the plain kernel otherwise) */
 } mtt_attn_desc;
 int mtt_attn_fwd(const mtt_attn_desc* d, void* stream);
 /* Flash backward of mtt_attn_fwd (autograd of taskprompter.py:201-210 / vit.py:184-191), bf16 storage + MTT_PREC_BF16 only
@@ -139,11 +146,13 @@ int mtt_softmax_bwd(const mtt_softmax_desc* d, void* stream);
 
 /* LayerNorm over the last dim C (eps 1e-6 ViT: taskprompter.py:310; 1e-5 InvPT: invpt.py:256).
  * x fp32 [rows, C] (ldx) -> y (y_dtype) [rows, C] (ldy); mean/rstd [rows] fp32 saved for backward.
- * bwd: dx (fp32, ACCUMULATED into dx: dx += ...) , dgamma/dbeta += column sums (fp32 atomics). */
+ * bwd: dx (fp32) = dx_in + dLN/dx   (dx_in: same layout as dx, e.g. the residual-stream gradient the LayerNorm branch joins;
+ *      NULL = accumulate in place, dx += ...), dgamma/dbeta += column sums (fp32 atomics, caller zeroes). */
 typedef struct {
   const float* x; void* y; const float* gamma; const float* beta; float* mean; float* rstd;
   const void* dy; float* dx; float* dgamma; float* dbeta;
   int64_t rows; int32_t C; int64_t ldx, ldy; int32_t y_dtype; float eps;
+  const float* dx_in;
 } mtt_ln_desc;
 int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream);
 int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream);

@@ -22,6 +22,8 @@ PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 STORE_ROWS, STORE_PIXSHUF2 = 0, 1
+GEMM_AUTO, GEMM_GENERAL, GEMM_DMA128, GEMM_DMA256 = 0, 1, 2, 3
+ATTN_AUTO, ATTN_PLAIN = 0, 1
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -51,12 +53,14 @@ class GemmDesc(C.Structure):
         ("resid", ptr), ("ldr", i64), ("r_mb", i32), ("r_bs", i64), ("r_zo", i64), ("r_zi", i64),
         ("n_store", i32), ("store_mode", i32),
         ("ps_H", i32), ("ps_W", i32), ("ps_Co", i32),
+        ("variant", i32),
     ]
 
 
 class AttnDesc(C.Structure):
     _fields_ = [("qkv", ptr), ("out", ptr), ("rawlog", ptr), ("lse", ptr),
-                ("B", i32), ("N", i32), ("nH", i32), ("T", i32), ("dtype", i32), ("prec", i32), ("scale", f32)]
+                ("B", i32), ("N", i32), ("nH", i32), ("T", i32), ("dtype", i32), ("prec", i32), ("scale", f32),
+                ("variant", i32)]
 
 
 class SoftmaxDesc(C.Structure):
@@ -68,7 +72,7 @@ class SoftmaxDesc(C.Structure):
 class LnDesc(C.Structure):
     _fields_ = [("x", ptr), ("y", ptr), ("gamma", ptr), ("beta", ptr), ("mean", ptr), ("rstd", ptr),
                 ("dy", ptr), ("dx", ptr), ("dgamma", ptr), ("dbeta", ptr),
-                ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32)]
+                ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32), ("dx_in", ptr)]
 
 
 class ChanLogitDesc(C.Structure):
@@ -175,7 +179,7 @@ DESC_EXTRA = {
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
 
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_debug_gemm_variant", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 

@@ -191,13 +191,15 @@ def attention_bwd_flash(qkv, ao, lse, dao, drawlog, B, N, nH, T, prec):
     return dqkv
 
 
-def _ln_bwd_into(dres, x, dy, gamma, mean, rstd, eps):
-    """dres += LayerNorm backward of dy (the kernel accumulates into dx): residual-stream gradient updated in place.
-    Returns (dgamma, dbeta)."""
+def _ln_bwd_join(dres, x, dy, gamma, mean, rstd, eps):
+    """-> (dres + LayerNorm backward of dy, dgamma, dbeta): the residual-stream gradient joined with the LayerNorm branch's in the
+    same pass that computes the latter (one read of dres, one write of the sum).  Out of place: `dres` is the grad_output autograd
+    handed to the Function and may be shared with hooks / retain_grad / other consumers, so it is never written."""
     dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
-    ops.call("layernorm_bwd", x=x, dy=dy, gamma=gamma, mean=mean, rstd=rstd, dx=dres, dgamma=dg, dbeta=db,
+    out = torch.empty_like(dres)
+    ops.call("layernorm_bwd", x=x, dy=dy, gamma=gamma, mean=mean, rstd=rstd, dx=out, dx_in=dres, dgamma=dg, dbeta=db,
              rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=eps)
-    return dg, db
+    return out, dg, db
 
 
 class AttnHalfFn(Function):
@@ -205,8 +207,8 @@ class AttnHalfFn(Function):
     residual [-> channel attention on the prompt rows] (taskprompter.py:195-254, :273-276; vit.py:199-202 without prompts).
     Fusing the node removes three [tokens, C] fp32 passes per block that autograd would add: the sum of the two gradients of
     the normalised tokens, the zero-initialised LayerNorm-backward buffer and its sum with the residual gradient — here the
-    channel-attention backward accumulates onto the qkv dgrad output, and the LayerNorm backward accumulates straight into
-    the incoming residual gradient."""
+    channel-attention backward accumulates onto the qkv dgrad output, and the LayerNorm backward adds the incoming
+    residual gradient in the pass that produces the branch gradient."""
 
     @staticmethod
     def forward(ctx, XT, g1, b1, eps, Wqkv, bqkv, Wproj, bproj, Wtt, btt, Wtt1, btt1, rowscale, geo, prec, tag):
@@ -277,8 +279,8 @@ class AttnHalfFn(Function):
             _gemm(dcq, wt[0], dp, B * T, C, hw, prec, b_op=OP_R, lda=hwp, ldb=wt.shape[-1], ldd=C, d_mb=T, d_bs=N * C,
                   resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
         # ---- norm1 backward accumulated into the residual gradient ------------------------------------------------
-        dg1, db1 = _ln_bwd_into(dXT2, XT, dxn, g1, mean, rstd, ctx.eps)
-        return (dXT2, dg1, db1, None, dWqkv, dbqkv, dWproj, dbproj, dWtt, dbtt, dWtt1, dbtt1, None, None, None, None)
+        dXT, dg1, db1 = _ln_bwd_join(dXT2, XT, dxn, g1, mean, rstd, ctx.eps)
+        return (dXT, dg1, db1, None, dWqkv, dbqkv, dWproj, dbproj, dWtt, dbtt, dWtt1, dbtt1, None, None, None, None)
 
 
 class MlpHalfFn(Function):
@@ -314,8 +316,8 @@ class MlpHalfFn(Function):
         dz = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
         dW1, db1 = _enc_wgrad(dz, xn2, Hd, C, prec)
         dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
-        dg2, dbn2 = _ln_bwd_into(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps)
-        return dXT3, dg2, dbn2, None, dW1, db1, dW2, db2, None, None, None, None
+        dXT2, dg2, dbn2 = _ln_bwd_join(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps)
+        return dXT2, dg2, dbn2, None, dW1, db1, dW2, db2, None, None, None, None
 
 
 class PatchEmbedFn(Function):

@@ -241,12 +241,8 @@ template <bool X3, bool F32>
 int launch_attn(const AttnP& p, hipStream_t s) {
   constexpr int NPL = X3 ? 2 : 1;
   constexpr int smem = 2 * (KTILE * 2 * NPL) + 4 * (16 * KV * 2) * NPL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<X3, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)attn_fwd_kernel<X3, F32>, smem, done)) return e;
   dim3 grid((unsigned)(((p.d.N + QB - 1) / QB) * p.d.nH * p.d.B));
   hipLaunchKernelGGL((attn_fwd_kernel<X3, F32>), grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
@@ -261,8 +257,7 @@ extern "C" int mtt_attn_fwd(const mtt_attn_desc* dd, void* stream) {
   if (dd->B <= 0 || dd->N <= 0 || dd->nH <= 0 || dd->T < 0 || dd->T > 16) return MTT_E_BADARG;
   if (dd->prec == MTT_PREC_X3 && dd->dtype != MTT_F32) return MTT_E_UNSUPPORTED;
   if ((uintptr_t)dd->qkv & 15) return MTT_E_ALIGN;
-  static const bool fast = []() { const char* e = getenv("MTT_ATTN_FAST"); return !(e && e[0] == '0'); }();
-  if (fast && dd->prec == MTT_PREC_BF16 && dd->dtype == MTT_BF16 && !((uintptr_t)dd->out & 15))
+  if (dd->variant != MTT_ATTN_PLAIN && dd->prec == MTT_PREC_BF16 && dd->dtype == MTT_BF16 && !((uintptr_t)dd->out & 15))
     return mtt_attn_fwd_fast(dd, (hipStream_t)stream);
   AttnP p; p.d = *dd;
   if (dd->prec == MTT_PREC_X3) return launch_attn<true, true>(p, (hipStream_t)stream);

@@ -390,14 +390,9 @@ extern "C" int mtt_attn_bwd(const mtt_attn_desc* d, const void* dout, const floa
   if (((uintptr_t)d->qkv | (uintptr_t)dout | (uintptr_t)d->out | (uintptr_t)stat | (uintptr_t)dqkv) & 15) return MTT_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   constexpr int smem_dq = 2 * 3 * KTILE, smem_dkv = 2 * 4 * KTILE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> done_dq{0}, done_dkv{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)attn_bwd_dq_kernel, smem_dq, done_dq)) return e;
+  if (int e = mtt_ensure_dyn_lds((const void*)attn_bwd_dkv_kernel, smem_dkv, done_dkv)) return e;
   const int Np = (d->N + 3) & ~3;
   const int64_t chunks = (int64_t)d->B * d->N * d->nH * 8;
   hipLaunchKernelGGL(attn_stat_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const bf16_t*)d->out, (const bf16_t*)dout,

@@ -8,7 +8,6 @@
 // double buffered with one barrier per K step, fragment reads are swizzled conflict-free
 // ds_read_b128.  Blocks are remapped so consecutive tiles of one XCD share A rows in its L2.
 #include "mtt_device.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -572,12 +571,8 @@ __global__ __launch_bounds__(256, 1) void gemm_fast_kernel(const GemmP p) {
 
 int launch_fast(const GemmP& p, hipStream_t stream) {
   constexpr int smem = TILE_BYTES * 2 * FSTAGES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_fast_kernel, smem, done)) return e;
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.d.batch);
   hipLaunchKernelGGL(gemm_fast_kernel, grid, dim3(256), smem, stream, p);
   return (int)hipGetLastError();
@@ -665,12 +660,8 @@ __global__ __launch_bounds__(512, 1) void gemm_fast256_kernel(const GemmP p) {
 
 int launch_fast256(const GemmP& p, hipStream_t stream) {
   constexpr int smem = TILE2 * 2 * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fast256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_fast256_kernel, smem, done)) return e;
   const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + BN2 - 1) / BN2;
   dim3 grid(tm * tn, 1, p.d.batch);
   hipLaunchKernelGGL(gemm_fast256_kernel, grid, dim3(512), smem, stream, p);
@@ -688,22 +679,14 @@ FastDiv make_div(uint32_t dv) {
 template <int AOP, int BOP, int MODE>
 int launch(const GemmP& p, hipStream_t stream) {
   constexpr int smem = TILE_BYTES * 2 * (MODE == 2 ? 2 : 1) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<AOP, BOP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_kernel<AOP, BOP, MODE>, smem, done)) return e;
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.d.batch);
   hipLaunchKernelGGL((gemm_kernel<AOP, BOP, MODE>), grid, dim3(256), smem, stream, p);
   return (int)hipGetLastError();
 }
 
 }  // namespace
-
-static int g_fast_override = -1;
-/* debug / benchmarking only: select the GEMM variant at run time (-1 = default policy) */
-extern "C" void mtt_debug_gemm_variant(int v) { g_fast_override = v; }
 
 extern "C" int mtt_abi_version(void) { return MTT_ABI_VERSION; }
 
@@ -731,10 +714,10 @@ extern "C" size_t mtt_desc_size(int which) {
   }
 }
 
-// 0 = register-staged 128 tile (general), 1 = LDS-DMA 128 tile, 3 = LDS-DMA 256 tile
+// 0 = register-staged 128 tile (general), 1 = LDS-DMA 128 tile, 3 = LDS-DMA 256 tile.  Pure function of the descriptor:
+// d.variant = MTT_GEMM_AUTO applies the library's policy, any other value forces that kernel where it is applicable.
 static int gemm_variant_for(const mtt_gemm_desc& d) {
-  static const int fast_env = []() { const char* e = getenv("MTT_GEMM_FAST"); return e ? atoi(e) : 2; }();
-  const int fast_mode = g_fast_override >= 0 ? g_fast_override : fast_env;
+  const int fast_mode = d.variant == MTT_GEMM_AUTO ? 2 : (d.variant == MTT_GEMM_GENERAL ? 0 : (d.variant == MTT_GEMM_DMA128 ? 1 : 3));
   const bool plain = d.prec == MTT_PREC_BF16 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16 &&
                      d.b_dtype == MTT_BF16;
   if (!plain || fast_mode == 0) return 0;
@@ -777,8 +760,7 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   p.divPsW = make_div(d.ps_W > 0 ? d.ps_W : 1); p.divPsH = make_div(d.ps_H > 0 ? d.ps_H : 1);
   p.divPsCo = make_div(d.ps_Co > 0 ? d.ps_Co : 1);
   p.tiles_m = (d.M + BM - 1) / BM; p.tiles_n = (d.N + BN - 1) / BN;
-  static const int gm_env = []() { const char* e = getenv("MTT_GEMM_GROUP_M"); return e ? atoi(e) : 4; }();
-  p.group_m = gm_env < 1 ? 1 : gm_env;
+  p.group_m = 4;
   hipStream_t s = (hipStream_t)stream;
   int mode;
   if (d.prec == MTT_PREC_X3) mode = 2;

@@ -10,7 +10,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "mtt_hip.h"
+
+// Host: opt a kernel in to more than 64 KiB of dynamic LDS, once per device (the attribute is per device, and a process may
+// drive several).  `done` is a per-call-site bit mask of devices already configured: a cache of an idempotent setup call, safe
+// under concurrent first use (two threads may both set the attribute; the result is the same).
+static inline int mtt_ensure_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
 
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

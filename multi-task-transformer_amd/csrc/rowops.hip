@@ -74,10 +74,11 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const mtt_ln_desc d) {
   }
   s1 = wave_sum(s1) / d.C; s2 = wave_sum(s2) / d.C;
   float* dx = d.dx + row * d.ldx;
+  const float* din = (d.dx_in ? d.dx_in : d.dx) + row * d.ldx;
   for (int c = lane; c < d.C; c += 64) {
     const float xh = (x[c] - mean) * rstd;
     const float g = ld_elem(d.dy, row * d.ldy + c, d.y_dtype) * d.gamma[c];
-    dx[c] += rstd * (g - s1 - xh * s2);
+    dx[c] = din[c] + rstd * (g - s1 - xh * s2);
   }
 }
 
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, 
       const int c4 = lane + 64 * k;
       if (c4 < C4) {
         float4* dx = (float4*)(d.dx + row * d.ldx + c4 * 4);
-        float4 o = *dx;
+        float4 o = *(const float4*)((d.dx_in ? d.dx_in : d.dx) + row * d.ldx + c4 * 4);
         o.x += rstd * (g[k].x - s1 - xh[k].x * s2); o.y += rstd * (g[k].y - s1 - xh[k].y * s2);
         o.z += rstd * (g[k].z - s1 - xh[k].z * s2); o.w += rstd * (g[k].w - s1 - xh[k].w * s2);
         *dx = o;
@@ -1068,7 +1069,7 @@ extern "C" int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream) {
 extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
   if (!d || !d->x || !d->dy || !d->gamma || !d->mean || !d->rstd || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
   if (d->C > 8192 || (d->C % 4) || (d->ldx % 4)) return MTT_E_UNSUPPORTED;
-  if (d->dx && d->dgamma && d->dbeta && d->C <= 1024 && (d->ldy % 4) == 0 && !(((uintptr_t)d->x | (uintptr_t)d->dx | (uintptr_t)d->dy) & 15)) {
+  if (d->dx && d->dgamma && d->dbeta && d->C <= 1024 && (d->ldy % 4) == 0 && !(((uintptr_t)d->x | (uintptr_t)d->dx | (uintptr_t)d->dy | (uintptr_t)d->dx_in) & 15)) {
     int64_t nblk = (d->rows + 63) / 64; if (nblk > 2048) nblk = 2048;
     const int rpb = (int)((d->rows + nblk - 1) / nblk);
     nblk = (d->rows + rpb - 1) / rpb;

@@ -261,7 +261,7 @@ def layernorm_bwd(**kw):
     if kw.get("dx") is not None:
         dx = rstd * (gm - gm.mean(-1, keepdim=True) - xh * (gm * xh).mean(-1, keepdim=True))
         idx = r * kw["ldx"] + c
-        _wr(kw["dx"], idx, _rd(kw["dx"], idx) + dx)
+        _wr(kw["dx"], idx, _rd(kw["dx_in"] if kw.get("dx_in") is not None else kw["dx"], idx) + dx)
     if kw.get("dgamma") is not None:
         ci = torch.arange(Cn)
         _wr(kw["dgamma"], ci, _rd(kw["dgamma"], ci) + (dy * xh).sum(0))

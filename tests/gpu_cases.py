@@ -264,6 +264,8 @@ def row_cases():
             kw = dict(x=x, dy=rnd(g, rows2, C2, dtype=DT[ydt]), gamma=rnd(g, C2), mean=mean, rstd=rstd, dx=rnd(g, rows2, C2),
                       dgamma=torch.zeros(C2), dbeta=torch.zeros(C2), rows=rows2, C=C2, ldx=C2, ldy=C2, y_dtype=ydt, eps=1e-6)
             cases.append((f"ln_bwd_{ydt}_C{C2}", "layernorm_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
+            kw = dict(kw, dx=torch.full((rows2, C2), 3.0), dx_in=rnd(g, rows2, C2), dgamma=torch.zeros(C2), dbeta=torch.zeros(C2))
+            cases.append((f"ln_bwd_join_{ydt}_C{C2}", "layernorm_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
     for sdt in (F32, BF16):
         rows, cols, ld = 50, 77, 80
         kw = dict(S=rnd(g, rows, ld, dtype=DT[sdt]), P=torch.full((rows, ld), 9.0, dtype=DT[sdt]), rows=rows, cols=cols, ld=ld,

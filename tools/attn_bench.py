@@ -1,5 +1,5 @@
 """Micro-benchmark of the attention kernels through the C ABI (HIP-event timed).  Usage: python tools/attn_bench.py [B] [N] [nH] [T]
-Set MTT_ATTN_FAST=0 for the straightforward forward kernel."""
+MTT_ATTN_PLAIN=1 forces the straightforward forward kernel (mtt_attn_desc.variant)."""
 import os
 import sys
 
@@ -12,6 +12,9 @@ from mtt_amd import ops  # noqa: E402
 B, N, nH, T = [int(a) for a in sys.argv[1:5]] + [40, 1030, 16, 6][len(sys.argv) - 1:]
 C = nH * 64
 prec = ops.Prec("bf16")
+if os.environ.get("MTT_ATTN_PLAIN") == "1":
+    _call = ops.call
+    ops.call = lambda name, **kw: _call(name, **(dict(kw, variant=1) if name == "attn_fwd" else kw))
 dev = torch.device("cuda")
 qkv = (torch.randn(B * N, 3 * C, device=dev) * 1.0).to(torch.bfloat16)
 dao = torch.randn(B * N, C, device=dev).to(torch.bfloat16)
@@ -44,5 +47,5 @@ def bwd():
 
 t_b = timed(bwd)
 gf = 4.0 * N * N * 64 * nH * B / 1e9
-print(f"attention B={B} N={N} nH={nH} T={T} fast={os.environ.get('MTT_ATTN_FAST', '1')}: fwd {t_f * 1e3:.0f} us = {gf / t_f:.0f} TFLOP/s (2 GEMMs);"
+print(f"attention B={B} N={N} nH={nH} T={T} plain={os.environ.get('MTT_ATTN_PLAIN', '0')}: fwd {t_f * 1e3:.0f} us = {gf / t_f:.0f} TFLOP/s (2 GEMMs);"
       f"  bwd {t_b * 1e3:.0f} us = {2.5 * gf / t_b:.0f} TFLOP/s (5 GEMMs algorithmic)")

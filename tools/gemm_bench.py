@@ -9,15 +9,16 @@ import torch  # noqa: E402
 import mtt_amd  # noqa: E402
 from mtt_amd import ops  # noqa: E402
 
-lib = mtt_amd._lib.load()
-lib.mtt_debug_gemm_variant.argtypes = [__import__("ctypes").c_int]
+_call = ops.call
+FORCE = {"v": 0}
+ops.call = lambda name, **kw: _call(name, **(dict(kw, variant=FORCE["v"]) if name == "gemm" else kw))     # mtt_gemm_desc.variant
 prec = ops.Prec("bf16")
 SHAPES = [("qkv", 8240, 3072, 1024), ("proj", 8240, 1024, 1024), ("fc1", 8240, 4096, 1024), ("fc2", 8240, 1024, 4096),
           ("big", 8192, 8192, 8192), ("fc1_b16", 16480, 4096, 1024)]
 
 
 def bench(M, N, K, variant, iters=20):
-    lib.mtt_debug_gemm_variant(variant)
+    FORCE["v"] = variant
     x = torch.randn(M, K, device="cuda").bfloat16()
     w = torch.randn(1, N, K, device="cuda").bfloat16()
     out = torch.empty(1, M, N, device="cuda", dtype=torch.bfloat16)
@@ -36,8 +37,7 @@ def bench(M, N, K, variant, iters=20):
 
 for name, M, N, K in SHAPES:
     row = [f"{name:8s} M={M:6d} N={N:5d} K={K:5d}"]
-    for v, vn in ((0, "reg128"), (1, "dma128"), (3, "dma256")):
+    for v, vn in ((1, "reg128"), (2, "dma128"), (3, "dma256")):
         tf, ms = bench(M, N, K, v)
         row.append(f"{vn} {tf:7.1f} TF/s ({ms * 1e3:7.1f} us)")
     print("  ".join(row), flush=True)
-lib.mtt_debug_gemm_variant(-1)
