@@ -1,14 +1,22 @@
-"""-m gpu: BASELINE.json's full-size configuration (TaskPrompter ViT-L/16, 512x512, 6 tasks) checked through size-independent
-properties — the CPU oracle needs minutes per image at this size, so instead of an element-wise comparison:
+"""-m gpu: BASELINE.json's full-size configuration (TaskPrompter ViT-L/16, 512x512, 6 tasks, N = 1030 tokens, 16 heads).
 
+Element-wise against the CPU oracle / the fp64 ABI emulator at the benchmarked shape:
+  * one training step in the BENCHMARKED mode (bf16: flash attention forward + backward, LDS-DMA GEMMs, implicit-GEMM convs):
+    outputs and every parameter gradient vs the oracle's autograd (B = 2),
+  * the flash attention kernels alone at (B = 2, N = 1030, nH = 16, T = 6) — eight 128-row tiles + the 6-row tail, XCD remap — and
+    at N = 8194 (cfg5's sequence length), forward and backward, vs the fp64 emulator; plus an online-softmax spike in the tail tile,
+  * the LDS-DMA bf16 GEMM / conv kernels vs the independently parity-gated x3 kernels at the bench's shapes.
+(The eval forward of every BASELINE config vs the oracle is in test_gpu_configs.py.)
+Size-independent properties:
   * eval-mode batch invariance: an image's prediction does not depend on what else is in the batch,
-  * the two arithmetic modes (bf16 throughput path, x3 fp32-parity path) agree to bf16 accuracy on every task head,
   * the hand-written backward is the derivative of the forward: a central finite difference of the real MultiTaskLoss along a
     random parameter direction matches <grad, direction> (x3 mode, train-mode BatchNorm, DropPath off).
-The miniature configurations are compared element-wise against the oracle / golden fixtures in test_gpu_model.py / test_gpu_train.py.
 """
 import pytest
 import torch
+
+import conftest
+import parity_util as pu
 
 
 def _build(prec, seed=0):
@@ -81,3 +89,113 @@ def test_fullsize_backward_is_the_derivative_of_forward():
 
     numeric = (shifted(+1) - shifted(-1)) / (2 * eps)
     assert abs(numeric - analytic) <= 3e-2 * max(abs(analytic), abs(numeric)) + 1e-4, (numeric, analytic, float(base.detach()))
+
+
+@pytest.mark.gpu
+def test_ns6_training_step_bf16_matches_oracle_autograd():
+    """The benchmarked mode end to end at the benchmarked shape: train-mode forward (batch-statistic BN) + hand-written backward
+    (flash attention backward, fast256 dgrad / transposed wgrad, conv dgrad / wgrad) vs the oracle's autograd on the host."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    from oracle import taskprompter_oracle as tpo
+    from tests.golden.make_golden import loss_of
+    cfg, sd, x, _ = pu.oracle_eval("ns6", 2)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    t0 = time.time()
+    ref_out = tpo.forward(dict(sd, **params), cfg, x, training=True)
+    loss_of(ref_out).backward()
+    pu.report("oracle_time", config="ns6 train fwd+bwd", batch=2, seconds=round(time.time() - t0, 1))
+    for prec, ftol, mtol in (("bf16", 4e-2, 6e-2), ("x3", 1e-3, 2e-3)):
+        model = conftest.build_product_model(cfg, prec, "cuda")
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        out = model(x.cuda())
+        loss_of({k: v.cpu() for k, v in out.items()}).backward()
+        fwd = {t: pu.rel(out[t].detach(), ref_out[t].detach()) for t in ref_out}
+        rels = []
+        for k, prm in model.named_parameters():
+            ref = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+            assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+            n = float(ref.norm())
+            if n > 1e-6:
+                rels.append((float((prm.grad.cpu() - ref).norm()) / n, k))
+        rels.sort(reverse=True)
+        med = rels[len(rels) // 2][0]
+        pu.report("train_parity", config="ns6", batch=2, prec=prec, fwd_worst=max(fwd.values()), grad_median=med, grad_worst=rels[0][0],
+                  grad_worst_param=rels[0][1], grad_p90=rels[len(rels) // 10][0], per_head=fwd)
+        assert max(fwd.values()) < ftol, fwd
+        assert med < mtol, (med, rels[:3])
+        del model, out
+        torch.cuda.empty_cache()
+
+
+def _attn_inputs(B, N, nH, seed, spike=None):
+    g = torch.Generator().manual_seed(seed)
+    C = nH * 64
+    qkv = torch.randn(B * N, 3 * C, generator=g)
+    if spike is not None:                      # one key row that dominates one query row's scores: the running max jumps at that tile
+        qrow, krow = spike
+        qkv[krow, C:C + 64] = qkv[qrow, :64] * 6.0
+    return qkv.to(torch.bfloat16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,nH,T,spike", [(2, 1030, 16, 6, None), (1, 1030, 2, 6, (1027, 1029)), (1, 8194, 2, 2, None)],
+                         ids=["ns6_shape", "ns6_tail_spike", "cfg5_seq"])
+def test_flash_attention_kernels_at_full_size(B, N, nH, T, spike):
+    """mtt_attn_fwd (swapped-product flash kernel) and mtt_attn_bwd vs the fp64 emulator at the benchmarked sequence lengths."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gpu_cases
+    from oracle import abi_emul
+    C = nH * 64
+    qkv = _attn_inputs(B, N, nH, 31, spike)
+    fw = dict(qkv=qkv, out=torch.zeros(B * N, C, dtype=torch.bfloat16), rawlog=torch.zeros(B, nH, T, N), lse=torch.zeros(B, nH, N),
+              B=B, N=N, nH=nH, T=T, dtype=1, prec=0, scale=0.125)
+    r = gpu_cases.run_case("attn_fwd", fw, None, dict(f32=2e-3, bf16=6e-3))
+    pu.report("kernel_parity", kernel="attn_fwd_fast", B=B, N=N, nH=nH, T=T, errs={k: v[0] if isinstance(v, tuple) else v for k, v in r["errs"].items()})
+    assert r["ok"], r["errs"]
+    g = torch.Generator().manual_seed(32)
+    kw = dict(qkv=qkv, out=fw["out"], rawlog=None, lse=fw["lse"], B=B, N=N, nH=nH, T=T, dtype=1, prec=0, scale=0.125,
+              xargs=[torch.randn(B * N, C, generator=g).to(torch.bfloat16), torch.randn(B, nH, T, N, generator=g) * 0.05,
+                     torch.zeros(B * N, 3 * C, dtype=torch.bfloat16), torch.zeros(B, nH, 2, (N + 3) // 4 * 4)])
+    r = gpu_cases.run_case("attn_bwd", kw, None, dict(f32=5e-3, bf16=1.5e-2))
+    pu.report("kernel_parity", kernel="attn_bwd", B=B, N=N, nH=nH, T=T, errs={k: v[0] if isinstance(v, tuple) else v for k, v in r["errs"].items()})
+    assert r["ok"], r["errs"]
+
+
+@pytest.mark.gpu
+def test_dma_gemm_and_conv_kernels_agree_with_x3_at_bench_shapes():
+    """The bf16 LDS-DMA GEMM (fast256) and the bf16 implicit-GEMM conv at the shapes of the benchmarked step against the x3 kernels
+    (fp32-class, parity-gated against the emulator and the oracle) on the same bf16-representable operands: what remains is fp32
+    accumulation order and the bf16 rounding of the output."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mtt_amd
+    ops = mtt_amd.ops
+    bf, x3 = ops.Prec("bf16"), ops.Prec("x3")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for tag, M, N, K in (("qkv", 8 * 1030, 3072, 1024), ("fc1", 8 * 1030, 4096, 1024), ("fc2", 8 * 1030, 1024, 4096), ("proj", 8 * 1030, 1024, 1024)):
+        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        w = (torch.randn(1, N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        b = torch.randn(1, N, device="cuda", generator=g)
+        assert mtt_amd._lib.gemm_variant(A=x, B=w, D=x, M=M, N=N, K=K, a_dtype=1, b_dtype=1, d_dtype=1, prec=0, lda=K, ldb=K, ldd=N, batch=1) == 3
+        y16 = ops.linear(x, w, N, bf, bias=b, out_dtype=torch.float32)
+        y32 = ops.linear(x.float(), w.float(), N, x3, bias=b)
+        e = pu.rel(y16, y32)
+        pu.report("kernel_parity", kernel="gemm_fast256", shape=tag, M=M, N=N, K=K, rel=e)
+        assert e < 2e-5, (tag, e)
+    B, H, W, F = 4, 128, 128, 350
+    Fp = ops.pad8(F)
+    xin = torch.zeros(2, B * H * W, Fp, device="cuda")
+    xin[..., :F] = torch.randn(2, B * H * W, F, device="cuda", generator=g)
+    xin = xin.bfloat16()
+    ws = [torch.nn.Parameter(torch.randn(F, F, 3, 3, device="cuda", generator=g) / (9 * F) ** 0.5) for _ in range(2)]
+    for wt in ws:
+        wt.data = wt.data.bfloat16().float()
+    y16 = ops.conv3x3(xin, ops.pack_conv3(ws, bf, "t16"), F, F, B, H, W, bf, out_dtype=torch.float32)
+    y32 = ops.conv3x3(xin.float(), ops.pack_conv3(ws, x3, "t32"), F, F, B, H, W, x3)
+    e = pu.rel(y16[..., :F], y32[..., :F])
+    pu.report("kernel_parity", kernel="conv3x3_bf16", shape="head conv 350ch 128x128", rel=e)
+    assert e < 2e-5, e
