@@ -1,16 +1,23 @@
 """Headline benchmark: training images/sec of the TaskPrompter ViT-L hot path, 512x512, 6 tasks (BASELINE.json),
 on N MI355X of one node (one process per GPU; RCCL all-reduce of gradients over xGMI via DistributedDataParallel).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config ns6|cfg2|cfg3|cfg4|cfg5] [--prec bf16|x3] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = forward + MultiTaskLoss + backward (+ gradient all-reduce) + clip_grad_norm_ + Adam step on one synthetic batch
-that is already resident in HBM (TaskPrompter/utils/train_utils.py:32-51).  Weak scaling: the per-GPU batch is fixed.
-Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     — the dominant kernel (`gemm_fast256_kernel`, the 256x256x64 bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time,
-                 measured in one extra instrumented step right after the timed region (keeps event overhead out of `value`)
+that is already resident in HBM (TaskPrompter/utils/train_utils.py:32-51), including the re-packing of every weight the optimizer
+changed.  Weak scaling: the per-GPU batch is fixed.  Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     — the dominant kernel (the 256-row LDS-DMA bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time, measured in one extra
+                 instrumented step right after the timed region (keeps event overhead out of `value`); `traffic` = HBM bytes per
+                 launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, tools/pmc_traffic.py)
+  parity       — the benchmarked arithmetic mode and its worst per-head relative error against the x3 (fp32-class) mode on this
+                 model and 2 of these images (x3 itself is gated at <= 1e-3 vs the CPU oracle, tests/test_gpu_configs.py)
+  ref_batch    — the same step at the reference's own per-GPU batch (trBatch: 2)
   cpu_baseline — the CPU oracle (restatement of the reference, `kind: "port"`) timed on this box's host cores on a
                  bounded sample of the same workload (rank 0, N = 1 only)
+
+`--config` selects the other BASELINE.json configurations (cfg2..cfg5) for their own img/s + roofline lines; the driver's default
+(no flag) is the metric's configuration, NS-6.
 """
 import argparse
 import json
@@ -24,8 +31,33 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-GFLOP_FWD_PER_IMG = 1046.8          # NS-6 algorithmic forward GFLOP / image (SURVEY.md §8d closed form)
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+PASCAL5 = ["semseg", "human_parts", "sal", "normals", "edge"]
+PASCAL6 = ["semseg", "depth", "human_parts", "sal", "normals", "edge"]      # TaskPrompter/utils/config.py:30-87 order
+# name -> (description, make_p kwargs, image size, default per-GPU batch, algorithmic forward GFLOP / image (SURVEY.md §8d closed form))
+CONFIGS = {
+    "ns6": ("TaskPrompter ViT-L/16 (taskprompter_vit_large_patch16_384), PASCAL-Context 5 tasks + depth = 6 tasks, 512x512, ConvHead, "
+            "embed 300/350, ctr; random-init weights",
+            dict(tasks=PASCAL6, backbone="TaskPrompter_vitL", head="conv", embed_dim=300, final_embed_dim=350, chan_nheads=1, use_ctr=True),
+            (512, 512), 63, 1046.8),
+    "cfg2": ("TaskPrompter ViT-B/16, PASCAL-Context 5 tasks, 512x512, ConvHead, embed 780/1024, 4x4 channel windows, ctr (pascal_vitBp16_taskprompter.yml)",
+             dict(tasks=PASCAL5, backbone="TaskPrompter_vitB", head="conv", embed_dim=780, final_embed_dim=1024, chan_nheads=16, use_ctr=True),
+             (512, 512), 24, 2306.7),
+    "cfg3": ("TaskPrompter ViT-L/16, NYUD-v2 4 tasks, 448x576, ConvHead, embed 768/768, 4x4 channel windows, no ctr (nyud_vitLp16_taskprompter.yml)",
+             dict(tasks=["semseg", "depth", "normals", "edge"], backbone="TaskPrompter_vitL", head="conv", embed_dim=768, final_embed_dim=768,
+                  chan_nheads=16, use_ctr=False, num_output=dict(semseg=40)),
+             (448, 576), 24, 1679.3),
+    "cfg4": ("InvPT ViT-L/16 (vit_large_patch16_384 + TransformerDecoder + MLPHead), PASCAL-Context 5 tasks + depth = 6 tasks, 512x512, "
+             "embed 512 + 64, intermediate supervision (pascal_vitLp16.yml)",
+             dict(tasks=PASCAL6, model="TransformerNet", backbone="vitL", head="mlp", embed_dim=512, PRED_OUT_NUM_CONSTANT=64,
+                  mtt_resolution_downsample_rate=2, intermediate_supervision=True),
+             (512, 512), 32, 1465.4),
+    "cfg5": ("TaskPrompter ViT-L/16, Cityscapes semseg(19) + depth, 1024x2048 (N = 8194 tokens), DEConvHead, embed 300/350, ctr",
+             dict(tasks=["semseg", "depth"], backbone="TaskPrompter_vitL", head="deconv", embed_dim=300, final_embed_dim=350, chan_nheads=1,
+                  use_ctr=True, num_output=dict(semseg=19)),
+             (1024, 2048), 4, 12543.0),
+}
 
 
 def parse():
@@ -33,13 +65,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=63,
-                    help="per-GPU batch (weak scaling).  63*1030 token rows = 254 row tiles of 256, so the N=1024/3072/4096 encoder GEMMs launch "
-                         "1016/3048/4064 workgroups = 3.97/11.9/15.9 full rounds of the 256 CUs (batch 40 left the last round half empty); 93 GB of HBM")
+    ap.add_argument("--config", default="ns6", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0,
+                    help="per-GPU batch (weak scaling); 0 = the config's default.  ns6: 63*1030 token rows = 254 row tiles of 256, so the "
+                         "N=1024/3072/4096 encoder GEMMs launch 3.97/11.9/15.9 full rounds of the 256 CUs; 93 GB of HBM")
     ap.add_argument("--prec", default="bf16", choices=["bf16", "x3"])
+    ap.add_argument("--bucket-mb", type=int, default=100, help="DDP gradient bucket size (MB)")
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
+                    help="gradient all-reduce payload: fp32 (reference semantics) or bf16-compressed (halves the xGMI bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-ref-batch", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
     return ap.parse_args()
 
@@ -53,7 +91,7 @@ class GemmTimer:
 
     def __enter__(self):
         def hooked(name, **kw):
-            if name == "gemm" and self.variant_of(**kw) == 3:          # the dominant kernel: gemm_fast256_kernel
+            if name == "gemm" and self.variant_of(**kw) == 3:          # the dominant kernel: 256-row LDS-DMA MFMA GEMM
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self.orig(name, **kw)
@@ -74,44 +112,85 @@ class GemmTimer:
         return flops, ms, len(self.rec)
 
 
-def _cpu_baseline_worker(batch, threads, q):
+def build(cfg_name, prec, mtt_amd):
+    desc, kw, size, _, _ = CONFIGS[cfg_name]
+    kw = dict(kw)
+    p = mtt_amd.factory.make_p(kw.pop("tasks"), size, prec=prec, **kw)
+    return p, mtt_amd.factory.get_model(p)
+
+
+def _cpu_baseline_worker(cfg_name, batch, threads, q):
     """Runs in a subprocess: oracle (CPU restatement of the reference) forward + loss + backward on a bounded sample."""
     import torch as T
     T.set_num_threads(threads)
-    from oracle import configs, taskprompter_oracle as tpo, weights
+    from oracle import configs, weights
     import mtt_amd
-    cfg = dict(configs.taskprompter("ns6"))
-    p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (512, 512), backbone="TaskPrompter_vitL", head="conv")
-    model = mtt_amd.factory.get_model(p)                         # only for the state-dict contract (names, shapes)
+    okey = {"ns6": "ns6", "cfg2": "cfg2", "cfg3": "cfg3", "cfg4": "cfg4_6", "cfg5": "cfg5"}[cfg_name]
+    invpt = cfg_name == "cfg4"
+    cfg = dict(configs.invpt(okey) if invpt else configs.taskprompter(okey))
+    p, model = build(cfg_name, "x3", mtt_amd)                     # only for the state-dict contract (names, shapes)
     contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
     del model
     sd = weights.synth_state_dict(contract, 0)
     params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
     x = weights.synth_images(batch, cfg["img_size"], 1)
     crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)
-    gt = mtt_amd.losses.synthetic_targets(p, batch, 512, 512, "cpu")
-    t0 = time.time()
-    out = tpo.forward(dict(sd, **params), cfg, x, training=True)
-    crit(out, gt)["total"].backward()
-    q.put(time.time() - t0)
+    gt = mtt_amd.losses.synthetic_targets(p, batch, cfg["img_size"][0], cfg["img_size"][1], "cpu")
+    if invpt:
+        from oracle import invpt_oracle as orc
+    else:
+        from oracle import taskprompter_oracle as orc
+    times = []
+    for _ in range(2):                                            # one warm-up (allocator, thread pool), one timed
+        for v in params.values():
+            v.grad = None
+        t0 = time.time()
+        out = orc.forward(dict(sd, **params), cfg, x, training=True)
+        crit(out, gt)["total"].backward()
+        times.append(time.time() - t0)
+    q.put(times)
 
 
-def cpu_baseline(batch, threads=16, limit_s=150):
+def cpu_baseline(cfg_name, batch, threads=16, limit_s=240):
     """images/s of one oracle training step on `threads` host cores; bounded by a subprocess timeout."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    pr = ctx.Process(target=_cpu_baseline_worker, args=(batch, threads, q))
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(cfg_name, batch, threads, q))
     pr.start()
     pr.join(limit_s)
+    host = dict(host_cores=os.cpu_count(), host_cpu=_cpu_model())
     if pr.is_alive():
         pr.terminate()
         pr.join()
-        return dict(value=None, unit="images/s", cores=threads, kind="port",
-                    sample=f"1 oracle training step at batch {batch} did not finish within {limit_s} s on {threads} threads")
-    dt = q.get(timeout=5)
-    return dict(value=batch / dt, unit="images/s", cores=threads, kind="port",
-                sample=f"1 training step (fwd+loss+bwd, no optimizer) of the same config at batch {batch} on the CPU oracle, {dt:.1f} s")
+        return dict(value=None, unit="images/s", cores=threads, kind="port", **host,
+                    sample=f"2 oracle training steps at batch {batch} did not finish within {limit_s} s on {threads} threads")
+    warm, dt = q.get(timeout=5)
+    return dict(value=batch / dt, unit="images/s", cores=threads, kind="port", **host,
+                sample=f"1 training step (fwd+loss+bwd, no optimizer) of the same config at batch {batch} on the CPU oracle after one warm-up "
+                       f"step ({warm:.1f} s): {dt:.1f} s on {threads} of {os.cpu_count()} host threads")
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if kernel_substr not in rec.get("kernel", ""):
+        return None, None
+    return rec.get("hbm_bytes_per_launch"), rec.get("source")
 
 
 def main():
@@ -125,32 +204,38 @@ def main():
         dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
     import mtt_amd
 
-    p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (512, 512), backbone="TaskPrompter_vitL", head="conv",
-                               embed_dim=300, final_embed_dim=350, chan_nheads=1, use_ctr=True, prec=a.prec)
+    desc, _, (H, W), dflt_batch, gflop_fwd = CONFIGS[a.config]
+    batch = a.batch or dflt_batch
     torch.manual_seed(0)
-    model = mtt_amd.factory.get_model(p)
+    p, model = build(a.config, a.prec, mtt_amd)
     if world > 1:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)          # TaskPrompter/main.py:92
     model = model.to(dev).train()
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
-                                                        gradient_as_bucket_view=True, bucket_cap_mb=100)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=a.config == "cfg4",
+                                                        gradient_as_bucket_view=True, bucket_cap_mb=a.bucket_mb)
+        if a.grad_comm == "bf16":
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            net.register_comm_hook(None, default_hooks.bf16_compress_hook)
     crit = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES).to(dev)      # HIP loss kernels (the CPU baseline uses the torch restatement)
     # pascal_vitLp16_taskprompter.yml:19-24: Adam(lr 2e-5, wd 1e-6) + clip_grad_norm_(10), fused into two multi-tensor HIP launches
     opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=2e-5, weight_decay=1e-6, max_norm=10.0)
     g = torch.Generator().manual_seed(1 + rank)
-    x = torch.randn(a.batch, 3, 512, 512, generator=g).to(dev)
-    gt = mtt_amd.losses.synthetic_targets(p, a.batch, 512, 512, dev, seed=rank)
+    x = torch.randn(batch, 3, H, W, generator=g).to(dev)
+    gt = mtt_amd.losses.synthetic_targets(p, batch, H, W, dev, seed=rank)
 
-    def step():
-        out = net(x)
-        loss = crit(out, gt)["total"]
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()                                        # global-norm clip (yml:24) + Adam
-        return loss
+    def make_step(xb, gtb):
+        def step():
+            out = net(xb)
+            loss = crit(out, gtb)["total"]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()                                        # global-norm clip (yml:24) + Adam
+            return loss
+        return step
 
+    step = make_step(x, gt)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -170,7 +255,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_step = dt / a.steps * 1e3
-    value = a.batch * world * a.steps / dt
+    value = batch * world * a.steps / dt
+    peak_gb = torch.cuda.max_memory_allocated() / 2**30
 
     # forward-only latency (the metric's second half), same process
     model.eval()
@@ -182,7 +268,7 @@ def main():
         for _ in range(3):
             model(x)
         torch.cuda.synchronize()
-    fwd_ms_img = (time.perf_counter() - t1) / 3 / a.batch * 1e3
+    fwd_ms_img = (time.perf_counter() - t1) / 3 / batch * 1e3
     model.train()
 
     roof = None
@@ -191,27 +277,69 @@ def main():
             step()
             flops, ms, n = gt_.result()
         tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, tsrc = _pmc_traffic("gemm_dma256")
         roof = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                    traffic=None, kernel="gemm_fast256_kernel (256x256x64 bf16 MFMA, LDS-DMA)", launches=n, kernel_ms_per_step=round(ms, 3))
+                    traffic=traffic, traffic_source=tsrc, kernel="gemm_dma256_kernel (256-row tile x 64 K, bf16 MFMA, LDS-DMA staging)",
+                    launches=n, kernel_ms_per_step=round(ms, 3), algorithmic_tflop_per_step=round(flops / 1e12, 2))
+
+    # the reference's own per-GPU batch (trBatch: 2, yml:8), same step, same process
+    ref_batch = None
+    if not a.no_ref_batch and rank == 0 and world == 1 and batch > 2:
+        s2 = make_step(x[:2].contiguous(), {k: v[:2].contiguous() for k, v in gt.items()})
+        for _ in range(2):
+            s2()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(5):
+            s2()
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t2) / 5 * 1e3
+        ref_batch = dict(per_gpu_batch=2, images_per_s=round(2e3 / ms2, 2), ms_per_step=round(ms2, 2))
+
+    parity = None
+    if not a.no_parity and rank == 0:
+        parity = dict(mode=a.prec)
+        try:
+            if a.prec == "bf16":
+                torch.manual_seed(0)
+                _, twin = build(a.config, "x3", mtt_amd)
+                twin = twin.to(dev)
+                twin.load_state_dict(model.state_dict())
+                twin.eval(), model.eval()
+                with torch.no_grad():
+                    o16, o32 = model(x[:2]), twin(x[:2])
+                errs = {t: float((o16[t].double() - o32[t].double()).norm() / o32[t].double().norm()) for t in p.TASKS.NAMES}
+                model.train()
+                del twin
+                parity.update(worst_head_rel_err=max(errs.values()), per_head=errs,
+                              reference="x3 mode (split-bf16 x3 MFMA, fp32 storage) on the same weights and 2 of the bench images; x3 is gated at "
+                                        "<= 1e-3 per head against the CPU oracle at this size (tests/test_gpu_configs.py)")
+            else:
+                parity.update(worst_head_rel_err=None, reference="x3 is the parity mode: <= 1e-3 per head vs the CPU oracle (tests/test_gpu_configs.py)")
+        except Exception as e:  # noqa: BLE001
+            parity["error"] = repr(e)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(a.cpu_sample_batch, a.cpu_threads)
+            cpu = cpu_baseline(a.config, a.cpu_sample_batch, a.cpu_threads)
         except Exception as e:  # noqa: BLE001
-            cpu = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e!r}")
+            cpu = dict(value=None, unit="images/s", cores=a.cpu_threads, kind="port", host_cores=os.cpu_count(), sample=f"failed: {e!r}")
     if rank == 0:
-        train_tflops = 3 * GFLOP_FWD_PER_IMG * value / 1e3
-        line = dict(metric="training images/sec (512x512, 6 tasks)", value=round(value, 3), unit="images/s", n_gpus=world,
+        train_tflops = 3 * gflop_fwd * value / 1e3
+        metric = "training images/sec (512x512, 6 tasks)" if a.config == "ns6" else f"training images/sec ({H}x{W}, {len(p.TASKS.NAMES)} tasks)"
+        line = dict(metric=metric, value=round(value, 3), unit="images/s", n_gpus=world,
                     steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="bf16" if a.prec == "bf16" else "f32(bf16x3)", data="synthetic",
-                    config=dict(workload="TaskPrompter ViT-L/16 (taskprompter_vit_large_patch16_384), PASCAL-Context 5 tasks + depth = 6 tasks, "
-                                         "512x512, ConvHead, embed 300/350, ctr; random-init weights",
-                                per_gpu_batch=a.batch, global_batch=a.batch * world, parallelism=f"dp{world}",
-                                optimizer="clip_grad_norm 10 + Adam (mtt_grad_sqnorm / mtt_adam_step)", loss=float(loss.detach())),
-                    fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                    config=dict(workload=desc, name=a.config, per_gpu_batch=batch, global_batch=batch * world, parallelism=f"dp{world}",
+                                optimizer="clip_grad_norm 10 + Adam (mtt_grad_sqnorm / mtt_adam_step)", loss=float(loss.detach()),
+                                grad_comm=a.grad_comm if world > 1 else None, bucket_mb=a.bucket_mb if world > 1 else None,
+                                rccl_ranks=world if world > 1 else None),
+                    fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(peak_gb, 1),
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
-                                      fwd=round(GFLOP_FWD_PER_IMG / fwd_ms_img, 1)),
-                    roofline=roof, cpu_baseline=cpu)
+                                      fwd=round(gflop_fwd / fwd_ms_img, 1), fwd_frac_of_bf16_peak=round(gflop_fwd / fwd_ms_img / MFMA_BF16_PEAK_TFLOPS, 4),
+                                      gflop_fwd_per_img=gflop_fwd),
+                    roofline=roof, parity=parity, ref_batch=ref_batch, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -48,7 +48,7 @@ enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
 /* kernel selection of mtt_gemm / mtt_attn_fwd: AUTO = the library's policy (a pure function of the descriptor); the other values
  * force one kernel where it is applicable (benchmarks, A/B measurements).  There is no process-global switch and no environment
  * variable: the library keeps no mutable state that affects results. */
-enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3 };
+enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3, MTT_GEMM_DMA256_V1 = 4 };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1 };
 
 /* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */
@@ -107,7 +107,8 @@ int mtt_abi_version(void);
  * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
-/* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128, 1 LDS-DMA 128x128, 3 LDS-DMA 256x256 */
+/* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128 (general), 1 LDS-DMA 128x128 ring, 3 / 4 phased
+ * LDS-DMA 256x256 / 256x128 (gemm_dma_kernel), 5 lock-step LDS-DMA 256x256 (round-1 kernel, forced only) */
 int mtt_gemm_variant(const mtt_gemm_desc* d);
 
 /*

@@ -22,7 +22,7 @@ PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 STORE_ROWS, STORE_PIXSHUF2 = 0, 1
-GEMM_AUTO, GEMM_GENERAL, GEMM_DMA128, GEMM_DMA256 = 0, 1, 2, 3
+GEMM_AUTO, GEMM_GENERAL, GEMM_DMA128, GEMM_DMA256, GEMM_DMA256_V1 = 0, 1, 2, 3, 4
 ATTN_AUTO, ATTN_PLAIN = 0, 1
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -241,7 +241,8 @@ def _stream():
 
 
 def gemm_variant(**kw):
-    """Kernel variant mtt_gemm would dispatch these descriptor fields to (0 general, 1 LDS-DMA 128, 3 LDS-DMA 256)."""
+    """Kernel mtt_gemm would dispatch these descriptor fields to (0 general, 1 LDS-DMA 128 ring, 3 / 4 phased LDS-DMA 256x256 / 256x128,
+    5 lock-step LDS-DMA 256x256)."""
     lib = load()
     desc = GemmDesc()
     for k, v in kw.items():

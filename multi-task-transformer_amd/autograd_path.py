@@ -70,6 +70,40 @@ def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
     return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
 
 
+SPLIT_TARGET_WGS, SPLIT_ROW_UNIT = 1024, 512        # (tests lower SPLIT_ROW_UNIT to exercise the sliced paths on miniature maps)
+
+
+def _n_splits(tiles, units, max_splits=16):
+    """Number of reduction slices for a weight-gradient GEMM with `tiles` output tiles (all batches) whose reduction has `units`
+    indivisible units (row blocks, or images for the 3x3 conv): enough slices to give every CU a few workgroups."""
+    if tiles >= SPLIT_TARGET_WGS * 3 // 4 or units < 2:
+        return 1
+    return max(1, min(max_splits, units, -(-SPLIT_TARGET_WGS // tiles)))
+
+
+def _wgrad_batched(dy, x, N, Kp, M, prec, Z, lda, ldb, a_zo, b_zo, a0=0, b0=0):
+    """dW[z] = dy[z]^T x[z] for z < Z (row-contiguous operands, element offsets a0 + z*a_zo / b0 + z*b_zo): one launch over
+    (task, reduction slice) with fp32 slabs summed afterwards when the tile count alone cannot fill the chip."""
+    tiles = Z * (-(-N // 128)) * (-(-Kp // 128))
+    S = _n_splits(tiles, M // SPLIT_ROW_UNIT)
+    A = dy.reshape(-1)[a0:] if a0 else dy
+    B = x.reshape(-1)[b0:] if b0 else x
+    if S == 1:
+        dW = torch.empty(Z, N, Kp, dtype=torch.float32, device=dy.device)
+        _gemm(A, B, dW, N, Kp, M, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp, batch=Z, a_zo=a_zo, b_zo=b_zo, d_zo=N * Kp)
+        return dW
+    c = (M // S) // 8 * 8
+    rem = M - c * S
+    slabs = torch.empty(Z, S + (1 if rem else 0), N, Kp, dtype=torch.float32, device=dy.device)
+    SS = slabs.shape[1]
+    _gemm(A, B, slabs, N, Kp, c, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp, batch=Z * S, batch_inner=S,
+          a_zo=a_zo, a_zi=c * lda, b_zo=b_zo, b_zi=c * ldb, d_zo=SS * N * Kp, d_zi=N * Kp)
+    if rem:
+        _gemm(dy.reshape(-1)[a0 + c * S * lda:], x.reshape(-1)[b0 + c * S * ldb:], slabs[:, S], N, Kp, rem, prec, a_op=OP_R, b_op=OP_R,
+              lda=lda, ldb=ldb, ldd=Kp, batch=Z, a_zo=a_zo, b_zo=b_zo, d_zo=SS * N * Kp)
+    return slabs.sum(1)
+
+
 def _transposed(x2d, cols, dtype=torch.bfloat16, colsum=None):
     """[rows, ld] -> [cols, pad64(rows)] (zero padded): reduction-contiguous operand for the fast weight-gradient GEMM.
     colsum (fp32 [cols], zero-initialised): also receives the column sums of x2d (the bias gradient) from the same pass."""
@@ -430,10 +464,12 @@ class BLinearFn(Function):
               b_zi=wpack.stride(0) if bi > 1 else 0, d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
         if Z == 1 and layout == 'plain':
             dW = _wgrad(dy.view(M, lda), x.reshape(M, x.shape[-1]), N, Kp, prec)[None]
+        elif layout == 'catpair':
+            # z = 2t + s: dy[t][:, s*Np:], x[z]; one (task, slice)-batched launch per s
+            halves = [_wgrad_batched(dy, x, N, Kp, M, prec, Z // 2, lda, x.shape[-1], M * lda, 2 * xz, a0=sft * Np, b0=sft * xz) for sft in (0, 1)]
+            dW = torch.stack(halves, 1).reshape(Z, N, Kp)
         else:
-            dW = torch.empty(Z, N, Kp, dtype=torch.float32, device=x.device)
-            _gemm(dy, x, dW, N, Kp, M, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=x.shape[-1], ldd=Kp, b_zo=xz * bi,
-                  b_zi=xz if bi > 1 else 0, d_zo=N * Kp * bi, d_zi=N * Kp if bi > 1 else 0, **az)
+            dW = _wgrad_batched(dy, x, N, Kp, M, prec, Z, lda, x.shape[-1], M * lda, xz)
         dys = dy.view(-1, M, lda)
         dws, dbs = [], []
         for z in range(Z):
@@ -479,9 +515,21 @@ class Conv3x3Fn(Function):
         rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
         wd = ops.pack_conv3(list(ws), prec, tag, transpose=True)                     # [Z, Ci, 9*Cop]
         dx = ops.conv3x3(dy, wd, Ci, Co, B, H, W, prec, flip=1, dil=dil, out_dtype=x.dtype)
-        dW = torch.empty(Z, Co, 9 * Cip, dtype=torch.float32, device=x.device)
-        _gemm(dy, x, dW, Co, 9 * Cip, rows, prec, a_op=OP_R, b_op=OP_CONV_R, lda=Cop, ldb=Cip, ldd=9 * Cip, batch=Z,
-              a_zo=rows * Cop, b_zo=rows * Cip, d_zo=Co * 9 * Cip, conv=dict(H=H, W=W, C=Ci, Cp=Cip, dil=dil, flip=0))
+        conv = dict(H=H, W=W, C=Ci, Cp=Cip, dil=dil, flip=0)
+        tiles = Z * (-(-Co // 128)) * (-(-9 * Cip // 128))
+        S = _n_splits(tiles, B)                                          # slices = whole images (the gather decomposes pixel -> (y, x))
+        while B % S:
+            S -= 1
+        if S == 1:
+            dW = torch.empty(Z, Co, 9 * Cip, dtype=torch.float32, device=x.device)
+            _gemm(dy, x, dW, Co, 9 * Cip, rows, prec, a_op=OP_R, b_op=OP_CONV_R, lda=Cop, ldb=Cip, ldd=9 * Cip, batch=Z,
+                  a_zo=rows * Cop, b_zo=rows * Cip, d_zo=Co * 9 * Cip, conv=conv)
+        else:
+            c = rows // S
+            slabs = torch.empty(Z, S, Co, 9 * Cip, dtype=torch.float32, device=x.device)
+            _gemm(dy, x, slabs, Co, 9 * Cip, c, prec, a_op=OP_R, b_op=OP_CONV_R, lda=Cop, ldb=Cip, ldd=9 * Cip, batch=Z * S, batch_inner=S,
+                  a_zo=rows * Cop, a_zi=c * Cop, b_zo=rows * Cip, b_zi=c * Cip, d_zo=S * Co * 9 * Cip, d_zi=Co * 9 * Cip, conv=conv)
+            dW = slabs.sum(1)
         dws = [dW[z].view(Co, 3, 3, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous() for z in range(Z)]
         dbs = [_colsum(dy[z], Co) if has_bias else None for z in range(Z)]
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)

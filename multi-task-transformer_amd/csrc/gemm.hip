@@ -668,6 +668,181 @@ int launch_fast256(const GemmP& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_dma_kernel<BN, CONV>: the round-2 main kernel.  256 x BN x 64 tile (BN = 256 or 128), 8 waves, operands streamed
+// HBM -> LDS by global_load_lds into 2 stages, like gemm_fast256_kernel, but with a PHASED, STAGGERED main loop:
+//
+//   * a K step is four phases  R0 | C0 | R1 | C1  (R = ds_read the fragments of one 32-deep half, C = its MFMAs), each closed by
+//     a workgroup barrier;
+//   * waves 4-7 run ONE phase behind waves 0-3 (one extra barrier before the loop, one after it for the other half).  Wave w and
+//     wave w+4 share a SIMD, so in every slot one of the SIMD's two waves reads LDS while the other issues MFMAs: fragment reads
+//     no longer alternate with an idle matrix pipe (the lock-step 2-stage loop measured ~56 % MFMA issue at K = 8192);
+//   * the next K tile is issued (LDS-DMA) in R0 and waited for (vmcnt(0)) at the end of R1, i.e. it has R0 + C0 + R1 to land;
+//     the barrier closing R1 of the later half precedes the first read of that tile by the earlier half.
+//   Hazards (slot numbering: waves 0-3 run phase p of K step kt in slot 4 kt + p, waves 4-7 in slot 4 kt + p + 1):
+//     RAW  tile kt+1 is first read in slot 4 kt + 4; its last writer waits vmcnt(0) in slot 4 kt + 3, a barrier separates them.
+//     WAR  stage (kt+1)&1 is overwritten from slot 4 kt on; its last readers (tile kt-1, R1) ran in slots 4 kt - 2 / 4 kt - 1 and
+//          waited lgkmcnt(0) before their closing barrier.
+// CONV: A is the implicit im2col of a 3x3 (dilated) convolution; every lane computes the source address of its 16-byte channel
+// chunk per K step (tap, channel tracked incrementally; halo / K tail chunks read a zero page) — address VALU work runs in the
+// R phases, under the other half's MFMAs.  K only needs to be a multiple of 8 (chunks past K read the zero page).
+// ---------------------------------------------------------------------------------------------
+template <int BN_, bool CONV>
+__global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WAVES_N = BN_ / 64, WAVES_M = 8 / WAVES_N, MT = 256 / WAVES_M / 16, NT = 4;
+  constexpr int TILE_A = BM2 * BK * 2, TILE_B = BN_ * BK * 2, STAGE = TILE_A + TILE_B;
+  constexpr int B_GLDS = BN_ / 64;                 // 1 KiB pieces of the B tile per wave (8 rows x 128 B each)
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + BN_ - 1) / BN_, tiles_m = (p.d.M + BM2 - 1) / BM2;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * BM2, n0 = tile_n * BN_;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  const bf16_t* Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
+  const bf16_t* Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int late = wave >> 2;                      // 1: this wave runs one phase behind (shares its SIMD with wave - 4)
+  const int K = p.d.K;
+
+  uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
+  asm volatile("" : "+s"(zpage));
+
+  // ---- per-lane source addressing ------------------------------------------------------------------------------------
+  // A: wave w streams rows [32 w, 32 w + 32) as 4 pieces of 8 rows x 128 B; lane -> (row, swizzled 16-byte chunk)
+  int64_t aoff[4];                                 // element offset of (row, chunk 0) [plain: + chunk]   (CONV: of the output pixel's row)
+  int ack[4];                                      // this lane's k offset inside a K step (chunk * 8)
+  unsigned tapmask[4]; int tap[4], ci[4];          // CONV only
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ lds_swz(row);
+    ack[i] = c * 8;
+    int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;      // ragged edge: re-read the last valid row (results unused)
+    if constexpr (CONV) {
+      const uint32_t t = fdiv((uint32_t)ra, p.divW);
+      const int px = ra - (int)t * p.d.conv.W;
+      const uint32_t bb = fdiv(t, p.divH);
+      const int py = (int)t - (int)bb * p.d.conv.H;
+      unsigned m = 0;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        int ty = tp / 3, tx = tp % 3;
+        if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+        const int yy = py + (ty - 1) * p.d.conv.dil, xx = px + (tx - 1) * p.d.conv.dil;
+        if (yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W) m |= 1u << tp;
+      }
+      tapmask[i] = m;
+      aoff[i] = (int64_t)ra * p.d.lda;
+      tap[i] = 0; ci[i] = ack[i];
+      while (ci[i] >= p.d.conv.Cp) { ci[i] -= p.d.conv.Cp; ++tap[i]; }
+    } else {
+      aoff[i] = row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + ack[i];
+      tapmask[i] = 0; tap[i] = 0; ci[i] = 0;
+    }
+  }
+  // B: BN_ rows; wave w streams rows [BN_/8 * w, ...) as B_GLDS pieces of 8 rows
+  int64_t boff[B_GLDS]; int bck[B_GLDS];
+#pragma unroll
+  for (int i = 0; i < B_GLDS; ++i) {
+    const int row = (wave * B_GLDS + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ lds_swz(row);
+    bck[i] = c * 8;
+    int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
+    boff[i] = (int64_t)rb * p.d.ldb + bck[i];
+  }
+
+  auto issue = [&](int stage, int kt) {
+    unsigned char* sA = smem + stage * STAGE + wave * 4096;
+    unsigned char* sB = smem + stage * STAGE + TILE_A + wave * (B_GLDS * 1024);
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint64_t src;
+      bool ok = k0 + ack[i] < K;
+      if constexpr (CONV) {
+        int ty = (tap[i] * 11) >> 5, tx = tap[i] - 3 * ty;             // tap / 3, tap % 3 for tap < 9 (garbage beyond K: masked by ok)
+        if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+        const int shift = ((ty - 1) * p.d.conv.W + (tx - 1)) * p.d.conv.dil;
+        ok = ok && ((tapmask[i] >> tap[i]) & 1u);
+        src = (uint64_t)(uintptr_t)(Abase + (aoff[i] + (int64_t)shift * p.d.lda + ci[i]));
+        ci[i] += BK;
+        while (ci[i] >= p.d.conv.Cp) { ci[i] -= p.d.conv.Cp; ++tap[i]; }
+      } else {
+        src = (uint64_t)(uintptr_t)(Abase + (aoff[i] + k0));
+      }
+      glds16((const bf16_t*)(uintptr_t)(ok ? src : zpage), sA + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < B_GLDS; ++i) {
+      const bool ok = k0 + bck[i] < K;
+      const uint64_t src = (uint64_t)(uintptr_t)(Bbase + (boff[i] + k0));
+      glds16((const bf16_t*)(uintptr_t)(ok ? src : zpage), sB + i * 1024);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // tile 0 is in LDS
+  if (late) __builtin_amdgcn_s_barrier();          // stagger: waves 4-7 start one slot later
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* Ah = smem + (kt & 1) * STAGE;
+    const unsigned char* Bh = Ah + TILE_A;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      // ---- R phase: fragments of this 32-deep half (and, in R0, the LDS-DMA of the next K tile) ----
+      if (kh == 0 && kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+      u32x4 fa[MT], fb[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * (MT * 16) + t * 16 + li, kh * 4 + lg));
+      if (kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // next tile (own part) landed; reads done
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- C phase ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();         // waves 0-3 wait one slot for the late half
+  __syncthreads();                                 // everyone is past its last LDS read: the epilogue may reuse the stages
+  gemm_epilogue<BN_, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+}
+
+template <int BN_, bool CONV>
+int launch_dma(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = (BM2 * BK * 2 + BN_ * BK * 2) * 2;
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_dma_kernel<BN_, CONV>, smem, done)) return e;
+  const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + BN_ - 1) / BN_;
+  dim3 grid(tm * tn, 1, p.d.batch);
+  hipLaunchKernelGGL((gemm_dma_kernel<BN_, CONV>), grid, dim3(512), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
 FastDiv make_div(uint32_t dv) {
   FastDiv f; f.d = dv ? dv : 1u;
   uint32_t s = 0; while ((1ull << s) < f.d) ++s;
@@ -714,17 +889,26 @@ extern "C" size_t mtt_desc_size(int which) {
   }
 }
 
-// 0 = register-staged 128 tile (general), 1 = LDS-DMA 128 tile, 3 = LDS-DMA 256 tile.  Pure function of the descriptor:
-// d.variant = MTT_GEMM_AUTO applies the library's policy, any other value forces that kernel where it is applicable.
+// Kernel choice, a pure function of the descriptor.  Return codes (also what mtt_gemm_variant reports):
+//   0 register-staged 128 x 128 (general: any operand layout / dtype / precision)
+//   1 LDS-DMA 128 x 128, 4-stage ring (round-1 kernel; forced only)
+//   3 LDS-DMA 256 x 256 phased / staggered (gemm_dma_kernel<256>)      4 the same with a 256 x 128 tile (gemm_dma_kernel<128>)
+//   5 LDS-DMA 256 x 256 lock-step 2-stage (round-1 kernel; forced only, kept for A/B measurements)
+// d.variant = MTT_GEMM_AUTO applies the policy; another value forces that kernel where it is applicable.
 static int gemm_variant_for(const mtt_gemm_desc& d) {
-  const int fast_mode = d.variant == MTT_GEMM_AUTO ? 2 : (d.variant == MTT_GEMM_GENERAL ? 0 : (d.variant == MTT_GEMM_DMA128 ? 1 : 3));
-  const bool plain = d.prec == MTT_PREC_BF16 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % BK) == 0 && d.a_dtype == MTT_BF16 &&
-                     d.b_dtype == MTT_BF16;
-  if (!plain || fast_mode == 0) return 0;
+  const bool conv = d.a_op == MTT_OP_CONV_K;
+  const bool dma = d.prec == MTT_PREC_BF16 && (d.a_op == MTT_OP_K || conv) && d.b_op == MTT_OP_K && (d.K % 8) == 0 &&
+                   d.a_dtype == MTT_BF16 && d.b_dtype == MTT_BF16;
+  if (!dma || d.variant == MTT_GEMM_GENERAL) return 0;
+  const bool v1_ok = !conv && (d.K % BK) == 0;
+  if (d.variant == MTT_GEMM_DMA128 && v1_ok) return 1;
+  if (d.variant == MTT_GEMM_DMA256_V1 && v1_ok) return 5;
+  const int n256 = (d.N + 255) / 256 * 256, n128 = (d.N + 127) / 128 * 128;
+  const int bn = 100 * n128 <= 85 * n256 ? 128 : 256;   // the narrower tile only where it saves >= 15 % of the columns (N = 300, 350, 576 ...)
+  if (d.variant == MTT_GEMM_DMA256) return bn == 256 ? 3 : 4;
   const int batch = d.batch < 1 ? 1 : d.batch;
-  const int64_t blocks256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * batch;
-  if ((fast_mode == 2 && blocks256 >= 96 && d.M >= 512 && d.N >= 512) || fast_mode == 3) return 3;
-  if (fast_mode == 1) return 1;
+  const int64_t blocks = (int64_t)((d.M + 255) / 256) * ((d.N + bn - 1) / bn) * batch;
+  if (d.M >= 512 && d.N >= 128 && blocks >= 96) return bn == 256 ? 3 : 4;
   return 0;
 }
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }
@@ -768,7 +952,10 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   else mode = d.a_dtype == MTT_F32 ? 1 : 0;
   if (mode == 0) {
     const int v = gemm_variant_for(d);
-    if (v == 3) return launch_fast256(p, s);
+    const bool conv_a = d.a_op == MTT_OP_CONV_K;
+    if (v == 3) return conv_a ? launch_dma<256, true>(p, s) : launch_dma<256, false>(p, s);
+    if (v == 4) return conv_a ? launch_dma<128, true>(p, s) : launch_dma<128, false>(p, s);
+    if (v == 5) return launch_fast256(p, s);
     if (v == 1) return launch_fast(p, s);
   }
 #define MTT_CASE(AO, BO) \

@@ -138,6 +138,23 @@ def gemm_cases():
               alpha=1.0, colshift=rnd(g, N), resid=XT[:, 3:], ldr=1032, r_mb=Mb, r_bs=(Mb + 3) * 1032,
               rowscale=torch.rand(Bn, 2, generator=g), n_prompt=5, n_store=1032)
     cases.append(("gemm_fast256_rowgroups_resid", "gemm", kw, TOL_BF))
+    # 1d. phased LDS-DMA kernels forced on small shapes (variant = 3: 256 x 256 or 256 x 128 by N): K tails (K % 64 != 0 -> zero page),
+    #     ragged M / N, one and many K tiles, both tile widths; then the implicit-GEMM 3x3 conv through the same kernels
+    for (M, N, K) in ((300, 260, 200), (70, 700, 64), (513, 350, 1096), (256, 128, 8), (1000, 300, 72)):
+        kw = base(M, N, K, BF16, BF16, BF16, 0, variant=3, colshift=rnd(g, N), act=1)
+        cases.append((f"gemm_dma_forced_{M}x{N}x{K}", "gemm", kw, TOL_BF))
+    for dil, flip, (Bn, H, W, Ci, Co) in ((1, 0, (2, 9, 7, 20, 30)), (2, 0, (2, 9, 7, 20, 30)), (1, 1, (2, 9, 7, 20, 30)), (1, 0, (3, 20, 17, 44, 300)),
+                                          (2, 1, (1, 33, 40, 72, 130))):
+        Cp, Cop = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
+        X = rnd(g, 2, Bn * H * W, Cp, dtype=torch.bfloat16); X[..., Ci:] = 0
+        Wt = rnd(g, 2, Co, 9, Cp, dtype=torch.bfloat16); Wt[..., Ci:] = 0
+        kw = dict(A=X, B=Wt, D=torch.zeros(2, Bn * H * W, Cop, dtype=torch.bfloat16), M=Bn * H * W, N=Co, K=9 * Cp,
+                  a_op=OP_CONV_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=Cp, ldb=9 * Cp, ldd=Cop,
+                  batch=2, batch_inner=1, a_zo=Bn * H * W * Cp, b_zo=Co * 9 * Cp, d_zo=Bn * H * W * Cop,
+                  conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, colshift=rnd(g, 2, Co), col_zo=Co, act=1, n_store=Cop, variant=3)
+        cases.append((f"gemm_dma_conv3_d{dil}f{flip}_{Bn}x{H}x{W}x{Ci}to{Co}", "gemm", kw, TOL_BF))
+    # the round-1 lock-step 256 x 256 kernel stays reachable (variant = 4) for A/B measurements
+    cases.append(("gemm_dma256_v1_forced", "gemm", base(300, 260, 192, BF16, BF16, BF16, 0, variant=4), TOL_BF))
     # 2. asymmetric identity check (A = I) catches transposed C layout
     kw = base(128, 128, 128, F32, F32, F32, 1)
     kw["A"] = torch.eye(128, 136)
