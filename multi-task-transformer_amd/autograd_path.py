@@ -767,34 +767,28 @@ def backbone_forward(model, img):
     return BilinearFn.apply(acc, (B, acc.shape[-1], h, w, 4 * h, 4 * w), prec.adt, False)
 
 
-def wrapper_forward(wrapper, x, target):
-    """Autograd twin of TaskPrompterWrapper.forward."""
-    from .taskprompter import ConvHead, DEConvHead
-    bb = wrapper.backbone
-    B = x.shape[0]
-    fea = backbone_forward(bb, x)
-    h4, w4 = bb.resolution[0] * 4, bb.resolution[1] * 4
-    F, prec = bb.p.final_embed_dim, bb.prec
-    heads = [wrapper.heads[t] for t in wrapper.tasks]
-    out = {}
-    if all(isinstance(hd, ConvHead) for hd in heads):
+def heads_forward(kind, heads, fea, B, h4, w4, target, prec, training):
+    """Autograd twin of taskprompter.run_heads: fea [Z, B*h4*w4, pad8(F)] -> list of fp32 NCHW predictions."""
+    F = heads[0].mt_proj[0].weight.shape[0]
+    outs = []
+    if kind == 'conv':
+        tgt = target or (h4, w4)
         y = Conv3x3Fn.apply(fea, (B, h4, w4, F, F), prec, 'hc', *[hd.mt_proj[0].weight for hd in heads],
                             *[hd.mt_proj[0].bias for hd in heads])
-        y = _bn_act(y, [hd.mt_proj[1] for hd in heads], F, ACT_GELU, wrapper.training)
+        y = _bn_act(y, [hd.mt_proj[1] for hd in heads], F, ACT_GELU, training)
         preds = TaskHeadsFn.apply(y, prec, 'hp', *[hd.linear_pred.weight for hd in heads], *[hd.linear_pred.bias for hd in heads])
-        for t, hd, pred in zip(wrapper.tasks, heads, preds):
+        for hd, pred in zip(heads, preds):
             n_out = hd.linear_pred.weight.shape[0]
-            out[t] = BilinearFn.apply(pred, (B, n_out, h4, w4, target[0], target[1]), torch.float32, True)
-        return out
-    if all(isinstance(hd, DEConvHead) for hd in heads):
-        F2 = F // 2
-        for i, (t, hd) in enumerate(zip(wrapper.tasks, heads)):
-            y = Deconv2x2Fn.apply(fea[i], hd.mt_proj[0].weight, hd.mt_proj[0].bias, (B, h4, w4), prec, ('hd0', t))
-            y = bn_act_single(y, hd.mt_proj[1].weight, hd.mt_proj[1].bias, hd.mt_proj[1], F2, ACT_GELU, wrapper.training)[None]
-            y = Conv3x3Fn.apply(y, (B, 2 * h4, 2 * w4, F2, F2), prec, ('hd3', t), hd.mt_proj[3].weight, hd.mt_proj[3].bias)
-            y = bn_act_single(y[0], hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, wrapper.training)[None]
-            n_out = hd.linear_pred.weight.shape[0]
-            pred = BLinearFn.apply(y, n_out, 'plain', None, torch.float32, prec, ('hp', t), hd.linear_pred.weight, hd.linear_pred.bias)
-            out[t] = BilinearFn.apply(pred, (B, n_out, 2 * h4, 2 * w4, target[0], target[1]), torch.float32, True)
-        return out
-    raise NotImplementedError('heads must all be ConvHead or all DEConvHead (the 3ddet FCOS3D head is out of scope)')
+            outs.append(BilinearFn.apply(pred, (B, n_out, h4, w4, tgt[0], tgt[1]), torch.float32, True))
+        return outs
+    F2 = F // 2
+    tgt = target or (2 * h4, 2 * w4)
+    for i, hd in enumerate(heads):
+        y = Deconv2x2Fn.apply(fea[i], hd.mt_proj[0].weight, hd.mt_proj[0].bias, (B, h4, w4), prec, 'hd0')
+        y = bn_act_single(y, hd.mt_proj[1].weight, hd.mt_proj[1].bias, hd.mt_proj[1], F2, ACT_GELU, training)[None]
+        y = Conv3x3Fn.apply(y, (B, 2 * h4, 2 * w4, F2, F2), prec, 'hd3', hd.mt_proj[3].weight, hd.mt_proj[3].bias)
+        y = bn_act_single(y[0], hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, training)[None]
+        n_out = hd.linear_pred.weight.shape[0]
+        pred = BLinearFn.apply(y, n_out, 'plain', None, torch.float32, prec, 'hp', hd.linear_pred.weight, hd.linear_pred.bias)
+        outs.append(BilinearFn.apply(pred, (B, n_out, 2 * h4, 2 * w4, tgt[0], tgt[1]), torch.float32, True))
+    return outs

@@ -295,15 +295,7 @@ class TaskPrompter(nn.Module):
         return (torch.einsum('btsj,tj->bts', z, W2) + b2[None, :, None]).contiguous()
 
     def _bn_fold(self, bns, conv_biases, tag):
-        """eval BatchNorm folded into the producing conv's epilogue: scale = g/sqrt(v+eps), shift = b + (cb - m)*scale."""
-        def build():
-            with torch.no_grad():
-                sc = torch.stack([bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps) for bn in bns])
-                cb = torch.stack([b.detach() for b in conv_biases])
-                sh = torch.stack([bn.bias.detach() - bn.running_mean * s for bn, s in zip(bns, sc)]) + cb * sc
-                return sc.contiguous(), sh.contiguous()
-        prm = [q for bn in bns for q in (bn.weight, bn.bias, bn.running_mean, bn.running_var)] + list(conv_biases)
-        return ops._cached((tag, tuple(id(q) for q in prm)), prm, build)
+        return bn_fold(bns, conv_biases, tag)
 
     def _bn_train(self, y, bns, C, act):
         """training-mode BatchNorm2d (+act) on [T, rows, ld] pre-activations; updates running stats like nn.BatchNorm2d."""
@@ -337,6 +329,18 @@ class TaskPrompter(nn.Module):
         return ops.ctr_mix(fea, wmix, B, F, acc)
 
 
+def bn_fold(bns, conv_biases, tag):
+    """eval BatchNorm folded into the producing conv's epilogue: scale = g/sqrt(v+eps), shift = b + (cb - m)*scale."""
+    def build():
+        with torch.no_grad():
+            sc = torch.stack([bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps) for bn in bns])
+            cb = torch.stack([b.detach() for b in conv_biases])
+            sh = torch.stack([bn.bias.detach() - bn.running_mean * s for bn, s in zip(bns, sc)]) + cb * sc
+            return sc.contiguous(), sh.contiguous()
+    prm = [q for bn in bns for q in (bn.weight, bn.bias, bn.running_mean, bn.running_var)] + list(conv_biases)
+    return ops._cached((tag, tuple(id(q) for q in prm)), prm, build)
+
+
 def _create_task_prompter(variant, pretrained=False, default_cfg=None, **kwargs):
     if pretrained:
         raise RuntimeError('pretrained ImageNet weights need network access (taskprompter.py:661 downloads them); '
@@ -361,7 +365,30 @@ def taskprompter_vit_base_patch16_384(pretrained=False, **kwargs):
     return _create_task_prompter('vit_base_patch16_384', pretrained=pretrained, **model_kwargs)
 
 
-class ConvHead(nn.Module):
+def _to_rows(x, prec):
+    """Reference-layout feature map [B, C, H, W] (any strides; our own channels-last views are copied once) -> NHWC rows
+    [1, B*H*W, pad8(C)] in the activation dtype with zero channel padding."""
+    B, C, H, W = x.shape
+    Cp = ops.pad8(C)
+    rows = torch.zeros(1, B * H * W, Cp, dtype=prec.adt, device=x.device)
+    rows.view(B, H, W, Cp)[..., :C] = x.permute(0, 2, 3, 1)
+    return rows
+
+
+class _HeadBase(nn.Module):
+    """A prediction head is usable on its own, like the reference's (taskprompter.py:688-715): `head(x)` with x [B, C, H, W] returns
+    fp32 [B, n_out, H', W'] computed by the same HIP kernels the wrapper batches over tasks (differentiable in training)."""
+    prec = None
+
+    def forward(self, x):
+        prec = self.prec or ops.Prec('bf16')
+        B, _, H, W = x.shape
+        rows = _to_rows(x, prec)
+        kind = 'conv' if isinstance(self, ConvHead) else 'deconv'
+        return run_heads(kind, [self], rows, B, H, W, None, prec, self.training)[0]
+
+
+class ConvHead(_HeadBase):
     """taskprompter.py:688-698 (parameter holder; executed task-batched by TaskPrompterWrapper)."""
 
     def __init__(self, in_channels, num_classes):
@@ -371,7 +398,7 @@ class ConvHead(nn.Module):
         self.linear_pred = nn.Conv2d(in_channels, num_classes, kernel_size=1)
 
 
-class DEConvHead(nn.Module):
+class DEConvHead(_HeadBase):
     """taskprompter.py:700-715."""
 
     def __init__(self, in_channels, num_classes):
@@ -385,8 +412,65 @@ class DEConvHead(nn.Module):
         trunc_normal_(self.linear_pred.weight, std=0.02)
 
 
+def run_heads(kind, heads, fea, B, h4, w4, target, prec, training):
+    """The per-task prediction heads of one kind on the task stack fea [Z, B*h4*w4, pad8(F)] -> list of fp32 NCHW predictions resized to
+    `target` (None: the head's native resolution).  ConvHead: ONE task-batched 3x3 conv + BN + GELU, then the 1x1s (taskprompter.py:
+    688-698); DEConvHead: ConvT 2x2 s2 as a pixel-shuffle GEMM + BN + GELU + 3x3 + BN + GELU + 1x1 (:700-715)."""
+    if torch.is_grad_enabled() and any(q.requires_grad for hd in heads for q in hd.parameters()):
+        from . import autograd_path
+        return autograd_path.heads_forward(kind, heads, fea, B, h4, w4, target, prec, training)
+    from . import bn as bn_mod
+    F = heads[0].mt_proj[0].weight.shape[0]
+    outs = []
+    if kind == 'conv':
+        tgt = target or (h4, w4)
+        Wc = ops.pack_conv3([hd.mt_proj[0].weight for hd in heads], prec, 'hc')
+        bns = [hd.mt_proj[1] for hd in heads]
+        if training:
+            y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=ops.stack_vec([hd.mt_proj[0].bias for hd in heads], 'hcb'))
+            y = bn_mod.train_forward(y, F, bns, ACT_GELU)[0]
+        else:
+            sc, sh = bn_fold(bns, [hd.mt_proj[0].bias for hd in heads], 'hbn')
+            y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
+        for i, hd in enumerate(heads):
+            n_out = hd.linear_pred.weight.shape[0]
+            pred = ops.linear(y[i], ops.pack_linear([hd.linear_pred.weight], prec, 'hp'), n_out, prec,
+                              bias=hd.linear_pred.bias.detach()[None], out_dtype=torch.float32)
+            outs.append(ops.bilinear(pred, B, n_out, h4, w4, tgt[0], tgt[1], torch.float32, nchw=True))
+        return outs
+    F2 = F // 2
+    tgt = target or (2 * h4, 2 * w4)
+    for i, hd in enumerate(heads):
+        wt = hd.mt_proj[0].weight                                   # [F, F2, 2, 2] -> rows n = (dy*2+dx)*F2 + co
+        Wd = ops._cached(('hd0', prec.name, id(wt)), [wt],
+                         lambda wt=wt: ops.pack_matrix(wt.detach().permute(2, 3, 1, 0).reshape(4 * F2, F), prec)[None])
+        b4v = ops._cached(('hd0b', id(hd.mt_proj[0].bias)), [hd.mt_proj[0].bias],
+                          lambda hd=hd: hd.mt_proj[0].bias.detach().repeat(4).contiguous())
+        y = ops.deconv2x2(fea[i], Wd, F2, F, B, h4, w4, prec, bias4=b4v)[None]      # [1, B*2h4*2w4, pad8(F2)]
+        Wc = ops.pack_conv3([hd.mt_proj[3].weight], prec, 'hd3')
+        bc = hd.mt_proj[3].bias.detach()[None].contiguous()
+        if training:
+            y = bn_mod.train_forward(y, F2, [hd.mt_proj[1]], ACT_GELU)[0]
+            y = ops.conv3x3(y, Wc, F2, F2, B, 2 * h4, 2 * w4, prec, bias=bc)
+            y = bn_mod.train_forward(y, F2, [hd.mt_proj[4]], ACT_GELU)[0]
+        else:
+            bn1 = hd.mt_proj[1]
+            y = ops.bn_apply(y, F2, bn1.running_mean, torch.rsqrt(bn1.running_var + bn1.eps), bn1.weight.detach(),
+                             bn1.bias.detach(), ACT_GELU)
+            sc, sh = bn_fold([hd.mt_proj[4]], [hd.mt_proj[3].bias], 'hd4')
+            y = ops.conv3x3(y, Wc, F2, F2, B, 2 * h4, 2 * w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
+        n_out = hd.linear_pred.weight.shape[0]
+        pred = ops.linear(y[0], ops.pack_linear([hd.linear_pred.weight], prec, 'hp'), n_out, prec,
+                          bias=hd.linear_pred.bias.detach()[None], out_dtype=torch.float32)
+        outs.append(ops.bilinear(pred, B, n_out, 2 * h4, 2 * w4, tgt[0], tgt[1], torch.float32, nchw=True))
+    return outs
+
+
 class TaskPrompterWrapper(nn.Module):
-    """taskprompter_wrapper.py:9-40: backbone -> per-task head -> bilinear resize to the input size."""
+    """taskprompter_wrapper.py:9-40: backbone -> per-task head -> bilinear resize to the input size (or `dd_label_map_size`).
+    ConvHead / DEConvHead tasks run task-batched on the HIP kernels; any other head module (a user's own, or the reference's '3ddet'
+    head) is called as `heads[task](feature)` on the reference-layout feature map, and a '3ddet' output is passed through un-resized
+    (taskprompter_wrapper.py:35-38)."""
 
     def __init__(self, p, backbone, heads):
         super().__init__()
@@ -394,62 +478,33 @@ class TaskPrompterWrapper(nn.Module):
         self.backbone = backbone
         self.heads = heads
         self.target_size = p.dd_label_map_size if 'dd_label_map_size' in p.keys() else None
+        for hd in heads.values():
+            if isinstance(hd, _HeadBase):
+                hd.prec = backbone.prec
 
     def forward(self, x):
         img_size = tuple(x.shape[-2:])
         target = tuple(self.target_size) if self.target_size is not None else img_size
-        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
-            from . import autograd_path
-            return autograd_path.wrapper_forward(self, x, target)
         bb = self.backbone
         B = x.shape[0]
         fea = bb.forward_nhwc(x)                                            # [T, B*4h*4w, Fp]
         h4, w4 = bb.resolution[0] * 4, bb.resolution[1] * 4
         F = bb.p.final_embed_dim
-        prec = bb.prec
-        heads = [self.heads[t] for t in self.tasks]
         out = {}
-        if all(isinstance(hd, ConvHead) for hd in heads):
-            Wc = ops.pack_conv3([hd.mt_proj[0].weight for hd in heads], prec, 'hc')
-            bc = ops.stack_vec([hd.mt_proj[0].bias for hd in heads], 'hcb')
-            bns = [hd.mt_proj[1] for hd in heads]
-            if self.training:
-                y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=bc)
-                y = bb._bn_train(y, bns, F, ACT_GELU)
-            else:
-                sc, sh = bb._bn_fold(bns, [hd.mt_proj[0].bias for hd in heads], 'hbn')
-                y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
-            for i, (t, hd) in enumerate(zip(self.tasks, heads)):
-                n_out = hd.linear_pred.weight.shape[0]
-                pred = ops.linear(y[i], ops.pack_linear([hd.linear_pred.weight], prec, ('hp', t)), n_out, prec,
-                                  bias=hd.linear_pred.bias.detach()[None], out_dtype=torch.float32)
-                out[t] = ops.bilinear(pred, B, n_out, h4, w4, target[0], target[1], torch.float32, nchw=True)
-        elif all(isinstance(hd, DEConvHead) for hd in heads):
-            F2 = F // 2
-            for i, (t, hd) in enumerate(zip(self.tasks, heads)):
-                wt = hd.mt_proj[0].weight                                   # [F, F2, 2, 2] -> rows n = (dy*2+dx)*F2 + co
-                Wd = ops._cached(('hd0', t, prec.name, id(wt)), [wt],
-                                 lambda wt=wt: ops.pack_matrix(wt.detach().permute(2, 3, 1, 0).reshape(4 * F2, F), prec)[None])
-                b4v = ops._cached(('hd0b', t, id(hd.mt_proj[0].bias)), [hd.mt_proj[0].bias],
-                                  lambda hd=hd: hd.mt_proj[0].bias.detach().repeat(4).contiguous())
-                y = ops.deconv2x2(fea[i], Wd, F2, F, B, h4, w4, prec, bias4=b4v)[None]      # [1, B*2h4*2w4, pad8(F2)]
-                Wc = ops.pack_conv3([hd.mt_proj[3].weight], prec, ('hd3', t))
-                bc = hd.mt_proj[3].bias.detach()[None].contiguous()
-                if self.training:
-                    y = bb._bn_train(y, [hd.mt_proj[1]], F2, ACT_GELU)
-                    y = ops.conv3x3(y, Wc, F2, F2, B, 2 * h4, 2 * w4, prec, bias=bc)
-                    y = bb._bn_train(y, [hd.mt_proj[4]], F2, ACT_GELU)
-                else:
-                    # BN1 cannot fold into the pixel-shuffle GEMM's epilogue (rows differ per tap? no: per channel) -> apply kernel
-                    bn1 = hd.mt_proj[1]
-                    y = ops.bn_apply(y, F2, bn1.running_mean, torch.rsqrt(bn1.running_var + bn1.eps), bn1.weight.detach(),
-                                     bn1.bias.detach(), ACT_GELU)
-                    sc, sh = bb._bn_fold([hd.mt_proj[4]], [hd.mt_proj[3].bias], ('hd4', t))
-                    y = ops.conv3x3(y, Wc, F2, F2, B, 2 * h4, 2 * w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
-                n_out = hd.linear_pred.weight.shape[0]
-                pred = ops.linear(y[0], ops.pack_linear([hd.linear_pred.weight], prec, ('hp', t)), n_out, prec,
-                                  bias=hd.linear_pred.bias.detach()[None], out_dtype=torch.float32)
-                out[t] = ops.bilinear(pred, B, n_out, 2 * h4, 2 * w4, target[0], target[1], torch.float32, nchw=True)
-        else:
-            raise NotImplementedError('heads must all be ConvHead or all DEConvHead (the 3ddet FCOS3D head is out of scope)')
-        return out
+        groups = {'conv': [], 'deconv': [], 'other': []}
+        for i, t in enumerate(self.tasks):
+            hd = self.heads[t]
+            groups['conv' if isinstance(hd, ConvHead) else ('deconv' if isinstance(hd, DEConvHead) else 'other')].append(i)
+        for kind in ('conv', 'deconv'):
+            idx = groups[kind]
+            if not idx:
+                continue
+            sub = fea if len(idx) == len(self.tasks) else fea[idx]
+            preds = run_heads(kind, [self.heads[self.tasks[i]] for i in idx], sub, B, h4, w4, target, bb.prec, self.training)
+            for i, pr in zip(idx, preds):
+                out[self.tasks[i]] = pr
+        for i in groups['other']:
+            t = self.tasks[i]
+            y = self.heads[t](fea[i].view(B, h4, w4, -1)[..., :F].permute(0, 3, 1, 2).float())
+            out[t] = y if t == '3ddet' else torch.nn.functional.interpolate(y, target, mode=INTERPOLATE_MODE)
+        return {t: out[t] for t in self.tasks}

@@ -298,3 +298,45 @@ def test_pack_cache_sees_raw_pointer_updates(emulated):
     m_before = opt2.state[w]["exp_avg"].clone()
     opt2.step()
     assert not torch.equal(opt2.state[w]["exp_avg"], m_before)
+
+
+def test_heads_standalone_and_mixed_head_sets(emulated):
+    """A head module is callable on its own (`head(x)`, reference layout in / out) and the wrapper accepts any mix of ConvHead,
+    DEConvHead and foreign modules (taskprompter_wrapper.py:29-38), each task through its own head."""
+    import mtt_amd
+    from oracle import taskprompter_oracle as tpo
+    tp = mtt_amd.taskprompter
+    cfg = configs.taskprompter("mini_deconv")
+    meta, _ = conftest.load_golden("mini_deconv")
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    model = conftest.build_product_model(cfg, "x3")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = weights.synth_images(1, cfg["img_size"], 3)
+    with torch.no_grad():
+        full = model(x)
+        feats, _ = model.backbone(x)
+        for t, n in cfg["tasks"]:
+            y = model.heads[t](feats[t])                               # DEConvHead alone: [B, n, 8h, 8w]
+            ref = tpo.head_forward(sd, f"heads.{t}", "deconv", feats[t].float())
+            assert y.shape == ref.shape and float((y - ref).norm() / ref.norm()) < 5e-5, t
+            up = torch.nn.functional.interpolate(y, size=tuple(x.shape[-2:]), mode="bilinear", align_corners=False)
+            assert float((up - full[t]).norm() / full[t].norm()) < 5e-5, t
+    # mixed: semseg keeps its DEConvHead, depth gets a ConvHead, plus a foreign torch head for a third pseudo-task
+    F = cfg["final_embed_dim"]
+    p2 = model.backbone.p
+    heads = torch.nn.ModuleDict({"semseg": model.heads["semseg"], "depth": tp.ConvHead(F, 1)})
+    mixed = tp.TaskPrompterWrapper(p2, model.backbone, heads).eval()
+    with torch.no_grad():
+        out = mixed(x)
+        assert float((out["semseg"] - full["semseg"]).abs().max()) < 1e-5
+        hd = heads["depth"]
+        sdh = {"h." + k: v for k, v in hd.state_dict().items()}
+        ref = tpo.head_forward(sdh, "h", "conv", feats["depth"].float())
+        ref = torch.nn.functional.interpolate(ref, size=tuple(x.shape[-2:]), mode="bilinear", align_corners=False)
+        assert float((out["depth"] - ref).norm() / ref.norm()) < 5e-5
+    # a training step through a standalone head reaches its parameters
+    hd.train()
+    y = hd(feats["depth"].float().requires_grad_(True))
+    y.square().mean().backward()
+    assert all(q.grad is not None for q in hd.parameters())
