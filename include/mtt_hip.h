@@ -279,6 +279,10 @@ typedef struct {
   int32_t B, heads, T, qh, qw, K; int64_t ldk, ldkp;
 } mtt_attnmsg_desc;
 int mtt_attn_msg(const mtt_attnmsg_desc* d, void* stream);
+/* backward of mtt_attn_msg (d->out unused): dcur, dup fp32 [B, heads, T*qh*qw, ldk] = gradients w.r.t. `cur` and w.r.t. the x2-upsampled
+ * `prev` (the gradient of `prev` itself is mtt_bilinear_bwd of dup); dw [heads, 2*heads] and dbias [heads] are ACCUMULATED
+ * (fp32 atomics; zeroed by the caller). */
+int mtt_attn_msg_bwd(const mtt_attnmsg_desc* d, const float* dout, float* dcur, float* dup, float* dw, float* dbias, void* stream);
 
 /* Gather half of nn.ConvTranspose2d(k=3, s=2, p=1, output_padding=1) (scale_embed[0], transformer_decoder.py:64):
  * yall [B*H*W, 9*Cop] = x @ Wall^T computed by mtt_gemm (column = tap*Cop + co) -> out [B*2H*2W, Cop] (+ bias[Cop]). */

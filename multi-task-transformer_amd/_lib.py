@@ -166,6 +166,7 @@ POSITIONAL = {
 # descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)
 DESC_EXTRA = {
     "bn_stats": (BnDesc, [ptr]), "bn_bwd_reduce": (BnDesc, [ptr]),
+    "attn_msg_bwd": (AttnMsgDesc, [ptr, ptr, ptr, ptr, ptr]),
     "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr]),
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),

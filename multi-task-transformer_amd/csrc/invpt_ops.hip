@@ -160,6 +160,90 @@ __global__ __launch_bounds__(256) void attn_msg_kernel(const mtt_attnmsg_desc d)
   }
 }
 
+// Backward of attn_msg_kernel w.r.t. everything but `prev` (whose gradient is the bilinear-backward gather of `dup`):
+//   dcur[b,h,q,k] = sum_o W[o,h] dout[b,o,q,k]          dup[b,h,q,k] = sum_o W[o,heads+h] dout[b,o,q,k]
+//   dw[o,h] += sum dout[b,o,..] cur[b,h,..]             dw[o,heads+h] += sum dout[b,o,..] up(prev)[b,h,..]        dbias[o] += sum dout[b,o,..]
+// One pass over the score tensors; per-thread partial sums of the (<= 36) parameter gradients are reduced through LDS and added with
+// one atomic per value per block (dw / dbias zeroed by the caller).
+__global__ __launch_bounds__(256) void attn_msg_bwd_kernel(const mtt_attnmsg_desc d, const float* dout, float* dcur, float* dup, float* dw,
+                                                           float* dbias) {
+  __shared__ float red[4][40];
+  const int Qt = d.qh * d.qw, Q = d.T * Qt, sh = d.qh / 2, sw = d.qw / 2, Qp = d.T * sh * sw;
+  const int H = d.heads, H2 = 2 * d.heads;
+  float pw[32], pb[4];                    // partial dw [H][2H] (H <= 4), dbias [H]
+#pragma unroll
+  for (int j = 0; j < 32; ++j) pw[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pb[j] = 0.f;
+  const int64_t total = (int64_t)d.B * Q * d.K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % d.K);
+    int64_t r = i / d.K;
+    const int q = (int)(r % Q);
+    const int b = (int)(r / Q);
+    const int t = q / Qt, p = q % Qt, y = p / d.qw, x = p % d.qw;
+    float sy = (y + 0.5f) * 0.5f - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = (x + 0.5f) * 0.5f - 0.5f; if (sx < 0.f) sx = 0.f;
+    int y0 = (int)sy, x0 = (int)sx;
+    if (y0 > sh - 1) y0 = sh - 1;
+    if (x0 > sw - 1) x0 = sw - 1;
+    const int y1 = y0 < sh - 1 ? y0 + 1 : y0, x1 = x0 < sw - 1 ? x0 + 1 : x0;
+    const float wy = sy - y0, wx = sx - x0;
+    float vin[8], g[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (h >= H) break;
+      const int64_t o = (((int64_t)b * H + h) * Q + q) * d.ldk + k;
+      vin[h] = d.cur[o];
+      g[h] = dout[o];
+      const float* pv = d.prev + (((int64_t)b * H + h) * Qp + (int64_t)t * sh * sw) * d.ldkp;
+      const float a00 = pv[(int64_t)(y0 * sw + x0) * d.ldkp + k], a01 = pv[(int64_t)(y0 * sw + x1) * d.ldkp + k];
+      const float a10 = pv[(int64_t)(y1 * sw + x0) * d.ldkp + k], a11 = pv[(int64_t)(y1 * sw + x1) * d.ldkp + k];
+      vin[H + h] = (a00 * (1.f - wx) + a01 * wx) * (1.f - wy) + (a10 * (1.f - wx) + a11 * wx) * wy;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (h >= H) break;
+      float a = 0.f, u = 0.f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (o >= H) break;
+        a += d.w[o * H2 + h] * g[o];
+        u += d.w[o * H2 + H + h] * g[o];
+      }
+      const int64_t oidx = (((int64_t)b * H + h) * Q + q) * d.ldk + k;
+      dcur[oidx] = a;
+      dup[oidx] = u;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o >= H) break;
+      pb[o] += g[o];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        if (h >= H2) break;
+        pw[o * 8 + h] += g[o] * vin[h];
+      }
+    }
+  }
+  // block reduction: wave shuffle, then the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) { const float v = wave_sum(pw[j]); if (lane == 0) red[wave][j] = v; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float v = wave_sum(pb[j]); if (lane == 0) red[wave][32 + j] = v; }
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 32) {
+      const int o = threadIdx.x >> 3, h = threadIdx.x & 7;
+      if (o < H && h < H2) atomicAdd(&dw[o * H2 + h], v);
+    } else if ((int)threadIdx.x - 32 < H) {
+      atomicAdd(&dbias[threadIdx.x - 32], v);
+    }
+  }
+}
+
 // ConvTranspose2d(k=3, s=2, p=1, output_padding=1) gather: yall [B*H*W, 9*Cop] = x @ Wall^T (tap-major columns) ->
 // out[b, oy, ox, co] = bias[co] + sum over taps with oy = 2*iy - 1 + ky, ox = 2*ix - 1 + kx
 __global__ __launch_bounds__(256) void convt3s2_gather_kernel(const mtt_convt_desc d) {
@@ -326,6 +410,14 @@ extern "C" int mtt_layernorm_mt(const mtt_lnmt_desc* d, void* stream) {
 extern "C" int mtt_attn_msg(const mtt_attnmsg_desc* d, void* stream) {
   if (!d || !d->cur || !d->prev || !d->out || !d->w || !d->bias || d->heads <= 0 || d->heads > 4 || (d->qh % 2) || (d->qw % 2)) return MTT_E_BADARG;
   hipLaunchKernelGGL(attn_msg_kernel, dim3(grid_for((int64_t)d->B * d->T * d->qh * d->qw * d->K)), dim3(256), 0, S_, *d);
+  return (int)hipGetLastError();
+}
+extern "C" int mtt_attn_msg_bwd(const mtt_attnmsg_desc* d, const float* dout, float* dcur, float* dup, float* dw, float* dbias, void* stream) {
+  if (!d || !d->cur || !d->prev || !d->w || !dout || !dcur || !dup || !dw || !dbias || d->heads <= 0 || d->heads > 4 || (d->qh % 2) || (d->qw % 2))
+    return MTT_E_BADARG;
+  int64_t g = ((int64_t)d->B * d->T * d->qh * d->qw * d->K + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(attn_msg_bwd_kernel, dim3((unsigned)g), dim3(256), 0, S_, *d, dout, dcur, dup, dw, dbias);
   return (int)hipGetLastError();
 }
 extern "C" int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream) {

@@ -233,6 +233,43 @@ class PVFn(Function):
         return dP, dv, None
 
 
+class FuseAttnFn(Function):
+    """Attention message passing (invpt.py:208-229): the previous stage's scores, bilinearly upsampled x2 over each task's query grid,
+    and the current scores are mixed over heads by the 1x1 conv `fuse_attn` — one fused kernel forward (mtt_attn_msg), one fused
+    kernel backward (mtt_attn_msg_bwd: dcur, the upsampled-space gradient, dW, dbias) + the bilinear-backward gather for dprev."""
+
+    @staticmethod
+    def forward(ctx, S, prev, weight, bias, geo):
+        B, heads, T, qh, qw, K = geo
+        S, prev = S.contiguous(), prev.contiguous()
+        w2 = weight.detach().reshape(heads, 2 * heads).contiguous()
+        out = torch.empty_like(S)
+        ops.call("attn_msg", cur=S, prev=prev, out=out, w=w2, bias=bias.detach(), B=B, heads=heads, T=T, qh=qh, qw=qw, K=K,
+                 ldk=S.shape[-1], ldkp=prev.shape[-1])
+        ctx.save_for_backward(S, prev, w2)
+        ctx.geo, ctx.wshape = geo, weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        S, prev, w2 = ctx.saved_tensors
+        B, heads, T, qh, qw, K = ctx.geo
+        dout = dout.contiguous()
+        dcur, dup = torch.empty_like(S), torch.empty_like(S)
+        if S.shape[-1] > K:                                            # padded key columns carry no gradient
+            dcur[..., K:] = 0
+            dup[..., K:] = 0
+        dw = torch.zeros(heads, 2 * heads, dtype=torch.float32, device=S.device)
+        db = torch.zeros(heads, dtype=torch.float32, device=S.device)
+        ops.call("attn_msg_bwd", cur=S, prev=prev, out=None, w=w2, bias=None, B=B, heads=heads, T=T, qh=qh, qw=qw, K=K,
+                 ldk=S.shape[-1], ldkp=prev.shape[-1], xargs=[dout, dcur, dup, dw, db])
+        Kp = prev.shape[-1]
+        dprev = torch.zeros_like(prev)
+        ops.call("bilinear_bwd", **{"in": dup}, out=dprev, B=B * heads * T, C=min(Kp, S.shape[-1]), Hin=qh // 2, Win=qw // 2, Hout=qh, Wout=qw,
+                 ld_in=Kp, ld_out=S.shape[-1], in_dtype=F32, out_dtype=F32, out_nchw=0, accumulate=1)
+        return dcur, dprev, dw.view(ctx.wshape), db, None
+
+
 # =================================================================================================
 def _check8(*dims):
     if any(d % 8 for d in dims):
@@ -293,13 +330,8 @@ def _block(dec, blk, si, Xf, B, T, D, gh, gw, prev_score):
         Kp = S.shape[-1]
         ph, pw = (gh // 2 - 1) // 2 + 1, (gw // 2 - 1) // 2 + 1                                   # previous stage's query grid
         assert prev_score.shape[2] == T * ph * pw and prev_score.shape[-1] == Kp
-        up = BilinearFn.apply(prev_score.reshape(1, -1, Kp), (B * heads * T, Kp, ph, pw, qh, qw), torch.float32, False)
-        up = up.view(B, heads, T * nq, Kp)
         fa = at.fuse_attn
-        wf = fa.weight.reshape(heads, 2 * heads)
-        S = torch.einsum('oh,bhqk->boqk', wf[:, :heads], S) + torch.einsum('oh,bhqk->boqk', wf[:, heads:], up) \
-            + fa.bias.view(1, heads, 1, 1)
-        S = S.contiguous()
+        S = FuseAttnFn.apply(S, prev_score, fa.weight, fa.bias, (B, heads, T, qh, qw, K))
     P = SoftmaxFn.apply(S, K, prec)
     o = PVFn.apply(P, v.contiguous(), prec)                                                     # [B, T*nq, D]
     o_tm = o.view(B, T, nq, D).permute(1, 0, 2, 3).reshape(1, T * B * nq, D)

@@ -578,6 +578,29 @@ def attn_msg(**kw):
     _wr(kw["out"], ci, out.reshape(B * heads * Q, K))
 
 
+def attn_msg_bwd(**kw):
+    """xargs = [dout, dcur, dup, dw (accumulated), dbias (accumulated)]"""
+    dout, dcur, dup, dw, dbias = kw["xargs"]
+    B, heads, T, qh, qw, K, ldk, ldkp = (kw[k] for k in ("B", "heads", "T", "qh", "qw", "K", "ldk", "ldkp"))
+    Q, sh, sw = T * qh * qw, qh // 2, qw // 2
+    Qp = T * sh * sw
+    ci = torch.arange(B * heads * Q)[:, None] * ldk + torch.arange(K)[None, :]
+    cur = _rd(kw["cur"], ci).view(B, heads, Q, K)
+    g = _rd(dout, ci).view(B, heads, Q, K)
+    pi = torch.arange(B * heads * Qp)[:, None] * ldkp + torch.arange(K)[None, :]
+    prev = _rd(kw["prev"], pi).view(B, heads, T, sh, sw, K)
+    up = torch.nn.functional.interpolate(prev.permute(0, 1, 2, 5, 3, 4).reshape(B * heads * T, K, sh, sw), scale_factor=2,
+                                         mode="bilinear", align_corners=False)
+    up = up.view(B, heads, T, K, qh * qw).permute(0, 1, 2, 4, 3).reshape(B, heads, Q, K)
+    w = _rd(kw["w"], torch.arange(heads * 2 * heads)).view(heads, 2 * heads)
+    _wr(dcur, ci, torch.einsum("oh,boqk->bhqk", w[:, :heads], g).reshape(B * heads * Q, K))
+    _wr(dup, ci, torch.einsum("oh,boqk->bhqk", w[:, heads:], g).reshape(B * heads * Q, K))
+    wi = torch.arange(heads * 2 * heads)
+    _wr(dw, wi, _rd(dw, wi) + torch.einsum("boqk,bhqk->oh", g, torch.cat([cur, up], 1)).reshape(-1))
+    bi = torch.arange(heads)
+    _wr(dbias, bi, _rd(dbias, bi) + g.sum((0, 2, 3)))
+
+
 def convt3x3s2_gather(**kw):
     B, H, W, Cop = kw["B"], kw["H"], kw["W"], kw["Cop"]
     ya = _rd(kw["yall"], torch.arange(B * H * W * 9 * Cop)).view(B, H, W, 3, 3, Cop)
@@ -761,7 +784,7 @@ _TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
               bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply,
               modulate_bwd=modulate_bwd, chan_logits_bwd=chan_logits_bwd, ctr_dw=ctr_dw,
-              dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg,
+              dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg, attn_msg_bwd=attn_msg_bwd,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
               loss_fwd=loss_fwd, loss_bwd=loss_bwd)

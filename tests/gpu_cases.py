@@ -446,6 +446,13 @@ def invpt_cases():
     kw = dict(cur=rnd(g, B, heads, Q, 16), prev=rnd(g, B, heads, Q // 4, 16), out=torch.zeros(B, heads, Q, 16), w=rnd(g, heads, 2 * heads),
               bias=rnd(g, heads), B=B, heads=heads, T=T, qh=qh, qw=qw, K=K, ldk=16, ldkp=16)
     cases.append(("attn_msg", "attn_msg", kw, TOL_ROW))
+    for (B, heads, T, qh, qw, K) in ((2, 2, 3, 4, 2, 9), (1, 2, 6, 8, 8, 96)):
+        Q = T * qh * qw
+        Kp = (K + 7) // 8 * 8
+        kw = dict(cur=rnd(g, B, heads, Q, Kp), prev=rnd(g, B, heads, Q // 4, Kp), out=None, w=rnd(g, heads, 2 * heads), bias=None,
+                  B=B, heads=heads, T=T, qh=qh, qw=qw, K=K, ldk=Kp, ldkp=Kp,
+                  xargs=[rnd(g, B, heads, Q, Kp), torch.zeros(B, heads, Q, Kp), torch.zeros(B, heads, Q, Kp), torch.zeros(heads, 2 * heads), torch.zeros(heads)])
+        cases.append((f"attn_msg_bwd_K{K}", "attn_msg_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
     return cases
 
 
