@@ -1,7 +1,9 @@
-"""CPU, world_size 2, gloo: the data-parallel path (DistributedDataParallel gradient all-reduce + cross-rank
-BatchNorm statistics through SyncBatchNorm holders) on the ABI emulator.  Two ranks with one image each must
-produce the gradients of a single process running both images (same global batch), as the reference's
-DDP + SyncBatchNorm training does (TaskPrompter/main.py:92-94)."""
+"""CPU, world_size 2 and 4, gloo: the data-parallel path (DistributedDataParallel gradient all-reduce + cross-rank
+BatchNorm statistics through SyncBatchNorm holders) on the ABI emulator.  The ranks, each with its share of the images — the shares
+may be UNEQUAL, the batch statistics are merged with per-rank counts — must produce the gradients of a single process running the
+whole batch, as the reference's DDP + SyncBatchNorm training does (TaskPrompter/main.py:92-94, InvPT/main.py:87-89).  Also checks
+that the stage-batched SyncBN exchange issues ONE collective per BatchNorm stage and that the fused clip + Adam step keeps the
+replicas identical."""
 import os
 import sys
 
@@ -12,8 +14,38 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+CASES = {
+    # name: (kind, config, image shares per rank)
+    "taskprompter_2ranks": ("TP", "mini_ctr", [[0], [1]]),
+    "taskprompter_3ranks_unequal": ("TP", "mini_ctr", [[0, 1], [2], [3]]),
+    "invpt_4ranks": ("IP", "mini8", [[0], [1], [2], [3]]),
+}
 
-def _worker(rank, world, port, q):
+
+def _loss(out, rows, n_total, world, seed=7):
+    """mean over the GLOBAL batch of <out, r> with global-batch random weights, restricted to this rank's images and scaled by the
+    world size (DDP averages the ranks' gradients)."""
+    g = torch.Generator().manual_seed(seed)
+    tot = 0.0
+    flat = {k: v for k, v in out.items() if k != "inter_preds"}
+    if "inter_preds" in out:
+        flat.update({"inter/" + k: v for k, v in out["inter_preds"].items()})
+    for k in sorted(flat):
+        r = torch.randn((n_total,) + tuple(flat[k].shape[1:]), generator=g)[rows]
+        tot = tot + (flat[k] * r).sum() / (n_total * flat[k][0].numel()) * world
+    return tot
+
+
+def _worker(rank, world, port, case, q):
+    try:
+        _worker_body(rank, world, port, case, q)
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put(("error", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+        raise
+
+
+def _worker_body(rank, world, port, case, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -23,68 +55,87 @@ def _worker(rank, world, port, q):
     import conftest
     import mtt_amd
     from oracle import abi_emul, configs, weights
-    from tests.golden.make_golden import loss_of
     mtt_amd.ops.call = abi_emul.call
-    cfg = configs.taskprompter("mini_ctr")
-    meta, _ = conftest.load_golden("mini_ctr")
+    kind, name, shares = CASES[case]
+    cfg = configs.taskprompter(name) if kind == "TP" else configs.invpt(name)
     model = conftest.build_product_model(cfg, "x3")
-    model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=True)
+    contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(weights.synth_state_dict(contract, 0), strict=True)
     model.train()
-    for m in model.modules():          # DDP refuses nn.SyncBatchNorm on CPU modules: flag the holders instead (same code path)
-        if isinstance(m, torch.nn.BatchNorm2d):
+    for m in model.modules():          # DDP refuses nn.SyncBatchNorm on CPU modules: plain holders flagged for sync (same code path)
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            if isinstance(m, torch.nn.SyncBatchNorm):
+                m.__class__ = torch.nn.BatchNorm2d
             m._mtt_sync = True
-    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=False)
-    x = weights.synth_images(2, cfg["img_size"], 2)[rank:rank + 1]
+    n_coll = {"gather": 0}
+    ag = dist.all_gather
+
+    def counted_gather(*a, **k):
+        n_coll["gather"] += 1
+        return ag(*a, **k)
+    dist.all_gather = counted_gather
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=(kind == "IP"))
+    n_total = sum(len(s) for s in shares)
+    rows = shares[rank]
+    x = weights.synth_images(n_total, cfg["img_size"], 2)[rows]
     out = ddp(x)
-    # per-rank loss on its image with the global-batch random weights -> DDP averages gradients over ranks
-    g = torch.Generator().manual_seed(7)
-    tot = 0.0
-    for k in sorted(out):
-        r = torch.randn((2,) + tuple(out[k].shape[1:]), generator=g)[rank:rank + 1]
-        tot = tot + (out[k] * r).sum() / (2 * out[k][0].numel()) * world      # mean over the global batch, undo DDP's 1/world
-    tot.backward()
-    grads = {k: v.grad.clone() for k, v in model.named_parameters()}
+    _loss(out, rows, n_total, world).backward()
+    grads = {k: (v.grad.clone() if v.grad is not None else None) for k, v in model.named_parameters()}
+    n_bn_stages = n_coll["gather"]
     # the fused clip + Adam step consumes DDP's (bucket-view) gradients: parameters must stay identical on every rank
-    opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-6, max_norm=0.5)
+    opt = mtt_amd.optim.FusedClipAdam([p_ for p_ in model.parameters() if p_.grad is not None], lr=1e-3, weight_decay=1e-6, max_norm=0.5)
     norm = opt.step()
     chk = torch.stack([p_.detach().double().sum() for p_ in model.parameters()]).sum() + norm.double().sum()
     seen = [torch.zeros_like(chk) for _ in range(world)]
-    dist.all_gather(seen, chk)
+    ag(seen, chk)
     assert all(bool(torch.equal(seen[0], s_)) for s_ in seen), seen
     if rank == 0:
-        q.put({k: v.numpy() for k, v in grads.items()})
+        q.put(({k: (v.numpy() if v is not None else None) for k, v in grads.items()}, n_bn_stages))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_ddp_two_ranks_match_single_process():
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_ddp_ranks_match_single_process(case):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import train_check
+    kind, name, shares = CASES[case]
+    world = len(shares)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 1000) + 7 * sorted(CASES).index(case)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p_ in procs:
         p_.start()
-    got = q.get(timeout=240)
+    got, n_stage_collectives = q.get(timeout=600)
+    assert got != "error", n_stage_collectives
     for p_ in procs:
-        p_.join(timeout=120)
+        p_.join(timeout=300)
         assert p_.exitcode == 0
-    # single-process oracle gradients on the 2-image batch (train_check uses the same inputs / loss)
+    # single-process oracle gradients on the whole batch, same loss
     import conftest
-    from oracle import configs, taskprompter_oracle as tpo, weights
-    from tests.golden.make_golden import loss_of
-    cfg = configs.taskprompter("mini_ctr")
-    meta, _ = conftest.load_golden("mini_ctr")
-    sd = weights.synth_state_dict(meta["contract"], 0)
+    from oracle import configs, weights
+    cfg = configs.taskprompter(name) if kind == "TP" else configs.invpt(name)
+    contract = [(k, list(v.shape)) for k, v in conftest.build_product_model(cfg, "x3").state_dict().items()]
+    sd = weights.synth_state_dict(contract, 0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
-    x = weights.synth_images(2, cfg["img_size"], 2)
-    loss_of(tpo.forward(dict(sd, **params), cfg, x, training=True)).backward()
+    n_total = sum(len(s) for s in shares)
+    x = weights.synth_images(n_total, cfg["img_size"], 2)
+    if kind == "TP":
+        from oracle import taskprompter_oracle as orc
+    else:
+        from oracle import invpt_oracle as orc
+    out = orc.forward(dict(sd, **params), cfg, x, training=True)
+    _loss(out, list(range(n_total)), n_total, 1).backward()
     worst = 0.0
     for k, ref in params.items():
         if ref.grad is None or float(ref.grad.norm()) < 1e-6:
             continue
+        assert got[k] is not None, k
         e = float((torch.from_numpy(got[k]) - ref.grad).norm() / ref.grad.norm())
         worst = max(worst, e)
     assert worst < 1e-3, worst
+    # SyncBN statistics: one all_gather per BatchNorm STAGE (a stage = all tasks' BatchNorms at one point of the network), not one
+    # per BatchNorm layer: TaskPrompter has 4 taps + 1 head stage; InvPT's decoder has 2 + 3*... stages (fewer than its 2*T*... layers)
+    n_layers = sum(1 for k in sd if k.endswith("running_mean"))
+    assert 0 < n_stage_collectives < n_layers, (n_stage_collectives, n_layers)
