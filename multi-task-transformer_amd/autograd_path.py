@@ -104,6 +104,13 @@ def _wgrad_batched(dy, x, N, Kp, M, prec, Z, lda, ldb, a_zo, b_zo, a0=0, b0=0):
     return slabs.sum(1)
 
 
+def _pad_last(t, width):
+    """contiguous copy of `t` with its last dim zero-padded to `width`."""
+    out = torch.zeros(t.shape[:-1] + (width,), dtype=t.dtype, device=t.device)
+    out[..., :t.shape[-1]] = t
+    return out
+
+
 def _transposed(x2d, cols, dtype=torch.bfloat16, colsum=None):
     """[rows, ld] -> [cols, pad64(rows)] (zero padded): reduction-contiguous operand for the fast weight-gradient GEMM.
     colsum (fp32 [cols], zero-initialised): also receives the column sums of x2d (the bias gradient) from the same pass."""
@@ -460,8 +467,14 @@ class BLinearFn(Function):
         xz = x.stride(0) if (x.dim() == 3 and x.shape[0] > 1) else 0
         bi = az['batch_inner']
         dx = torch.empty(Z, M, Kp, dtype=x.dtype, device=x.device)
-        _gemm(dy, wpack, dx, M, Kp, N, prec, b_op=OP_R, lda=lda, ldb=Kp, ldd=Kp, b_zo=wpack.stride(0) * bi,
-              b_zi=wpack.stride(0) if bi > 1 else 0, d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
+        if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and M >= FAST_MIN_ROWS and Kp >= 128:
+            # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T
+            wT = _pad_last(wpack.transpose(1, 2), Np)                  # [Z, Kp, pad8(N)]: a few MB, once per backward of this node
+            _gemm(dy, wT, dx, M, Kp, Np, prec, lda=lda, ldb=Np, ldd=Kp, b_zo=wT.stride(0) * bi, b_zi=wT.stride(0) if bi > 1 else 0,
+                  d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
+        else:
+            _gemm(dy, wpack, dx, M, Kp, N, prec, b_op=OP_R, lda=lda, ldb=Kp, ldd=Kp, b_zo=wpack.stride(0) * bi,
+                  b_zi=wpack.stride(0) if bi > 1 else 0, d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
         if Z == 1 and layout == 'plain':
             dW = _wgrad(dy.view(M, lda), x.reshape(M, x.shape[-1]), N, Kp, prec)[None]
         elif layout == 'catpair':

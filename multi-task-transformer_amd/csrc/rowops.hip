@@ -640,35 +640,51 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const mtt_bn_desc d, int
   }
 }
 
+// Merge of the per-block partials, in a fixed order: block = 32 channels x 8 partial lanes (lane l takes partials l, l+8, ...), the 8
+// lanes are combined through LDS by lane 0.  Grid (ceil(C / 32), Z).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_final_kernel(const mtt_bn_desc d, int rows_per_block, int nblk, const float* ws) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d.C) return;
+  __shared__ float sh[3][8][32];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   const int z = blockIdx.y;
   const int Cp = ((d.C + 7) >> 3) * 8;
-  const float* p = ws + (int64_t)z * nblk * 2 * Cp + c;
-  float o0, o1;
-  if (MODE == 0) {
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
+  const bool cok = c < d.C;
+  const float* p = ws + (int64_t)z * nblk * 2 * Cp + (cok ? c : 0);
+  float n = 0.f, a0 = 0.f, a1 = 0.f;                 // MODE 0: (count, mean, M2); MODE 2: (-, sum0, sum1)
+  for (int b = pl; b < nblk; b += 8) {
+    const float v0 = p[(int64_t)b * 2 * Cp], v1 = p[(int64_t)b * 2 * Cp + Cp];
+    if (MODE == 0) {
       const int64_t r0 = (int64_t)b * rows_per_block;
       const float nb = (float)((r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows) - r0);
-      const float mb = p[(int64_t)b * 2 * Cp], qb = p[(int64_t)b * 2 * Cp + Cp];
-      const float tot = n + nb, delta = mb - mean;
-      mean += delta * (nb / tot);
-      m2 += qb + delta * delta * (n * nb / tot);
+      const float tot = n + nb, delta = v0 - a0;
+      a0 += delta * (nb / tot);
+      a1 += v1 + delta * delta * (n * nb / tot);
       n = tot;
+    } else {
+      a0 += v0; a1 += v1;
     }
-    o0 = mean; o1 = m2;
-  } else {
-    float s0 = 0.f, s1 = 0.f;
-    for (int b = 0; b < nblk; ++b) { s0 += p[(int64_t)b * 2 * Cp]; s1 += p[(int64_t)b * 2 * Cp + Cp]; }
-    o0 = s0; o1 = s1;
+  }
+  sh[0][pl][cl] = n; sh[1][pl][cl] = a0; sh[2][pl][cl] = a1;
+  __syncthreads();
+  if (pl != 0 || !cok) return;
+  for (int l = 1; l < 8; ++l) {
+    const float nb = sh[0][l][cl], v0 = sh[1][l][cl], v1 = sh[2][l][cl];
+    if (MODE == 0) {
+      if (nb > 0.f) {
+        const float tot = n + nb, delta = v0 - a0;
+        a0 += delta * (nb / tot);
+        a1 += v1 + delta * delta * (n * nb / tot);
+        n = tot;
+      }
+    } else {
+      a0 += v0; a1 += v1;
+    }
   }
   float* const q0 = MODE == 0 ? d.mean_out : d.dsum;
   float* const q1 = MODE == 0 ? d.m2_out : d.dsumxh;
-  q0[(int64_t)z * d.p_zs + c] = o0;
-  q1[(int64_t)z * d.p_zs + c] = o1;
+  q0[(int64_t)z * d.p_zs + c] = a0;
+  q1[(int64_t)z * d.p_zs + c] = a1;
 }
 
 // y = act((x - mean) * rstd * gamma + beta); channels >= C are written as zeros (padding).
@@ -1175,7 +1191,7 @@ extern "C" int mtt_bn_stats(const mtt_bn_desc* d, float* ws, void* stream) {
   if (!d->x || !d->mean_out || !d->m2_out || !ws) return MTT_E_BADARG;
   const int Z = bn_batch(d);
   hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk, Z), dim3(256), 0, S_, *d, rpb, ws);
-  hipLaunchKernelGGL(bn_final_kernel<0>, dim3((d->C + 255) / 256, Z), dim3(256), 0, S_, *d, rpb, nblk, ws);
+  hipLaunchKernelGGL(bn_final_kernel<0>, dim3((d->C + 31) / 32, Z), dim3(256), 0, S_, *d, rpb, nblk, ws);
   return LAUNCH_OK();
 }
 extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream) {
@@ -1195,7 +1211,7 @@ extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, float* ws, void* stream) 
   if (!d->x || !d->dy || !d->dsum || !d->dsumxh || !d->mean || !d->rstd || !d->gamma || !d->beta || !ws) return MTT_E_BADARG;
   const int Z = bn_batch(d);
   hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(nblk, Z), dim3(256), 0, S_, *d, rpb, ws);
-  hipLaunchKernelGGL(bn_final_kernel<2>, dim3((d->C + 255) / 256, Z), dim3(256), 0, S_, *d, rpb, nblk, ws);
+  hipLaunchKernelGGL(bn_final_kernel<2>, dim3((d->C + 31) / 32, Z), dim3(256), 0, S_, *d, rpb, nblk, ws);
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_apply(const mtt_bn_desc* d, void* stream) {

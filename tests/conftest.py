@@ -14,8 +14,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+HOST_THREADS = min(16, os.cpu_count() or 1)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle / emulator legs: a fixed, modest thread count.  The GPU box has 256 hardware threads and torch's default (all of
+    # them) THRASHES on these workloads — measured in round 2: the NS-6 oracle forward took 220 s on 256 threads vs 5 s on 8.
+    torch.set_num_threads(HOST_THREADS)
 
 
 def has_gpu():

@@ -40,7 +40,7 @@ def oracle_eval(name, B, seed=0):
         cfg = get_cfg(name)
         sd = weights.synth_state_dict(contract_of(cfg), seed)
         x = weights.synth_images(B, cfg["img_size"], seed + 1)
-        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        torch.set_num_threads(conftest.HOST_THREADS)
         t0 = time.time()
         with torch.no_grad():
             if cfg["model"] == "TransformerNet":

@@ -1,5 +1,8 @@
-"""Micro-benchmark of mtt_gemm variants on the real shapes of the NS-6 training step (TFLOP/s per shape and variant)."""
+"""Micro-benchmark of the mtt_gemm kernels on the real shapes of the NS-6 training step at per-GPU batch 63 (TFLOP/s per shape and
+kernel).  Interleaved rounds inside ONE process (cdna_hip_programming.md §5.4 rule 24): every round runs every kernel once per shape;
+the median and best round are printed.  Operands are uniform random (rule 25)."""
 import os
+import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,31 +16,39 @@ _call = ops.call
 FORCE = {"v": 0}
 ops.call = lambda name, **kw: _call(name, **(dict(kw, variant=FORCE["v"]) if name == "gemm" else kw))     # mtt_gemm_desc.variant
 prec = ops.Prec("bf16")
-SHAPES = [("qkv", 8240, 3072, 1024), ("proj", 8240, 1024, 1024), ("fc1", 8240, 4096, 1024), ("fc2", 8240, 1024, 4096),
-          ("big", 8192, 8192, 8192), ("fc1_b16", 16480, 4096, 1024)]
+M63 = 63 * 1030
+SHAPES = [("qkv", M63, 3072, 1024, 0), ("proj", M63, 1024, 1024, 0), ("fc1+gelu", M63, 4096, 1024, 1), ("fc2", M63, 1024, 4096, 0),
+          ("dec N=300", 63 * 1024, 300, 1024, 0), ("f0 K=608", 63 * 1024, 350, 608, 0), ("big", 8192, 8192, 8192, 0)]
+KERNELS = [(1, "reg128"), (4, "dma256 lock-step (r01)"), (3, "dma phased (r02)")]
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
-def bench(M, N, K, variant, iters=20):
-    FORCE["v"] = variant
-    x = torch.randn(M, K, device="cuda").bfloat16()
-    w = torch.randn(1, N, K, device="cuda").bfloat16()
-    out = torch.empty(1, M, N, device="cuda", dtype=torch.bfloat16)
-    for _ in range(3):
-        ops.linear(x, w, N, prec, out=out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        ops.linear(x, w, N, prec, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    return 2.0 * M * N * K / ms / 1e9, ms
+def run(x, w, b, out, N, act):
+    ops.linear(x, w, N, prec, bias=b, act=act, out=out)
 
 
-for name, M, N, K in SHAPES:
-    row = [f"{name:8s} M={M:6d} N={N:5d} K={K:5d}"]
-    for v, vn in ((1, "reg128"), (2, "dma128"), (3, "dma256")):
-        tf, ms = bench(M, N, K, v)
-        row.append(f"{vn} {tf:7.1f} TF/s ({ms * 1e3:7.1f} us)")
-    print("  ".join(row), flush=True)
+for name, M, N, K, act in SHAPES:
+    x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
+    w = (torch.rand(1, N, K, device="cuda") * 2 - 1).bfloat16()
+    b = torch.randn(1, N, device="cuda")
+    out = torch.empty(1, M, ops.pad8(N), device="cuda", dtype=torch.bfloat16)
+    res = {v: [] for v, _ in KERNELS}
+    for v, _ in KERNELS:
+        FORCE["v"] = v
+        run(x, w, b, out, N, act)
+    for _ in range(ROUNDS):
+        for v, _ in KERNELS:
+            FORCE["v"] = v
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                run(x, w, b, out, N, act)
+            e1.record()
+            torch.cuda.synchronize()
+            res[v].append(e0.elapsed_time(e1) / 3)
+    row = [f"{name:10s} M={M:6d} N={N:5d} K={K:5d}"]
+    for v, vn in KERNELS:
+        med, best = statistics.median(res[v]), min(res[v])
+        row.append(f"{vn}: {2.0 * M * N * K / med / 1e9:6.0f} TF/s median ({2.0 * M * N * K / best / 1e9:6.0f} best, {med * 1e3:7.1f} us)")
+    print("  |  ".join(row), flush=True)
