@@ -906,9 +906,14 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   const int n256 = (d.N + 255) / 256 * 256, n128 = (d.N + 127) / 128 * 128;
   const int bn = 100 * n128 <= 85 * n256 ? 128 : 256;   // the narrower tile only where it saves >= 15 % of the columns (N = 300, 350, 576 ...)
   if (d.variant == MTT_GEMM_DMA256) return bn == 256 ? 3 : 4;
+  // AUTO.  Measured on MI355X (profiles/r02_gemm_bench_b*.log, r02_conv_bench_b.log, B = 63 shapes): the 256 x 256 DMA tile wins for
+  // wide outputs (qkv / proj / fc1 / fc2: 830-1170 vs 610-740 TFLOP/s on the register-staged 128 x 128 kernel), but the 256 x 128 DMA
+  // tile LOSES to it on the narrow decoder shapes (N = 300 / 350: 280-330 vs 300-370) and on the implicit-GEMM 3x3 conv
+  // (510 vs 640): with half the MFMAs per K step the 6 LDS-DMA pieces a wave issues (+ the im2col address math) are no longer
+  // covered.  So: DMA kernel for plain GEMMs with N >= 512 columns of 256-wide tiles, the general kernel otherwise.
   const int batch = d.batch < 1 ? 1 : d.batch;
-  const int64_t blocks = (int64_t)((d.M + 255) / 256) * ((d.N + bn - 1) / bn) * batch;
-  if (d.M >= 512 && d.N >= 128 && blocks >= 96) return bn == 256 ? 3 : 4;
+  const int64_t blocks = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * batch;
+  if (!conv && bn == 256 && d.M >= 512 && d.N >= 512 && blocks >= 96) return 3;
   return 0;
 }
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }
