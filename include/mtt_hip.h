@@ -48,7 +48,8 @@ enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
 /* kernel selection of mtt_gemm / mtt_attn_fwd: AUTO = the library's policy (a pure function of the descriptor); the other values
  * force one kernel where it is applicable (benchmarks, A/B measurements).  There is no process-global switch and no environment
  * variable: the library keeps no mutable state that affects results. */
-enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3, MTT_GEMM_DMA256_V1 = 4 };
+enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3, MTT_GEMM_DMA256_V1 = 4,
+       MTT_GEMM_DMA256_S0 = 5 /* phased kernel with its first LDS-DMA schedule (A/B measurements) */ };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1 };
 
 /* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */

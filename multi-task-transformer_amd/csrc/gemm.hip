@@ -8,6 +8,7 @@
 // double buffered with one barrier per K step, fragment reads are swizzled conflict-free
 // ds_read_b128.  Blocks are remapped so consecutive tiles of one XCD share A rows in its L2.
 #include "mtt_device.h"
+#include <type_traits>
 
 namespace {
 
@@ -687,7 +688,12 @@ int launch_fast256(const GemmP& p, hipStream_t stream) {
 // chunk per K step (tap, channel tracked incrementally; halo / K tail chunks read a zero page) — address VALU work runs in the
 // R phases, under the other half's MFMAs.  K only needs to be a multiple of 8 (chunks past K read the zero page).
 // ---------------------------------------------------------------------------------------------
-template <int BN_, bool CONV>
+// SCHED selects where the LDS-DMA pieces of the next K tile are issued (an LDS-DMA instruction costs its wave ~60-100 cycles of issue;
+// eight of them in one burst made R0 twice as long as a C phase):
+//   0  all 8 pieces in R0 (first version: profiles/r02_gemm_bench_b*.log — no gain over the lock-step kernel)
+//   1  balanced: waves 0-3 issue the A pieces in R0 and the B pieces in R1; waves 4-7 (one slot behind) issue the A pieces of tile
+//      kt+2 between the MFMAs of C1(kt) and the B pieces of tile kt+1... see the schedule table in the loop body.
+template <int BN_, bool CONV, int SCHED>
 __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WAVES_N = BN_ / 64, WAVES_M = 8 / WAVES_N, MT = 256 / WAVES_M / 16, NT = 4;
@@ -756,9 +762,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
     boff[i] = (int64_t)rb * p.d.ldb + bck[i];
   }
 
-  auto issue = [&](int stage, int kt) {
+  auto issueA = [&](int stage, int kt) {
     unsigned char* sA = smem + stage * STAGE + wave * 4096;
-    unsigned char* sB = smem + stage * STAGE + TILE_A + wave * (B_GLDS * 1024);
     const int k0 = kt * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -777,6 +782,10 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
       }
       glds16((const bf16_t*)(uintptr_t)(ok ? src : zpage), sA + i * 1024);
     }
+  };
+  auto issueB = [&](int stage, int kt) {
+    unsigned char* sB = smem + stage * STAGE + TILE_A + wave * (B_GLDS * 1024);
+    const int k0 = kt * BK;
 #pragma unroll
     for (int i = 0; i < B_GLDS; ++i) {
       const bool ok = k0 + bck[i] < K;
@@ -784,6 +793,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
       glds16((const bf16_t*)(uintptr_t)(ok ? src : zpage), sB + i * 1024);
     }
   };
+  auto issue = [&](int stage, int kt) { issueA(stage, kt); issueB(stage, kt); };
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -795,51 +805,89 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // tile 0 is in LDS
+  if (SCHED == 1 && late && nk > 1) issueA(1, 1);  // what C1(-1) would have issued
   if (late) __builtin_amdgcn_s_barrier();          // stagger: waves 4-7 start one slot later
   __builtin_amdgcn_sched_barrier(0);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* Ah = smem + (kt & 1) * STAGE;
-    const unsigned char* Bh = Ah + TILE_A;
+  // Schedule of the LDS-DMA of tile kt+1 (SCHED 1); slot = 4 kt + phase (+1 for the late half); deadline = the barrier closing slot 4 kt + 3:
+  //   waves 0-3:  A pieces in R0(kt) [slot 4kt], B pieces in R1(kt) [slot 4kt+2], vmcnt(0) at the end of C1(kt) [slot 4kt+3]
+  //   waves 4-7:  A pieces in C1(kt-1) [slot 4kt] between its MFMAs, B pieces in R0(kt) [slot 4kt+1], vmcnt(0) at the end of R1(kt) [4kt+3]
+  //   (the stage being written held tile kt-1, whose last reads — R1(kt-1) of the late half — ended in slot 4kt-1.)
+  // The loop body is instantiated once per half (LATE is a compile-time constant inside it: no per-phase branching, and the
+  // register allocator sees one straight-line schedule per half).
+  auto main_loop = [&](auto late_tag) {
+    constexpr bool LATE = decltype(late_tag)::value;
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* Ah = smem + (kt & 1) * STAGE;
+      const unsigned char* Bh = Ah + TILE_A;
+      const bool more = kt + 1 < nk;
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      // ---- R phase: fragments of this 32-deep half (and, in R0, the LDS-DMA of the next K tile) ----
-      if (kh == 0 && kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
-      u32x4 fa[MT], fb[NT];
+      for (int kh = 0; kh < 2; ++kh) {
+        // ---- R phase: fragments of this 32-deep half (+ this wave's share of the next tile's LDS-DMA) ----
+        if (SCHED == 0) {
+          if (kh == 0 && more) issue((kt + 1) & 1, kt + 1);
+        } else if (more) {
+          if (kh == 0) { if (!LATE) issueA((kt + 1) & 1, kt + 1); else issueB((kt + 1) & 1, kt + 1); }
+          else if (!LATE) issueB((kt + 1) & 1, kt + 1);
+        }
+        u32x4 fa[MT], fb[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+        for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
 #pragma unroll
-      for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * (MT * 16) + t * 16 + li, kh * 4 + lg));
-      if (kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // next tile (own part) landed; reads done
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- C phase ----
-      __builtin_amdgcn_s_setprio(1);
+        for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * (MT * 16) + t * 16 + li, kh * 4 + lg));
+        if (kh == 1 && (SCHED == 0 || LATE)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile (own part) landed
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C phase ----
+        __builtin_amdgcn_s_setprio(1);
+        if (SCHED == 1 && kh == 1 && LATE && !CONV) {
+          // late half: the A pieces of tile kt+2 between the MFMAs (stage kt&1: its last reads, R1(kt), ended before this slot)
+          unsigned char* sA = smem + (kt & 1) * STAGE + wave * 4096;
+          const int k0 = (kt + 2) * BK;
+          const bool more2 = kt + 2 < nk;
 #pragma unroll
-      for (int a = 0; a < MT; ++a)
+          for (int a = 0; a < MT; ++a) {
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+            for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+            if ((a & 1) == 1 && more2) {
+              const int i = a >> 1;
+              const bool ok = k0 + ack[i] < K;
+              const uint64_t src = (uint64_t)(uintptr_t)(Abase + (aoff[i] + k0));
+              glds16((const bf16_t*)(uintptr_t)(ok ? src : zpage), sA + i * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+          if (SCHED == 1 && kh == 1 && LATE && CONV && kt + 2 < nk) issueA(kt & 1, kt + 2);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (SCHED == 1 && kh == 1 && !LATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // early half: tile kt+1 landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  }
+  };
+  if (late) main_loop(std::true_type{}); else main_loop(std::false_type{});
   if (!late) __builtin_amdgcn_s_barrier();         // waves 0-3 wait one slot for the late half
   __syncthreads();                                 // everyone is past its last LDS read: the epilogue may reuse the stages
   gemm_epilogue<BN_, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
 }
 
-template <int BN_, bool CONV>
+template <int BN_, bool CONV, int SCHED>
 int launch_dma(const GemmP& p, hipStream_t stream) {
   constexpr int smem = (BM2 * BK * 2 + BN_ * BK * 2) * 2;
   static std::atomic<unsigned long long> done{0};
-  if (int e = mtt_ensure_dyn_lds((const void*)gemm_dma_kernel<BN_, CONV>, smem, done)) return e;
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_dma_kernel<BN_, CONV, SCHED>, smem, done)) return e;
   const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + BN_ - 1) / BN_;
   dim3 grid(tm * tn, 1, p.d.batch);
-  hipLaunchKernelGGL((gemm_dma_kernel<BN_, CONV>), grid, dim3(512), smem, stream, p);
+  hipLaunchKernelGGL((gemm_dma_kernel<BN_, CONV, SCHED>), grid, dim3(512), smem, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -905,7 +953,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   if (d.variant == MTT_GEMM_DMA256_V1 && v1_ok) return 5;
   const int n256 = (d.N + 255) / 256 * 256, n128 = (d.N + 127) / 128 * 128;
   const int bn = 100 * n128 <= 85 * n256 ? 128 : 256;   // the narrower tile only where it saves >= 15 % of the columns (N = 300, 350, 576 ...)
-  if (d.variant == MTT_GEMM_DMA256) return bn == 256 ? 3 : 4;
+  if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S0) return bn == 256 ? 3 : 4;
   // AUTO.  Measured on MI355X (profiles/r02_gemm_bench_b*.log, r02_conv_bench_b.log, B = 63 shapes): the 256 x 256 DMA tile wins for
   // wide outputs (qkv / proj / fc1 / fc2: 830-1170 vs 610-740 TFLOP/s on the register-staged 128 x 128 kernel), but the 256 x 128 DMA
   // tile LOSES to it on the narrow decoder shapes (N = 300 / 350: 280-330 vs 300-370) and on the implicit-GEMM 3x3 conv
@@ -958,8 +1006,8 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (mode == 0) {
     const int v = gemm_variant_for(d);
     const bool conv_a = d.a_op == MTT_OP_CONV_K;
-    if (v == 3) return conv_a ? launch_dma<256, true>(p, s) : launch_dma<256, false>(p, s);
-    if (v == 4) return conv_a ? launch_dma<128, true>(p, s) : launch_dma<128, false>(p, s);
+    if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S0 ? launch_dma<256, false, 0>(p, s) : launch_dma<256, false, 1>(p, s));
+    if (v == 4) return conv_a ? launch_dma<128, true, 0>(p, s) : launch_dma<128, false, 0>(p, s);
     if (v == 5) return launch_fast256(p, s);
     if (v == 1) return launch_fast(p, s);
   }

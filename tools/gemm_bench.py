@@ -18,8 +18,8 @@ ops.call = lambda name, **kw: _call(name, **(dict(kw, variant=FORCE["v"]) if nam
 prec = ops.Prec("bf16")
 M63 = 63 * 1030
 SHAPES = [("qkv", M63, 3072, 1024, 0), ("proj", M63, 1024, 1024, 0), ("fc1+gelu", M63, 4096, 1024, 1), ("fc2", M63, 1024, 4096, 0),
-          ("dec N=300", 63 * 1024, 300, 1024, 0), ("f0 K=608", 63 * 1024, 350, 608, 0), ("big", 8192, 8192, 8192, 0)]
-KERNELS = [(1, "reg128"), (4, "dma256 lock-step (r01)"), (3, "dma phased (r02)")]
+          ("big", 8192, 8192, 8192, 0)]
+KERNELS = [(1, "reg128"), (4, "dma256 lock-step (r01)"), (5, "phased, burst DMA"), (3, "phased, balanced DMA")]
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
