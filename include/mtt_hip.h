@@ -49,7 +49,8 @@ enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
  * force one kernel where it is applicable (benchmarks, A/B measurements).  There is no process-global switch and no environment
  * variable: the library keeps no mutable state that affects results. */
 enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3, MTT_GEMM_DMA256_V1 = 4,
-       MTT_GEMM_DMA256_S0 = 5 /* phased kernel with its first LDS-DMA schedule (A/B measurements) */ };
+       MTT_GEMM_DMA256_S1 = 5 /* phased kernel with the balanced LDS-DMA schedule (A/B measurements) */,
+       MTT_GEMM_ABLATE_NO_EPILOGUE = 6, MTT_GEMM_ABLATE_NO_KLOOP = 7 /* measurement-only: WRONG results by construction */ };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1 };
 
 /* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */

@@ -801,7 +801,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K + BK - 1) / BK;
+  // SCHED 2 / 3 are measurement-only ablations (cdna_hip_programming.md §5.4 rule 17): 2 = main loop without the epilogue (accumulators
+  // kept alive, nothing stored), 3 = prologue + epilogue without the K loop (one K tile).  Never dispatched by the policy.
+  const int nk = SCHED == 3 ? 1 : (K + BK - 1) / BK;
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // tile 0 is in LDS
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
         // ---- R phase: fragments of this 32-deep half (+ this wave's share of the next tile's LDS-DMA) ----
-        if (SCHED == 0) {
+        if (SCHED != 1) {
           if (kh == 0 && more) issue((kt + 1) & 1, kt + 1);
         } else if (more) {
           if (kh == 0) { if (!LATE) issueA((kt + 1) & 1, kt + 1); else issueB((kt + 1) & 1, kt + 1); }
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
         for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
 #pragma unroll
         for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * (MT * 16) + t * 16 + li, kh * 4 + lg));
-        if (kh == 1 && (SCHED == 0 || LATE)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile (own part) landed
+        if (kh == 1 && (SCHED != 1 || LATE)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile (own part) landed
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -877,6 +879,13 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   if (late) main_loop(std::true_type{}); else main_loop(std::false_type{});
   if (!late) __builtin_amdgcn_s_barrier();         // waves 0-3 wait one slot for the late half
   __syncthreads();                                 // everyone is past its last LDS read: the epilogue may reuse the stages
+  if (SCHED == 2) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) asm volatile("" :: "v"(acc[a][b]));
+    return;
+  }
   gemm_epilogue<BN_, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
 }
 
@@ -953,7 +962,8 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   if (d.variant == MTT_GEMM_DMA256_V1 && v1_ok) return 5;
   const int n256 = (d.N + 255) / 256 * 256, n128 = (d.N + 127) / 128 * 128;
   const int bn = 100 * n128 <= 85 * n256 ? 128 : 256;   // the narrower tile only where it saves >= 15 % of the columns (N = 300, 350, 576 ...)
-  if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S0) return bn == 256 ? 3 : 4;
+  if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S1) return bn == 256 ? 3 : 4;
+  if (d.variant == MTT_GEMM_ABLATE_NO_EPILOGUE || d.variant == MTT_GEMM_ABLATE_NO_KLOOP) return 3;
   // AUTO.  Measured on MI355X (profiles/r02_gemm_bench_b*.log, r02_conv_bench_b.log, B = 63 shapes): the 256 x 256 DMA tile wins for
   // wide outputs (qkv / proj / fc1 / fc2: 830-1170 vs 610-740 TFLOP/s on the register-staged 128 x 128 kernel), but the 256 x 128 DMA
   // tile LOSES to it on the narrow decoder shapes (N = 300 / 350: 280-330 vs 300-370) and on the implicit-GEMM 3x3 conv
@@ -1006,7 +1016,12 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (mode == 0) {
     const int v = gemm_variant_for(d);
     const bool conv_a = d.a_op == MTT_OP_CONV_K;
-    if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S0 ? launch_dma<256, false, 0>(p, s) : launch_dma<256, false, 1>(p, s));
+    // LDS-DMA schedule: 0 (one burst in R0) by default — measured equal or better than the balanced schedule on 4 of 5 shapes
+    // (profiles/r02_gemm_bench_c_dma_schedules.log: qkv 871 / 869, proj 896 / 889, fc2 1171 / 1157, 8192^3 1326 / 1272 TFLOP/s;
+    // fc1+GELU 789 / 817) and it is the one the full-size parity tests ran on; MTT_GEMM_DMA256_S1 forces the balanced one
+    if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_EPILOGUE) return launch_dma<256, false, 2>(p, s);
+    if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_KLOOP) return launch_dma<256, false, 3>(p, s);
+    if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S1 ? launch_dma<256, false, 1>(p, s) : launch_dma<256, false, 0>(p, s));
     if (v == 4) return conv_a ? launch_dma<128, true, 0>(p, s) : launch_dma<128, false, 0>(p, s);
     if (v == 5) return launch_fast256(p, s);
     if (v == 1) return launch_fast(p, s);

@@ -153,7 +153,7 @@ def gemm_cases():
                   batch=2, batch_inner=1, a_zo=Bn * H * W * Cp, b_zo=Co * 9 * Cp, d_zo=Bn * H * W * Cop,
                   conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, colshift=rnd(g, 2, Co), col_zo=Co, act=1, n_store=Cop, variant=3)
         cases.append((f"gemm_dma_conv3_d{dil}f{flip}_{Bn}x{H}x{W}x{Ci}to{Co}", "gemm", kw, TOL_BF))
-    # first LDS-DMA schedule of the phased kernel (variant = 5) and many K tiles / both parities of the tile count under the balanced one
+    # balanced LDS-DMA schedule of the phased kernel (variant = 5) and many K tiles / both parities of the tile count under the default one
     for (M, N, K, v) in ((300, 520, 200, 5), (513, 600, 1096, 5), (520, 700, 1152, 3), (300, 512, 1088, 3), (256, 256, 64, 3), (256, 256, 128, 3)):
         cases.append((f"gemm_dma_sched{v}_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0, variant=v, colshift=rnd(g, N)), TOL_BF))
     # the round-1 lock-step 256 x 256 kernel stays reachable (variant = 4) for A/B measurements
