@@ -257,35 +257,8 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
   }
   const bool full_chunk = ncol0 + 8 <= d.N && d.store_mode == MTT_STORE_ROWS;
 
-  constexpr int NIT = 64 / RPP;                    // rows of a slab each thread handles
-  const bool col_active = ncol0 < n_store || (d.store_mode == MTT_STORE_PIXSHUF2 && ncol0 < d.N);
-  const bool pre_resid = d.resid != nullptr && full_chunk;
-  const bool pre_aux = full_chunk && d.aux_in != nullptr && d.aux_dtype == MTT_BF16 && (d.act == MTT_ACT_GELU_BWD || d.act == MTT_ACT_RELU_BWD);
-
 #pragma unroll 1
   for (int half = 0; half < NSLAB; ++half) {          // 64-row slabs of the block tile
-    // 1. Issue this slab's global READS (residual rows, GELU' / ReLU' inputs) before the accumulators go through LDS: they are in
-    //    flight during the staging and the barrier.  (Measured, profiles/r02_gemm_ablate_d_tile_time.log: with the loads issued one
-    //    row at a time inside the store loop, the epilogue of the residual-adding GEMMs took 18 us per tile against 10 us for the
-    //    store-only one — four dependent HBM round trips per slab while every CU of the chip is in its epilogue at the same time.)
-    //    One register set serves both (no call site of the hot path combines a residual with an activation backward; if one does,
-    //    the aux rows are read in place below).
-    u32x4 rA[NIT], rB[NIT];                            // raw bits: 2 x 4 fp32 of the residual row, or 8 bf16 of the aux row (in rA)
-    const bool aux_in_regs = pre_aux && !pre_resid;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int rl = threadIdx.x / CHUNKS + RPP * i;
-      const int m = m0 + half * 64 + rl;
-      const bool rowok = m < d.M && col_active;
-      const int64_t roff = zR + row_off((uint32_t)(rowok ? m : m0), d.r_mb, d.r_bs, d.ldr, p.divRmb) + ncol0;
-      const int64_t aoff = zAux + (int64_t)(rowok ? m : m0) * d.ldaux + ncol0;
-      // address-clamped loads from the GLOBAL operands only (a select with another address space would make them FLAT loads, which
-      // the compiler must complete before the LDS writes below); rows past M load row m0 and are ignored
-      rA[i] = rB[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (pre_resid) { rA[i] = *(const u32x4*)(d.resid + roff); rB[i] = *(const u32x4*)(d.resid + roff + 4); }
-      else if (aux_in_regs) rA[i] = *(const u32x4*)((const bf16_t*)d.aux_in + aoff);
-    }
-    // 2. accumulators -> LDS
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
       const int gt = wm * MT + a;                      // m-tile index inside the block tile
@@ -297,27 +270,26 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
           ep[((gt & 3) * 16 + lg * 4 + r) * EP_LD + (wn * NTL + b) * 16 + li] = acc[a][b][r];
     }
     __syncthreads();
-    // 3. every thread: 8 consecutive columns of NIT rows.  Full 8-column chunks take the unrolled vector path (prefetched rows in
-    //    registers); ragged chunks (N tail / channel padding) and the pixel-shuffle store take a rolled element-wise loop.
-    if (col_active && full_chunk) {
-#pragma unroll
-      for (int i = 0; i < NIT; ++i) {
+    if (ncol0 < n_store || (d.store_mode == MTT_STORE_PIXSHUF2 && ncol0 < d.N)) {
+#pragma unroll 1
+      for (int i = 0; i < 64 / RPP; ++i) {
         const int rl = threadIdx.x / CHUNKS + RPP * i;
         const int m = m0 + half * 64 + rl;
-        if (m < d.M) {
-          float v[8];
-          {
-            const float4 lo4 = *(const float4*)(ep + rl * EP_LD + c8 * 8);
-            const float4 hi4 = *(const float4*)(ep + rl * EP_LD + c8 * 8 + 4);
-            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-          }
-          uint32_t q = 0, rem = (uint32_t)m;
-          if (d.d_mb > 0) { q = fdiv((uint32_t)m, p.divDmb); rem = m - q * d.d_mb; }
-          const int64_t doff = zD + (d.d_mb > 0 ? (int64_t)q * d.d_bs + (int64_t)rem * d.ldd : (int64_t)m * d.ldd) + ncol0;
-          const int64_t auxoff = zAux + (int64_t)m * d.ldaux + ncol0;
-          const float rs = d.rowscale ? d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)] : 1.0f;
+        if (m >= d.M) continue;
+        float v[8];
+        {
+          const float4 lo4 = *(const float4*)(ep + rl * EP_LD + c8 * 8);
+          const float4 hi4 = *(const float4*)(ep + rl * EP_LD + c8 * 8 + 4);
+          v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+        }
+        uint32_t q = 0, rem = (uint32_t)m;
+        if (d.d_mb > 0) { q = fdiv((uint32_t)m, p.divDmb); rem = m - q * d.d_mb; }
+        const int64_t doff = zD + (d.d_mb > 0 ? (int64_t)q * d.d_bs + (int64_t)rem * d.ldd : (int64_t)m * d.ldd) + ncol0;
+        const int64_t auxoff = zAux + (int64_t)m * d.ldaux + ncol0;
+        const float rs = d.rowscale ? d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)] : 1.0f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha * cs[j] + sh[j];
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha * cs[j] + sh[j];
+        if (full_chunk) {
           if (d.aux_out) {
             if (d.aux_dtype == MTT_F32) {
               *(float4*)((float*)d.aux_out + auxoff) = make_float4(v[0], v[1], v[2], v[3]);
@@ -339,9 +311,9 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
               const float4 z1 = *(const float4*)((const float*)d.aux_in + auxoff + 4);
               z[0] = z0.x; z[1] = z0.y; z[2] = z0.z; z[3] = z0.w; z[4] = z1.x; z[5] = z1.y; z[6] = z1.z; z[7] = z1.w;
             } else {
-              const u32x4 u = aux_in_regs ? rA[i] : *(const u32x4*)((const bf16_t*)d.aux_in + auxoff);
-              z[0] = lo_of(u.x); z[1] = hi_of(u.x); z[2] = lo_of(u.y); z[3] = hi_of(u.y);
-              z[4] = lo_of(u.z); z[5] = hi_of(u.z); z[6] = lo_of(u.w); z[7] = hi_of(u.w);
+              const u32x4 u = *(const u32x4*)((const bf16_t*)d.aux_in + auxoff);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { z[2 * t] = lo_of(u[t]); z[2 * t + 1] = hi_of(u[t]); }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = d.act == MTT_ACT_GELU_BWD ? v[j] * gelu_grad_f(z[j]) : (z[j] > 0.0f ? v[j] : 0.0f);
@@ -349,10 +321,10 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] *= rs;
           if (d.resid) {
-            const u32x4 ra = rA[i], rb = rB[i];
-            v[0] += __builtin_bit_cast(float, ra.x); v[1] += __builtin_bit_cast(float, ra.y); v[2] += __builtin_bit_cast(float, ra.z);
-            v[3] += __builtin_bit_cast(float, ra.w); v[4] += __builtin_bit_cast(float, rb.x); v[5] += __builtin_bit_cast(float, rb.y);
-            v[6] += __builtin_bit_cast(float, rb.z); v[7] += __builtin_bit_cast(float, rb.w);
+            const int64_t roff = zR + row_off((uint32_t)m, d.r_mb, d.r_bs, d.ldr, p.divRmb) + ncol0;
+            const float4 r0 = *(const float4*)(d.resid + roff);
+            const float4 r1 = *(const float4*)(d.resid + roff + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
           }
           if (d.d_dtype == MTT_F32) {
             *(float4*)((float*)d.D + doff) = make_float4(v[0], v[1], v[2], v[3]);
@@ -360,48 +332,37 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
           } else {
             *(u32x4*)((bf16_t*)d.D + doff) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
           }
-        }
-      }
-    } else if (col_active) {
+        } else {
+          // ragged chunk (N tail / channel padding) or pixel-shuffle store: element by element
+          int64_t roff = 0;
+          if (d.resid) roff = zR + row_off((uint32_t)m, d.r_mb, d.r_bs, d.ldr, p.divRmb) + ncol0;
 #pragma unroll 1
-      for (int i = 0; i < NIT; ++i) {
-        const int rl = threadIdx.x / CHUNKS + RPP * i;
-        const int m = m0 + half * 64 + rl;
-        if (m >= d.M) continue;
-        uint32_t q = 0, rem = (uint32_t)m;
-        if (d.d_mb > 0) { q = fdiv((uint32_t)m, p.divDmb); rem = m - q * d.d_mb; }
-        const int64_t doff = zD + (d.d_mb > 0 ? (int64_t)q * d.d_bs + (int64_t)rem * d.ldd : (int64_t)m * d.ldd) + ncol0;
-        const int64_t auxoff = zAux + (int64_t)m * d.ldaux + ncol0;
-        const float rs = d.rowscale ? d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)] : 1.0f;
-        int64_t roff = 0;
-        if (d.resid) roff = zR + row_off((uint32_t)m, d.r_mb, d.r_bs, d.ldr, p.divRmb) + ncol0;
-#pragma unroll 1
-        for (int j = 0; j < 8; ++j) {
-          const int n = ncol0 + j;
-          float w = 0.0f;
-          if (n < d.N) {
-            const float csj = d.colscale ? d.colscale[zcol + n] : 1.0f, shj = d.colshift ? d.colshift[zcol + n] : 0.0f;
-            w = ep[rl * EP_LD + c8 * 8 + j] * d.alpha * csj + shj;
-            if (d.aux_out) st_elem(d.aux_out, auxoff + j, d.aux_dtype, w);
-            if (d.act == MTT_ACT_GELU) w = gelu_f(w);
-            else if (d.act == MTT_ACT_RELU) w = fmaxf(w, 0.0f);
-            else if (d.act == MTT_ACT_GELU_BWD) w *= gelu_grad_f(ld_elem(d.aux_in, auxoff + j, d.aux_dtype));
-            else if (d.act == MTT_ACT_RELU_BWD) w = ld_elem(d.aux_in, auxoff + j, d.aux_dtype) > 0.0f ? w : 0.0f;
-            w *= rs;
-            if (d.resid) w += d.resid[roff + j];
-          }
-          if (d.store_mode == MTT_STORE_PIXSHUF2) {
-            if (n >= d.N) continue;
-            const uint32_t qq = fdiv((uint32_t)n, p.divPsCo);
-            const int co = n - (int)qq * d.ps_Co;
-            const uint32_t t = fdiv((uint32_t)m, p.divPsW);
-            const int x = m - (int)t * d.ps_W;
-            const uint32_t bb = fdiv(t, p.divPsH);
-            const int y = (int)t - (int)bb * d.ps_H;
-            const int64_t orow = ((int64_t)bb * (2 * d.ps_H) + 2 * y + (int)(qq >> 1)) * (2 * d.ps_W) + 2 * x + (int)(qq & 1);
-            st_elem(d.D, zD + orow * d.ldd + co, d.d_dtype, w);
-          } else if (n < n_store) {
-            st_elem(d.D, doff + j, d.d_dtype, w);
+          for (int j = 0; j < 8; ++j) {
+            const int n = ncol0 + j;
+            float w = 0.0f;
+            if (n < d.N) {
+              w = v[j];
+              if (d.aux_out) st_elem(d.aux_out, auxoff + j, d.aux_dtype, w);
+              if (d.act == MTT_ACT_GELU) w = gelu_f(w);
+              else if (d.act == MTT_ACT_RELU) w = fmaxf(w, 0.0f);
+              else if (d.act == MTT_ACT_GELU_BWD) w *= gelu_grad_f(ld_elem(d.aux_in, auxoff + j, d.aux_dtype));
+              else if (d.act == MTT_ACT_RELU_BWD) w = ld_elem(d.aux_in, auxoff + j, d.aux_dtype) > 0.0f ? w : 0.0f;
+              w *= rs;
+              if (d.resid) w += d.resid[roff + j];
+            }
+            if (d.store_mode == MTT_STORE_PIXSHUF2) {
+              if (n >= d.N) continue;
+              const uint32_t qq = fdiv((uint32_t)n, p.divPsCo);
+              const int co = n - (int)qq * d.ps_Co;
+              const uint32_t t = fdiv((uint32_t)m, p.divPsW);
+              const int x = m - (int)t * d.ps_W;
+              const uint32_t bb = fdiv(t, p.divPsH);
+              const int y = (int)t - (int)bb * d.ps_H;
+              const int64_t orow = ((int64_t)bb * (2 * d.ps_H) + 2 * y + (int)(qq >> 1)) * (2 * d.ps_W) + 2 * x + (int)(qq & 1);
+              st_elem(d.D, zD + orow * d.ldd + co, d.d_dtype, w);
+            } else if (n < n_store) {
+              st_elem(d.D, doff + j, d.d_dtype, w);
+            }
           }
         }
       }
