@@ -50,7 +50,10 @@ enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
  * variable: the library keeps no mutable state that affects results. */
 enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3, MTT_GEMM_DMA256_V1 = 4,
        MTT_GEMM_DMA256_S1 = 5 /* phased kernel with the balanced LDS-DMA schedule (A/B measurements) */,
-       MTT_GEMM_ABLATE_NO_EPILOGUE = 6, MTT_GEMM_ABLATE_NO_KLOOP = 7 /* measurement-only: WRONG results by construction */ };
+       MTT_GEMM_ABLATE_NO_EPILOGUE = 6, MTT_GEMM_ABLATE_NO_KLOOP = 7 /* measurement-only: WRONG results by construction */,
+       MTT_GEMM_DMA256_SKEW = 8 /* phased kernel with first-round workgroups started 0..7 x 1.5 us apart (experiment) */,
+       MTT_GEMM_ABLATE_NO_STORES = 9, MTT_GEMM_ABLATE_NO_STAGING = 10 /* measurement-only epilogue ablations */,
+       MTT_GEMM_GENERAL_EPILOGUE = 11 /* policy kernel, but always the general (run-time configured) epilogue: A/B of the specialised one */ };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1 };
 
 /* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */

@@ -226,7 +226,9 @@ MTT_DEV void stager_init_b(S& s, const GemmP& p, const void* base, int row0) {
 // Shared epilogue.  Block tile TBN columns wide, WAVES_M x WAVES_N waves, each wave MT x NTL tiles of 16 x 16:
 //   acc[a][b][r] = D[(wm*MT + a)*16 + lg*4 + r][(wn*NTL + b)*16 + li]
 // ---------------------------------------------------------------------------------------------
-template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+// EPI_ABL (measurement only): 1 = everything but the global stores of the vector path, 2 = no LDS staging / barriers (stores of
+// register garbage at the right addresses).
+template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL, int EPI_ABL = 0>
 MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -266,10 +268,12 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
 #pragma unroll
       for (int b = 0; b < NTL; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ep[((gt & 3) * 16 + lg * 4 + r) * EP_LD + (wn * NTL + b) * 16 + li] = acc[a][b][r];
+        for (int r = 0; r < 4; ++r) {
+          if (EPI_ABL == 2) asm volatile("" :: "v"(acc[a][b][r]));
+          else ep[((gt & 3) * 16 + lg * 4 + r) * EP_LD + (wn * NTL + b) * 16 + li] = acc[a][b][r];
+        }
     }
-    __syncthreads();
+    if (EPI_ABL != 2) __syncthreads();
     if (ncol0 < n_store || (d.store_mode == MTT_STORE_PIXSHUF2 && ncol0 < d.N)) {
 #pragma unroll 1
       for (int i = 0; i < 64 / RPP; ++i) {
@@ -277,7 +281,10 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
         const int m = m0 + half * 64 + rl;
         if (m >= d.M) continue;
         float v[8];
-        {
+        if (EPI_ABL == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (float)(rl + j);
+        } else {
           const float4 lo4 = *(const float4*)(ep + rl * EP_LD + c8 * 8);
           const float4 hi4 = *(const float4*)(ep + rl * EP_LD + c8 * 8 + 4);
           v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
@@ -326,7 +333,10 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
             const float4 r1 = *(const float4*)(d.resid + roff + 4);
             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
           }
-          if (d.d_dtype == MTT_F32) {
+          if (EPI_ABL == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(v[j]));
+          } else if (d.d_dtype == MTT_F32) {
             *(float4*)((float*)d.D + doff) = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)((float*)d.D + doff + 4) = make_float4(v[4], v[5], v[6], v[7]);
           } else {
@@ -367,8 +377,136 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
         }
       }
     }
+    if (EPI_ABL != 2) __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Specialised epilogue for INTERIOR tiles of the hot call sites.  The general epilogue above decides everything per row at run
+// time (dtype, activation, aux, residual, row groups, ragged columns: ~150 instructions and a dozen scalar branches per 8 outputs);
+// measured on MI355X it costs 12-18 us of a 40-46 us K = 1024 tile and is bound by INSTRUCTION ISSUE, not by its stores or its LDS
+// staging (profiles/r02_gemm_ablate_g_epilogue_parts.log: removing the global stores saves 1.7 us, removing the staging 0.9 us).
+// Here the feature set is a template parameter, the tile is known to be full (no bounds checks) and rows are contiguous, so a row of 8
+// outputs is a handful of instructions.  KIND:
+//   0  D bf16 = acc + bias                              (qkv, bf16 dgrads)
+//   1  D f32  = acc + bias                              (weight-gradient slabs, fp32 dgrads)
+//   2  D bf16 = GELU(z), z = acc + bias; aux_out bf16 = z when given   (fc1)
+//   3  D f32  = rowscale * (acc + bias) + resid         (proj / fc2 into the fp32 residual stream; rowscale / resid optional)
+//   4  D bf16 = (acc + bias) * GELU'(aux_in bf16)       (fc2 dgrad)
+// ---------------------------------------------------------------------------------------------
+MTT_DEV int fast_epilogue_kind(const mtt_gemm_desc& d, int m0, int n0, int tbm, int tbn) {
+  if (d.store_mode != MTT_STORE_ROWS || d.colscale || d.alpha != 1.0f) return -1;
+  if (m0 + tbm > d.M || n0 + tbn > d.N) return -1;                                   // interior tiles only
+  if (d.d_mb > 0 && d.d_bs != (int64_t)d.d_mb * d.ldd) return -1;                    // D rows contiguous
+  const bool auxi = d.aux_in != nullptr, auxo = d.aux_out != nullptr;
+  if ((auxi || auxo) && d.aux_dtype != MTT_BF16) return -1;
+  if (d.resid && ((d.r_mb > 0 && d.r_bs != (int64_t)d.r_mb * d.ldr) || d.d_dtype != MTT_F32)) return -1;
+  if (d.rowscale && (d.d_dtype != MTT_F32 || d.d_mb <= 0)) return -1;
+  if (d.act == MTT_ACT_NONE && !auxi && !auxo) {
+    if (d.d_dtype == MTT_F32) return (d.resid || d.rowscale) ? 3 : 1;
+    return (d.resid || d.rowscale) ? -1 : 0;
+  }
+  if (d.act == MTT_ACT_GELU && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && !auxi) return 2;
+  if (d.act == MTT_ACT_GELU_BWD && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && auxi && !auxo) return 4;
+  return -1;
+}
+
+template <int KIND, int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  constexpr int NTHREADS = 64 * WAVES_M * WAVES_N, CHUNKS = TBN / 8, RPP = NTHREADS / CHUNKS, NSLAB = WAVES_M * MT / 4, NIT = 64 / RPP;
+  constexpr int EP_LD = TBN + 4;
+  const mtt_gemm_desc& d = p.d;
+  float* const ep = (float*)smem;
+  const int c8 = threadIdx.x % CHUNKS, rl0 = threadIdx.x / CHUNKS;
+  const int ncol0 = n0 + c8 * 8;
+  float sh[8];
+  {
+    const int64_t zcol = (int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi + ncol0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[j] = d.colshift ? d.colshift[zcol + j] : 0.0f;
+  }
+  const int64_t zD = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi + ncol0;
+  const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + ncol0;
+  const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi + ncol0;
+  const float* const epr = ep + rl0 * EP_LD + c8 * 8;
+
+#pragma unroll 1
+  for (int half = 0; half < NSLAB; ++half) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const int gt = wm * MT + a;
+      if ((gt >> 2) != half) continue;
+#pragma unroll
+      for (int b = 0; b < NTL; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[((gt & 3) * 16 + lg * 4 + r) * EP_LD + (wn * NTL + b) * 16 + li] = acc[a][b][r];
+    }
+    __syncthreads();
+    const int mrow = m0 + half * 64 + rl0;                    // first of this thread's NIT rows (stride RPP)
+    // KIND 3 / 4: this slab's residual / GELU' input rows, all issued before they are used
+    float4 ra[NIT], rb[NIT];
+    u32x4 za[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int64_t m = mrow + RPP * i;
+      if (KIND == 3) {
+        if (d.resid) { ra[i] = *(const float4*)(d.resid + (zR + m * d.ldr)); rb[i] = *(const float4*)(d.resid + (zR + m * d.ldr) + 4); }
+        else { ra[i] = rb[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      }
+      if (KIND == 4) za[i] = *(const u32x4*)((const bf16_t*)d.aux_in + (zAux + m * d.ldaux));
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int64_t m = mrow + RPP * i;
+      const float4 lo4 = *(const float4*)(epr + RPP * i * EP_LD);
+      const float4 hi4 = *(const float4*)(epr + RPP * i * EP_LD + 4);
+      float v[8] = {lo4.x + sh[0], lo4.y + sh[1], lo4.z + sh[2], lo4.w + sh[3], hi4.x + sh[4], hi4.y + sh[5], hi4.z + sh[6], hi4.w + sh[7]};
+      if (KIND == 2) {
+        if (d.aux_out)
+          *(u32x4*)((bf16_t*)d.aux_out + (zAux + m * d.ldaux)) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+      }
+      if (KIND == 4) {
+        const u32x4 u = za[i];
+        v[0] *= gelu_grad_f(lo_of(u.x)); v[1] *= gelu_grad_f(hi_of(u.x)); v[2] *= gelu_grad_f(lo_of(u.y)); v[3] *= gelu_grad_f(hi_of(u.y));
+        v[4] *= gelu_grad_f(lo_of(u.z)); v[5] *= gelu_grad_f(hi_of(u.z)); v[6] *= gelu_grad_f(lo_of(u.w)); v[7] *= gelu_grad_f(hi_of(u.w));
+      }
+      if (KIND == 3) {
+        if (d.rowscale) {
+          const uint32_t q = fdiv((uint32_t)m, p.divDmb), rem = (uint32_t)m - q * (uint32_t)d.d_mb;
+          const float rs = d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= rs;
+        }
+        v[0] += ra[i].x; v[1] += ra[i].y; v[2] += ra[i].z; v[3] += ra[i].w; v[4] += rb[i].x; v[5] += rb[i].y; v[6] += rb[i].z; v[7] += rb[i].w;
+      }
+      if (KIND == 1 || KIND == 3) {
+        float* dp = (float*)d.D + (zD + m * d.ldd);
+        *(float4*)dp = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(dp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        *(u32x4*)((bf16_t*)d.D + (zD + m * d.ldd)) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+      }
+    }
     __syncthreads();
   }
+}
+
+// epilogue dispatch (workgroup-uniform): specialised path for interior tiles of the hot call sites, general path otherwise
+template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+MTT_DEV void gemm_epilogue_auto(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
+  const int kind = p.d.variant == MTT_GEMM_GENERAL_EPILOGUE ? -1 : fast_epilogue_kind(p.d, m0, n0, WAVES_M * MT * 16, TBN);
+  if (kind == 0) gemm_epilogue_fast<0, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 1) gemm_epilogue_fast<1, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 2) gemm_epilogue_fast<2, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 3) gemm_epilogue_fast<3, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 4) gemm_epilogue_fast<4, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
+  else gemm_epilogue<TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -473,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     __syncthreads();
   }
 
-  gemm_epilogue<BN, 2, 2, 4, 4>(p, acc, smem, m0, n0, zo, zi);
+  gemm_epilogue_auto<BN, 2, 2, 4, 4>(p, acc, smem, m0, n0, zo, zi);
 }
 
 
@@ -567,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void gemm_fast_kernel(const GemmP p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[kh][a], fb[kh][b], acc[a][b]);
   }
   __syncthreads();                          // all waves done with the last stage before LDS is reused by the epilogue
-  gemm_epilogue<BN, 2, 2, 4, 4>(p, acc, smem, m0, n0, zo, zi);
+  gemm_epilogue_auto<BN, 2, 2, 4, 4>(p, acc, smem, m0, n0, zo, zi);
 }
 
 int launch_fast(const GemmP& p, hipStream_t stream) {
@@ -656,7 +794,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fast256_kernel(const GemmP p) {
     }
   }
   __syncthreads();
-  gemm_epilogue<BN2, 2, 4, 8, 4>(p, acc, smem, m0, n0, zo, zi);
+  gemm_epilogue_auto<BN2, 2, 4, 8, 4>(p, acc, smem, m0, n0, zo, zi);
 }
 
 int launch_fast256(const GemmP& p, hipStream_t stream) {
@@ -804,6 +942,13 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   // SCHED 2 / 3 are measurement-only ablations (cdna_hip_programming.md §5.4 rule 17): 2 = main loop without the epilogue (accumulators
   // kept alive, nothing stored), 3 = prologue + epilogue without the K loop (one K tile).  Never dispatched by the policy.
   const int nk = SCHED == 3 ? 1 : (K + BK - 1) / BK;
+  if (SCHED == 4 && blockIdx.x < 256 && blockIdx.z == 0) {
+    // experiment: phase skew.  Every tile of a round finishes at the same time, so all 256 CUs store their tiles at once (a
+    // 33-134 MB burst at the fabric's bandwidth limit: profiles/r02_gemm_ablate_d_tile_time.log) while HBM idles during the K loops.
+    // Delaying the first-round workgroups by 0..7 x ~1.5 us spreads the later rounds' epilogues over time.
+    const int steps = blockIdx.x & 7;
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(47);
+  }
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // tile 0 is in LDS
@@ -886,7 +1031,10 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
       for (int b = 0; b < NT; ++b) asm volatile("" :: "v"(acc[a][b]));
     return;
   }
-  gemm_epilogue<BN_, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  if constexpr (SCHED == 5 || SCHED == 6 || SCHED == 3)
+    gemm_epilogue<BN_, WAVES_M, WAVES_N, MT, NT, (SCHED == 5 ? 1 : (SCHED == 6 ? 2 : 0))>(p, acc, smem, m0, n0, zo, zi);
+  else
+    gemm_epilogue_auto<BN_, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
 }
 
 template <int BN_, bool CONV, int SCHED>
@@ -963,7 +1111,8 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   const int n256 = (d.N + 255) / 256 * 256, n128 = (d.N + 127) / 128 * 128;
   const int bn = 100 * n128 <= 85 * n256 ? 128 : 256;   // the narrower tile only where it saves >= 15 % of the columns (N = 300, 350, 576 ...)
   if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S1) return bn == 256 ? 3 : 4;
-  if (d.variant == MTT_GEMM_ABLATE_NO_EPILOGUE || d.variant == MTT_GEMM_ABLATE_NO_KLOOP) return 3;
+  if (d.variant == MTT_GEMM_ABLATE_NO_EPILOGUE || d.variant == MTT_GEMM_ABLATE_NO_KLOOP || d.variant == MTT_GEMM_DMA256_SKEW ||
+      d.variant == MTT_GEMM_ABLATE_NO_STORES || d.variant == MTT_GEMM_ABLATE_NO_STAGING) return 3;
   // AUTO.  Measured on MI355X (profiles/r02_gemm_bench_b*.log, r02_conv_bench_b.log, B = 63 shapes): the 256 x 256 DMA tile wins for
   // wide outputs (qkv / proj / fc1 / fc2: 830-1170 vs 610-740 TFLOP/s on the register-staged 128 x 128 kernel), but the 256 x 128 DMA
   // tile LOSES to it on the narrow decoder shapes (N = 300 / 350: 280-330 vs 300-370) and on the implicit-GEMM 3x3 conv
@@ -1021,6 +1170,9 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     // fc1+GELU 789 / 817) and it is the one the full-size parity tests ran on; MTT_GEMM_DMA256_S1 forces the balanced one
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_EPILOGUE) return launch_dma<256, false, 2>(p, s);
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_KLOOP) return launch_dma<256, false, 3>(p, s);
+    if (v == 3 && !conv_a && d.variant == MTT_GEMM_DMA256_SKEW) return launch_dma<256, false, 4>(p, s);
+    if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STORES) return launch_dma<256, false, 5>(p, s);
+    if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STAGING) return launch_dma<256, false, 6>(p, s);
     if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S1 ? launch_dma<256, false, 1>(p, s) : launch_dma<256, false, 0>(p, s));
     if (v == 4) return conv_a ? launch_dma<128, true, 0>(p, s) : launch_dma<128, false, 0>(p, s);
     if (v == 5) return launch_fast256(p, s);

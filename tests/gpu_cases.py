@@ -158,6 +158,30 @@ def gemm_cases():
         cases.append((f"gemm_dma_sched{v}_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0, variant=v, colshift=rnd(g, N)), TOL_BF))
     # the round-1 lock-step 256 x 256 kernel stays reachable (variant = 4) for A/B measurements
     cases.append(("gemm_dma256_v1_forced", "gemm", base(300, 260, 192, BF16, BF16, BF16, 0, variant=4), TOL_BF))
+    # 1e. specialised interior-tile epilogues (KIND 0..4 of gemm_epilogue_fast) on the DMA kernel (variant 3) and the general kernel
+    #     (variant 1), next to edge tiles that take the general epilogue in the same launch; variant 11 = general epilogue everywhere
+    for v in (3, 1, 11):
+        M, N, K = 600, 520, 136
+        A16 = rnd(g, M, K, dtype=torch.bfloat16)
+        B16 = rnd(g, N, K, dtype=torch.bfloat16)
+        common = dict(A=A16, B=B16, M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, prec=0, lda=K, ldb=K,
+                      batch=1, batch_inner=1, alpha=1.0, variant=v)
+        cases.append((f"gemm_epi_kind0_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528,
+                                                               colshift=rnd(g, N), n_store=N), TOL_BF))
+        cases.append((f"gemm_epi_kind1_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0), d_dtype=F32, ldd=528, n_store=N), TOL_BF))
+        cases.append((f"gemm_epi_kind2_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528,
+                                                               colshift=rnd(g, N), act=1, aux_out=torch.full((M, 536), 3.0, dtype=torch.bfloat16),
+                                                               aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
+        cases.append((f"gemm_epi_kind2_noaux_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528,
+                                                                     colshift=rnd(g, N), act=1, n_store=N), TOL_BF))
+        XT = rnd(g, M, 528)
+        cases.append((f"gemm_epi_kind3_v{v}", "gemm", dict(common, D=XT, d_dtype=F32, ldd=528, d_mb=100, d_bs=100 * 528, colshift=rnd(g, N),
+                                                               resid=XT, ldr=528, r_mb=100, r_bs=100 * 528, rowscale=torch.rand(6, 2, generator=g),
+                                                               n_prompt=7, n_store=N), TOL_BF))
+        cases.append((f"gemm_epi_kind3_norowscale_v{v}", "gemm", dict(common, D=torch.zeros(M, 528), d_dtype=F32, ldd=528, colshift=rnd(g, N),
+                                                                          resid=rnd(g, M, 520), ldr=520, n_store=N), TOL_BF))
+        cases.append((f"gemm_epi_kind4_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528, act=3,
+                                                               aux_in=rnd(g, M, 536, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
     # 2. asymmetric identity check (A = I) catches transposed C layout
     kw = base(128, 128, 128, F32, F32, F32, 1)
     kw["A"] = torch.eye(128, 136)

@@ -19,7 +19,7 @@ prec = ops.Prec("bf16")
 M63 = 63 * 1030
 SHAPES = [("qkv", M63, 3072, 1024, 0), ("proj", M63, 1024, 1024, 0), ("fc1+gelu", M63, 4096, 1024, 1), ("fc2", M63, 1024, 4096, 0),
           ("big", 8192, 8192, 8192, 0)]
-KERNELS = [(1, "reg128"), (4, "dma256 lock-step (r01)"), (3, "phased, burst DMA"), (5, "phased, balanced DMA")]
+KERNELS = [(4, "dma256 lock-step (r01)"), (3, "phased"), (8, "phased + start skew")]
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
