@@ -113,7 +113,8 @@ int mtt_abi_version(void);
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
 /* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128 (general), 1 LDS-DMA 128x128 ring, 3 / 4 phased
- * LDS-DMA 256x256 / 256x128 (gemm_dma_kernel), 5 lock-step LDS-DMA 256x256 (round-1 kernel, forced only) */
+ * LDS-DMA 256x256 / 256x128 (gemm_dma_kernel), 5 lock-step LDS-DMA 256x256 (round-1 kernel, forced only), 6 token-major weight-gradient
+ * kernel (gemm_tn_kernel: both operands MTT_OP_R, LDS-DMA + LDS transpose reads) */
 int mtt_gemm_variant(const mtt_gemm_desc* d);
 
 /*

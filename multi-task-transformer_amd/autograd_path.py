@@ -145,10 +145,37 @@ def _wgrad_fast(dy, x, N, Kp, prec, colsum=None):
     return _gemm(dyT, xT, dW, N, Kp, Mp, prec, lda=Mp, ldb=Mp, ldd=Kp)
 
 
+WGRAD_TN = os.environ.get("MTT_WGRAD_TN", "1") != "0"     # host-side A/B switch: 0 = round-1 path (transposing copies + K-contiguous GEMM)
+
+
+def _wgrad_tn(dy, x, N, Kp, prec):
+    """dW[N, Kp] = dy^T x straight from the token-major operands (mtt_gemm MTT_OP_R x MTT_OP_R -> gemm_tn_kernel: LDS-DMA of the rows as
+    they sit in memory + LDS transpose reads), the token reduction sliced over the batch dimension into fp32 slabs when the 256 x 256
+    output tiles alone cannot fill the chip."""
+    rows = dy.shape[0]
+    lda, ldb = dy.stride(0), x.stride(0)
+    tiles = -(-N // 256) * -(-Kp // 256)
+    if tiles < 192 and rows >= 4096:
+        S = max(2, min(32, -(-256 // tiles)))
+        c = (rows // S) // 64 * 64
+        if c >= 512:
+            nz = rows // c
+            rem = rows - nz * c
+            slabs = torch.empty(nz + (1 if rem else 0), N, Kp, dtype=torch.float32, device=dy.device)
+            _gemm(dy, x, slabs, N, Kp, c, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp, batch=nz, a_zo=c * lda, b_zo=c * ldb, d_zo=N * Kp)
+            if rem:
+                _gemm(dy[nz * c:], x[nz * c:], slabs[nz], N, Kp, rem, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
+            return slabs.sum(0)
+    dW = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
+    return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
+
+
 def _enc_wgrad(dy, x, N, Kp, prec):
     """-> (dW [N, Kp], dbias [N]) of y = x W^T + b given dy."""
     if (prec.name == "bf16" and FAST_BWD and N >= FAST_MIN_DIM and Kp >= FAST_MIN_DIM and dy.shape[0] >= FAST_MIN_ROWS
             and N % 8 == 0 and dy.stride(0) % 8 == 0):
+        if WGRAD_TN and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
+            return _wgrad_tn(dy, x, N, Kp, prec), _colsum(dy, N)
         db = torch.zeros(N, dtype=torch.float32, device=dy.device)
         return _wgrad_fast(dy, x, N, Kp, prec, colsum=db), db
     return _wgrad(dy, x, N, Kp, prec), _colsum(dy, N)

@@ -1048,6 +1048,195 @@ int launch_dma(const GemmP& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_tn_kernel<CONVB>: D[m, n] = sum_k A[k, m] * B[k, n] with BOTH operands "row = reduction index" (MTT_OP_R: element (r, k) at
+// base + k * ld + r) — the weight-gradient form dW = dy^T x on the token-major activations as they sit in HBM, no transposing copies
+// (round 1 transposed both operands into reduction-contiguous buffers first: 26 ms of a 450 ms step) and, with CONVB, the 3x3 conv
+// weight gradient (B = implicit im2col^T of x: n = (tap, ci), k = pixel).
+//
+// Same tile / wave / phase structure as gemm_dma_kernel<256> (256 x 256 x 64, 8 waves, LDS-DMA, staggered R / C phases).  What differs
+// is the LDS image and the fragment read:
+//   * a stage holds the A tile as [64 k][256 m] and the B tile as [64 k][256 n] (512-byte rows, exactly as in memory: every LDS-DMA
+//     instruction moves two 512-byte row segments);
+//   * MFMA fragments (lane (i, g) needs 8 consecutive k of column i) come from ds_read_b64_tr_b16, the LDS transpose read.  Measured
+//     semantics on gfx950 (profiles/r02_probe_ds_read_b64_tr_b16.txt): inside a 16-lane group, lane r supplies an 8-byte address and
+//     receives out[j] = element (r & 3) of the 8 bytes supplied by lane 4 j + (r >> 2).  With lane r pointing at row k0 + (r >> 2),
+//     columns c0 + 4 (r & 3) .. + 3, lane r gets rows k0 .. k0 + 3 of column c0 + r: two such reads are one 16 x 32 fragment;
+//   * bank conflicts: the 8 rows a 32-lane half touches are 512 bytes apart (same banks), so 32-byte units of a row are XOR-ed with
+//     f(k) = (k & 3) | ((k >> 3) & 1) << 2 — applied to the per-lane SOURCE column of the DMA (the LDS image stays lane-linear) and
+//     to the read address; f is a per-lane constant on the read side.
+// ---------------------------------------------------------------------------------------------
+MTT_DEV u32x2 ds_read_tr16(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+
+template <bool CONVB>
+__global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MT = 8, NT = 4, WAVES_N = 4;
+  constexpr int TILE = BK * 256 * 2, STAGE = 2 * TILE;          // 32 KiB per operand tile, 64 KiB per stage
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + 255) / 256;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  const bf16_t* Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
+  const bf16_t* Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int late = wave >> 2;
+  const int K = p.d.K;
+  uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
+  asm volatile("" : "+s"(zpage));
+
+  // ---- LDS-DMA source addressing: wave w moves k rows [8 w, 8 w + 8) of each tile as 4 pieces of 2 rows; lane -> (row, 16-byte chunk) ----
+  const int c16 = lane & 31;                                    // 16-byte chunk of the 512-byte LDS row this lane fills
+  int64_t a_col, b_col;                                         // element offset of this lane's source chunk inside a row (or -1)
+  int fk[4];                                                    // f(k) of the 4 rows this lane fills (one per piece)
+  int b_tapmask = 0, b_shift = 0;                               // CONVB: validity of this lane's tap per pixel is computed per K step
+  int conv_dy = 0, conv_dx = 0;
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = wave * 8 + 2 * i + (lane >> 5);
+      fk[i] = (k & 3) | (((k >> 3) & 1) << 2);
+    }
+  }
+  // the source column depends on the row through the swizzle: col(i) = ((unit' & 8) | ((unit' & 7) ^ fk[i])) * 16 + (c16 & 1) * 8
+  const int unitp = c16 >> 1, hb = c16 & 1;
+  auto src_col = [&](int i) { return (((unitp & 8) | ((unitp & 7) ^ fk[i])) * 2 + hb) * 8; };
+
+  auto issue = [&](int stage, int kt) {
+    unsigned char* sA = smem + stage * STAGE + wave * 4096;     // 8 rows x 512 B per wave
+    unsigned char* sB = sA + TILE;
+    const int k0 = kt * BK + wave * 8 + (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + 2 * i;
+      const int ca = m0 + src_col(i);
+      const bool oka = k < K && ca < p.d.M;
+      const uint64_t srca = (uint64_t)(uintptr_t)(Abase + ((int64_t)k * p.d.lda + ca));
+      glds16((const bf16_t*)(uintptr_t)(oka ? srca : zpage), sA + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + 2 * i;
+      const int cb = n0 + src_col(i);
+      bool okb = k < K && cb < p.d.N;
+      uint64_t srcb;
+      if constexpr (CONVB) {
+        // n = tap * Cp + ci (chunks never straddle taps: Cp % 8 == 0); k = pixel inside this batch slice (slices are whole images)
+        const uint32_t cbu = okb ? (uint32_t)cb : 0u;
+        const uint32_t tap = fdiv(cbu, p.divCp);
+        const int ci = (int)cbu - (int)tap * p.d.conv.Cp;
+        const int ty = (int)fdiv(tap, p.div3), tx = (int)tap - 3 * ty;
+        const int dy = (ty - 1) * p.d.conv.dil, dx = (tx - 1) * p.d.conv.dil;
+        const uint32_t ku = k < K ? (uint32_t)k : 0u;
+        const uint32_t t = fdiv(ku, p.divW);
+        const int x = (int)(ku - t * (uint32_t)p.d.conv.W);
+        const uint32_t bb = fdiv(t, p.divH);
+        const int y = (int)(t - bb * (uint32_t)p.d.conv.H);
+        okb = okb && ci < p.d.conv.C && (unsigned)(y + dy) < (unsigned)p.d.conv.H && (unsigned)(x + dx) < (unsigned)p.d.conv.W;
+        srcb = (uint64_t)(uintptr_t)(Bbase + ((int64_t)((int)ku + dy * p.d.conv.W + dx) * p.d.ldb + ci));
+      } else {
+        srcb = (uint64_t)(uintptr_t)(Bbase + ((int64_t)k * p.d.ldb + cb));
+      }
+      glds16((const bf16_t*)(uintptr_t)(okb ? srcb : zpage), sB + i * 1024);
+    }
+  };
+
+  // ---- transpose-read addressing (per-lane constants) ----
+  const int r16 = lane & 15, g = lane >> 4;
+  const int fr = (r16 >> 2) | ((g & 1) << 2);                   // f(k) of every row this lane reads
+  const unsigned lbase = (unsigned)(uintptr_t)smem + (unsigned)((8 * g + (r16 >> 2)) * 512 + (r16 & 3) * 8);
+  unsigned a_addr[MT], b_addr[NT];                              // stage 0, kh = 0, first 4-row half
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_addr[t] = lbase + (unsigned)((wm * 8 + (t ^ fr)) * 32);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int unit = wn * 4 + t;
+    b_addr[t] = lbase + (unsigned)TILE + (unsigned)(((unit & 8) | ((unit & 7) ^ fr)) * 32);
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned st = (unsigned)((kt & 1) * STAGE);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      // ---- R phase ----
+      if (kh == 0 && kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+      const unsigned off = st + (unsigned)(kh * 32 * 512);
+      u32x2 bl[NT], bh[NT], al[MT], ah[MT];                  // asm loads: hipcc neither counts nor waits for them (guide §5.7)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { bl[t] = ds_read_tr16(b_addr[t] + off); bh[t] = ds_read_tr16(b_addr[t] + off + 4 * 512); }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) { al[t] = ds_read_tr16(a_addr[t] + off); ah[t] = ds_read_tr16(a_addr[t] + off + 4 * 512); }
+      // the wait names every destination as an in/out operand: no use (not even a register copy) can be scheduled above it
+#define TNW(x) "+v"(x)
+      if (kh == 1)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : TNW(bl[0]), TNW(bl[1]), TNW(bl[2]), TNW(bl[3]), TNW(bh[0]), TNW(bh[1]), TNW(bh[2]), TNW(bh[3]),
+                       TNW(al[0]), TNW(al[1]), TNW(al[2]), TNW(al[3]), TNW(al[4]), TNW(al[5]), TNW(al[6]), TNW(al[7]),
+                       TNW(ah[0]), TNW(ah[1]), TNW(ah[2]), TNW(ah[3]), TNW(ah[4]), TNW(ah[5]), TNW(ah[6]), TNW(ah[7]) :: "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : TNW(bl[0]), TNW(bl[1]), TNW(bl[2]), TNW(bl[3]), TNW(bh[0]), TNW(bh[1]), TNW(bh[2]), TNW(bh[3]),
+                       TNW(al[0]), TNW(al[1]), TNW(al[2]), TNW(al[3]), TNW(al[4]), TNW(al[5]), TNW(al[6]), TNW(al[7]),
+                       TNW(ah[0]), TNW(ah[1]), TNW(ah[2]), TNW(ah[3]), TNW(ah[4]), TNW(ah[5]), TNW(ah[6]), TNW(ah[7]) :: "memory");
+#undef TNW
+      u32x4 fa[MT], fb[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fb[t] = (u32x4){bl[t][0], bl[t][1], bh[t][0], bh[t][1]};
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa[t] = (u32x4){al[t][0], al[t][1], ah[t][0], ah[t][1]};
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- C phase ----
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+  __syncthreads();
+  gemm_epilogue_auto<256, 2, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+}
+
+template <bool CONVB>
+int launch_tn(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = 2 * 2 * BK * 256 * 2;
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_tn_kernel<CONVB>, smem, done)) return e;
+  const int tm = (p.d.M + 255) / 256, tn = (p.d.N + 255) / 256;
+  dim3 grid(tm * tn, 1, p.d.batch);
+  hipLaunchKernelGGL((gemm_tn_kernel<CONVB>), grid, dim3(512), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
 FastDiv make_div(uint32_t dv) {
   FastDiv f; f.d = dv ? dv : 1u;
   uint32_t s = 0; while ((1ull << s) < f.d) ++s;
@@ -1099,8 +1288,21 @@ extern "C" size_t mtt_desc_size(int which) {
 //   1 LDS-DMA 128 x 128, 4-stage ring (round-1 kernel; forced only)
 //   3 LDS-DMA 256 x 256 phased / staggered (gemm_dma_kernel<256>)      4 the same with a 256 x 128 tile (gemm_dma_kernel<128>)
 //   5 LDS-DMA 256 x 256 lock-step 2-stage (round-1 kernel; forced only, kept for A/B measurements)
+//   6 token-major weight-gradient kernel (gemm_tn_kernel): LDS-DMA + ds_read_b64_tr_b16 fragments
 // d.variant = MTT_GEMM_AUTO applies the policy; another value forces that kernel where it is applicable.
 static int gemm_variant_for(const mtt_gemm_desc& d) {
+  // 6: token-major weight-gradient kernel (gemm_tn_kernel): both operands MTT_OP_R (B may be the implicit im2col^T), bf16
+  const bool tn = d.prec == MTT_PREC_BF16 && d.a_op == MTT_OP_R && (d.b_op == MTT_OP_R || d.b_op == MTT_OP_CONV_R) &&
+                  d.a_dtype == MTT_BF16 && d.b_dtype == MTT_BF16 && d.store_mode == MTT_STORE_ROWS;
+  if (tn && d.variant != MTT_GEMM_GENERAL) {
+    if (d.variant == MTT_GEMM_DMA256) return 6;
+    const int64_t pm = (d.M + 255) / 256 * 256, pn = (d.N + 255) / 256 * 256;
+    const int batch = d.batch < 1 ? 1 : d.batch;
+    const bool fills = (pm / 256) * (pn / 256) * batch >= 64 && d.K >= 512;
+    // 256-wide tiles must not waste more than ~40 % of the MFMA work (narrow decoder outputs stay on the 128-wide general kernel)
+    if (fills && 100 * (int64_t)d.M * d.N >= 60 * pm * pn) return 6;
+    return 0;
+  }
   const bool conv = d.a_op == MTT_OP_CONV_K;
   const bool dma = d.prec == MTT_PREC_BF16 && (d.a_op == MTT_OP_K || conv) && d.b_op == MTT_OP_K && (d.K % 8) == 0 &&
                    d.a_dtype == MTT_BF16 && d.b_dtype == MTT_BF16;
@@ -1175,6 +1377,7 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STAGING) return launch_dma<256, false, 6>(p, s);
     if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S1 ? launch_dma<256, false, 1>(p, s) : launch_dma<256, false, 0>(p, s));
     if (v == 4) return conv_a ? launch_dma<128, true, 0>(p, s) : launch_dma<128, false, 0>(p, s);
+    if (v == 6) return d.b_op == MTT_OP_CONV_R ? launch_tn<true>(p, s) : launch_tn<false>(p, s);
     if (v == 5) return launch_fast256(p, s);
     if (v == 1) return launch_fast(p, s);
   }

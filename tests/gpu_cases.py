@@ -182,6 +182,37 @@ def gemm_cases():
                                                                           resid=rnd(g, M, 520), ldr=520, n_store=N), TOL_BF))
         cases.append((f"gemm_epi_kind4_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528, act=3,
                                                                aux_in=rnd(g, M, 536, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
+    # 1f. token-major weight-gradient kernel (gemm_tn_kernel, forced by variant 3 on small shapes): ragged M / N / K, several K tiles of
+    #     both parities, batch slabs (split K), asymmetric operands (an M <-> N swap or a k permutation cannot pass), then the 3x3 conv
+    #     weight gradient (implicit im2col^T on the B side; halo, dilation, channel padding)
+    for (Mtok, Nf, Kf) in ((203, 72, 40), (64, 256, 256), (1000, 300, 520), (129, 264, 16), (448, 520, 264)):
+        kw = dict(A=rnd(g, Mtok, Nf + 8, dtype=torch.bfloat16), B=rnd(g, Mtok, Kf + 16, dtype=torch.bfloat16), D=torch.full((Nf, Kf + 8), 5.0),
+                  M=Nf, N=Kf, K=Mtok, a_op=OP_R, b_op=OP_R, a_dtype=BF16, b_dtype=BF16, d_dtype=F32, prec=0, lda=Nf + 8, ldb=Kf + 16, ldd=Kf + 8,
+                  batch=1, batch_inner=1, alpha=1.0, variant=3)
+        cases.append((f"gemm_tn_{Mtok}x{Nf}x{Kf}", "gemm", kw, TOL_BF))
+    Z, c, Nf, Kf = 3, 192, 300, 264
+    kw = dict(A=rnd(g, Z * c, Nf + 4, dtype=torch.bfloat16), B=rnd(g, Z * c, Kf, dtype=torch.bfloat16), D=torch.full((Z, Nf, Kf), 5.0),
+              M=Nf, N=Kf, K=c, a_op=OP_R, b_op=OP_R, a_dtype=BF16, b_dtype=BF16, d_dtype=F32, prec=0, lda=Nf + 4, ldb=Kf, ldd=Kf,
+              batch=Z, batch_inner=1, a_zo=c * (Nf + 4), b_zo=c * Kf, d_zo=Nf * Kf, alpha=1.0, variant=3)
+    cases.append(("gemm_tn_batched_slabs", "gemm", kw, TOL_BF))
+    for dil, (Bn, H, W, Ci, Co) in ((1, (2, 9, 7, 20, 30)), (2, (2, 9, 7, 20, 30)), (1, (3, 20, 17, 44, 300)), (1, (2, 16, 16, 350, 350))):
+        Cp, Cop = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
+        X = rnd(g, Bn * H * W, Cp, dtype=torch.bfloat16); X[..., Ci:] = 0
+        dY = rnd(g, Bn * H * W, Cop, dtype=torch.bfloat16); dY[..., Co:] = 0
+        kw = dict(A=dY, B=X, D=torch.full((Co, 9 * Cp), 5.0), M=Co, N=9 * Cp, K=Bn * H * W, a_op=OP_R, b_op=OP_CONV_R,
+                  a_dtype=BF16, b_dtype=BF16, d_dtype=F32, prec=0, lda=Cop, ldb=Cp, ldd=9 * Cp, batch=1, batch_inner=1,
+                  conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=0), alpha=1.0, variant=3)
+        cases.append((f"gemm_tn_conv3_wgrad_d{dil}_{Bn}x{H}x{W}x{Ci}to{Co}", "gemm", kw, TOL_BF))
+    # two image slices as a (task, slice) batch, as Conv3x3Fn.backward launches it
+    Bn, H, W, Ci, Co, S = 4, 8, 6, 24, 40, 2
+    X = rnd(g, 2, Bn * H * W, Ci, dtype=torch.bfloat16)
+    dY = rnd(g, 2, Bn * H * W, Co, dtype=torch.bfloat16)
+    cc = Bn * H * W // S
+    kw = dict(A=dY, B=X, D=torch.full((2, S, Co, 9 * Ci), 5.0), M=Co, N=9 * Ci, K=cc, a_op=OP_R, b_op=OP_CONV_R, a_dtype=BF16, b_dtype=BF16,
+              d_dtype=F32, prec=0, lda=Co, ldb=Ci, ldd=9 * Ci, batch=2 * S, batch_inner=S, a_zo=Bn * H * W * Co, a_zi=cc * Co,
+              b_zo=Bn * H * W * Ci, b_zi=cc * Ci, d_zo=S * Co * 9 * Ci, d_zi=Co * 9 * Ci, conv=dict(H=H, W=W, C=Ci, Cp=Ci, dil=1, flip=0),
+              alpha=1.0, variant=3)
+    cases.append(("gemm_tn_conv3_wgrad_slices", "gemm", kw, TOL_BF))
     # 2. asymmetric identity check (A = I) catches transposed C layout
     kw = base(128, 128, 128, F32, F32, F32, 1)
     kw["A"] = torch.eye(128, 136)
