@@ -186,8 +186,9 @@ def gemm_cases():
     #     both parities, batch slabs (split K), asymmetric operands (an M <-> N swap or a k permutation cannot pass), then the 3x3 conv
     #     weight gradient (implicit im2col^T on the B side; halo, dilation, channel padding)
     for (Mtok, Nf, Kf) in ((203, 72, 40), (64, 256, 256), (1000, 300, 520), (129, 264, 16), (448, 520, 264)):
-        kw = dict(A=rnd(g, Mtok, Nf + 8, dtype=torch.bfloat16), B=rnd(g, Mtok, Kf + 16, dtype=torch.bfloat16), D=torch.full((Nf, Kf + 8), 5.0),
-                  M=Nf, N=Kf, K=Mtok, a_op=OP_R, b_op=OP_R, a_dtype=BF16, b_dtype=BF16, d_dtype=F32, prec=0, lda=Nf + 8, ldb=Kf + 16, ldd=Kf + 8,
+        la = (Nf + 7) // 8 * 8 + 8
+        kw = dict(A=rnd(g, Mtok, la, dtype=torch.bfloat16), B=rnd(g, Mtok, Kf + 16, dtype=torch.bfloat16), D=torch.full((Nf, Kf + 8), 5.0),
+                  M=Nf, N=Kf, K=Mtok, a_op=OP_R, b_op=OP_R, a_dtype=BF16, b_dtype=BF16, d_dtype=F32, prec=0, lda=la, ldb=Kf + 16, ldd=Kf + 8,
                   batch=1, batch_inner=1, alpha=1.0, variant=3)
         cases.append((f"gemm_tn_{Mtok}x{Nf}x{Kf}", "gemm", kw, TOL_BF))
     Z, c, Nf, Kf = 3, 192, 300, 264
