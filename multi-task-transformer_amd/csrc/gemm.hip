@@ -388,6 +388,7 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
 // staging (profiles/r02_gemm_ablate_g_epilogue_parts.log: removing the global stores saves 1.7 us, removing the staging 0.9 us).
 // Here the feature set is a template parameter, the tile is known to be full (no bounds checks) and rows are contiguous, so a row of 8
 // outputs is a handful of instructions.  KIND:
+//   (acc below = acc * colscale + colshift; colscale is the folded eval-mode BatchNorm of the conv call sites, absent elsewhere)
 //   0  D bf16 = acc + bias                              (qkv, bf16 dgrads)
 //   1  D f32  = acc + bias                              (weight-gradient slabs, fp32 dgrads)
 //   2  D bf16 = GELU(z), z = acc + bias; aux_out bf16 = z when given   (fc1)
@@ -395,7 +396,7 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
 //   4  D bf16 = (acc + bias) * GELU'(aux_in bf16)       (fc2 dgrad)
 // ---------------------------------------------------------------------------------------------
 MTT_DEV int fast_epilogue_kind(const mtt_gemm_desc& d, int m0, int n0, int tbm, int tbn) {
-  if (d.store_mode != MTT_STORE_ROWS || d.colscale || d.alpha != 1.0f) return -1;
+  if (d.store_mode != MTT_STORE_ROWS || d.alpha != 1.0f) return -1;
   if (m0 + tbm > d.M || n0 + tbn > d.N) return -1;                                   // interior tiles only
   if (d.d_mb > 0 && d.d_bs != (int64_t)d.d_mb * d.ldd) return -1;                    // D rows contiguous
   const bool auxi = d.aux_in != nullptr, auxo = d.aux_out != nullptr;
@@ -422,11 +423,11 @@ MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned 
   float* const ep = (float*)smem;
   const int c8 = threadIdx.x % CHUNKS, rl0 = threadIdx.x / CHUNKS;
   const int ncol0 = n0 + c8 * 8;
-  float sh[8];
+  float sh[8], cs[8];
   {
     const int64_t zcol = (int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi + ncol0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sh[j] = d.colshift ? d.colshift[zcol + j] : 0.0f;
+    for (int j = 0; j < 8; ++j) { sh[j] = d.colshift ? d.colshift[zcol + j] : 0.0f; cs[j] = d.colscale ? d.colscale[zcol + j] : 1.0f; }
   }
   const int64_t zD = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi + ncol0;
   const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + ncol0;
@@ -464,7 +465,8 @@ MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned 
       const int64_t m = mrow + RPP * i;
       const float4 lo4 = *(const float4*)(epr + RPP * i * EP_LD);
       const float4 hi4 = *(const float4*)(epr + RPP * i * EP_LD + 4);
-      float v[8] = {lo4.x + sh[0], lo4.y + sh[1], lo4.z + sh[2], lo4.w + sh[3], hi4.x + sh[4], hi4.y + sh[5], hi4.z + sh[6], hi4.w + sh[7]};
+      float v[8] = {fmaf(lo4.x, cs[0], sh[0]), fmaf(lo4.y, cs[1], sh[1]), fmaf(lo4.z, cs[2], sh[2]), fmaf(lo4.w, cs[3], sh[3]),
+                    fmaf(hi4.x, cs[4], sh[4]), fmaf(hi4.y, cs[5], sh[5]), fmaf(hi4.z, cs[6], sh[6]), fmaf(hi4.w, cs[7], sh[7])};
       if (KIND == 2) {
         if (d.aux_out)
           *(u32x4*)((bf16_t*)d.aux_out + (zAux + m * d.ldaux)) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};

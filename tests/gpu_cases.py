@@ -169,6 +169,8 @@ def gemm_cases():
         cases.append((f"gemm_epi_kind0_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528,
                                                                colshift=rnd(g, N), n_store=N), TOL_BF))
         cases.append((f"gemm_epi_kind1_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0), d_dtype=F32, ldd=528, n_store=N), TOL_BF))
+        cases.append((f"gemm_epi_kind2_colscale_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528,
+                                                                        colshift=rnd(g, N), colscale=rnd(g, N).abs() + 0.5, act=1, n_store=N), TOL_BF))
         cases.append((f"gemm_epi_kind2_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528,
                                                                colshift=rnd(g, N), act=1, aux_out=torch.full((M, 536), 3.0, dtype=torch.bfloat16),
                                                                aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
