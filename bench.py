@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-ref-batch", action="store_true")
+    ap.add_argument("--no-fuse-upsample", action="store_true",
+                    help="A/B: materialise the x4-upsampled task features and run ConvHead's 3x3 conv on them (the reference's operation order)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
     return ap.parse_args()
@@ -211,6 +213,8 @@ def main():
 
     desc, _, (H, W), dflt_batch, gflop_fwd = CONFIGS[a.config]
     batch = a.batch or dflt_batch
+    if a.no_fuse_upsample:
+        mtt_amd.taskprompter.TaskPrompterWrapper.fuse_upsample = False
     torch.manual_seed(0)
     p, model = build(a.config, a.prec, mtt_amd)
     if world > 1:
@@ -334,6 +338,13 @@ def main():
             cpu = dict(value=None, unit="images/s", cores=a.cpu_threads, kind="port", host_cores=os.cpu_count(), sample=f"failed: {e!r}")
     if rank == 0:
         train_tflops = 3 * gflop_fwd * value / 1e3
+        # model FLOPs follow the REFERENCE's operation order.  ConvHeads run "taps first" (3x3 conv commuted with the x4
+        # bilinear resize: the channel mixing happens on the h x w map), which executes 15/16 of the head conv's MACs less:
+        fused_heads = (not a.no_fuse_upsample) and any(type(hd).__name__ == "ConvHead" for hd in getattr(model, "heads", {}).values())
+        gflop_exec = gflop_fwd
+        if fused_heads:
+            F_, n_conv = p.final_embed_dim, sum(1 for hd in model.heads.values() if type(hd).__name__ == "ConvHead")
+            gflop_exec = gflop_fwd - (15.0 / 16.0) * 2.0 * (H // 4) * (W // 4) * F_ * F_ * 9 * n_conv / 1e9
         metric = "training images/sec (512x512, 6 tasks)" if a.config == "ns6" else f"training images/sec ({H}x{W}, {len(p.TASKS.NAMES)} tasks)"
         line = dict(metric=metric, value=round(value, 3), unit="images/s", n_gpus=world,
                     steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling="weak",
@@ -345,7 +356,9 @@ def main():
                     fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(peak_gb, 1),
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                       fwd=round(gflop_fwd / fwd_ms_img, 1), fwd_frac_of_bf16_peak=round(gflop_fwd / fwd_ms_img / MFMA_BF16_PEAK_TFLOPS, 4),
-                                      gflop_fwd_per_img=gflop_fwd),
+                                      gflop_fwd_per_img=gflop_fwd, gflop_fwd_executed_per_img=round(gflop_exec, 1),
+                                      convention="FLOPs of the reference's operation order; 'executed' subtracts what the taps-first "
+                                                 "ConvHead (upsample x4 + 3x3 conv commuted) does not compute"),
                     roofline=roof, parity=parity, ref_batch=ref_batch, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 2
+#define MTT_ABI_VERSION 3
 
 enum { MTT_F32 = 0, MTT_BF16 = 1 };
 enum { MTT_PREC_BF16 = 0, MTT_PREC_X3 = 1 };
@@ -109,7 +109,7 @@ typedef struct {
 
 int mtt_abi_version(void);
 /* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom, (15 adam, 16 loss)
- * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt */
+ * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt, 17 upconv */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
 /* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128 (general), 1 LDS-DMA 128x128 ring, 3 / 4 phased
@@ -298,6 +298,23 @@ typedef struct {
 int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream);
 /* backward: dyall [B*H*W, 9*Cop] (d->dtype) gathered from dout [B*2H*2W, Cop] (d->out_dtype) */
 int mtt_convt3x3s2_gather_bwd(const mtt_convt_desc* d, const void* dout, void* dyall, void* stream);
+
+/* ConvHead's first stage on the backbone's low-resolution task features: F.interpolate(x, scale_factor=4, 'bilinear') followed by
+ * Conv2d(C, C, 3, padding=1)  (taskprompter.py:420 -> :692), evaluated "taps first".  Both operators are linear, so
+ *   conv3x3(up4(x))(Y, X) = bias + sum over taps (ky, kx) of [ up4(W[ky,kx] x) ](Y + ky - 1, X + kx - 1)   (zero outside the 4h x 4w map):
+ * the channel mixing runs as ONE GEMM on the h x w map (mtt_gemm, N = 9 * Cp: 16x fewer MACs than the conv on the upsampled map), and
+ * these two entry points do what is left — an HBM-bound 36-point stencil — without materialising the upsampled features:
+ *   mtt_upconv4_expand : z [Z][B*h*w][9*Cp] (column (ky*3+kx)*Cp + c holds W[ky,kx] x, channel padding zero)
+ *                        -> y [Z][B*4h*4w][Cp] = act((sum of the shifted x4 bilinear expansions) * colscale + bias)
+ *   mtt_upconv4_gather : the adjoint, dz [Z][B*h*w][9*Cp] from dy [Z][B*4h*4w][Cp] (the caller applies act' / BatchNorm backward first).
+ * Bilinear semantics are PyTorch's align_corners=False (source index clamped at the borders); the x4 phase weights are the constants
+ * 1/8, 3/8, 5/8, 7/8.  bias / colscale: fp32 [Z][C] or NULL.  z_dtype / y_dtype: MTT_F32 or MTT_BF16 (both the same). */
+typedef struct {
+  void* z; void* y; const float* bias; const float* colscale;
+  int32_t Z, B, h, w, C, Cp; int32_t z_dtype, y_dtype, act;
+} mtt_upconv_desc;
+int mtt_upconv4_expand(const mtt_upconv_desc* d, void* stream);
+int mtt_upconv4_gather(const mtt_upconv_desc* d, void* stream);
 
 /* Fused multi-tensor clip_grad_norm_ + Adam (TaskPrompter/utils/train_utils.py:47-51, torch.optim.Adam semantics: L2 weight decay
  * added to the gradient, bias-corrected moments).  All n tensors are fp32; grads/params/exp_avg/exp_avg_sq/numel are DEVICE arrays

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16 = 0, 1
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -129,6 +129,12 @@ class ConvtDesc(C.Structure):
                 ("dtype", i32), ("out_dtype", i32)]
 
 
+class UpconvDesc(C.Structure):
+    _fields_ = [("z", ptr), ("y", ptr), ("bias", ptr), ("colscale", ptr),
+                ("Z", i32), ("B", i32), ("h", i32), ("w", i32), ("C", i32), ("Cp", i32),
+                ("z_dtype", i32), ("y_dtype", i32), ("act", i32)]
+
+
 class AdamDesc(C.Structure):
     _fields_ = [("grads", ptr), ("params", ptr), ("exp_avg", ptr), ("exp_avg_sq", ptr), ("numel", ptr),
                 ("chunk_tensor", ptr), ("chunk_off", ptr), ("n_chunks", i32),
@@ -150,9 +156,10 @@ DESCS = {
     "bn_apply": BnDesc, "bn_bwd_apply": BnDesc,
     "dwconv3x3s2": DwconvDesc, "avgpool_ceil": PoolDesc, "layernorm_mt": LnMtDesc, "attn_msg": AttnMsgDesc,
     "convt3x3s2_gather": ConvtDesc,
+    "upconv4_expand": UpconvDesc, "upconv4_gather": UpconvDesc,
 }
 _SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom,
-               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc, LossDesc]
+               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc, LossDesc, UpconvDesc]
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],

@@ -575,6 +575,46 @@ class Conv3x3Fn(Function):
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 
+class UpConv3x3Fn(Function):
+    """F.interpolate(x, scale_factor=4, 'bilinear') -> task-batched Conv2d(3x3, padding 1) (+bias) on the LOW-resolution task stack
+    x [Z, B*h*w, pad8(Ci)] (taskprompter.py:420 -> ConvHead.mt_proj[0], :692), "taps first" (include/mtt_hip.h, mtt_upconv_desc):
+    forward = ONE GEMM with the nine stacked tap matrices + the expansion kernel; backward = the gather kernel + the input / weight
+    gradient GEMMs of that linear layer on the h x w map.  geo = (B, h, w, Co, Ci)."""
+
+    @staticmethod
+    def forward(ctx, x, geo, prec, tag, *wb):
+        B, h, w, Co, Ci = geo
+        Z = len(wb) // 2
+        ws, bs = wb[:Z], wb[Z:]
+        w9 = ops.pack_upconv9(list(ws), prec, tag)
+        xa = x if x.dtype == prec.adt else ops.cast2d(x.reshape(-1, x.shape[-1]), x.shape[0] * x.shape[1], x.shape[-1], x.shape[-1],
+                                                      prec.adt, ldd=x.shape[-1]).view(x.shape)
+        y = ops.upconv3x3(xa, w9, Co, B, h, w, prec, bias=ops.stack_vec(list(bs), (tag, 'b')))
+        ctx.save_for_backward(xa, w9)
+        ctx.meta = (geo, prec, Z, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, w9 = ctx.saved_tensors
+        (B, h, w, Co, Ci), prec, Z, xdtype = ctx.meta
+        dy = dy.contiguous()
+        M, Kp, N9 = xa.shape[1], xa.shape[2], w9.shape[1]
+        dz = ops.upconv4_gather(dy, Co, B, h, w)                         # [Z, M, N9]
+        dx = torch.empty(Z, M, Kp, dtype=xdtype, device=dy.device)
+        if prec.name == "bf16" and FAST_BWD and M >= FAST_MIN_ROWS and Kp >= 128:
+            wT = w9.transpose(1, 2).contiguous()                         # [Z, Kp, N9]: reduction-contiguous dgrad operand
+            _gemm(dz, wT, dx, M, Kp, N9, prec, lda=N9, ldb=N9, ldd=Kp, batch=Z, a_zo=M * N9, b_zo=Kp * N9, d_zo=M * Kp, n_store=Kp)
+        else:
+            _gemm(dz, w9, dx, M, Kp, N9, prec, b_op=OP_R, lda=N9, ldb=Kp, ldd=Kp, batch=Z, a_zo=M * N9, b_zo=N9 * Kp, d_zo=M * Kp,
+                  n_store=Kp)
+        dW9 = _wgrad_batched(dz, xa, N9, Kp, M, prec, Z, N9, Kp, M * N9, M * Kp)              # [Z, N9, Kp] fp32
+        Cop = N9 // 9
+        dws = [dW9[z].view(3, 3, Cop, Kp)[:, :, :Co, :Ci].permute(2, 3, 0, 1).contiguous() for z in range(Z)]
+        dbs = [_colsum(dy[z], Co) for z in range(Z)]
+        return (dx, None, None, None) + tuple(dws) + tuple(dbs)
+
+
 class BnActStackFn(Function):
     """BatchNorm2d (+GELU / ReLU) over a task stack [Z, rows, ld], one BatchNorm holder per task (taskprompter.py:362,692,705;
     invpt.py:14).  training: centred batch statistics, merged across ranks in one collective when the holders are SyncBatchNorm
@@ -778,8 +818,9 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
     return CtrMixFn.apply(fea, wmix, acc, B, F)
 
 
-def backbone_forward(model, img):
-    """Autograd twin of TaskPrompter._forward_nograd -> [T, B*4h*4w, pad8(F)] task features."""
+def backbone_forward(model, img, upsample=True):
+    """Autograd twin of TaskPrompter._forward_nograd -> [T, B*4h*4w, pad8(F)] task features (upsample=False: the fp32 h x w sums
+    [T, B*h*w, pad8(F)] before the x4 resize, for heads that fuse it)."""
     p, prec = model.p, model.prec
     B = img.shape[0]
     assert tuple(img.shape[-2:]) == tuple(model.patch_embed.img_size)
@@ -804,17 +845,25 @@ def backbone_forward(model, img):
             acc = _task_features(model, XT, rawlog, rawchan, model._tap_index(i), B, acc)
     xf = LayerNormFn.apply(XT, model.norm.weight, model.norm.bias, model.norm.eps, prec, torch.float32)
     acc = _task_features(model, xf, rawlog, rawchan, 3, B, acc)
+    return upsample4(acc, B, h, w, prec) if upsample else acc
+
+
+def upsample4(acc, B, h, w, prec):
     return BilinearFn.apply(acc, (B, acc.shape[-1], h, w, 4 * h, 4 * w), prec.adt, False)
 
 
-def heads_forward(kind, heads, fea, B, h4, w4, target, prec, training):
-    """Autograd twin of taskprompter.run_heads: fea [Z, B*h4*w4, pad8(F)] -> list of fp32 NCHW predictions."""
+def heads_forward(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False):
+    """Autograd twin of taskprompter.run_heads: fea [Z, B*h4*w4, pad8(F)] (lowres: [Z, B*(h4/4)*(w4/4), pad8(F)], ConvHeads only) ->
+    list of fp32 NCHW predictions."""
     F = heads[0].mt_proj[0].weight.shape[0]
     outs = []
     if kind == 'conv':
         tgt = target or (h4, w4)
-        y = Conv3x3Fn.apply(fea, (B, h4, w4, F, F), prec, 'hc', *[hd.mt_proj[0].weight for hd in heads],
-                            *[hd.mt_proj[0].bias for hd in heads])
+        conv_w, conv_b = [hd.mt_proj[0].weight for hd in heads], [hd.mt_proj[0].bias for hd in heads]
+        if lowres:
+            y = UpConv3x3Fn.apply(fea, (B, h4 // 4, w4 // 4, F, F), prec, 'hc9', *conv_w, *conv_b)
+        else:
+            y = Conv3x3Fn.apply(fea, (B, h4, w4, F, F), prec, 'hc', *conv_w, *conv_b)
         y = _bn_act(y, [hd.mt_proj[1] for hd in heads], F, ACT_GELU, training)
         preds = TaskHeadsFn.apply(y, prec, 'hp', *[hd.linear_pred.weight for hd in heads], *[hd.linear_pred.bias for hd in heads])
         for hd, pred in zip(heads, preds):

@@ -1281,6 +1281,7 @@ extern "C" size_t mtt_desc_size(int which) {
     case 14: return sizeof(mtt_convt_desc);
     case 15: return sizeof(mtt_adam_desc);
     case 16: return sizeof(mtt_loss_desc);
+    case 17: return sizeof(mtt_upconv_desc);
     default: return 0;
   }
 }

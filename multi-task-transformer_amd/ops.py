@@ -118,6 +118,22 @@ def pack_conv3(weights, prec, tag, transpose=False):
     return _cached((tag, prec.name, transpose, tuple(id(w) for w in weights)), weights, build)
 
 
+def pack_upconv9(weights, prec, tag):
+    """List of Z conv weights [Co, Ci, 3, 3] -> [Z, 9*pad8(Co), pad8(Ci)]: row (ky*3+kx)*pad8(Co) + co holds W[co, :, ky, kx] — the nine
+    tap matrices of the "taps first" form of upsample x4 + 3x3 conv (mtt_upconv_desc) stacked as ONE linear layer; rows of the channel
+    padding are zero, so its output planes carry zero padding channels."""
+    def build():
+        with torch.no_grad():
+            out = []
+            for w in weights:
+                Co, Ci = w.shape[:2]
+                buf = torch.zeros(9, pad8(Co), Ci, dtype=torch.float32, device=w.device)
+                buf[:, :Co] = w.detach().permute(2, 3, 0, 1).reshape(9, Co, Ci)
+                out.append(pack_matrix(buf.reshape(9 * pad8(Co), Ci), prec))
+            return torch.stack(out, 0)
+    return _cached((tag, prec.name, 'up9', tuple(id(w) for w in weights)), weights, build)
+
+
 def stack_vec(vs, tag):
     def build():
         with torch.no_grad():
@@ -211,6 +227,34 @@ def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=AC
         kw.update(colscale=colscale)
     call("gemm", **kw)
     return out
+
+
+def upconv4_expand(z, C, B, h, w, *, bias=None, colscale=None, act=ACT_NONE):
+    """z [Z, B*h*w, 9*Cp] (tap planes from linear(x, pack_upconv9(...))) -> [Z, B*4h*4w, Cp] = act(conv3x3(up4(x)) * colscale + bias)."""
+    Z, rows, n9 = z.shape
+    Cp = n9 // 9
+    assert rows == B * h * w and n9 == 9 * Cp and z.is_contiguous()
+    y = torch.empty(Z, B * 16 * h * w, Cp, dtype=z.dtype, device=z.device)
+    call("upconv4_expand", z=z, y=y, bias=bias, colscale=colscale, Z=Z, B=B, h=h, w=w, C=C, Cp=Cp,
+         z_dtype=dtype_code(z), y_dtype=dtype_code(y), act=act)
+    return y
+
+
+def upconv4_gather(dy, C, B, h, w):
+    """adjoint of upconv4_expand (without act / scale): dy [Z, B*4h*4w, Cp] -> dz [Z, B*h*w, 9*Cp]."""
+    Z, rows, Cp = dy.shape
+    assert rows == B * 16 * h * w and dy.is_contiguous()
+    dz = torch.empty(Z, B * h * w, 9 * Cp, dtype=dy.dtype, device=dy.device)
+    call("upconv4_gather", z=dz, y=dy, bias=None, colscale=None, Z=Z, B=B, h=h, w=w, C=C, Cp=Cp,
+         z_dtype=dtype_code(dz), y_dtype=dtype_code(dy), act=ACT_NONE)
+    return dz
+
+
+def upconv3x3(x, w9, Co, B, h, w, prec, *, bias=None, colscale=None, act=ACT_NONE):
+    """F.interpolate(x, scale_factor=4, 'bilinear') -> Conv2d(3x3, padding 1) on the LOW-resolution task stack x [Z, B*h*w, Cip]
+    (taskprompter.py:420 -> :692) in its taps-first form: one GEMM with the nine stacked tap matrices, then the expansion kernel."""
+    z = linear(x, w9, w9.shape[1], prec)
+    return upconv4_expand(z, Co, B, h, w, bias=bias, colscale=colscale, act=act)
 
 
 def deconv2x2(x, wpack, Co, Ci, B, H, W, prec, *, bias4=None, out_dtype=None):

@@ -186,14 +186,23 @@ class TaskPrompter(nn.Module):
         out = {t: fea[i].view(B, h4, w4, -1)[..., :F].permute(0, 3, 1, 2) for i, t in enumerate(self.p.TASKS.NAMES)}
         return out, {}
 
-    def forward_nhwc(self, img):
-        """-> [T, B*4h*4w, pad8(F)] activation-dtype task features (x4-upsampled sum over the 4 taps)."""
+    def forward_nhwc(self, img, upsample=True):
+        """-> [T, B*4h*4w, pad8(F)] activation-dtype task features (x4-upsampled sum over the 4 taps; taskprompter.py:420).
+        upsample=False stops before the resize: fp32 [T, B*h*w, pad8(F)], for heads that fuse it into their first conv."""
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             from . import autograd_path
-            return autograd_path.backbone_forward(self, img)
-        return self._forward_nograd(img)
+            return autograd_path.backbone_forward(self, img, upsample)
+        return self._forward_nograd(img, upsample)
 
-    def _forward_nograd(self, img):
+    def upsample4(self, acc, B):
+        """the x4 bilinear resize of forward_nhwc(upsample=False)'s result (differentiable when that is)."""
+        h, w = self.resolution
+        if torch.is_grad_enabled() and acc.requires_grad:
+            from . import autograd_path
+            return autograd_path.upsample4(acc, B, h, w, self.prec)
+        return ops.bilinear(acc, B, acc.shape[-1], h, w, 4 * h, 4 * w, self.prec.adt)
+
+    def _forward_nograd(self, img, upsample=True):
         p, prec = self.p, self.prec
         B = img.shape[0]
         H, W = img.shape[-2:]
@@ -222,7 +231,7 @@ class TaskPrompter(nn.Module):
         xf, _, _ = ops.layernorm(XT, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps, prec,
                                  out_dtype=torch.float32)
         acc = self._task_features(xf, xf.view(B, N, C)[:, T:], rawlog, rawchan, 3, B, acc)
-        return ops.bilinear(acc, B, acc.shape[-1], h, w, 4 * h, 4 * w, prec.adt)
+        return ops.bilinear(acc, B, acc.shape[-1], h, w, 4 * h, 4 * w, prec.adt) if upsample else acc
 
     def _block(self, blk, i, XT, B, N, T, grid, nwin):
         prec, C, nH = self.prec, self.embed_dim, self.num_heads
@@ -412,26 +421,41 @@ class DEConvHead(_HeadBase):
         trunc_normal_(self.linear_pred.weight, std=0.02)
 
 
-def run_heads(kind, heads, fea, B, h4, w4, target, prec, training):
+def run_heads(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False):
     """The per-task prediction heads of one kind on the task stack fea [Z, B*h4*w4, pad8(F)] -> list of fp32 NCHW predictions resized to
     `target` (None: the head's native resolution).  ConvHead: ONE task-batched 3x3 conv + BN + GELU, then the 1x1s (taskprompter.py:
-    688-698); DEConvHead: ConvT 2x2 s2 as a pixel-shuffle GEMM + BN + GELU + 3x3 + BN + GELU + 1x1 (:700-715)."""
-    if torch.is_grad_enabled() and any(q.requires_grad for hd in heads for q in hd.parameters()):
+    688-698); DEConvHead: ConvT 2x2 s2 as a pixel-shuffle GEMM + BN + GELU + 3x3 + BN + GELU + 1x1 (:700-715).
+    lowres (ConvHeads only): fea is the backbone's result BEFORE its x4 resize, [Z, B*(h4/4)*(w4/4), pad8(F)], and the resize is fused
+    into the 3x3 conv in its taps-first form (ops.upconv3x3) — the upsampled features are never materialised."""
+    if torch.is_grad_enabled() and (fea.requires_grad or any(q.requires_grad for hd in heads for q in hd.parameters())):
         from . import autograd_path
-        return autograd_path.heads_forward(kind, heads, fea, B, h4, w4, target, prec, training)
+        return autograd_path.heads_forward(kind, heads, fea, B, h4, w4, target, prec, training, lowres)
     from . import bn as bn_mod
     F = heads[0].mt_proj[0].weight.shape[0]
     outs = []
     if kind == 'conv':
         tgt = target or (h4, w4)
-        Wc = ops.pack_conv3([hd.mt_proj[0].weight for hd in heads], prec, 'hc')
+        conv_w = [hd.mt_proj[0].weight for hd in heads]
         bns = [hd.mt_proj[1] for hd in heads]
+        if lowres:
+            if fea.dtype != prec.adt:
+                fea = ops.cast2d(fea.reshape(-1, fea.shape[-1]), fea.shape[0] * fea.shape[1], fea.shape[-1], fea.shape[-1], prec.adt,
+                                 ldd=fea.shape[-1]).view(fea.shape)
+            W9 = ops.pack_upconv9(conv_w, prec, 'hc9')
+
+            def conv(**epi):
+                return ops.upconv3x3(fea, W9, F, B, h4 // 4, w4 // 4, prec, **epi)
+        else:
+            Wc = ops.pack_conv3(conv_w, prec, 'hc')
+
+            def conv(**epi):
+                return ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, **epi)
         if training:
-            y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=ops.stack_vec([hd.mt_proj[0].bias for hd in heads], 'hcb'))
+            y = conv(bias=ops.stack_vec([hd.mt_proj[0].bias for hd in heads], 'hcb'))
             y = bn_mod.train_forward(y, F, bns, ACT_GELU)[0]
         else:
             sc, sh = bn_fold(bns, [hd.mt_proj[0].bias for hd in heads], 'hbn')
-            y = ops.conv3x3(fea, Wc, F, F, B, h4, w4, prec, bias=sh, colscale=sc, act=ACT_GELU)
+            y = conv(bias=sh, colscale=sc, act=ACT_GELU)
         for i, hd in enumerate(heads):
             n_out = hd.linear_pred.weight.shape[0]
             pred = ops.linear(y[i], ops.pack_linear([hd.linear_pred.weight], prec, 'hp'), n_out, prec,
@@ -472,6 +496,8 @@ class TaskPrompterWrapper(nn.Module):
     head) is called as `heads[task](feature)` on the reference-layout feature map, and a '3ddet' output is passed through un-resized
     (taskprompter_wrapper.py:35-38)."""
 
+    fuse_upsample = True        # False: materialise the x4-upsampled features and run the 3x3 conv on them (A/B + parity tests)
+
     def __init__(self, p, backbone, heads):
         super().__init__()
         self.tasks = p.TASKS.NAMES
@@ -487,7 +513,6 @@ class TaskPrompterWrapper(nn.Module):
         target = tuple(self.target_size) if self.target_size is not None else img_size
         bb = self.backbone
         B = x.shape[0]
-        fea = bb.forward_nhwc(x)                                            # [T, B*4h*4w, Fp]
         h4, w4 = bb.resolution[0] * 4, bb.resolution[1] * 4
         F = bb.p.final_embed_dim
         out = {}
@@ -495,14 +520,25 @@ class TaskPrompterWrapper(nn.Module):
         for i, t in enumerate(self.tasks):
             hd = self.heads[t]
             groups['conv' if isinstance(hd, ConvHead) else ('deconv' if isinstance(hd, DEConvHead) else 'other')].append(i)
+        # ConvHeads take the backbone's h x w sums and fuse its x4 resize into their 3x3 conv (taskprompter.py:420 -> :692, taps first);
+        # the upsampled stack [T, B*4h*4w, Fp] is only built if some other head needs it
+        fuse = self.fuse_upsample and bool(groups['conv'])
+        lo = bb.forward_nhwc(x, upsample=not fuse)
+        fea = None if fuse else lo
         for kind in ('conv', 'deconv'):
             idx = groups[kind]
             if not idx:
                 continue
-            sub = fea if len(idx) == len(self.tasks) else fea[idx]
-            preds = run_heads(kind, [self.heads[self.tasks[i]] for i in idx], sub, B, h4, w4, target, bb.prec, self.training)
+            lowres = fuse and kind == 'conv'
+            if not lowres and fea is None:
+                fea = bb.upsample4(lo, B)                                   # [T, B*4h*4w, Fp]
+            src = lo if lowres else fea
+            sub = src if len(idx) == len(self.tasks) else src[idx]
+            preds = run_heads(kind, [self.heads[self.tasks[i]] for i in idx], sub, B, h4, w4, target, bb.prec, self.training, lowres)
             for i, pr in zip(idx, preds):
                 out[self.tasks[i]] = pr
+        if groups['other'] and fea is None:
+            fea = bb.upsample4(lo, B)
         for i in groups['other']:
             t = self.tasks[i]
             y = self.heads[t](fea[i].view(B, h4, w4, -1)[..., :F].permute(0, 3, 1, 2).float())

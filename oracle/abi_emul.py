@@ -779,7 +779,41 @@ def convt3x3s2_gather_bwd(**kw):
     _wr(dyall, torch.arange(out.numel()), out.reshape(-1))
 
 
-_TABLE = dict(gemm=gemm, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
+def _upconv_expand_math(z, h, w):
+    """z [n, h, w, 3, 3, Cp] (tap planes W[ky,kx] x) -> [n, 4h, 4w, Cp]: sum over taps of the x4 bilinear expansion of plane (ky, kx)
+    read at (Y + ky - 1, X + kx - 1), zero outside the 4h x 4w map — mtt_upconv_desc, restated with F.interpolate + zero-padded
+    shifts (independent of the kernels' separable constant-weight form)."""
+    n, Cp = z.shape[0], z.shape[-1]
+    out = torch.zeros(n, Cp, 4 * h, 4 * w, dtype=z.dtype)
+    for ky in range(3):
+        for kx in range(3):
+            up = torch.nn.functional.interpolate(z[:, :, :, ky, kx].permute(0, 3, 1, 2), scale_factor=4, mode="bilinear", align_corners=False)
+            out = out + torch.nn.functional.pad(up, (1, 1, 1, 1))[:, :, ky:ky + 4 * h, kx:kx + 4 * w]
+    return out.permute(0, 2, 3, 1)
+
+
+def upconv4_expand(**kw):
+    Z, B, h, w, Cn, Cp = (kw[k] for k in ("Z", "B", "h", "w", "C", "Cp"))
+    n = Z * B
+    z = _rd(kw["z"], torch.arange(n * h * w * 9 * Cp)).view(n, h, w, 3, 3, Cp)
+    y = _upconv_expand_math(z, h, w).reshape(Z, B * 16 * h * w, Cp)
+    sc = _rd(kw["colscale"], torch.arange(Z * Cn)).view(Z, 1, Cn) if kw.get("colscale") is not None else 1.0
+    bs = _rd(kw["bias"], torch.arange(Z * Cn)).view(Z, 1, Cn) if kw.get("bias") is not None else 0.0
+    out = torch.zeros_like(y)
+    out[..., :Cn] = _act(y[..., :Cn] * sc + bs, kw.get("act", 0) or 0)
+    _wr(kw["y"], torch.arange(out.numel()), out.reshape(-1))
+
+
+def upconv4_gather(**kw):
+    Z, B, h, w, Cp = (kw[k] for k in ("Z", "B", "h", "w", "Cp"))
+    n = Z * B
+    g = _rd(kw["y"], torch.arange(n * 16 * h * w * Cp)).view(n, 4 * h, 4 * w, Cp)
+    z = torch.zeros(n, h, w, 3, 3, Cp, dtype=torch.float64, requires_grad=True)
+    (dz,) = torch.autograd.grad(_upconv_expand_math(z, h, w), z, g)
+    _wr(kw["z"], torch.arange(dz.numel()), dz.reshape(-1))
+
+
+_TABLE = dict(gemm=gemm, upconv4_expand=upconv4_expand, upconv4_gather=upconv4_gather, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
               bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply,
@@ -793,7 +827,7 @@ _POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_ro
 
 
 def call(name, **kw):
-    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd") else torch.no_grad():
+    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd", "upconv4_gather") else torch.no_grad():
         if name in _POS:
             return _POS[name](kw["args"])
         return _TABLE[name](**kw)

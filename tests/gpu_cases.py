@@ -517,5 +517,28 @@ def invpt_cases():
     return cases
 
 
+def upconv_cases():
+    """mtt_upconv4_expand / _gather (upsample x4 + 3x3 conv, taps first): borders (1-pixel maps, single rows / columns), several column
+    blocks per row, more than 8 images (every XCD slot of the block numbering + the ragged last group), bias / scale / activation."""
+    cases = []
+    g = torch.Generator().manual_seed(29)
+    shapes = ((2, 2, 3, 5, 11), (1, 1, 1, 1, 8), (1, 3, 1, 4, 20), (1, 2, 5, 1, 12), (3, 4, 4, 6, 350), (1, 1, 32, 32, 350))
+    for dt in (F32, BF16):
+        for (Z, B, h, w, C) in shapes:
+            Cp = (C + 7) // 8 * 8
+            z = torch.zeros(Z, B * h * w, 9, Cp)
+            z[..., :C] = rnd(g, Z, B * h * w, 9, C)
+            for act, has_sc in ((0, False), (1, True)):
+                kw = dict(z=z.to(DT[dt]), y=torch.full((Z, B * 16 * h * w, Cp), 7.0, dtype=DT[dt]), bias=rnd(g, Z, C),
+                          colscale=rnd(g, Z, C) if has_sc else None, Z=Z, B=B, h=h, w=w, C=C, Cp=Cp, z_dtype=dt, y_dtype=dt, act=act)
+                cases.append((f"upconv4_expand_{dt}_{Z}x{B}x{h}x{w}x{C}_act{act}", "upconv4_expand", kw, TOL_ROW))
+            dy = torch.zeros(Z, B * 16 * h * w, Cp)
+            dy[..., :C] = rnd(g, Z, B * 16 * h * w, C)
+            kw = dict(z=torch.full((Z, B * h * w, 9 * Cp), 7.0, dtype=DT[dt]), y=dy.to(DT[dt]), bias=None, colscale=None,
+                      Z=Z, B=B, h=h, w=w, C=C, Cp=Cp, z_dtype=dt, y_dtype=dt, act=0)
+            cases.append((f"upconv4_gather_{dt}_{Z}x{B}x{h}x{w}x{C}", "upconv4_gather", kw, TOL_ROW))
+    return cases
+
+
 def all_cases():
-    return gemm_cases() + attn_cases() + row_cases() + invpt_cases()
+    return gemm_cases() + attn_cases() + row_cases() + invpt_cases() + upconv_cases()

@@ -138,3 +138,78 @@ def test_bn_train_fwd_bwd():
     dx = torch.zeros(rows, 16)
     E.call("bn_bwd_apply", x=xp, dy=dyp, dx=dx, mean=mean, rstd=rstd, gamma=gam, beta=bet, dsum=ds, dsumxh=dsx, rows=rows, C=C, ld=16, act=1)
     assert torch.allclose(dx[:, :C], x.grad, atol=1e-4)
+
+
+def test_upconv_taps_first_is_upsample_then_conv():
+    """mtt_upconv4_expand / _gather: (a) GEMM with the nine stacked tap matrices + expansion == F.conv2d(F.interpolate(x, 4)) and its
+    autograd adjoint; (b) the kernels' algorithm — separable passes with the constant x4 phase weights, replicated-border slots and
+    hi-res zero-padding masks (csrc/upconv.hip), restated here lane by lane — equals the emulator on degenerate and ragged maps."""
+    torch.manual_seed(0)
+    B, h, w, C = 2, 3, 5, 11
+    x = torch.randn(B, C, h, w, dtype=torch.float64)
+    wt = torch.randn(C, C, 3, 3, dtype=torch.float64) * 0.2
+    z = torch.einsum("bchw,ocyx->bhwyxo", x, wt)                       # tap planes W[ky,kx] x
+    ref = F.conv2d(F.interpolate(x, scale_factor=4, mode="bilinear"), wt, padding=1).permute(0, 2, 3, 1)
+    assert (E._upconv_expand_math(z, h, w) - ref).abs().max() < 1e-12
+
+    SA, SB = [0, 0, 0, 1, 1, 1], [1, 1, 1, 2, 2, 2]
+    WA = [.625, .375, .125, .875, .625, .375]
+    base = [.125, .375, .625, .875, .875, .625, .375, .125]
+
+    def border_weights(i, n):
+        wv = list(base)
+        if i == 0:
+            wv[0] = wv[1] = 0.0; wv[2] += .375; wv[3] += .125
+        if i == n - 1:
+            wv[6] = wv[7] = 0.0; wv[4] += .125; wv[5] += .375
+        return wv
+
+    for (h, w) in ((1, 1), (1, 4), (3, 2), (4, 5), (2, 1)):
+        n, Cp = 2, 8
+        z = torch.randn(n, h, w, 3, 3, Cp, dtype=torch.float64)
+        out = torch.zeros(n, 4 * h, 4 * w, Cp, dtype=torch.float64)
+        for i in range(h):
+            for j in range(w):
+                cs, rs = [max(j - 1, 0), j, min(j + 1, w - 1)], [max(i - 1, 0), i, min(i + 1, h - 1)]
+                mx, my = {0: float(j > 0), 5: float(j < w - 1)}, {0: float(i > 0), 5: float(i < h - 1)}
+                acc = torch.zeros(n, 4, 4, Cp, dtype=torch.float64)
+                for dy in range(3):
+                    for s in range(3):
+                        v = torch.zeros(n, 4, Cp, dtype=torch.float64)
+                        for dx in range(3):
+                            f = [z[:, rs[s], cs[c], dy, dx] for c in range(3)]
+                            for q in range(4):
+                                r1 = q + dx
+                                v[:, q] += mx.get(r1, 1.0) * (WA[r1] * f[SA[r1]] + (1 - WA[r1]) * f[SB[r1]])
+                        for p in range(4):
+                            r1 = p + dy
+                            R = (WA[r1] if SA[r1] == s else ((1 - WA[r1]) if SB[r1] == s else 0.0)) * my.get(r1, 1.0)
+                            acc[:, p] += R * v
+                out[:, 4 * i:4 * i + 4, 4 * j:4 * j + 4] = acc
+        assert (out - E._upconv_expand_math(z, h, w)).abs().max() < 1e-12
+
+        g = torch.randn(n, 4 * h, 4 * w, Cp, dtype=torch.float64)
+        zz = z.clone().requires_grad_(True)
+        (dref,) = torch.autograd.grad(E._upconv_expand_math(zz, h, w), zz, g)
+        dz = torch.zeros_like(z)
+        for i in range(h):
+            wy = border_weights(i, h)
+            for j in range(w):
+                wx = border_weights(j, w)
+                acc = torch.zeros(n, 3, 3, Cp, dtype=torch.float64)
+                for tr in range(10):
+                    rho = 4 * i - 3 + tr
+                    if not 0 <= rho < 4 * h:
+                        continue
+                    s = torch.zeros(n, 3, Cp, dtype=torch.float64)
+                    for u in range(10):
+                        X = 4 * j - 3 + u
+                        if 0 <= X < 4 * w:
+                            for dx in range(3):
+                                if 0 <= u + dx - 2 < 8:
+                                    s[:, dx] += wx[u + dx - 2] * g[:, rho, X]
+                    for dy in range(3):
+                        if 0 <= tr + dy - 2 < 8:
+                            acc[:, dy] += wy[tr + dy - 2] * s
+                dz[:, i, j] = acc
+        assert (dz - dref).abs().max() < 1e-12

@@ -340,3 +340,47 @@ def test_heads_standalone_and_mixed_head_sets(emulated):
     y = hd(feats["depth"].float().requires_grad_(True))
     y.square().mean().backward()
     assert all(q.grad is not None for q in hd.parameters())
+
+
+def test_fused_upsample_conv_matches_the_materialised_path(emulated):
+    """ConvHeads fuse the backbone's x4 bilinear resize into their 3x3 conv ("taps first": GEMM with the nine stacked tap matrices on the
+    h x w map + mtt_upconv4_expand, backward mtt_upconv4_gather).  It must give what resize-then-conv gives — outputs (eval, BN folded
+    into the expansion's scale / bias), train-mode outputs and every parameter gradient — and never build the upsampled stack."""
+    import mtt_amd
+    import train_check
+    tp = mtt_amd.taskprompter
+    cfg = configs.taskprompter("mini_ctr")
+    meta, _ = conftest.load_golden("mini_ctr")
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    x = weights.synth_images(2, cfg["img_size"], 5)
+    names = []
+    real = mtt_amd.ops.call
+    mtt_amd.ops.call = lambda name, **kw: (names.append(name), real(name, **kw))[1]
+    res = {}
+    try:
+        for fuse in (True, False):
+            tp.TaskPrompterWrapper.fuse_upsample = fuse
+            del names[:]
+            model = conftest.build_product_model(cfg, "x3")
+            model.load_state_dict(sd, strict=True)
+            model.eval()
+            with torch.no_grad():
+                ev = model(x)
+            n_up = sum(1 for n in names if n == "upconv4_expand")
+            assert n_up == (1 if fuse else 0)
+            model.train()
+            out = model(x)
+            sum((v * torch.linspace(-1, 1, v.numel()).view(v.shape)).sum() for v in out.values()).backward()
+            assert ("upconv4_gather" in names) == fuse
+            res[fuse] = (ev, {k: v.detach() for k, v in out.items()}, {k: q.grad.clone() for k, q in model.named_parameters() if q.grad is not None})
+    finally:
+        tp.TaskPrompterWrapper.fuse_upsample = True
+        mtt_amd.ops.call = real
+    for part in (0, 1, 2):
+        a, b = res[True][part], res[False][part]
+        assert a.keys() == b.keys()
+        floor = 1e-3 * max(float(v.norm()) for v in b.values())       # a bias in front of a BatchNorm has a zero gradient: rounding noise only
+        for k in a:
+            den = float(b[k].norm())
+            if den > floor:
+                assert float((a[k] - b[k]).norm()) / den < 2e-4, (part, k)
