@@ -245,7 +245,10 @@ int mtt_transpose_pad(const void* src, void* dst, int64_t rows, int64_t cols, in
  * free with the transposing copy the fast weight-gradient GEMM needs anyway. */
 int mtt_transpose_pad_sum(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int src_dtype,
                           int dst_dtype, float* colsum, void* stream);
-int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream);
+/* dst[c] = sum_r src[r, c] for c < cols (bias gradients; ld >= pad8(cols), columns up to pad8(cols) are read).  Deterministic two-stage
+ * reduction through the caller-owned workspace ws (>= mtt_colsum_ws_floats(rows, cols) floats, contents unspecified afterwards). */
+size_t mtt_colsum_ws_floats(int64_t rows, int32_t cols);
+int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, float* ws, void* stream);
 int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype,
                  float alpha, void* stream);
 

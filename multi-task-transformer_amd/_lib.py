@@ -163,7 +163,7 @@ _SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateD
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
-    "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr],
+    "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
     "transpose_pad": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, ptr],
@@ -187,7 +187,7 @@ DESC_EXTRA = {
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
 
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 
@@ -207,6 +207,8 @@ def load():
     lib.mtt_desc_size.argtypes = [C.c_int]
     lib.mtt_bn_reduce_ws_floats.restype = C.c_size_t
     lib.mtt_bn_reduce_ws_floats.argtypes = [i64, i32, i32]
+    lib.mtt_colsum_ws_floats.restype = C.c_size_t
+    lib.mtt_colsum_ws_floats.argtypes = [i64, i32]
     if lib.mtt_abi_version() != ABI_VERSION:
         raise RuntimeError("libmtt_hip.so ABI version mismatch")
     for idx, st in enumerate(_SIZE_INDEX):

@@ -1,8 +1,8 @@
 // HBM-bound row / elementwise kernels of the hot path: LayerNorm, row softmax, BatchNorm (training
 // statistics), patchify, channel-attention logits, task-feature modulation, cross-task mixing,
 // bilinear resize, casts and column sums.  All are coalesced over the channel (last) dimension with
-// 8 channels (16 B of bf16 / 32 B of fp32) per lane; reductions over rows use per-block LDS partials
-// and one fp32 atomic per column per block.
+// 8 channels (16 B of bf16 / 32 B of fp32) per lane; reductions over rows (BatchNorm, column sums) go through per-block
+// partials in a caller-owned workspace that a second kernel merges in block order (deterministic, no atomics).
 #include "mtt_device.h"
 
 namespace {
@@ -543,31 +543,67 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const mtt_resize_desc
 MTT_DEV float act_fwd(float u, int act) { return act == MTT_ACT_GELU ? gelu_f(u) : (act == MTT_ACT_RELU ? fmaxf(u, 0.f) : u); }
 MTT_DEV float act_bwd(float u, int act) { return act == MTT_ACT_GELU ? gelu_grad_f(u) : (act == MTT_ACT_RELU ? (u > 0.f ? 1.f : 0.f) : 1.f); }
 
-// MODE 1 (column sums for bias gradients): per-block LDS partials, one fp32 atomic per column per block (caller zeroes dst).
-__global__ __launch_bounds__(256) void colsum_kernel(const mtt_bn_desc d, int rows_per_block) {
-  extern __shared__ float lsm[];   // [C8*8]
-  const int C8 = (d.C + 7) >> 3, Cp = C8 * 8;
-  for (int c = threadIdx.x; c < Cp; c += 256) lsm[c] = 0.f;
-  __syncthreads();
-  const int lanes = 256 / C8 > 0 ? 256 / C8 : 1;     // row lanes per block
+// Column sums (bias gradients), deterministic: no atomics, fixed summation order.  Stage 1, grid (row blocks, chunks of 2048 columns):
+// every lane sums its rows of one 8-column group with four independent loads in flight, the row lanes of the block are combined
+// through LDS in lane order, one partial row per block goes to ws [nblk][pad8(cols)].  Stage 2 sums the partials in block order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* src, float* ws, int64_t rows, int cols, int64_t ld, int dtype,
+                                                             int rows_per_block) {
+  __shared__ float lsm[2048];
+  const int c0 = blockIdx.y * 2048;
+  const int ncol = cols - c0 < 2048 ? cols - c0 : 2048;
+  const int C8 = (ncol + 7) >> 3, Cp = C8 * 8;
+  const int lanes = 256 / C8;                           // >= 1 row lanes
   const int c8 = threadIdx.x % C8, rl = threadIdx.x / C8;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   if (rl < lanes) {
-    float a0[8];
+    float a[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a0[j] = 0.f;
-    for (int64_t r = r0 + rl; r < r1; r += lanes) {
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    const int64_t col = c0 + c8 * 8;
+    int64_t r = r0 + rl;
+    for (; r + 3 * lanes < r1; r += 4 * lanes) {
+      float v0[8], v1[8], v2[8], v3[8];
+      ld8(src, r * ld + col, dtype, v0);
+      ld8(src, (r + lanes) * ld + col, dtype, v1);
+      ld8(src, (r + 2 * lanes) * ld + col, dtype, v2);
+      ld8(src, (r + 3 * lanes) * ld + col, dtype, v3);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += (v0[j] + v1[j]) + (v2[j] + v3[j]);
+    }
+    for (; r < r1; r += lanes) {
       float v[8];
-      ld8(d.dy, r * d.ld + c8 * 8, d.dtype, v);
+      ld8(src, r * ld + col, dtype, v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a0[j] += v[j];
+      for (int j = 0; j < 8; ++j) a[j] += v[j];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&lsm[c8 * 8 + j], a0[j]);
+    for (int j = 0; j < 8; ++j) lsm[rl * Cp + c8 * 8 + j] = a[j];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < d.C; c += 256) atomicAdd(&d.dsum[c], lsm[c]);
+  const int64_t colsP = ((int64_t)cols + 7) / 8 * 8;
+  for (int c = threadIdx.x; c < Cp; c += 256) {
+    float t = lsm[c];
+    for (int l = 1; l < lanes; ++l) t += lsm[l * Cp + c];
+    ws[(int64_t)blockIdx.x * colsP + c0 + c] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* ws, float* dst, int cols, int nblk) {
+  __shared__ float sh[8][32];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int64_t colsP = ((int64_t)cols + 7) / 8 * 8;
+  float t = 0.f;
+  if (c < cols)
+    for (int b = pl; b < nblk; b += 8) t += ws[(int64_t)b * colsP + c];
+  sh[pl][cl] = t;
+  __syncthreads();
+  if (pl == 0 && c < cols) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) t += sh[l][cl];
+    dst[c] = t;
+  }
 }
 
 // BatchNorm reductions, deterministic (no atomics) and centred.  Grid (row blocks, Z maps).  Each block reduces its rows to one
@@ -1194,16 +1230,25 @@ extern "C" int mtt_bn_stats(const mtt_bn_desc* d, float* ws, void* stream) {
   hipLaunchKernelGGL(bn_final_kernel<0>, dim3((d->C + 31) / 32, Z), dim3(256), 0, S_, *d, rpb, nblk, ws);
   return LAUNCH_OK();
 }
-extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, void* stream) {
-  if (!src || !dst || rows <= 0 || cols <= 0 || (ld % 8)) return MTT_E_BADARG;
-  const int es = src_dtype == MTT_F32 ? 4 : 2;
-  for (int c0 = 0; c0 < cols; c0 += 2040) {             // 255 chunks of 8 columns per launch
-    mtt_bn_desc d = {};
-    d.dy = (const unsigned char*)src + (int64_t)c0 * es; d.dsum = dst + c0; d.rows = rows;
-    d.C = cols - c0 < 2040 ? cols - c0 : 2040; d.ld = ld; d.dtype = src_dtype;
-    int nblk, rpb; int e = colreduce_cfg(&d, nblk, rpb); if (e) return e;
-    hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), ((d.C + 7) / 8) * 8 * sizeof(float), S_, d, rpb);
-  }
+static void colsum_cfg(int64_t rows, int32_t cols, int& nblk, int& rpb, int& nchunk) {
+  nchunk = (cols + 2047) / 2048;
+  int64_t nb = (rows + 63) / 64;
+  const int64_t cap = 1536 / nchunk > 1 ? 1536 / nchunk : 1;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  rpb = (int)((rows + nb - 1) / nb);
+  nblk = (int)((rows + rpb - 1) / rpb);
+}
+extern "C" size_t mtt_colsum_ws_floats(int64_t rows, int32_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  int nblk, rpb, nchunk; colsum_cfg(rows, cols, nblk, rpb, nchunk);
+  return (size_t)nblk * (size_t)((cols + 7) / 8 * 8);
+}
+extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, float* ws, void* stream) {
+  if (!src || !dst || !ws || rows <= 0 || cols <= 0 || (ld % 8) || ld < (cols + 7) / 8 * 8) return MTT_E_BADARG;
+  int nblk, rpb, nchunk; colsum_cfg(rows, cols, nblk, rpb, nchunk);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, nchunk), dim3(256), 0, S_, src, ws, rows, cols, ld, src_dtype, rpb);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, S_, (const float*)ws, dst, cols, nblk);
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, float* ws, void* stream) {

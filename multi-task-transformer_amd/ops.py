@@ -360,6 +360,14 @@ def workspace(nfloats, device):
     return buf
 
 
+def colsum(x2d, cols):
+    """fp32 [cols] column sums of x2d [rows, ld] (bias gradients): deterministic two-stage reduction (mtt_colsum)."""
+    out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    ws = workspace(_lib.load().mtt_colsum_ws_floats(x2d.shape[0], cols), x2d.device)
+    call("colsum", args=[x2d, out, x2d.shape[0], cols, x2d.stride(0), dtype_code(x2d), ws])
+    return out
+
+
 def _bn_ws(rows, C, Z, device):
     return workspace(_lib.load().mtt_bn_reduce_ws_floats(rows, C, Z), device)
 

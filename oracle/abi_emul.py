@@ -449,7 +449,7 @@ def colsum(args):
     src, dst, rows, cols, ld, sdt = args[:6]
     r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
     ci = torch.arange(cols)
-    _wr(dst, ci, _rd(dst, ci) + _rd(src, r * ld + c).sum(0))
+    _wr(dst, ci, _rd(src, r * ld + c).sum(0))
 
 
 def add_rows(args):

@@ -465,7 +465,10 @@ def row_cases():
                   dsum=rnd(g, Zs, C), dsumxh=rnd(g, Zs, C), rows=rows2, C=C, ld=ld, dtype=dt, act=2, Z=Zs, x_zs=rows2 * ld, p_zs=C)
         cases.append((f"bn_bwd_apply_stack_{dt}", "bn_bwd_apply", kw, TOL_ROW))
         cases.append((f"cast2d_{dt}", "cast2d", dict(args=[rnd(g, 30, 20), torch.full((30, 24), 4.0, dtype=DT[dt]), 30, 18, 20, 24, F32, dt, 1]), TOL_ROW))
-        cases.append((f"colsum_{dt}", "colsum", dict(args=[rnd(g, 300, 56, dtype=DT[dt]), torch.zeros(52), 300, 52, 56, dt]), TOL_ROW))
+        cases.append((f"colsum_{dt}", "colsum", dict(args=[rnd(g, 300, 56, dtype=DT[dt]), torch.full((52,), 3.0), 300, 52, 56, dt, scratch(300 * 56)]), TOL_ROW))
+        for (r_, c_, ld_) in ((5000, 4104, 4112), (1031, 350, 352), (70, 1024, 1024)):     # two column chunks + ragged tail / row lanes / few rows
+            cases.append((f"colsum_{dt}_{r_}x{c_}", "colsum",
+                          dict(args=[rnd(g, r_, ld_, dtype=DT[dt]), torch.full((c_,), 3.0), r_, c_, ld_, dt, scratch(1536 * ld_)]), TOL_ROW))
         cases.append((f"add_rows_{dt}", "add_rows", dict(args=[rnd(g, 30, 24, dtype=DT[dt]), rnd(g, 30, 32), 30, 20, 24, 32, dt, 0.5]), TOL_ROW))
     return cases
 
