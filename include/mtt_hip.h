@@ -154,13 +154,16 @@ int mtt_softmax_bwd(const mtt_softmax_desc* d, void* stream);
 /* LayerNorm over the last dim C (eps 1e-6 ViT: taskprompter.py:310; 1e-5 InvPT: invpt.py:256).
  * x fp32 [rows, C] (ldx) -> y (y_dtype) [rows, C] (ldy); mean/rstd [rows] fp32 saved for backward.
  * bwd: dx (fp32) = dx_in + dLN/dx   (dx_in: same layout as dx, e.g. the residual-stream gradient the LayerNorm branch joins;
- *      NULL = accumulate in place, dx += ...), dgamma/dbeta += column sums (fp32 atomics, caller zeroes). */
+ *      NULL = accumulate in place, dx += ...); dgamma / dbeta = the column sums of dy * xhat / dy (overwritten), reduced
+ *      deterministically through the caller-owned workspace ws (>= mtt_layernorm_bwd_ws_floats(rows, C) floats; required with dgamma). */
 typedef struct {
   const float* x; void* y; const float* gamma; const float* beta; float* mean; float* rstd;
   const void* dy; float* dx; float* dgamma; float* dbeta;
   int64_t rows; int32_t C; int64_t ldx, ldy; int32_t y_dtype; float eps;
   const float* dx_in;
+  float* ws;
 } mtt_ln_desc;
+size_t mtt_layernorm_bwd_ws_floats(int64_t rows, int32_t C);
 int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream);
 int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream);
 

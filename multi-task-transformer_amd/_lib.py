@@ -72,7 +72,7 @@ class SoftmaxDesc(C.Structure):
 class LnDesc(C.Structure):
     _fields_ = [("x", ptr), ("y", ptr), ("gamma", ptr), ("beta", ptr), ("mean", ptr), ("rstd", ptr),
                 ("dy", ptr), ("dx", ptr), ("dgamma", ptr), ("dbeta", ptr),
-                ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32), ("dx_in", ptr)]
+                ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32), ("dx_in", ptr), ("ws", ptr)]
 
 
 class ChanLogitDesc(C.Structure):
@@ -187,7 +187,7 @@ DESC_EXTRA = {
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
 
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 
@@ -207,6 +207,8 @@ def load():
     lib.mtt_desc_size.argtypes = [C.c_int]
     lib.mtt_bn_reduce_ws_floats.restype = C.c_size_t
     lib.mtt_bn_reduce_ws_floats.argtypes = [i64, i32, i32]
+    lib.mtt_layernorm_bwd_ws_floats.restype = C.c_size_t
+    lib.mtt_layernorm_bwd_ws_floats.argtypes = [i64, i32]
     lib.mtt_colsum_ws_floats.restype = C.c_size_t
     lib.mtt_colsum_ws_floats.argtypes = [i64, i32]
     if lib.mtt_abi_version() != ABI_VERSION:

@@ -214,9 +214,10 @@ class LayerNormFn(Function):
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
-        dx, dg, db = torch.zeros_like(x), torch.zeros_like(gamma), torch.zeros_like(gamma)
+        dx, dg, db = torch.zeros_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
         ops.call("layernorm_bwd", x=x, dy=dy, gamma=gamma, mean=mean, rstd=rstd, dx=dx, dgamma=dg, dbeta=db,
-                 rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=ctx.eps)
+                 rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=ctx.eps,
+                 ws=ops.ln_bwd_ws(x.shape[0], x.shape[1], x.device))
         return dx, dg, db, None, None, None
 
 
@@ -261,10 +262,11 @@ def _ln_bwd_join(dres, x, dy, gamma, mean, rstd, eps):
     """-> (dres + LayerNorm backward of dy, dgamma, dbeta): the residual-stream gradient joined with the LayerNorm branch's in the
     same pass that computes the latter (one read of dres, one write of the sum).  Out of place: `dres` is the grad_output autograd
     handed to the Function and may be shared with hooks / retain_grad / other consumers, so it is never written."""
-    dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+    dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     out = torch.empty_like(dres)
     ops.call("layernorm_bwd", x=x, dy=dy, gamma=gamma, mean=mean, rstd=rstd, dx=out, dx_in=dres, dgamma=dg, dbeta=db,
-             rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=eps)
+             rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=eps,
+             ws=ops.ln_bwd_ws(x.shape[0], x.shape[1], x.device))
     return out, dg, db
 
 

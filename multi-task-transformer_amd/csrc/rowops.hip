@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const mtt_ln_desc d) {
 
 // backward, fused (C <= 1024): one read of x and dy per row.  A wave owns a row at a time (4 float4 chunks per lane kept in
 // registers between the statistics pass and the dx pass) and keeps per-column partial sums of dgamma / dbeta for all its rows;
-// the 4 waves are combined through LDS and the block issues one atomic per column.
+// the 4 waves are combined through LDS and the block writes one partial row to the workspace (merged by ln_dgb_final_kernel).
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, int rows_per_block) {
   __shared__ float part[4][2][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -142,41 +142,63 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, 
     if (c4 < C4) { *(float4*)&part[wave][0][c4 * 4] = ag[k]; *(float4*)&part[wave][1][c4 * 4] = ab[k]; }
   }
   __syncthreads();
+  float* wsb = d.ws + (int64_t)blockIdx.x * 2 * d.C;
   for (int c = threadIdx.x; c < d.C; c += 256) {
-    atomicAdd(&d.dgamma[c], part[0][0][c] + part[1][0][c] + part[2][0][c] + part[3][0][c]);
-    atomicAdd(&d.dbeta[c], part[0][1][c] + part[1][1][c] + part[2][1][c] + part[3][1][c]);
+    wsb[c] = (part[0][0][c] + part[1][0][c]) + (part[2][0][c] + part[3][0][c]);
+    wsb[d.C + c] = (part[0][1][c] + part[1][1][c]) + (part[2][1][c] + part[3][1][c]);
   }
 }
 
-// backward, part 2 (column-parallel): dgamma += sum_rows dy*xhat, dbeta += sum_rows dy.  Thread = one column group of 4,
-// row slices across blockIdx.y-style chunks; partials combined through LDS then one atomic per column per block.
-__global__ __launch_bounds__(256) void ln_bwd_dgb_kernel(const mtt_ln_desc d, int rows_per_block) {
-  extern __shared__ float lsm[];           // [2][C]
-  for (int c = threadIdx.x; c < 2 * d.C; c += 256) lsm[c] = 0.f;
+// dgamma / dbeta = the per-block partials of ws [nblk][2][C] summed in block order (deterministic; 32 columns x 8 partial lanes).
+__global__ __launch_bounds__(256) void ln_dgb_final_kernel(const float* ws, float* dgamma, float* dbeta, int C, int nblk) {
+  __shared__ float sh[2][8][32];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float t0 = 0.f, t1 = 0.f;
+  if (c < C)
+    for (int b = pl; b < nblk; b += 8) { t0 += ws[(int64_t)b * 2 * C + c]; t1 += ws[(int64_t)b * 2 * C + C + c]; }
+  sh[0][pl][cl] = t0; sh[1][pl][cl] = t1;
   __syncthreads();
+  if (pl == 0 && c < C) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) { t0 += sh[0][l][cl]; t1 += sh[1][l][cl]; }
+    dgamma[c] = t0; dbeta[c] = t1;
+  }
+}
+
+// backward, part 2 (column-parallel, any C): per-block partial sums of dy*xhat and dy.  Thread = one column group of 4 (and, for
+// C < 1024, one of 256 / (C/4) row lanes, combined through LDS in lane order); one partial row per block goes to ws [nblk][2][C].
+__global__ __launch_bounds__(256) void ln_bwd_dgb_kernel(const mtt_ln_desc d, int rows_per_block) {
+  extern __shared__ float lsm[];           // [lanes][2][C]
   const int C4 = d.C >> 2;
-  const int lanes = 256 / C4 > 0 ? 256 / C4 : 1;
+  const int lanes = C4 < 256 ? 256 / C4 : 1;
+  const int rl = C4 < 256 ? threadIdx.x / C4 : 0;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
-  for (int c4 = threadIdx.x % (C4 < 256 ? C4 : 256); c4 < C4; c4 += 256) {
-    const int rl = C4 < 256 ? threadIdx.x / C4 : 0;
-    if (rl >= lanes) break;
-    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = r0 + rl; r < r1; r += lanes) {
-      const float mean = d.mean[r], rstd = d.rstd[r];
-      const float4 xv = *(const float4*)(d.x + r * d.ldx + c4 * 4);
-      float dy[4];
+  if (rl < lanes) {
+    for (int c4 = threadIdx.x % (C4 < 256 ? C4 : 256); c4 < C4; c4 += 256) {
+      float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int64_t r = r0 + rl; r < r1; r += lanes) {
+        const float mean = d.mean[r], rstd = d.rstd[r];
+        const float4 xv = *(const float4*)(d.x + r * d.ldx + c4 * 4);
+        float dy[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dy[j] = ld_elem(d.dy, r * d.ldy + c4 * 4 + j, d.y_dtype);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        for (int j = 0; j < 4; ++j) dy[j] = ld_elem(d.dy, r * d.ldy + c4 * 4 + j, d.y_dtype);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ag[j] += dy[j] * (xs[j] - mean) * rstd; ab[j] += dy[j]; }
+        for (int j = 0; j < 4; ++j) { ag[j] += dy[j] * (xs[j] - mean) * rstd; ab[j] += dy[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lsm[(rl * 2) * d.C + c4 * 4 + j] = ag[j]; lsm[(rl * 2 + 1) * d.C + c4 * 4 + j] = ab[j]; }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { atomicAdd(&lsm[c4 * 4 + j], ag[j]); atomicAdd(&lsm[d.C + c4 * 4 + j], ab[j]); }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < d.C; c += 256) { atomicAdd(&d.dgamma[c], lsm[c]); atomicAdd(&d.dbeta[c], lsm[d.C + c]); }
+  float* wsb = d.ws + (int64_t)blockIdx.x * 2 * d.C;
+  for (int c = threadIdx.x; c < d.C; c += 256) {
+    float t0 = lsm[c], t1 = lsm[d.C + c];
+    for (int l = 1; l < lanes; ++l) { t0 += lsm[(l * 2) * d.C + c]; t1 += lsm[(l * 2 + 1) * d.C + c]; }
+    wsb[c] = t0; wsb[d.C + c] = t1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1118,24 +1140,37 @@ extern "C" int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream) {
   return LAUNCH_OK();
 }
 
+static void ln_bwd_cfg(const mtt_ln_desc* d, bool& fused, int& nblk, int& rpb) {
+  fused = d->dx && d->dgamma && d->dbeta && d->C <= 1024 && (d->ldy % 4) == 0 &&
+          !(((uintptr_t)d->x | (uintptr_t)d->dx | (uintptr_t)d->dy | (uintptr_t)d->dx_in) & 15);
+  int64_t nb = fused ? (d->rows + 63) / 64 : (d->rows + 31) / 32;
+  const int64_t cap = fused ? 2048 : 1024;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  rpb = (int)((d->rows + nb - 1) / nb);
+  nblk = (int)((d->rows + rpb - 1) / rpb);
+}
+extern "C" size_t mtt_layernorm_bwd_ws_floats(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)2048 * 2 * (size_t)C;                   // upper bound over both kernel choices (<= 2048 row blocks)
+}
 extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
   if (!d || !d->x || !d->dy || !d->gamma || !d->mean || !d->rstd || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
   if (d->C > 8192 || (d->C % 4) || (d->ldx % 4)) return MTT_E_UNSUPPORTED;
-  if (d->dx && d->dgamma && d->dbeta && d->C <= 1024 && (d->ldy % 4) == 0 && !(((uintptr_t)d->x | (uintptr_t)d->dx | (uintptr_t)d->dy | (uintptr_t)d->dx_in) & 15)) {
-    int64_t nblk = (d->rows + 63) / 64; if (nblk > 2048) nblk = 2048;
-    const int rpb = (int)((d->rows + nblk - 1) / nblk);
-    nblk = (d->rows + rpb - 1) / rpb;
+  if (d->dgamma && (!d->dbeta || !d->ws)) return MTT_E_BADARG;
+  bool fused; int nblk, rpb;
+  ln_bwd_cfg(d, fused, nblk, rpb);
+  if (fused) {
     hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)nblk), dim3(256), 0, S_, *d, rpb);
-    return LAUNCH_OK();
+  } else {
+    if (d->dx) hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
+    if (d->dgamma) {
+      const int C4 = d->C / 4, lanes = C4 < 256 ? 256 / C4 : 1;
+      hipLaunchKernelGGL(ln_bwd_dgb_kernel, dim3((unsigned)nblk), dim3(256), (size_t)lanes * 2 * d->C * sizeof(float), S_, *d, rpb);
+    }
   }
-  if (d->dx) hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
-  if (d->dgamma) {
-    if (!d->dbeta) return MTT_E_BADARG;
-    int64_t nblk = (d->rows + 31) / 32; if (nblk > 1024) nblk = 1024;
-    const int rpb = (int)((d->rows + nblk - 1) / nblk);
-    nblk = (d->rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(ln_bwd_dgb_kernel, dim3((unsigned)nblk), dim3(256), 2 * d->C * sizeof(float), S_, *d, rpb);
-  }
+  if (d->dgamma)
+    hipLaunchKernelGGL(ln_dgb_final_kernel, dim3((unsigned)((d->C + 31) / 32)), dim3(256), 0, S_, (const float*)d->ws, d->dgamma, d->dbeta, d->C, nblk);
   return LAUNCH_OK();
 }
 

@@ -360,6 +360,10 @@ def workspace(nfloats, device):
     return buf
 
 
+def ln_bwd_ws(rows, C, device):
+    return workspace(_lib.load().mtt_layernorm_bwd_ws_floats(rows, C), device)
+
+
 def colsum(x2d, cols):
     """fp32 [cols] column sums of x2d [rows, ld] (bias gradients): deterministic two-stage reduction (mtt_colsum)."""
     out = torch.empty(cols, dtype=torch.float32, device=x2d.device)

@@ -264,8 +264,8 @@ def layernorm_bwd(**kw):
         _wr(kw["dx"], idx, _rd(kw["dx_in"] if kw.get("dx_in") is not None else kw["dx"], idx) + dx)
     if kw.get("dgamma") is not None:
         ci = torch.arange(Cn)
-        _wr(kw["dgamma"], ci, _rd(kw["dgamma"], ci) + (dy * xh).sum(0))
-        _wr(kw["dbeta"], ci, _rd(kw["dbeta"], ci) + dy.sum(0))
+        _wr(kw["dgamma"], ci, (dy * xh).sum(0))
+        _wr(kw["dbeta"], ci, dy.sum(0))
 
 
 def patchify16(args):

@@ -334,15 +334,25 @@ def row_cases():
         x = rnd(g, rows, C)
         mean = x.mean(-1); rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
         kw = dict(x=x, dy=rnd(g, rows, C, dtype=DT[ydt]), gamma=rnd(g, C), mean=mean, rstd=rstd, dx=rnd(g, rows, C),
-                  dgamma=torch.zeros(C), dbeta=torch.zeros(C), rows=rows, C=C, ldx=C, ldy=C, y_dtype=ydt, eps=1e-6)
+                  dgamma=torch.full((C,), 3.0), dbeta=torch.full((C,), 3.0), rows=rows, C=C, ldx=C, ldy=C, y_dtype=ydt, eps=1e-6,
+                  ws=scratch(2048 * 2 * C))
         cases.append((f"ln_bwd_{ydt}", "layernorm_bwd", kw, TOL_ROW))
+        # parameter gradients only (no dx): the column-parallel kernel with 16 row lanes per block combined in LDS
+        x = rnd(g, 300, 64)
+        mean = x.mean(-1); rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
+        kw = dict(x=x, dy=rnd(g, 300, 64, dtype=DT[ydt]), gamma=rnd(g, 64), mean=mean, rstd=rstd, dx=None,
+                  dgamma=torch.full((64,), 3.0), dbeta=torch.full((64,), 3.0), rows=300, C=64, ldx=64, ldy=64, y_dtype=ydt, eps=1e-6,
+                  ws=scratch(2048 * 2 * 64))
+        cases.append((f"ln_bwd_params_only_{ydt}", "layernorm_bwd", kw, TOL_ROW))
         for rows2, C2 in ((301, 1024), (70, 2048)):          # fused single-pass kernel (C <= 1024, several row blocks) / two-kernel path
             x = rnd(g, rows2, C2)
             mean = x.mean(-1); rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
             kw = dict(x=x, dy=rnd(g, rows2, C2, dtype=DT[ydt]), gamma=rnd(g, C2), mean=mean, rstd=rstd, dx=rnd(g, rows2, C2),
-                      dgamma=torch.zeros(C2), dbeta=torch.zeros(C2), rows=rows2, C=C2, ldx=C2, ldy=C2, y_dtype=ydt, eps=1e-6)
+                      dgamma=torch.full((C2,), 3.0), dbeta=torch.full((C2,), 3.0), rows=rows2, C=C2, ldx=C2, ldy=C2, y_dtype=ydt, eps=1e-6,
+                      ws=scratch(2048 * 2 * C2))
             cases.append((f"ln_bwd_{ydt}_C{C2}", "layernorm_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
-            kw = dict(kw, dx=torch.full((rows2, C2), 3.0), dx_in=rnd(g, rows2, C2), dgamma=torch.zeros(C2), dbeta=torch.zeros(C2))
+            kw = dict(kw, dx=torch.full((rows2, C2), 3.0), dx_in=rnd(g, rows2, C2), dgamma=torch.zeros(C2), dbeta=torch.zeros(C2),
+                      ws=scratch(2048 * 2 * C2))
             cases.append((f"ln_bwd_join_{ydt}_C{C2}", "layernorm_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
     for sdt in (F32, BF16):
         rows, cols, ld = 50, 77, 80
