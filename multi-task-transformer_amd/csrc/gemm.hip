@@ -395,9 +395,9 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
 //   3  D f32  = rowscale * (acc + bias) + resid         (proj / fc2 into the fp32 residual stream; rowscale / resid optional)
 //   4  D bf16 = (acc + bias) * GELU'(aux_in bf16)       (fc2 dgrad)
 // ---------------------------------------------------------------------------------------------
-MTT_DEV int fast_epilogue_kind(const mtt_gemm_desc& d, int m0, int n0, int tbm, int tbn) {
+// feature set -> KIND (-1: general epilogue only); a pure function of the descriptor, shared by the device dispatch and the host policy
+__host__ __device__ inline int epilogue_kind_of(const mtt_gemm_desc& d) {
   if (d.store_mode != MTT_STORE_ROWS || d.alpha != 1.0f) return -1;
-  if (m0 + tbm > d.M || n0 + tbn > d.N) return -1;                                   // interior tiles only
   if (d.d_mb > 0 && d.d_bs != (int64_t)d.d_mb * d.ldd) return -1;                    // D rows contiguous
   const bool auxi = d.aux_in != nullptr, auxo = d.aux_out != nullptr;
   if ((auxi || auxo) && d.aux_dtype != MTT_BF16) return -1;
@@ -410,6 +410,10 @@ MTT_DEV int fast_epilogue_kind(const mtt_gemm_desc& d, int m0, int n0, int tbm, 
   if (d.act == MTT_ACT_GELU && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && !auxi) return 2;
   if (d.act == MTT_ACT_GELU_BWD && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && auxi && !auxo) return 4;
   return -1;
+}
+MTT_DEV int fast_epilogue_kind(const mtt_gemm_desc& d, int m0, int n0, int tbm, int tbn) {
+  if (m0 + tbm > d.M || n0 + tbn > d.N) return -1;                                   // interior tiles only
+  return epilogue_kind_of(d);
 }
 
 template <int KIND, int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
@@ -1051,6 +1055,251 @@ int launch_dma(const GemmP& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_pdma_kernel<KIND, STAG>: PERSISTENT form of gemm_dma_kernel<256, false, 0> for the hot encoder GEMMs (plain bf16 operands,
+// N a multiple of 256, one of the specialised epilogue kinds).  Measured on the non-persistent kernel (profiles/r02_gemm_ablate_*):
+// of a 37.7 us K = 1024 tile only 26 us are K steps; ~5 us are the prologue (workgroup launch, address setup, the first LDS-DMA
+// round trip with nothing to overlap it) and 6 us the epilogue, whose accumulators go through the operand stages (so nothing can
+// be prefetched under it) with 8 workgroup barriers.  Here:
+//   * a workgroup walks tiles f = blockIdx.x, + gridDim.x, ... (grid = one workgroup per CU; the XCD-aware grouped tile order is
+//     applied to the flat tile index, so a workgroup keeps its XCD's share of the order);
+//   * the K loop is CONTINUOUS across output tiles: the R0 phase of a tile's last K step issues the LDS-DMA of the NEXT tile's first
+//     K tile into the free stage, exactly where a longer K loop would have issued tile kt + 1 (same hazards, see gemm_dma_kernel);
+//   * the epilogue runs out of a 4 KiB PER-WAVE scratch behind the two stages (160 KiB of LDS in all): each wave moves its own
+//     128 x 64 accumulator block 16 rows at a time through LDS (ds_write_b32 in the MFMA layout, ds_read_b128 as rows: conflict-free
+//     in both directions with a plain 256-byte row pitch) and stores full 128-byte (bf16) / 256-byte (fp32) row segments.  No
+//     workgroup barrier, and the stages stay untouched, so the prefetched K tile survives;
+//   * residual / GELU' input rows of block a + 1 are loaded before block a is stored (D and resid alias: the compiler may not move
+//     loads over stores itself).
+// STAG = false: the early half waits one slot at the end of a tile (as the non-persistent kernel does) so that both halves run
+// their epilogues at the same time, and the late half re-staggers at the start of the next tile.  STAG = true: the stagger is kept
+// across tiles (the halves' epilogues run one after the other, each beside the other half's phase).  M may be ragged (rows are
+// predicated), K only needs K % 8 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+MTT_DEV void gemm_epilogue_wave(const GemmP& p, f32x4 (&acc)[8][4], float* scr, int mw, int nw, int zo, int zi) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lg = lane >> 4;
+  const mtt_gemm_desc& d = p.d;
+  const int ncol = nw + li * 4;                    // this lane's 4 output columns (read side)
+  float sh[4], cs[4];
+  {
+    const int64_t zcol = (int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi + ncol;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[j] = d.colshift ? d.colshift[zcol + j] : 0.0f; cs[j] = d.colscale ? d.colscale[zcol + j] : 1.0f; }
+  }
+  const int64_t zD = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi + ncol;
+  const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + ncol;
+  const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi + ncol;
+  float* const wr = scr + lg * 256 + li;           // acc[a][b][r] -> row lg*4 + r, column b*16 + li
+  const float* const rd = scr + lg * 64 + li * 4;  // rows lg + 4 i, columns 4 li .. 4 li + 3
+  const int mlast = d.M - 1;
+  const bool has_res = KIND == 3 && d.resid != nullptr;
+
+  float4 rn[4]; u32x2 zn[4];                       // residual / GELU' input rows of the block being prefetched
+  auto prefetch = [&](int a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = mw + a * 16 + lg + 4 * i; if (m > mlast) m = mlast;
+      if (KIND == 3) rn[i] = has_res ? *(const float4*)(d.resid + (zR + (int64_t)m * d.ldr)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KIND == 4) zn[i] = *(const u32x2*)((const bf16_t*)d.aux_in + (zAux + (int64_t)m * d.ldaux));
+    }
+  };
+  if (KIND == 3 || KIND == 4) prefetch(0);
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    float4 rc[4]; u32x2 zc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (KIND == 3) rc[i] = rn[i]; if (KIND == 4) zc[i] = zn[i]; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wr[r * 64 + b * 16] = acc[a][b][r];
+    float4 v4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v4[i] = *(const float4*)(rd + i * 256);
+    if ((KIND == 3 || KIND == 4) && a + 1 < 8) prefetch(a + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mw + a * 16 + lg + 4 * i;
+      float v[4] = {fmaf(v4[i].x, cs[0], sh[0]), fmaf(v4[i].y, cs[1], sh[1]), fmaf(v4[i].z, cs[2], sh[2]), fmaf(v4[i].w, cs[3], sh[3])};
+      if (m <= mlast) {
+        if (KIND == 2) {
+          if (d.aux_out) *(u32x2*)((bf16_t*)d.aux_out + (zAux + (int64_t)m * d.ldaux)) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+        }
+        if (KIND == 4) {
+          v[0] *= gelu_grad_f(lo_of(zc[i].x)); v[1] *= gelu_grad_f(hi_of(zc[i].x));
+          v[2] *= gelu_grad_f(lo_of(zc[i].y)); v[3] *= gelu_grad_f(hi_of(zc[i].y));
+        }
+        if (KIND == 3) {
+          if (d.rowscale) {
+            const uint32_t q = fdiv((uint32_t)m, p.divDmb), rem = (uint32_t)m - q * (uint32_t)d.d_mb;
+            const float rs = d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= rs;
+          }
+          v[0] += rc[i].x; v[1] += rc[i].y; v[2] += rc[i].z; v[3] += rc[i].w;
+        }
+        if (KIND == 1 || KIND == 3) *(float4*)((float*)d.D + (zD + (int64_t)m * d.ldd)) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(u32x2*)((bf16_t*)d.D + (zD + (int64_t)m * d.ldd)) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+      }
+    }
+  }
+}
+
+template <int KIND, bool STAG>
+__global__ __launch_bounds__(512, 1) void gemm_pdma_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MT = 8, NT = 4;
+  constexpr int TILE_A = BM2 * BK * 2, STAGE = 2 * TILE_A;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int late = wave >> 2;                      // waves 4-7 run one phase behind waves 0-3 (they share SIMDs pairwise)
+  const int K = p.d.K, nk = (K + BK - 1) / BK;
+  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + 255) / 256;
+  const int per_z = tiles_m * tiles_n, total = per_z * p.d.batch;
+  float* const scr = (float*)(smem + 2 * STAGE) + wave * 1024;
+
+  uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
+  asm volatile("" : "+s"(zpage));
+
+  // per-lane constants of the staging pattern (row within the tile -> swizzled 16-byte chunk)
+  int ack[4], bck[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    ack[i] = bck[i] = (((lane & 7) ^ lds_swz(row)) * 8);
+  }
+  // state of the tile whose operands are being STREAMED (runs ahead of the tile being accumulated at a tile seam)
+  int m0 = 0, n0 = 0, zo = 0, zi = 0;
+  const bf16_t* Abase = nullptr; const bf16_t* Bbase = nullptr;
+  int64_t aoff[4], boff[4];
+  auto setup = [&](int f) {
+    int z = 0, t = f;
+    if (p.d.batch > 1) { z = f / per_z; t = f - z * per_z; }
+    int tile_m, tile_n;
+    grouped_tile(xcd_remap(t, per_z), tiles_m, tiles_n, p.group_m, tile_m, tile_n);
+    m0 = tile_m * BM2; n0 = tile_n * 256;
+    zo = z / p.d.batch_inner; zi = z - zo * p.d.batch_inner;
+    Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
+    Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + (lane >> 3);
+      int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;        // ragged edge: re-read the last valid row (results unused)
+      aoff[i] = row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + ack[i];
+      int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
+      boff[i] = (int64_t)rb * p.d.ldb + bck[i];
+    }
+  };
+  auto issue = [&](int stage, int kt) {
+    unsigned char* sA = smem + stage * STAGE + wave * 4096;
+    unsigned char* sB = sA + TILE_A;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint64_t src = (uint64_t)(uintptr_t)(Abase + (aoff[i] + k0));
+      glds16((const bf16_t*)(uintptr_t)(k0 + ack[i] < K ? src : zpage), sA + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint64_t src = (uint64_t)(uintptr_t)(Bbase + (boff[i] + k0));
+      glds16((const bf16_t*)(uintptr_t)(k0 + bck[i] < K ? src : zpage), sB + i * 1024);
+    }
+  };
+
+  int f = blockIdx.x;
+  setup(f);
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // K tile 0 of the first tile is in LDS
+  if (late) __builtin_amdgcn_s_barrier();          // stagger: waves 4-7 start one slot later
+  __builtin_amdgcn_sched_barrier(0);
+  int g = 0;                                       // K steps done so far by this workgroup (stage = g & 1)
+
+  while (true) {
+    const int cm0 = m0, cn0 = n0, czo = zo, czi = zi;        // the tile being accumulated
+    const int fn = f + (int)gridDim.x;
+    const bool has_next = fn < total;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      const unsigned char* Ah = smem + (g & 1) * STAGE;
+      const unsigned char* Bh = Ah + TILE_A;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        // ---- R phase ----
+        if (kh == 0) {
+          if (kt + 1 < nk) issue((g + 1) & 1, kt + 1);
+          else if (has_next) { setup(fn); issue((g + 1) & 1, 0); }     // tile seam: the next tile's first K tile
+        }
+        u32x4 fa[MT], fb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * 128 + t * 16 + li, kh * 4 + lg));
+        if (kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next K tile (own pieces) landed
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C phase ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!STAG && !late) __builtin_amdgcn_s_barrier();        // early half waits one slot: both halves store at the same time
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_epilogue_wave<KIND>(p, acc, scr, cm0 + wm * 128, cn0 + wn * 64, czo, czi);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!has_next) break;
+    f = fn;
+    if (!STAG && late) __builtin_amdgcn_s_barrier();         // re-stagger for the next tile
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (STAG && !late) __builtin_amdgcn_s_barrier();           // pairs with the late half's start-up barrier
+}
+
+template <int KIND, bool STAG>
+int launch_pdma_k(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = 2 * (2 * BM2 * BK * 2) + 8 * 4096;    // two 64 KiB stages + 4 KiB of epilogue scratch per wave = 160 KiB
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_pdma_kernel<KIND, STAG>, smem, done)) return e;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return (int)hipGetLastError();
+  const int64_t total = (int64_t)((p.d.M + 255) / 256) * ((p.d.N + 255) / 256) * p.d.batch;
+  dim3 grid((unsigned)(total < cus ? total : cus), 1, 1);
+  hipLaunchKernelGGL((gemm_pdma_kernel<KIND, STAG>), grid, dim3(512), smem, stream, p);
+  return (int)hipGetLastError();
+}
+template <bool STAG>
+int launch_pdma(const GemmP& p, int kind, hipStream_t stream) {
+  switch (kind) {
+    case 0: return launch_pdma_k<0, STAG>(p, stream);
+    case 1: return launch_pdma_k<1, STAG>(p, stream);
+    case 2: return launch_pdma_k<2, STAG>(p, stream);
+    case 3: return launch_pdma_k<3, STAG>(p, stream);
+    case 4: return launch_pdma_k<4, STAG>(p, stream);
+    default: return MTT_E_UNSUPPORTED;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_tn_kernel<CONVB>: D[m, n] = sum_k A[k, m] * B[k, n] with BOTH operands "row = reduction index" (MTT_OP_R: element (r, k) at
 // base + k * ld + r) — the weight-gradient form dW = dy^T x on the token-major activations as they sit in HBM, no transposing copies
 // (round 1 transposed both operands into reduction-contiguous buffers first: 26 ms of a 450 ms step) and, with CONVB, the 3x3 conv
@@ -1292,7 +1541,13 @@ extern "C" size_t mtt_desc_size(int which) {
 //   3 LDS-DMA 256 x 256 phased / staggered (gemm_dma_kernel<256>)      4 the same with a 256 x 128 tile (gemm_dma_kernel<128>)
 //   5 LDS-DMA 256 x 256 lock-step 2-stage (round-1 kernel; forced only, kept for A/B measurements)
 //   6 token-major weight-gradient kernel (gemm_tn_kernel): LDS-DMA + ds_read_b64_tr_b16 fragments
+//   7 persistent LDS-DMA 256 x 256 (gemm_pdma_kernel): plain bf16 operands, N % 256 == 0, one of the specialised epilogue kinds
 // d.variant = MTT_GEMM_AUTO applies the policy; another value forces that kernel where it is applicable.
+static bool pdma_eligible(const mtt_gemm_desc& d) {
+  return (d.N % 256) == 0 && d.n_store <= d.N && epilogue_kind_of(d) >= 0;
+}
+// AUTO policy switch for the persistent kernel (set after the A/B on MI355X: tools/gemm_bench.py, profiles/r02_gemm_bench_m_*)
+constexpr bool PDMA_BY_DEFAULT = false;
 static int gemm_variant_for(const mtt_gemm_desc& d) {
   // 6: token-major weight-gradient kernel (gemm_tn_kernel): both operands MTT_OP_R (B may be the implicit im2col^T), bf16
   const bool tn = d.prec == MTT_PREC_BF16 && d.a_op == MTT_OP_R && (d.b_op == MTT_OP_R || d.b_op == MTT_OP_CONV_R) &&
@@ -1315,7 +1570,9 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   if (d.variant == MTT_GEMM_DMA256_V1 && v1_ok) return 5;
   const int n256 = (d.N + 255) / 256 * 256, n128 = (d.N + 127) / 128 * 128;
   const int bn = 100 * n128 <= 85 * n256 ? 128 : 256;   // the narrower tile only where it saves >= 15 % of the columns (N = 300, 350, 576 ...)
-  if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S1) return bn == 256 ? 3 : 4;
+  if (d.variant == MTT_GEMM_DMA256_PERSIST || d.variant == MTT_GEMM_DMA256_PERSIST_STAG)
+    return (!conv && bn == 256 && pdma_eligible(d)) ? 7 : (bn == 256 ? 3 : 4);
+  if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S1 || d.variant == MTT_GEMM_DMA256_NONPERSIST) return bn == 256 ? 3 : 4;
   if (d.variant == MTT_GEMM_ABLATE_NO_EPILOGUE || d.variant == MTT_GEMM_ABLATE_NO_KLOOP || d.variant == MTT_GEMM_DMA256_SKEW ||
       d.variant == MTT_GEMM_ABLATE_NO_STORES || d.variant == MTT_GEMM_ABLATE_NO_STAGING) return 3;
   // AUTO.  Measured on MI355X (profiles/r02_gemm_bench_b*.log, r02_conv_bench_b.log, B = 63 shapes): the 256 x 256 DMA tile wins for
@@ -1325,7 +1582,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   // covered.  So: DMA kernel for plain GEMMs with N >= 512 columns of 256-wide tiles, the general kernel otherwise.
   const int batch = d.batch < 1 ? 1 : d.batch;
   const int64_t blocks = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * batch;
-  if (!conv && bn == 256 && d.M >= 512 && d.N >= 512 && blocks >= 96) return 3;
+  if (!conv && bn == 256 && d.M >= 512 && d.N >= 512 && blocks >= 96) return (PDMA_BY_DEFAULT && pdma_eligible(d)) ? 7 : 3;
   return 0;
 }
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }
@@ -1380,6 +1637,7 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STAGING) return launch_dma<256, false, 6>(p, s);
     if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S1 ? launch_dma<256, false, 1>(p, s) : launch_dma<256, false, 0>(p, s));
     if (v == 4) return conv_a ? launch_dma<128, true, 0>(p, s) : launch_dma<128, false, 0>(p, s);
+    if (v == 7) return d.variant == MTT_GEMM_DMA256_PERSIST_STAG ? launch_pdma<true>(p, epilogue_kind_of(d), s) : launch_pdma<false>(p, epilogue_kind_of(d), s);
     if (v == 6) return d.b_op == MTT_OP_CONV_R ? launch_tn<true>(p, s) : launch_tn<false>(p, s);
     if (v == 5) return launch_fast256(p, s);
     if (v == 1) return launch_fast(p, s);
