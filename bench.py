@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-ref-batch", action="store_true")
     ap.add_argument("--no-fuse-upsample", action="store_true",
                     help="A/B: materialise the x4-upsampled task features and run ConvHead's 3x3 conv on them (the reference's operation order)")
+    ap.add_argument("--gemm-variant", type=int, default=None,
+                    help="A/B: mtt_gemm_desc.variant for every GEMM left at AUTO (12 = policy + persistent kernel, 14 = policy without it)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
     return ap.parse_args()
@@ -89,11 +91,15 @@ class GemmTimer:
     dominant variant, with its algorithmic FLOPs."""
 
     def __init__(self, lib, variant_of):
-        self.lib, self.orig, self.rec, self.variant_of = lib, lib.call, [], variant_of
+        self.lib, self.orig, self.rec, self.variant_of, self.persistent = lib, lib.call, [], variant_of, 0
 
     def __enter__(self):
         def hooked(name, **kw):
-            if name == "gemm" and self.variant_of(**kw) == 3:          # the dominant kernel: 256-row LDS-DMA MFMA GEMM
+            if name == "gemm" and getattr(self.lib, "GEMM_VARIANT", None) is not None and not kw.get("variant"):
+                kw["variant"] = self.lib.GEMM_VARIANT
+            v = self.variant_of(**kw) if name == "gemm" else -1
+            if v in (3, 7):                                            # the dominant kernel: 256 x 256 LDS-DMA MFMA GEMM (7 = persistent form)
+                self.persistent += int(v == 7)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self.orig(name, **kw)
@@ -215,6 +221,8 @@ def main():
     batch = a.batch or dflt_batch
     if a.no_fuse_upsample:
         mtt_amd.taskprompter.TaskPrompterWrapper.fuse_upsample = False
+    if a.gemm_variant is not None:
+        mtt_amd.ops.GEMM_VARIANT = a.gemm_variant
     torch.manual_seed(0)
     p, model = build(a.config, a.prec, mtt_amd)
     if world > 1:
@@ -286,11 +294,16 @@ def main():
             step()
             flops, ms, n = gt_.result()
         tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, tsrc = _pmc_traffic("gemm_dma_kernel<256")
+        pers = gt_.persistent * 2 > n
+        traffic, tsrc = _pmc_traffic("gemm_pdma_kernel" if pers else "gemm_dma_kernel<256")
         roof = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc, algorithmic_bytes_per_launch=int(gt_.algorithmic_bytes / max(n, 1)),
-                    kernel="gemm_dma_kernel<256, false, 0> (256x256x64 tile, bf16 MFMA 16x16x32, LDS-DMA staging, staggered read / MFMA phases, "
-                           "specialised interior-tile epilogue): every encoder Linear forward and input gradient of the step",
+                    kernel=("gemm_pdma_kernel<KIND> (persistent workgroups, K loop continuous across 256x256x64 tiles, bf16 MFMA 16x16x32, LDS-DMA "
+                            "staging, staggered read / MFMA phases, per-wave epilogue) + gemm_dma_kernel<256> for the ineligible calls"
+                            if pers else
+                            "gemm_dma_kernel<256, false, 0> (256x256x64 tile, bf16 MFMA 16x16x32, LDS-DMA staging, staggered read / MFMA phases, "
+                            "specialised interior-tile epilogue)") + ": every encoder Linear forward and input gradient of the step",
+                    persistent_launches=gt_.persistent,
                     launches=n, kernel_ms_per_step=round(ms, 3), algorithmic_tflop_per_step=round(flops / 1e12, 2))
 
     # the reference's own per-GPU batch (trBatch: 2, yml:8), same step, same process

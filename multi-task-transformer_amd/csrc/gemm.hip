@@ -1570,9 +1570,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   if (d.variant == MTT_GEMM_DMA256_V1 && v1_ok) return 5;
   const int n256 = (d.N + 255) / 256 * 256, n128 = (d.N + 127) / 128 * 128;
   const int bn = 100 * n128 <= 85 * n256 ? 128 : 256;   // the narrower tile only where it saves >= 15 % of the columns (N = 300, 350, 576 ...)
-  if (d.variant == MTT_GEMM_DMA256_PERSIST || d.variant == MTT_GEMM_DMA256_PERSIST_STAG)
-    return (!conv && bn == 256 && pdma_eligible(d)) ? 7 : (bn == 256 ? 3 : 4);
-  if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S1 || d.variant == MTT_GEMM_DMA256_NONPERSIST) return bn == 256 ? 3 : 4;
+  if (d.variant == MTT_GEMM_DMA256 || d.variant == MTT_GEMM_DMA256_S1) return bn == 256 ? 3 : 4;
   if (d.variant == MTT_GEMM_ABLATE_NO_EPILOGUE || d.variant == MTT_GEMM_ABLATE_NO_KLOOP || d.variant == MTT_GEMM_DMA256_SKEW ||
       d.variant == MTT_GEMM_ABLATE_NO_STORES || d.variant == MTT_GEMM_ABLATE_NO_STAGING) return 3;
   // AUTO.  Measured on MI355X (profiles/r02_gemm_bench_b*.log, r02_conv_bench_b.log, B = 63 shapes): the 256 x 256 DMA tile wins for
@@ -1582,7 +1580,10 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   // covered.  So: DMA kernel for plain GEMMs with N >= 512 columns of 256-wide tiles, the general kernel otherwise.
   const int batch = d.batch < 1 ? 1 : d.batch;
   const int64_t blocks = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * batch;
-  if (!conv && bn == 256 && d.M >= 512 && d.N >= 512 && blocks >= 96) return (PDMA_BY_DEFAULT && pdma_eligible(d)) ? 7 : 3;
+  // MTT_GEMM_DMA256_PERSIST(_STAG) = this policy with the persistent kernel wherever it is eligible (so that a whole training step can
+  // be A/B-ed by forcing one variant value on every mtt_gemm call: bench.py --gemm-variant)
+  const bool want_p = (PDMA_BY_DEFAULT && d.variant != MTT_GEMM_DMA256_NONPERSIST) || d.variant == MTT_GEMM_DMA256_PERSIST || d.variant == MTT_GEMM_DMA256_PERSIST_STAG;
+  if (!conv && bn == 256 && d.M >= 512 && d.N >= 512 && blocks >= 96) return (want_p && pdma_eligible(d)) ? 7 : 3;
   return 0;
 }
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }

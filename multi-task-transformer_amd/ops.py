@@ -35,7 +35,12 @@ class Prec:
         return f"Prec({self.name})"
 
 
+GEMM_VARIANT = None            # A/B hook (bench.py --gemm-variant): mtt_gemm_desc.variant for every call that leaves it at AUTO
+
+
 def call(name, **kw):          # single indirection point (tests monkeypatch this with the CPU emulator)
+    if GEMM_VARIANT is not None and name == "gemm" and not kw.get("variant"):
+        kw["variant"] = GEMM_VARIANT
     return _lib.call(name, **kw)
 
 
