@@ -55,8 +55,11 @@ enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DM
        MTT_GEMM_ABLATE_NO_STORES = 9, MTT_GEMM_ABLATE_NO_STAGING = 10 /* measurement-only epilogue ablations */,
        MTT_GEMM_GENERAL_EPILOGUE = 11 /* policy kernel, but always the general (run-time configured) epilogue: A/B of the specialised one */,
        MTT_GEMM_DMA256_PERSIST = 12 /* AUTO policy, with the persistent 256 x 256 LDS-DMA kernel (K loop continuous across tiles, per-wave epilogue) wherever the policy picks the 256 x 256 kernel and the call is eligible */,
-       MTT_GEMM_DMA256_PERSIST_STAG = 13 /* the same, stagger of the two wave halves kept across tiles (A/B measurements) */,
-       MTT_GEMM_DMA256_NONPERSIST = 14 /* AUTO policy without the persistent kernel (A/B) */ };
+       MTT_GEMM_DMA256_PERSIST_V0 = 13 /* the same with block-by-block stores and the plain one-tile-ahead prefetch instead of deferred stores (A/B measurements) */,
+       MTT_GEMM_DMA256_NONPERSIST = 14 /* AUTO policy without the persistent kernel (A/B) */,
+       MTT_GEMM_DMA256_SLOWADDR = 18 /* AUTO policy, but the 256 x 256 kernel with general (K-tail capable, 64-bit) source addressing even where the fast form applies (A/B) */,
+       MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE = 15, MTT_GEMM_PDMA_ABLATE_NO_STORES = 16, MTT_GEMM_PDMA_ABLATE_NO_BIAS = 17
+       /* measurement-only ablations of the persistent kernel (bf16 output + bias calls): WRONG results by construction */ };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1 };
 
 /* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */

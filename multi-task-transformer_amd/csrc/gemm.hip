@@ -906,9 +906,27 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
     boff[i] = (int64_t)rb * p.d.ldb + bck[i];
   }
 
+  // SCHED 7 = SCHED 0 for calls with K % 64 == 0 and operand spans < 2 GiB (host-checked): the source address of a piece is a
+  // wave-uniform base (advanced by the K offset on the scalar unit) + a constant 32-bit per-lane byte offset, and there is no K tail,
+  // so a piece costs one 64-bit add instead of two adds, a compare and two selects (58 -> 32 VALU instructions per K step; measured
+  // on the persistent kernel's identical loop: 1 469 vs 1 395 TFLOP/s at 8192^3 without epilogue, profiles/r02_gemm_ablate_o_*.log)
+  constexpr bool FASTADDR = SCHED == 7 && !CONV;
+  uint32_t aoff32[4], boff32[B_GLDS];
+  if constexpr (FASTADDR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff32[i] = (uint32_t)aoff[i] * 2u;
+#pragma unroll
+    for (int i = 0; i < B_GLDS; ++i) boff32[i] = (uint32_t)boff[i] * 2u;
+  }
   auto issueA = [&](int stage, int kt) {
     unsigned char* sA = smem + stage * STAGE + wave * 4096;
     const int k0 = kt * BK;
+    if constexpr (FASTADDR) {
+      const unsigned char* Ak = (const unsigned char*)Abase + (size_t)kt * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Ak + aoff32[i]), sA + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint64_t src;
@@ -930,6 +948,12 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   auto issueB = [&](int stage, int kt) {
     unsigned char* sB = smem + stage * STAGE + TILE_A + wave * (B_GLDS * 1024);
     const int k0 = kt * BK;
+    if constexpr (FASTADDR) {
+      const unsigned char* Bk = (const unsigned char*)Bbase + (size_t)kt * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < B_GLDS; ++i) glds16((const bf16_t*)(Bk + boff32[i]), sB + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < B_GLDS; ++i) {
       const bool ok = k0 + bck[i] < K;
@@ -1055,76 +1079,102 @@ int launch_dma(const GemmP& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm_pdma_kernel<KIND, STAG>: PERSISTENT form of gemm_dma_kernel<256, false, 0> for the hot encoder GEMMs (plain bf16 operands,
-// N a multiple of 256, one of the specialised epilogue kinds).  Measured on the non-persistent kernel (profiles/r02_gemm_ablate_*):
-// of a 37.7 us K = 1024 tile only 26 us are K steps; ~5 us are the prologue (workgroup launch, address setup, the first LDS-DMA
-// round trip with nothing to overlap it) and 6 us the epilogue, whose accumulators go through the operand stages (so nothing can
-// be prefetched under it) with 8 workgroup barriers.  Here:
+// gemm_pdma_kernel<KIND, V>: PERSISTENT form of gemm_dma_kernel<256, false, 0> for the hot encoder GEMMs (plain bf16 operands,
+// N % 256 == 0, K % 64 == 0, K >= 128, one of the specialised epilogue kinds).  Measured on the one-tile-per-workgroup kernel
+// (profiles/r02_gemm_ablate_n_*.log): of a 35.5 us K = 1024 tile 26 us are K steps; ~2 us are the prologue (workgroup launch,
+// address setup, the first LDS-DMA round trip with nothing to overlap it) and ~7.7 us the epilogue, whose accumulators go through
+// the operand stages (so nothing can be prefetched under it) with 8 workgroup barriers.  Here:
 //   * a workgroup walks tiles f = blockIdx.x, + gridDim.x, ... (grid = one workgroup per CU; the XCD-aware grouped tile order is
 //     applied to the flat tile index, so a workgroup keeps its XCD's share of the order);
-//   * the K loop is CONTINUOUS across output tiles: the R0 phase of a tile's last K step issues the LDS-DMA of the NEXT tile's first
-//     K tile into the free stage, exactly where a longer K loop would have issued tile kt + 1 (same hazards, see gemm_dma_kernel);
+//   * the K loop is CONTINUOUS across output tiles: the R0 phase of a tile's last K step (the "seam" step, a separate instantiation
+//     so that the hot loop carries no tile bookkeeping) streams the NEXT tile's first K tile into the free stage, exactly where a
+//     longer K loop would have issued tile kt + 1 (same hazards, see gemm_dma_kernel), and loads the tile's bias / column scale;
 //   * the epilogue runs out of a 4 KiB PER-WAVE scratch behind the two stages (160 KiB of LDS in all): each wave moves its own
 //     128 x 64 accumulator block 16 rows at a time through LDS (ds_write_b32 in the MFMA layout, ds_read_b128 as rows: conflict-free
 //     in both directions with a plain 256-byte row pitch) and stores full 128-byte (bf16) / 256-byte (fp32) row segments.  No
-//     workgroup barrier, and the stages stay untouched, so the prefetched K tile survives;
-//   * residual / GELU' input rows of block a + 1 are loaded before block a is stored (D and resid alias: the compiler may not move
+//     workgroup barrier, and the stages stay untouched;
+//   * V = 1 (deferred stores): vmcnt counts stores as well as LDS-DMA, so a K step's "my pieces landed" wait would also drain the
+//     epilogue's stores.  Therefore the next tile's SECOND K tile is issued right after the last stage read (before the epilogue),
+//     the epilogue keeps its results in registers (they take the place of the accumulators they came from), waits once for
+//     everything outstanding and only then issues all its stores; the next tile's first K step neither issues nor waits, so the
+//     stores have ~1.7 K steps of MFMA work to drain under.  V = 0 stores block by block and keeps the plain one-tile-ahead prefetch.
+//   * residual / GELU' input rows of block a + 1 are loaded before block a is finished (D and resid alias: the compiler may not move
 //     loads over stores itself).
-// STAG = false: the early half waits one slot at the end of a tile (as the non-persistent kernel does) so that both halves run
-// their epilogues at the same time, and the late half re-staggers at the start of the next tile.  STAG = true: the stagger is kept
-// across tiles (the halves' epilogues run one after the other, each beside the other half's phase).  M may be ragged (rows are
-// predicated), K only needs K % 8 == 0.
+// The early half waits one slot at the end of a tile (as the one-tile kernel does) so that both halves run their epilogues together
+// and every wave is past its last stage read; the late half re-staggers at the start of the next tile.  M may be ragged (rows are
+// predicated).  Source addresses are a wave-uniform base + a 32-bit per-lane byte offset (host-checked span < 2 GiB).
 // ---------------------------------------------------------------------------------------------
-template <int KIND>
-MTT_DEV void gemm_epilogue_wave(const GemmP& p, f32x4 (&acc)[8][4], float* scr, int mw, int nw, int zo, int zi) {
-  const int lane = threadIdx.x & 63;
-  const int li = lane & 15, lg = lane >> 4;
-  const mtt_gemm_desc& d = p.d;
-  const int ncol = nw + li * 4;                    // this lane's 4 output columns (read side)
+// ABL (measurement only, KIND 0): 1 = no epilogue (accumulators kept alive), 2 = everything but the global stores, 3 = no bias loads
+template <int KIND, int V, int ABL>
+struct WaveEpilogue {
+  static constexpr bool F32OUT = KIND == 1 || KIND == 3;
+  const GemmP& p;
   float sh[4], cs[4];
-  {
+  float4 of[V && F32OUT ? 8 : 1][4];               // deferred outputs (V = 1)
+  u32x2 ob[V && !F32OUT ? 8 : 1][4], oz[V && KIND == 2 ? 8 : 1][4];
+
+  MTT_DEV explicit WaveEpilogue(const GemmP& p_) : p(p_) {}
+
+  // bias / column scale of this lane's 4 output columns (issued in the seam step, waited for by that step's own vmcnt(0))
+  MTT_DEV void load_cols(int ncol, int zo, int zi) {
+    const mtt_gemm_desc& d = p.d;
     const int64_t zcol = (int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi + ncol;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { sh[j] = d.colshift ? d.colshift[zcol + j] : 0.0f; cs[j] = d.colscale ? d.colscale[zcol + j] : 1.0f; }
-  }
-  const int64_t zD = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi + ncol;
-  const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + ncol;
-  const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi + ncol;
-  float* const wr = scr + lg * 256 + li;           // acc[a][b][r] -> row lg*4 + r, column b*16 + li
-  const float* const rd = scr + lg * 64 + li * 4;  // rows lg + 4 i, columns 4 li .. 4 li + 3
-  const int mlast = d.M - 1;
-  const bool has_res = KIND == 3 && d.resid != nullptr;
-
-  float4 rn[4]; u32x2 zn[4];                       // residual / GELU' input rows of the block being prefetched
-  auto prefetch = [&](int a) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = mw + a * 16 + lg + 4 * i; if (m > mlast) m = mlast;
-      if (KIND == 3) rn[i] = has_res ? *(const float4*)(d.resid + (zR + (int64_t)m * d.ldr)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KIND == 4) zn[i] = *(const u32x2*)((const bf16_t*)d.aux_in + (zAux + (int64_t)m * d.ldaux));
+    for (int j = 0; j < 4; ++j) {
+      sh[j] = (d.colshift && ABL != 3) ? d.colshift[zcol + j] : 0.0f;
+      cs[j] = (d.colscale && ABL != 3) ? d.colscale[zcol + j] : 1.0f;
     }
-  };
-  if (KIND == 3 || KIND == 4) prefetch(0);
+  }
+
+  // acc -> (LDS transpose) -> rows; stores immediately (V = 0) or into of / ob / oz (V = 1)
+  MTT_DEV void compute(f32x4 (&acc)[8][4], float* scr, int mw, int ncol, int zo, int zi) {
+    if (ABL == 1) {
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    float4 rc[4]; u32x2 zc[4];
+      for (int a = 0; a < 8; ++a)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { if (KIND == 3) rc[i] = rn[i]; if (KIND == 4) zc[i] = zn[i]; }
+        for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(acc[a][b]));
+      return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    const mtt_gemm_desc& d = p.d;
+    const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + ncol;
+    const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi + ncol;
+    float* const wr = scr + lg * 256 + li;           // acc[a][b][r] -> row lg*4 + r, column b*16 + li
+    const float* const rd = scr + lg * 64 + li * 4;  // rows lg + 4 i, columns 4 li .. 4 li + 3
+    const int mlast = d.M - 1;
+    const bool has_res = KIND == 3 && d.resid != nullptr;
+
+    float4 rn[4]; u32x2 zn[4];                       // residual / GELU' input rows of the block being prefetched
+    auto prefetch = [&](int a) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+      for (int i = 0; i < 4; ++i) {
+        int m = mw + a * 16 + lg + 4 * i; if (m > mlast) m = mlast;
+        if (KIND == 3) rn[i] = has_res ? *(const float4*)(d.resid + (zR + (int64_t)m * d.ldr)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND == 4) zn[i] = *(const u32x2*)((const bf16_t*)d.aux_in + (zAux + (int64_t)m * d.ldaux));
+      }
+    };
+    if (KIND == 3 || KIND == 4) prefetch(0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wr[r * 64 + b * 16] = acc[a][b][r];
-    float4 v4[4];
+    for (int a = 0; a < 8; ++a) {
+      float4 rc[4]; u32x2 zc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v4[i] = *(const float4*)(rd + i * 256);
-    if ((KIND == 3 || KIND == 4) && a + 1 < 8) prefetch(a + 1);
+      for (int i = 0; i < 4; ++i) { if (KIND == 3) rc[i] = rn[i]; if (KIND == 4) zc[i] = zn[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mw + a * 16 + lg + 4 * i;
-      float v[4] = {fmaf(v4[i].x, cs[0], sh[0]), fmaf(v4[i].y, cs[1], sh[1]), fmaf(v4[i].z, cs[2], sh[2]), fmaf(v4[i].w, cs[3], sh[3])};
-      if (m <= mlast) {
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[r * 64 + b * 16] = acc[a][b][r];
+      float4 v4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v4[i] = *(const float4*)(rd + i * 256);
+      if ((KIND == 3 || KIND == 4) && a + 1 < 8) prefetch(a + 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mw + a * 16 + lg + 4 * i;
+        float v[4] = {fmaf(v4[i].x, cs[0], sh[0]), fmaf(v4[i].y, cs[1], sh[1]), fmaf(v4[i].z, cs[2], sh[2]), fmaf(v4[i].w, cs[3], sh[3])};
         if (KIND == 2) {
-          if (d.aux_out) *(u32x2*)((bf16_t*)d.aux_out + (zAux + (int64_t)m * d.ldaux)) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+          if (V) oz[V ? a : 0][i] = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+          else if (d.aux_out && m <= mlast) *(u32x2*)((bf16_t*)d.aux_out + (zAux + (int64_t)m * d.ldaux)) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
         }
@@ -1134,21 +1184,53 @@ MTT_DEV void gemm_epilogue_wave(const GemmP& p, f32x4 (&acc)[8][4], float* scr, 
         }
         if (KIND == 3) {
           if (d.rowscale) {
-            const uint32_t q = fdiv((uint32_t)m, p.divDmb), rem = (uint32_t)m - q * (uint32_t)d.d_mb;
+            const uint32_t mm = (uint32_t)(m <= mlast ? m : mlast);
+            const uint32_t q = fdiv(mm, p.divDmb), rem = mm - q * (uint32_t)d.d_mb;
             const float rs = d.rowscale[q * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= rs;
           }
           v[0] += rc[i].x; v[1] += rc[i].y; v[2] += rc[i].z; v[3] += rc[i].w;
         }
-        if (KIND == 1 || KIND == 3) *(float4*)((float*)d.D + (zD + (int64_t)m * d.ldd)) = make_float4(v[0], v[1], v[2], v[3]);
-        else *(u32x2*)((bf16_t*)d.D + (zD + (int64_t)m * d.ldd)) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+        if (V) {
+          if (F32OUT) of[V ? a : 0][i] = make_float4(v[0], v[1], v[2], v[3]);
+          else ob[V ? a : 0][i] = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+        } else if (m <= mlast) {
+          store_row(m, ncol, zo, zi, make_float4(v[0], v[1], v[2], v[3]), (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+        }
       }
     }
   }
-}
 
-template <int KIND, bool STAG>
+  MTT_DEV void store_row(int m, int ncol, int zo, int zi, float4 vf, u32x2 vb) {
+    const mtt_gemm_desc& d = p.d;
+    const int64_t off = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi + ncol + (int64_t)m * d.ldd;
+    if (ABL == 2) asm volatile("" :: "v"(vb), "v"(vf.x));
+    else if (F32OUT) *(float4*)((float*)d.D + off) = vf;
+    else *(u32x2*)((bf16_t*)d.D + off) = vb;
+  }
+
+  // V = 1: all the tile's stores in one burst
+  MTT_DEV void store_all(int mw, int ncol, int zo, int zi) {
+    if (!V || ABL == 1) return;
+    const int lg = (threadIdx.x & 63) >> 4;
+    const mtt_gemm_desc& d = p.d;
+    const int mlast = d.M - 1;
+    const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + ncol;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mw + a * 16 + lg + 4 * i;
+        if (m <= mlast) {
+          if (KIND == 2 && d.aux_out) *(u32x2*)((bf16_t*)d.aux_out + (zAux + (int64_t)m * d.ldaux)) = oz[V && KIND == 2 ? a : 0][i];
+          store_row(m, ncol, zo, zi, of[V && F32OUT ? a : 0][i], ob[V && !F32OUT ? a : 0][i]);
+        }
+      }
+  }
+};
+
+template <int KIND, int V, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_pdma_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MT = 8, NT = 4;
@@ -1157,25 +1239,24 @@ __global__ __launch_bounds__(512, 1) void gemm_pdma_kernel(const GemmP p) {
   const int li = lane & 15, lg = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
   const int late = wave >> 2;                      // waves 4-7 run one phase behind waves 0-3 (they share SIMDs pairwise)
-  const int K = p.d.K, nk = (K + BK - 1) / BK;
-  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + 255) / 256;
+  const int nk = p.d.K / BK;                       // >= 2 (host-checked)
+  const int tiles_n = p.d.N / 256, tiles_m = (p.d.M + 255) / 256;
   const int per_z = tiles_m * tiles_n, total = per_z * p.d.batch;
   float* const scr = (float*)(smem + 2 * STAGE) + wave * 1024;
 
-  uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
-  asm volatile("" : "+s"(zpage));
-
   // per-lane constants of the staging pattern (row within the tile -> swizzled 16-byte chunk)
-  int ack[4], bck[4];
+  int ack[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + (lane >> 3);
-    ack[i] = bck[i] = (((lane & 7) ^ lds_swz(row)) * 8);
+    ack[i] = (((lane & 7) ^ lds_swz(row)) * 8);
   }
-  // state of the tile whose operands are being STREAMED (runs ahead of the tile being accumulated at a tile seam)
+  // state of the tile whose operands are being STREAMED (runs ahead of the tile being accumulated at a tile seam).  Source addresses
+  // are a wave-uniform base (advanced by the K offset) + a 32-bit per-lane byte offset: no per-piece 64-bit offset arithmetic, and
+  // K % 64 == 0 means no K-tail selects either.
   int m0 = 0, n0 = 0, zo = 0, zi = 0;
-  const bf16_t* Abase = nullptr; const bf16_t* Bbase = nullptr;
-  int64_t aoff[4], boff[4];
+  const unsigned char* Abase = nullptr; const unsigned char* Bbase = nullptr;
+  uint32_t aoff[4], boff[4];
   auto setup = [&](int f) {
     int z = 0, t = f;
     if (p.d.batch > 1) { z = f / per_z; t = f - z * per_z; }
@@ -1183,44 +1264,42 @@ __global__ __launch_bounds__(512, 1) void gemm_pdma_kernel(const GemmP p) {
     grouped_tile(xcd_remap(t, per_z), tiles_m, tiles_n, p.group_m, tile_m, tile_n);
     m0 = tile_m * BM2; n0 = tile_n * 256;
     zo = z / p.d.batch_inner; zi = z - zo * p.d.batch_inner;
-    Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
-    Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
+    Abase = (const unsigned char*)((const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi));
+    Bbase = (const unsigned char*)((const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (wave * 4 + i) * 8 + (lane >> 3);
       int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;        // ragged edge: re-read the last valid row (results unused)
-      aoff[i] = row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + ack[i];
-      int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
-      boff[i] = (int64_t)rb * p.d.ldb + bck[i];
+      aoff[i] = (uint32_t)(row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + ack[i]) * 2u;
+      const int rb = n0 + row;
+      boff[i] = (uint32_t)((int64_t)rb * p.d.ldb + ack[i]) * 2u;
     }
   };
   auto issue = [&](int stage, int kt) {
     unsigned char* sA = smem + stage * STAGE + wave * 4096;
     unsigned char* sB = sA + TILE_A;
-    const int k0 = kt * BK;
+    const unsigned char* Ak = Abase + (size_t)kt * (BK * 2);
+    const unsigned char* Bk = Bbase + (size_t)kt * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint64_t src = (uint64_t)(uintptr_t)(Abase + (aoff[i] + k0));
-      glds16((const bf16_t*)(uintptr_t)(k0 + ack[i] < K ? src : zpage), sA + i * 1024);
-    }
+    for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Ak + aoff[i]), sA + i * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint64_t src = (uint64_t)(uintptr_t)(Bbase + (boff[i] + k0));
-      glds16((const bf16_t*)(uintptr_t)(k0 + bck[i] < K ? src : zpage), sB + i * 1024);
-    }
+    for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Bk + boff[i]), sB + i * 1024);
   };
 
+  WaveEpilogue<KIND, V, ABL> epi(p);
   int f = blockIdx.x;
   setup(f);
   issue(0, 0);
+  if (V) issue(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                    // K tile 0 of the first tile is in LDS
+  __builtin_amdgcn_s_barrier();                    // K tile 0 (V: and 1) of the first tile is in LDS
   if (late) __builtin_amdgcn_s_barrier();          // stagger: waves 4-7 start one slot later
   __builtin_amdgcn_sched_barrier(0);
   int g = 0;                                       // K steps done so far by this workgroup (stage = g & 1)
 
   while (true) {
     const int cm0 = m0, cn0 = n0, czo = zo, czi = zi;        // the tile being accumulated
+    const int ncol = cn0 + wn * 64 + li * 4;                 // this lane's 4 output columns in the epilogue
     const int fn = f + (int)gridDim.x;
     const bool has_next = fn < total;
     f32x4 acc[MT][NT];
@@ -1229,22 +1308,29 @@ __global__ __launch_bounds__(512, 1) void gemm_pdma_kernel(const GemmP p) {
 #pragma unroll
       for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < nk; ++kt, ++g) {
+    // one K step.  MODE 0: stream K tile kt + 1 in R0, wait for it at the end of R1.  MODE 1 (V = 1, a tile's first step): K tile 1
+    // is already there or in flight behind a wait that has been done; nothing to issue, nothing to wait for.  MODE 2 (the tile's
+    // last step, the "seam"): R0 streams the NEXT tile's first K tile and loads this tile's bias / column scale.
+    auto kstep = [&](auto mode_tag, int kt) {
+      constexpr int MODE = decltype(mode_tag)::value;
       const unsigned char* Ah = smem + (g & 1) * STAGE;
       const unsigned char* Bh = Ah + TILE_A;
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
         // ---- R phase ----
         if (kh == 0) {
-          if (kt + 1 < nk) issue((g + 1) & 1, kt + 1);
-          else if (has_next) { setup(fn); issue((g + 1) & 1, 0); }     // tile seam: the next tile's first K tile
+          if (MODE == 0) issue((g + 1) & 1, kt + 1);
+          if (MODE == 2) {
+            epi.load_cols(ncol, czo, czi);
+            if (has_next) { setup(fn); issue((g + 1) & 1, 0); }
+          }
         }
         u32x4 fa[MT], fb[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
 #pragma unroll
         for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * 128 + t * 16 + li, kh * 4 + lg));
-        if (kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next K tile (own pieces) landed
+        if (kh == 1 && MODE != 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the streamed K tile (own pieces) landed
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1260,41 +1346,52 @@ __global__ __launch_bounds__(512, 1) void gemm_pdma_kernel(const GemmP p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    if (!STAG && !late) __builtin_amdgcn_s_barrier();        // early half waits one slot: both halves store at the same time
+      ++g;
+    };
+    int kt = 0;
+    if (V) { kstep(std::integral_constant<int, 1>{}, 0); kt = 1; }
+    for (; kt + 1 < nk; ++kt) kstep(std::integral_constant<int, 0>{}, kt);
+    kstep(std::integral_constant<int, 2>{}, nk - 1);
+
+    if (!late) __builtin_amdgcn_s_barrier();                 // early half waits one slot: every wave is past its last stage read
     __builtin_amdgcn_sched_barrier(0);
-    gemm_epilogue_wave<KIND>(p, acc, scr, cm0 + wm * 128, cn0 + wn * 64, czo, czi);
+    if (V && has_next) issue((g + 1) & 1, 1);                // the next tile's SECOND K tile, into the stage the seam step just read
+    epi.compute(acc, scr, cm0 + wm * 128, ncol, czo, czi);
+    if (V) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // that K tile and the epilogue's own loads: nothing but stores from here on
+      __builtin_amdgcn_sched_barrier(0);
+      epi.store_all(cm0 + wm * 128, ncol, czo, czi);
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (!has_next) break;
     f = fn;
-    if (!STAG && late) __builtin_amdgcn_s_barrier();         // re-stagger for the next tile
+    if (late) __builtin_amdgcn_s_barrier();                  // re-stagger for the next tile
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (STAG && !late) __builtin_amdgcn_s_barrier();           // pairs with the late half's start-up barrier
 }
 
-template <int KIND, bool STAG>
+template <int KIND, int V, int ABL = 0>
 int launch_pdma_k(const GemmP& p, hipStream_t stream) {
   constexpr int smem = 2 * (2 * BM2 * BK * 2) + 8 * 4096;    // two 64 KiB stages + 4 KiB of epilogue scratch per wave = 160 KiB
   static std::atomic<unsigned long long> done{0};
-  if (int e = mtt_ensure_dyn_lds((const void*)gemm_pdma_kernel<KIND, STAG>, smem, done)) return e;
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_pdma_kernel<KIND, V, ABL>, smem, done)) return e;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return (int)hipGetLastError();
-  const int64_t total = (int64_t)((p.d.M + 255) / 256) * ((p.d.N + 255) / 256) * p.d.batch;
+  const int64_t total = (int64_t)((p.d.M + 255) / 256) * (p.d.N / 256) * p.d.batch;
   dim3 grid((unsigned)(total < cus ? total : cus), 1, 1);
-  hipLaunchKernelGGL((gemm_pdma_kernel<KIND, STAG>), grid, dim3(512), smem, stream, p);
+  hipLaunchKernelGGL((gemm_pdma_kernel<KIND, V, ABL>), grid, dim3(512), smem, stream, p);
   return (int)hipGetLastError();
 }
-template <bool STAG>
+template <int V>
 int launch_pdma(const GemmP& p, int kind, hipStream_t stream) {
   switch (kind) {
-    case 0: return launch_pdma_k<0, STAG>(p, stream);
-    case 1: return launch_pdma_k<1, STAG>(p, stream);
-    case 2: return launch_pdma_k<2, STAG>(p, stream);
-    case 3: return launch_pdma_k<3, STAG>(p, stream);
-    case 4: return launch_pdma_k<4, STAG>(p, stream);
+    case 0: return launch_pdma_k<0, V>(p, stream);
+    case 1: return launch_pdma_k<1, V>(p, stream);
+    case 2: return launch_pdma_k<2, V>(p, stream);
+    case 3: return launch_pdma_k<3, V>(p, stream);
+    case 4: return launch_pdma_k<4, V>(p, stream);
     default: return MTT_E_UNSUPPORTED;
   }
 }
@@ -1543,8 +1640,19 @@ extern "C" size_t mtt_desc_size(int which) {
 //   6 token-major weight-gradient kernel (gemm_tn_kernel): LDS-DMA + ds_read_b64_tr_b16 fragments
 //   7 persistent LDS-DMA 256 x 256 (gemm_pdma_kernel): plain bf16 operands, N % 256 == 0, one of the specialised epilogue kinds
 // d.variant = MTT_GEMM_AUTO applies the policy; another value forces that kernel where it is applicable.
+// K % 64 == 0 and 32-bit per-lane byte offsets from the batch member's base: the fast source addressing of the 256 x 256 LDS-DMA kernels
+static bool dma_fastaddr_ok(const mtt_gemm_desc& d) {
+  if (d.K % 64) return false;
+  const int64_t a_span = (d.a_mb > 0 ? (int64_t)((d.M - 1) / d.a_mb) * d.a_bs + (int64_t)((d.M - 1) % d.a_mb) * d.lda : (int64_t)(d.M - 1) * d.lda) + d.K;
+  const int64_t b_span = (int64_t)(d.N - 1) * d.ldb + d.K;
+  return a_span < (1ll << 31) && b_span < (1ll << 31);
+}
 static bool pdma_eligible(const mtt_gemm_desc& d) {
-  return (d.N % 256) == 0 && d.n_store <= d.N && epilogue_kind_of(d) >= 0;
+  if ((d.N % 256) || (d.K % 64) || d.K < 128 || d.n_store > d.N || epilogue_kind_of(d) < 0) return false;
+  // 32-bit per-lane byte offsets from the batch member's base
+  const int64_t a_span = (d.a_mb > 0 ? (int64_t)((d.M - 1) / d.a_mb) * d.a_bs + (int64_t)((d.M - 1) % d.a_mb) * d.lda : (int64_t)(d.M - 1) * d.lda) + d.K;
+  const int64_t b_span = (int64_t)(d.N - 1) * d.ldb + d.K;
+  return a_span < (1ll << 31) && b_span < (1ll << 31);
 }
 // AUTO policy switch for the persistent kernel (set after the A/B on MI355X: tools/gemm_bench.py, profiles/r02_gemm_bench_m_*)
 constexpr bool PDMA_BY_DEFAULT = false;
@@ -1582,7 +1690,8 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   const int64_t blocks = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * batch;
   // MTT_GEMM_DMA256_PERSIST(_STAG) = this policy with the persistent kernel wherever it is eligible (so that a whole training step can
   // be A/B-ed by forcing one variant value on every mtt_gemm call: bench.py --gemm-variant)
-  const bool want_p = (PDMA_BY_DEFAULT && d.variant != MTT_GEMM_DMA256_NONPERSIST) || d.variant == MTT_GEMM_DMA256_PERSIST || d.variant == MTT_GEMM_DMA256_PERSIST_STAG;
+  const bool want_p = (PDMA_BY_DEFAULT && d.variant != MTT_GEMM_DMA256_NONPERSIST) || d.variant == MTT_GEMM_DMA256_PERSIST || d.variant == MTT_GEMM_DMA256_PERSIST_V0 ||
+                      (d.variant >= MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE && d.variant <= MTT_GEMM_PDMA_ABLATE_NO_BIAS);
   if (!conv && bn == 256 && d.M >= 512 && d.N >= 512 && blocks >= 96) return (want_p && pdma_eligible(d)) ? 7 : 3;
   return 0;
 }
@@ -1636,9 +1745,13 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_DMA256_SKEW) return launch_dma<256, false, 4>(p, s);
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STORES) return launch_dma<256, false, 5>(p, s);
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STAGING) return launch_dma<256, false, 6>(p, s);
+    if (v == 3 && !conv_a && d.variant != MTT_GEMM_DMA256_S1 && d.variant != MTT_GEMM_DMA256_SLOWADDR && dma_fastaddr_ok(d)) return launch_dma<256, false, 7>(p, s);
     if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S1 ? launch_dma<256, false, 1>(p, s) : launch_dma<256, false, 0>(p, s));
     if (v == 4) return conv_a ? launch_dma<128, true, 0>(p, s) : launch_dma<128, false, 0>(p, s);
-    if (v == 7) return d.variant == MTT_GEMM_DMA256_PERSIST_STAG ? launch_pdma<true>(p, epilogue_kind_of(d), s) : launch_pdma<false>(p, epilogue_kind_of(d), s);
+    if (v == 7 && epilogue_kind_of(d) == 0 && d.variant >= MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE && d.variant <= MTT_GEMM_PDMA_ABLATE_NO_BIAS)
+      return d.variant == MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE ? launch_pdma_k<0, 1, 1>(p, s)
+             : (d.variant == MTT_GEMM_PDMA_ABLATE_NO_STORES ? launch_pdma_k<0, 1, 2>(p, s) : launch_pdma_k<0, 1, 3>(p, s));
+    if (v == 7) return d.variant == MTT_GEMM_DMA256_PERSIST_V0 ? launch_pdma<0>(p, epilogue_kind_of(d), s) : launch_pdma<1>(p, epilogue_kind_of(d), s);
     if (v == 6) return d.b_op == MTT_OP_CONV_R ? launch_tn<true>(p, s) : launch_tn<false>(p, s);
     if (v == 5) return launch_fast256(p, s);
     if (v == 1) return launch_fast(p, s);

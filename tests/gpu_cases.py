@@ -184,13 +184,13 @@ def gemm_cases():
                                                                           resid=rnd(g, M, 520), ldr=520, n_store=N), TOL_BF))
         cases.append((f"gemm_epi_kind4_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528, act=3,
                                                                aux_in=rnd(g, M, 536, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
-    # 1e'. persistent 256 x 256 kernel (variant 12; 13 keeps the half-wave stagger across tiles): more than 256 tiles so that workgroups
-    #      walk several tiles (K loop continuous across the seam, per-wave epilogue), ragged M, K tails, one K tile, every epilogue
-    #      kind, task batches (flat tile index over z)
+    # 1e'. persistent 256 x 256 kernel (variant 12 = deferred stores + two-tile prefetch across the seam; 13 = block-by-block stores):
+    #      more than 256 tiles so that workgroups walk several tiles (K loop continuous across the seam, per-wave epilogue), ragged M,
+    #      2 .. 17 K tiles, every epilogue kind, task batches (flat tile index over z); K = 8 is ineligible (falls back to the one-tile kernel)
     for v in (12, 13):
-        for (M, N, K) in ((8498, 2048, 136), (20000, 1024, 1096), (33 * 256, 2048, 64), (9000, 2048, 8)):
+        for (M, N, K) in ((8498, 2048, 192), (20000, 1024, 1088), (33 * 256, 2048, 128), (9000, 2048, 8)):
             cases.append((f"gemm_pdma_v{v}_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0, variant=v, colshift=rnd(g, N), n_store=N), TOL_BF))
-        M, N, K = 8498, 2048, 200
+        M, N, K = 8498, 2048, 256
         A16 = rnd(g, M, K, dtype=torch.bfloat16)
         B16 = rnd(g, N, K, dtype=torch.bfloat16)
         common = dict(A=A16, B=B16, M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, prec=0, lda=K, ldb=K,
@@ -209,13 +209,13 @@ def gemm_cases():
                                                                            resid=rnd(g, M, N), ldr=N), TOL_BF))
         cases.append((f"gemm_pdma_kind4_v{v}", "gemm", dict(common, D=torch.full((M, N + 8), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=N + 8, act=3,
                                                                 aux_in=rnd(g, M, N + 16, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=N + 16), TOL_BF))
-        Z, M, N, K = 3, 6000, 1024, 328
+        Z, M, N, K = 3, 6000, 1024, 320
         kw = dict(A=rnd(g, Z, M, K, dtype=torch.bfloat16), B=rnd(g, Z, N, K, dtype=torch.bfloat16), D=torch.zeros(Z, M, N, dtype=torch.bfloat16),
                   M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=N, batch=Z, batch_inner=1,
                   a_zo=M * K, b_zo=N * K, d_zo=M * N, alpha=1.0, colshift=rnd(g, Z, N), col_zo=N, n_store=N, variant=v)
         cases.append((f"gemm_pdma_batched_v{v}", "gemm", kw, TOL_BF))
         # a_mb row groups on the A side (prompt rows skipped), as the encoder's patch-only GEMMs address the token buffer
-        Bn, Mb, K, N = 18, 517, 136, 1024
+        Bn, Mb, K, N = 18, 517, 192, 1024
         XA = rnd(g, Bn, Mb + 3, K, dtype=torch.bfloat16)
         kw = dict(A=XA[:, 3:], B=rnd(g, N, K, dtype=torch.bfloat16), D=torch.zeros(Bn * Mb, N, dtype=torch.bfloat16), M=Bn * Mb, N=N, K=K,
                   a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=N, a_mb=Mb, a_bs=(Mb + 3) * K,
