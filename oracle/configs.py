@@ -50,6 +50,26 @@ def taskprompter(name):
     return dict(t, name=name, model="TaskPrompter")
 
 
+def swin(name):
+    """TaskPrompter-Swin configs (taskprompter_swin.py:545-700; cs_swinB_taskprompter.yml:13-15,31-40).  Keys: patch, window, embed
+    (stage-0 dim), depths, heads, img_size, img_ds_ratio, tasks, level_embed_dim, final_embed_dim, chan_embed_dim, chan_nheads,
+    prompt_len, head.  backbone_channels / strides follow common_config.py:36-38 ([2, 4, 8, 8] x embed, strides [8, 16, 32, 32])."""
+    t = {
+        # TaskPrompter/configs/cityscapes3d/cs_swinB_taskprompter.yml without the 3ddet task (FCOS3D head needs mmdet3d: absent)
+        "cs_swinB": dict(patch=4, window=12, embed=128, depths=(2, 2, 18, 2), heads=(4, 8, 16, 32), img_size=(1024, 2048), img_ds_ratio=0.75,
+                         tasks=CS2, level_embed_dim=256, final_embed_dim=450, chan_embed_dim=256, chan_nheads=1, prompt_len=1, head="deconv"),
+        # miniatures: same code paths (shifted windows with masks, 4 stages with patch merging, head dim 32 like Swin-B, DEConv heads)
+        "mini_swin": dict(patch=4, window=4, embed=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8), img_size=(128, 192), img_ds_ratio=1.0,
+                          tasks=CS2, level_embed_dim=24, final_embed_dim=40, chan_embed_dim=16, chan_nheads=4, prompt_len=1, head="deconv"),
+        # window 5 does not divide the 48 x 72 ... 6 x 9 grids (zero padding after norm1, also with the shift), 0.75 input resize,
+        # 3 tasks, ConvHeads
+        "mini_swin_pad": dict(patch=4, window=5, embed=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8), img_size=(256, 384), img_ds_ratio=0.75,
+                              tasks=(("semseg", 19), ("depth", 1), ("normals", 3)), level_embed_dim=16, final_embed_dim=24,
+                              chan_embed_dim=64, chan_nheads=1, prompt_len=1, head="conv"),
+    }[name]
+    return dict(t, name=name, model="TaskPrompterSwin")
+
+
 def invpt(name):
     """InvPT configs.  Keys: backbone, img_size, tasks, embed_dim, pred_const, mtt_down."""
     t = {
@@ -74,6 +94,19 @@ def to_p(cfg, attrdict):
     H, W = cfg["img_size"]
     p.TRAIN = attrdict(SCALE=(H, W))
     p.spatial_dim = [[H // 16, W // 16] for _ in range(4)]
+    if cfg["model"] == "TaskPrompterSwin":
+        e = cfg["embed"]
+        p.backbone_channels = [2 * e, 4 * e, 8 * e, 8 * e]                    # common_config.py:36
+        p.ori_spatial_dim = [[H // st, W // st] for st in (8, 16, 32, 32)]    # common_config.py:37-39
+        p.img_ds_ratio = cfg["img_ds_ratio"]
+        p.fea_ds_ratio = 1
+        p.level_embed_dim = cfg["level_embed_dim"]
+        p.final_embed_dim = cfg["final_embed_dim"]
+        p.chan_embed_dim = cfg["chan_embed_dim"]
+        p.chan_nheads = cfg["chan_nheads"]
+        p.prompt_len = cfg["prompt_len"]
+        p.head = cfg["head"]
+        return p
     if cfg["model"] == "TaskPrompter":
         p.embed_dim = cfg["embed_dim"]
         p.final_embed_dim = cfg["final_embed_dim"]

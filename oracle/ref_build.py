@@ -25,8 +25,19 @@ def build_reference(cfg, seed=0, drop_path_rate=0.0, randomize=True):
     """Reference model for `cfg` (oracle/configs.py), weights under torch.manual_seed(seed)."""
     ED = ref_import.easydict()
     p = configs.to_p(cfg, ED)
-    C, depth, nH, select = configs.VIT[cfg["backbone"]]
     torch.manual_seed(seed)
+    if cfg["model"] == "TaskPrompterSwin":
+        ns = ref_import.load_reference("TPS")
+        backbone = ns.create("swin_base_patch4_window12_384", pretrained=False, p=p, patch_size=cfg["patch"], window_size=cfg["window"],
+                             embed_dim=cfg["embed"], depths=tuple(cfg["depths"]), num_heads=tuple(cfg["heads"]),
+                             drop_path_rate=drop_path_rate, img_size=tuple(cfg["img_size"]))
+        Head = ns.ConvHead if cfg["head"] == "conv" else ns.DEConvHead
+        heads = torch.nn.ModuleDict({t: Head(p.final_embed_dim, n) for t, n in cfg["tasks"]})
+        model = ns.TaskPrompterWrapper(p, backbone, heads)
+        if randomize:
+            randomize_norm_state(model)
+        return model, p
+    C, depth, nH, select = configs.VIT[cfg["backbone"]]
     if cfg["model"] == "TaskPrompter":
         ns = ref_import.load_reference("TP")
         backbone = ns.create("vit_large_patch16_384", pretrained=False, p=p, select_list=list(select), patch_size=16,

@@ -16,7 +16,7 @@ from types import SimpleNamespace
 
 REFERENCE_ROOT = os.environ.get("MTT_REFERENCE_ROOT", "/root/reference")
 _SHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_refshim")
-_SUBPROJECT = {"TP": "TaskPrompter", "IP": "InvPT"}
+_SUBPROJECT = {"TP": "TaskPrompter", "TPS": "TaskPrompter", "IP": "InvPT"}
 
 
 def reference_available():
@@ -58,6 +58,17 @@ def load_reference(which):
             ns.vit_large = tp.taskprompter_vit_large_patch16_384
             ns.vit_base = tp.taskprompter_vit_base_patch16_384
             ns.create = tp._create_task_prompter
+            ns.TaskPrompterWrapper = wr.TaskPrompterWrapper
+        elif which == "TPS":
+            sw = importlib.import_module("models.transformers.taskprompter_swin")
+            tp = importlib.import_module("models.transformers.taskprompter")
+            wr = importlib.import_module("models.taskprompter_wrapper")
+            ns.module = sw
+            ns.TaskPrompterSwin = sw.TaskPrompterSwin
+            ns.create = sw.taskprompter_create_swin_transformer
+            ns.swin_base = sw.taskprompter_swin_base_patch4_window12_384
+            ns.ConvHead = tp.ConvHead
+            ns.DEConvHead = tp.DEConvHead
             ns.TaskPrompterWrapper = wr.TaskPrompterWrapper
         else:
             vit = importlib.import_module("models.transformers.vit")

@@ -21,6 +21,8 @@ def synth_tensor(name, shape, g):
         return torch.randn(shape, generator=g) * 0.1
     if leaf == "running_var":
         return torch.rand(shape, generator=g) * 0.5 + 0.75
+    if leaf == "relative_position_bias_table":                 # taskprompter_swin.py:143-144 (learned; O(1) so that it shapes the softmax)
+        return torch.randn(shape, generator=g) * 0.5
     if leaf == "task_prompts":
         return torch.randn(shape, generator=g) + 1.0           # taskprompter.py:343-344 (mean 1, std 1)
     if leaf in ("pos_embed", "cls_token"):
@@ -42,10 +44,22 @@ def synth_tensor(name, shape, g):
     raise KeyError(f"no synthetic rule for {name} {shape}")
 
 
-def synth_state_dict(contract, seed=0):
-    """contract: ordered list of (name, shape).  Returns {name: tensor} (fp32, int64 for counters)."""
+DERIVED_BUFFERS = ("relative_position_index", "attn_mask")     # functions of the geometry (taskprompter_swin.py:147-157, 281-300)
+
+
+def synth_state_dict(contract, seed=0, keep=None):
+    """contract: ordered list of (name, shape).  Returns {name: tensor} (fp32, int64 for counters).  Buffers that are pure functions
+    of the geometry (DERIVED_BUFFERS) are not synthesised: they are taken from `keep` (a state dict holding the model's own values)
+    when given and left out otherwise (load with strict=False)."""
     g = torch.Generator().manual_seed(seed)
-    return {name: synth_tensor(name, shape, g) for name, shape in contract}
+    out = {}
+    for name, shape in contract:
+        if name.rsplit(".", 1)[-1] in DERIVED_BUFFERS:
+            if keep is not None:
+                out[name] = keep[name].clone()
+            continue
+        out[name] = synth_tensor(name, shape, g)
+    return out
 
 
 def synth_images(batch, img_size, seed=1):

@@ -22,8 +22,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import configs, ref_build, weights  # noqa: E402
 
-CASES = [("TP", "mini_ctr", 1), ("TP", "mini_win", 1), ("TP", "mini_deconv", 2), ("IP", "mini", 1)]
-EVAL_STRIDE = {"mini": 2}      # InvPT also returns inter_preds: store every 2nd pixel to keep the fixture small
+CASES = [("TP", "mini_ctr", 1), ("TP", "mini_win", 1), ("TP", "mini_deconv", 2), ("IP", "mini", 1), ("TPS", "mini_swin", 2), ("TPS", "mini_swin_pad", 1)]
+EVAL_STRIDE = {"mini": 2, "mini_swin": 2, "mini_swin_pad": 3}      # store every n-th pixel to keep the fixtures small
+TRAIN_STRIDE = {"mini_swin": 4, "mini_swin_pad": 6}
 
 
 def loss_of(out, seed=7):
@@ -42,10 +43,10 @@ def main(only=None):
     for kind, name, batch in CASES:
         if only and name not in only:
             continue
-        cfg = configs.taskprompter(name) if kind == "TP" else configs.invpt(name)
+        cfg = configs.taskprompter(name) if kind == "TP" else (configs.swin(name) if kind == "TPS" else configs.invpt(name))
         model, p = ref_build.build_reference(cfg, randomize=False)
         contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
-        sd = weights.synth_state_dict(contract, seed=0)
+        sd = weights.synth_state_dict(contract, seed=0, keep=model.state_dict())     # geometry-derived buffers keep the model's own values
         model.load_state_dict(sd, strict=True)
         x = weights.synth_images(batch, cfg["img_size"], seed=1)
         arrays = {}
@@ -63,12 +64,13 @@ def main(only=None):
         model.train()
         x2 = weights.synth_images(2, cfg["img_size"], seed=2)
         out = model(x2)
+        ts = TRAIN_STRIDE.get(name, 2)
         for k, v in out.items():
             if k == "inter_preds":
                 for kk, vv in v.items():
-                    arrays[f"train/inter/{kk}"] = vv.detach()[:, :, ::2, ::2].numpy()
+                    arrays[f"train/inter/{kk}"] = vv.detach()[:, :, ::ts, ::ts].numpy()
             else:
-                arrays[f"train/{k}"] = v.detach()[:, :, ::2, ::2].numpy()   # subsampled: fixture size
+                arrays[f"train/{k}"] = v.detach()[:, :, ::ts, ::ts].numpy()   # subsampled: fixture size
         loss_of(out).backward()
         gstat = {}
         for k, prm in model.named_parameters():
@@ -79,7 +81,7 @@ def main(only=None):
         for k, v in model.state_dict().items():
             if k.endswith("running_mean") or k.endswith("running_var"):
                 arrays[f"bn/{k}"] = v.numpy()
-        meta = dict(kind=kind, name=name, batch=batch, eval_stride=es, contract=contract, grad_stats=gstat,
+        meta = dict(kind=kind, name=name, batch=batch, eval_stride=es, train_stride=ts, contract=contract, grad_stats=gstat,
                     torch=torch.__version__)
         with open(os.path.join(HERE, f"{name}.json"), "w") as f:
             json.dump(meta, f)

@@ -71,3 +71,41 @@ def test_invpt_oracle_matches_reference_golden():
         assert float((out_tr[t][:, :, ::2, ::2] - g).norm() / g.norm()) < 2e-5, t
     for k, v in upd.items():
         assert float((v - torch.from_numpy(gold[f"bn/{k}"])).abs().max()) < 1e-4, k
+
+
+SWIN_CASES = ["mini_swin", "mini_swin_pad"]
+
+
+@pytest.mark.parametrize("name", SWIN_CASES)
+def test_swin_oracle_matches_reference_golden(name):
+    """oracle/swin_oracle.py against the unmodified taskprompter_swin.py: eval outputs, train-mode outputs (batch-stat BN), BN buffer
+    updates and per-parameter gradient norms through the restatement's autograd (shifted / padded windows, patch merging of features,
+    attention maps and prompts, channel attention with 1 and 4 windows, Conv and DEConv heads)."""
+    from oracle import swin_oracle as swo
+    cfg = configs.swin(name)
+    meta, gold = conftest.load_golden(name)
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    es, ts = meta["eval_stride"], meta["train_stride"]
+    with torch.no_grad():
+        out = swo.forward(sd, cfg, weights.synth_images(meta["batch"], cfg["img_size"], 1))
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        assert float((out[t][:, :, ::es, ::es] - g).norm() / g.norm()) < 2e-5, t
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    upd = {}
+    out = swo.forward(dict(sd, **params), cfg, weights.synth_images(2, cfg["img_size"], 2), training=True, bn_updates=upd)
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"train/{t}"])
+        assert float((out[t].detach()[:, :, ::ts, ::ts] - g).norm() / g.norm()) < 2e-5, t
+    for k, v in upd.items():
+        assert float((v - torch.from_numpy(gold[f"bn/{k}"])).abs().max()) < 1e-4, k
+    loss_of(out).backward()
+    bad = []
+    for k, st in meta["grad_stats"].items():
+        if st is None:
+            assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
+            continue
+        gn = float(params[k].grad.double().norm()) if params[k].grad is not None else 0.0
+        if abs(gn - st[0]) > 2e-3 * max(st[0], 1e-6) + 1e-7:
+            bad.append((k, gn, st[0]))
+    assert not bad, bad[:5]
