@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 3
+#define MTT_ABI_VERSION 4
 
 enum { MTT_F32 = 0, MTT_BF16 = 1 };
 enum { MTT_PREC_BF16 = 0, MTT_PREC_X3 = 1 };
@@ -114,7 +114,7 @@ typedef struct {
 } mtt_gemm_desc;
 
 int mtt_abi_version(void);
-/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom, (15 adam, 16 loss)
+/* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom, (15 adam, 16 loss, 17 upconv, 18 gather, 19 winattn, 20 chanattn, 21 conv3s2)
  * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt, 17 upconv */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
@@ -188,11 +188,12 @@ int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream);
 int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* drawchan, void* dq, int dq_dtype, float* dxn, void* stream);
 
 /* Task-feature modulation, taskprompter.py:436-467: from x fp32 [B, hw, C] (row pitch/batch stride given)
- *   out[2t  ][b,p,c] = x[b,p,c] * (1 + rawlog[b, c/64, t, T+p])
+ *   out[2t  ][b,p,c] = x[b,p,c] * (1 + rawlog[b, c/hg, t, T+p])          (rawlog fp32 [B, C/hg, T, N])
  *   out[2t+1][b,p,c] = x[b,p,c] * (1 + rawchan[b, t, win(p), c])            out dtype act, [2T, B*hw, C] */
 typedef struct {
   const float* x; int64_t x_ld, x_bs; const float* rawlog; const float* rawchan; void* out;
   int32_t B, T, N, C, h, w, nh, nw; int32_t out_dtype;
+  int32_t hg;                    /* channels per attention head (a multiple of 8; 0 = 64, the ViT variants; 32 in the last Swin stage) */
 } mtt_modulate_desc;
 int mtt_modulate(const mtt_modulate_desc* d, void* stream);
 /* backward: dout [2T, B*hw, C] (d->out_dtype) -> dx += (fp32, same addressing as x), drawlog[b,head,t,T+p] = (fp32 [B,nH,T,N],
@@ -359,6 +360,64 @@ typedef struct {
 int mtt_loss_label_stats(const mtt_loss_desc* d, float* stats, void* stream);
 int mtt_loss_fwd(const mtt_loss_desc* d, void* stream);
 int mtt_loss_bwd(const mtt_loss_desc* d, const float* gout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * TaskPrompter-Swin forward (TaskPrompter/models/transformers/taskprompter_swin.py).
+ * --------------------------------------------------------------------------------------------------------------------------- */
+
+/* Patchify for a k = s = P patch-embed conv, P in {2, 4, 8} (timm PatchEmbed, taskprompter_swin.py:605-607):
+ * img fp32 NCHW [B,3,H,W] -> cols [B*(H/P)*(W/P), ldc] (k = (c*P + dy)*P + dx, columns >= 3*P*P zero), dtype out_dtype. */
+int mtt_patchify(const float* img, void* cols, int B, int H, int W, int P, int64_t ldc, int out_dtype, void* stream);
+
+/* Bilinear resize (align_corners = False, as F.interpolate) of `planes` fp32 maps [Hin, Win] -> [Hout, Wout]: the img_ds_ratio
+ * input resize (taskprompter_swin.py:666-667) on the NCHW image. */
+int mtt_resize_nchw(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, void* stream);
+
+/* Row gather with zero fill: for b < B, r < rows, c < C:
+ *   dst[b*dst_bs + r*ld_dst + c] = idx[b*idx_bs + r] >= 0 ? src[b*src_bs + idx[...]*ld_src + c] : 0      (dtype conversion on the way)
+ * One kernel for the window partition of the (cyclically shifted, zero padded) token map with the prompts joined to every window
+ * (taskprompter_swin.py:340-354,175-177), its inverse (:366-384), and the 2x2 patch-merging gather (:450-456: 4 calls, one per column
+ * block of dst).  C % 8 == 0; pitches / strides in elements. */
+typedef struct {
+  const void* src; void* dst; const int32_t* idx;
+  int64_t rows; int32_t C; int64_t ld_src, ld_dst; int32_t src_dtype, dst_dtype;
+  int32_t B; int64_t src_bs, dst_bs, idx_bs;
+} mtt_gather_desc;
+int mtt_gather_rows(const mtt_gather_desc* d, void* stream);
+
+/* Window attention with the task prompts as the first T tokens of every window (taskprompter_swin.py:168-210), head_dim 32:
+ *   qkv (dtype) [nwin, N = T + ws2, 3*nH*32] -> out (dtype) [nwin, N, nH*32],
+ *   S = scale * q k^T;  S[i >= T, j >= T] += bias[h, i-T, j-T] (+ mask[w % nW, i-T, j-T] when mask != NULL);  P = softmax(S);  out = P v
+ *   rawmap fp32: the UNSCALED q.k of the prompt rows against the window's pixels, written straight into image layout
+ *                rawmap[(b*nH + h)*T + t][map_off + pix[w % nW][j]]  (row pitch map_ld; pix < 0 = padding pixel, dropped; b = w / nW)
+ *                — the re-assembly, reverse shift and un-padding of :376-388 folded into the store.
+ * bias fp32 [nH, ws2, ws2] (the relative-position table gathered by the host once per parameter version), mask fp32 [nW, ws2, ws2]
+ * (0 / -100), pix int32 [nW, ws2].  N <= 160. */
+typedef struct {
+  const void* qkv; void* out; float* rawmap; const float* bias; const float* mask; const int32_t* pix;
+  int32_t nwin, nW, nH, T, ws2, dtype; float scale; int64_t map_ld, map_off;
+} mtt_winattn_desc;
+int mtt_winattn_fwd(const mtt_winattn_desc* d, void* stream);
+
+/* Channel attention of the prompts over the feature channels (taskprompter_swin.py:391-409), windows over the sqrt(ce) x sqrt(ce) grid
+ * of the channel-embedding dimension:
+ *   q fp32 [B, T, ce];  kvT (dtype) [B, 2*ce, ldk]: rows 0..ce-1 = k^T, ce..2ce-1 = v^T, columns = feature channels c < C
+ *   rawchan[b, t, win, c] = sum_{e in win} q[b,t,e] * kT[b,e,c]        (fp32 [B, T, nwin, C], unscaled)
+ *   cx[b, t, e in win]    = sum_c softmax_c(scale * rawchan[b,t,win,:]) * vT[b,e,c]      (fp32 [B, T, ce]) */
+typedef struct {
+  const float* q; const void* kvT; float* rawchan; float* cx;
+  int32_t B, T, C, ce, nh, nw, kv_dtype; int64_t ldk; float scale;
+  const float* kvbias;           /* fp32 [2*ce] added to the rows of kvT (the bias of the Linear that produced them), or NULL */
+} mtt_chanattn_desc;
+int mtt_chanattn_fwd(const mtt_chanattn_desc* d, void* stream);
+
+/* Small-channel 3x3 stride-2 pad-1 convolution on fp32 maps (PatchMerging.spa_attn_ds, taskprompter_swin.py:437,463):
+ *   x[b][ci][y*W + x] at x + b*x_bs + ci*x_cs + x_off;  w fp32 [Co, Ci, 3, 3];  y[b][co][...] at y + b*y_bs + co*y_cs + y_off  (H, W even) */
+typedef struct {
+  const float* x; const float* w; const float* bias; float* y;
+  int32_t B, Ci, Co, H, W; int64_t x_bs, x_cs, x_off, y_bs, y_cs, y_off;
+} mtt_conv3s2_desc;
+int mtt_conv3s2_nchw(const mtt_conv3s2_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

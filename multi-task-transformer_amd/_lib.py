@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, BF16 = 0, 1
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -84,7 +84,7 @@ class ChanLogitDesc(C.Structure):
 class ModulateDesc(C.Structure):
     _fields_ = [("x", ptr), ("x_ld", i64), ("x_bs", i64), ("rawlog", ptr), ("rawchan", ptr), ("out", ptr),
                 ("B", i32), ("T", i32), ("N", i32), ("C", i32), ("h", i32), ("w", i32), ("nh", i32), ("nw", i32),
-                ("out_dtype", i32)]
+                ("out_dtype", i32), ("hg", i32)]
 
 
 class CtrDesc(C.Structure):
@@ -147,6 +147,28 @@ class LossDesc(C.Structure):
                 ("C", i32), ("Cl", i32), ("kind", i32), ("ignore", f32), ("pos_weight", f32)]
 
 
+class GatherDesc(C.Structure):
+    _fields_ = [("src", ptr), ("dst", ptr), ("idx", ptr), ("rows", i64), ("C", i32), ("ld_src", i64), ("ld_dst", i64),
+                ("src_dtype", i32), ("dst_dtype", i32), ("B", i32), ("src_bs", i64), ("dst_bs", i64), ("idx_bs", i64)]
+
+
+class WinAttnDesc(C.Structure):
+    _fields_ = [("qkv", ptr), ("out", ptr), ("rawmap", ptr), ("bias", ptr), ("mask", ptr), ("pix", ptr),
+                ("nwin", i32), ("nW", i32), ("nH", i32), ("T", i32), ("ws2", i32), ("dtype", i32), ("scale", f32),
+                ("map_ld", i64), ("map_off", i64)]
+
+
+class ChanAttnDesc(C.Structure):
+    _fields_ = [("q", ptr), ("kvT", ptr), ("rawchan", ptr), ("cx", ptr),
+                ("B", i32), ("T", i32), ("C", i32), ("ce", i32), ("nh", i32), ("nw", i32), ("kv_dtype", i32), ("ldk", i64), ("scale", f32), ("kvbias", ptr)]
+
+
+class Conv3s2Desc(C.Structure):
+    _fields_ = [("x", ptr), ("w", ptr), ("bias", ptr), ("y", ptr),
+                ("B", i32), ("Ci", i32), ("Co", i32), ("H", i32), ("W", i32),
+                ("x_bs", i64), ("x_cs", i64), ("x_off", i64), ("y_bs", i64), ("y_cs", i64), ("y_off", i64)]
+
+
 # entry point -> (descriptor struct, size index in mtt_desc_size) ; None = positional-argument entry
 DESCS = {
     "loss_fwd": LossDesc,
@@ -157,11 +179,15 @@ DESCS = {
     "dwconv3x3s2": DwconvDesc, "avgpool_ceil": PoolDesc, "layernorm_mt": LnMtDesc, "attn_msg": AttnMsgDesc,
     "convt3x3s2_gather": ConvtDesc,
     "upconv4_expand": UpconvDesc, "upconv4_gather": UpconvDesc,
+    "gather_rows": GatherDesc, "winattn_fwd": WinAttnDesc, "chanattn_fwd": ChanAttnDesc, "conv3s2_nchw": Conv3s2Desc,
 }
 _SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom,
-               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc, LossDesc, UpconvDesc]
+               DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc, LossDesc, UpconvDesc,
+               GatherDesc, WinAttnDesc, ChanAttnDesc, Conv3s2Desc]
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
+    "patchify": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int, ptr],
+    "resize_nchw": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],

@@ -1628,6 +1628,10 @@ extern "C" size_t mtt_desc_size(int which) {
     case 15: return sizeof(mtt_adam_desc);
     case 16: return sizeof(mtt_loss_desc);
     case 17: return sizeof(mtt_upconv_desc);
+    case 18: return sizeof(mtt_gather_desc);
+    case 19: return sizeof(mtt_winattn_desc);
+    case 20: return sizeof(mtt_chanattn_desc);
+    case 21: return sizeof(mtt_conv3s2_desc);
     default: return 0;
   }
 }

@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void modulate_kernel(const mtt_modulate_desc d) {
   const int hw = d.h * d.w, C8 = d.C >> 3, nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw;
-  const int nH = d.C >> 6;
+  const int hg = d.hg > 0 ? d.hg : 64;
+  const int nH = d.C / hg;
   const int64_t total = (int64_t)d.B * hw * C8;
   const int64_t plane = (int64_t)d.B * hw * d.C;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const mtt_modulate_desc d
     const int win = (y / wh) * d.nw + (x / ww);
     float xv[8], ov[8];
     ld8(d.x, (int64_t)b * d.x_bs + (int64_t)p * d.x_ld + c8 * 8, MTT_F32, xv);
-    const int head = (c8 * 8) >> 6;
+    const int head = (c8 * 8) / hg;
     for (int tk = 0; tk < d.T; ++tk) {
       const float a = d.rawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + p];
 #pragma unroll
@@ -1205,7 +1206,7 @@ extern "C" int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream) {
 }
 
 extern "C" int mtt_modulate(const mtt_modulate_desc* d, void* stream) {
-  if (!d || !d->x || !d->rawlog || !d->rawchan || !d->out || (d->C % 64)) return MTT_E_BADARG;
+  if (!d || !d->x || !d->rawlog || !d->rawchan || !d->out || d->hg < 0 || (d->hg % 8) || (d->C % (d->hg > 0 ? d->hg : 64))) return MTT_E_BADARG;
   hipLaunchKernelGGL(modulate_kernel, dim3(grid_for((int64_t)d->B * d->h * d->w * (d->C / 8))), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }
@@ -1323,6 +1324,7 @@ extern "C" int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t c
 
 extern "C" int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, void* stream) {
   if (!d || !d->x || !d->rawlog || !d->rawchan || !dout || !dx || !drawlog || !drawchan || (d->C % 64)) return MTT_E_BADARG;
+  if (d->hg != 0 && d->hg != 64) return MTT_E_UNSUPPORTED;      /* the head reduction of drawlog is written for 64-channel heads */
   if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw)) return MTT_E_BADARG;
   const int P = (d->h / d->nh) * (d->w / d->nw);
   int splits = P / 64; if (splits < 1) splits = 1; if (splits > 32) splits = 32;

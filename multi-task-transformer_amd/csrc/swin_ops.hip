@@ -1,0 +1,425 @@
+// TaskPrompter-Swin forward kernels (TaskPrompter/models/transformers/taskprompter_swin.py): general patchify, row gather (window
+// partition / reverse / patch merging), window attention with the task prompts joined to every window (bf16: MFMA, swapped product
+// so that softmax statistics are per-lane; fp32: exact VALU kernel for the parity mode), channel attention of the prompts over the
+// feature channels, and the small-channel 3x3 stride-2 convolution of the attention maps.
+#include "mtt_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Patchify, k = s = P: one thread per (patch, c, dy) moves P consecutive pixels.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void patchify_p_kernel(const float* img, void* cols, int B, int H, int W, int64_t ldc, int out_dtype) {
+  const int gh = H / P, gw = W / P;
+  const int KP = 3 * P * P;
+  const int per_patch = 3 * P + 1;                 // 3*P row pieces + one thread that zeroes the padding columns
+  const int64_t total = (int64_t)B * gh * gw * per_patch;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int piece = (int)(t % per_patch);
+    const int64_t patch = t / per_patch;
+    if (piece == 3 * P) {
+      for (int k = KP; k < ldc; ++k) st_elem(cols, patch * ldc + k, out_dtype, 0.0f);
+      continue;
+    }
+    const int c = piece / P, dy = piece % P;
+    const int px = (int)(patch % gw), py = (int)((patch / gw) % gh), b = (int)(patch / ((int64_t)gw * gh));
+    const float* src = img + (((int64_t)b * 3 + c) * H + py * P + dy) * W + px * P;
+#pragma unroll
+    for (int dx = 0; dx < P; ++dx) st_elem(cols, patch * ldc + (c * P + dy) * P + dx, out_dtype, src[dx]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row gather with zero fill: one thread per 8 columns of a destination row.
+// ------------------------------------------------------------------------------------------------
+MTT_DEV void ld8g(const void* p, int64_t idx, int dtype, float (&v)[8]) {
+  if (dtype == MTT_BF16) {
+    const u32x4 u = *(const u32x4*)((const bf16_t*)p + idx);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = lo_of(u[q]); v[2 * q + 1] = hi_of(u[q]); }
+  } else {
+    const float4 a = *(const float4*)((const float*)p + idx);
+    const float4 b = *(const float4*)((const float*)p + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+MTT_DEV void st8g(void* p, int64_t idx, int dtype, const float (&v)[8]) {
+  if (dtype == MTT_BF16) {
+    *(u32x4*)((bf16_t*)p + idx) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+  } else {
+    *(float4*)((float*)p + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)p + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const mtt_gather_desc d) {
+  const int chunks = d.C / 8;
+  const int64_t total = (int64_t)d.B * d.rows * chunks;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(t % chunks);
+    const int64_t r = (t / chunks) % d.rows;
+    const int64_t b = t / ((int64_t)chunks * d.rows);
+    const int src_row = d.idx[b * d.idx_bs + r];
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (src_row >= 0) ld8g(d.src, b * d.src_bs + (int64_t)src_row * d.ld_src + ch * 8, d.src_dtype, v);
+    st8g(d.dst, b * d.dst_bs + r * d.ld_dst + ch * 8, d.dst_dtype, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window attention, bf16 storage: one workgroup (4 waves) per (window, head), head_dim 32 = ONE 16x16x32 MFMA per 16 x 16 score tile.
+//   S^T tile j = K_j Q_i^T  ->  s[j][r] = S[query 16 i + li][key 16 j + 4 lg + r]: a lane owns one query, so the softmax statistics
+//   are per-lane scalars (+ 2 xor-shuffles over the 4 lane groups);
+//   the C layout of two P^T tiles is a valid B fragment of O^T += V^T P^T once the A side (V^T, transposed through LDS once per
+//   workgroup) reads its keys in the same permuted order (two 8-byte reads): P never touches LDS.
+// Q / K fragments are 16-byte global loads (rows are 64 contiguous bytes; K is re-read from L2 by the 10 query tiles).
+// NKT = number of 16-key tiles (even): N <= 16 NKT.
+// ------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_desc d) {
+  constexpr int NP = NKT * 16, PITCH = NP + 8;     // V^T rows: NP keys (+ 8 bf16 of padding: 2-way instead of 8-way bank conflicts)
+  __shared__ __attribute__((aligned(16))) bf16_t vT[32 * PITCH];
+  const int nH = d.nH, T = d.T, ws2 = d.ws2, N = T + ws2, C = nH * 32, ld = 3 * C;
+  const int win = blockIdx.x / nH, h = blockIdx.x % nH;
+  const int wl = win % d.nW, b = win / d.nW;
+  const bf16_t* base = (const bf16_t*)d.qkv + (int64_t)win * N * ld + h * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // ---- V^T into LDS (zeros for keys >= N: P is 0 there, but 0 * garbage must stay finite) ----
+  for (int key = tid; key < NP; key += 256) {
+    u32x4 v4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v4[q] = key < N ? *(const u32x4*)(base + 2 * C + (int64_t)key * ld + q * 8) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vT[(q * 8 + 2 * e) * PITCH + key] = (bf16_t)(v4[q][e] & 0xffffu);
+        vT[(q * 8 + 2 * e + 1) * PITCH + key] = (bf16_t)(v4[q][e] >> 16);
+      }
+  }
+  __syncthreads();
+
+  const float* bias_h = d.bias + (int64_t)h * ws2 * ws2;
+  const float* mask_w = d.mask ? d.mask + (int64_t)wl * ws2 * ws2 : nullptr;
+  const int nqt = (N + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int query = qt * 16 + li;
+    const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
+    const u32x4 qf = query < N ? *(const u32x4*)(base + (int64_t)query * ld + lg * 8) : zero4;
+    f32x4 s[NKT];
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int krow = j * 16 + li;
+      const u32x4 kf = krow < N ? *(const u32x4*)(base + C + (int64_t)krow * ld + lg * 8) : zero4;
+      s[j] = mfma16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
+    // raw prompt logits -> image layout
+    if (qt == 0 && li < T && d.rawmap) {
+      float* row = d.rawmap + (((int64_t)b * nH + h) * T + li) * d.map_ld + d.map_off;
+      const int32_t* px = d.pix + (int64_t)wl * ws2;
+#pragma unroll
+      for (int j = 0; j < NKT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = j * 16 + lg * 4 + r;
+          if (key >= T && key < N) {
+            const int pp = px[key - T];
+            if (pp >= 0) row[pp] = s[j][r];
+          }
+        }
+    }
+    // scale, bias, mask, softmax over the keys of this lane's query
+    const bool qwin = query >= T && query < N;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j * 16 + lg * 4 + r;
+        float v = s[j][r] * d.scale;
+        if (qwin && key >= T && key < N) {
+          const int64_t o = (int64_t)(query - T) * ws2 + (key - T);
+          v += bias_h[o];
+          if (mask_w) v += mask_w[o];
+        }
+        if (key >= N) v = -INFINITY;
+        s[j][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(s[j][r] - mx);
+        s[j][r] = pv;
+        l += pv;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    // O^T += V^T P^T over 32-key chunks
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < NKT / 2; ++c) {
+      const u32x4 pb = (u32x4){pack2(s[2 * c][0], s[2 * c][1]), pack2(s[2 * c][2], s[2 * c][3]),
+                               pack2(s[2 * c + 1][0], s[2 * c + 1][1]), pack2(s[2 * c + 1][2], s[2 * c + 1][3])};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16_t* vr = vT + (dt * 16 + li) * PITCH + 32 * c + 4 * lg;
+        const u32x2 lo = *(const u32x2*)vr;
+        const u32x2 hi = *(const u32x2*)(vr + 16);
+        o[dt] = mfma16((u32x4){lo[0], lo[1], hi[0], hi[1]}, pb, o[dt]);
+      }
+    }
+    if (query < N) {
+      const float inv = 1.0f / l;
+      bf16_t* op = (bf16_t*)d.out + ((int64_t)win * N + query) * C + h * 32 + lg * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        *(u32x2*)(op + dt * 16) = (u32x2){pack2(o[dt][0] * inv, o[dt][1] * inv), pack2(o[dt][2] * inv, o[dt][3] * inv)};
+    }
+  }
+}
+
+// fp32 storage (the x3 parity mode): exact VALU arithmetic, one thread per query, K / V staged in LDS; two passes over the keys
+// (max, then exp / sum / PV) so that no N-long score row is kept.
+__global__ __launch_bounds__(256) void winattn_f32_kernel(const mtt_winattn_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* ks = (float*)smem_raw;                    // [N][33]
+  const int nH = d.nH, T = d.T, ws2 = d.ws2, N = T + ws2, C = nH * 32, ld = 3 * C;
+  float* vs = ks + N * 33;                         // [N][33]
+  const int win = blockIdx.x / nH, h = blockIdx.x % nH;
+  const int wl = win % d.nW, b = win / d.nW;
+  const float* base = (const float*)d.qkv + (int64_t)win * N * ld + h * 32;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < N * 32; e += 256) {
+    const int key = e >> 5, dd = e & 31;
+    ks[key * 33 + dd] = base[C + (int64_t)key * ld + dd];
+    vs[key * 33 + dd] = base[2 * C + (int64_t)key * ld + dd];
+  }
+  __syncthreads();
+  const int query = tid;
+  if (query >= N) return;
+  float q[32];
+#pragma unroll
+  for (int dd = 0; dd < 32; ++dd) q[dd] = base[(int64_t)query * ld + dd];
+  const float* bias_h = d.bias + (int64_t)h * ws2 * ws2;
+  const float* mask_w = d.mask ? d.mask + (int64_t)wl * ws2 * ws2 : nullptr;
+  const bool qwin = query >= T;
+  float* rawrow = (query < T && d.rawmap) ? d.rawmap + (((int64_t)b * nH + h) * T + query) * d.map_ld + d.map_off : nullptr;
+  const int32_t* px = d.pix + (int64_t)wl * ws2;
+  auto logit = [&](int key, float& raw) {
+    float a = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) a = fmaf(q[dd], ks[key * 33 + dd], a);
+    raw = a;
+    float v = a * d.scale;
+    if (qwin && key >= T) {
+      const int64_t o = (int64_t)(query - T) * ws2 + (key - T);
+      v += bias_h[o];
+      if (mask_w) v += mask_w[o];
+    }
+    return v;
+  };
+  float mx = -INFINITY;
+  for (int key = 0; key < N; ++key) {
+    float raw;
+    const float v = logit(key, raw);
+    mx = fmaxf(mx, v);
+    if (rawrow && key >= T) {
+      const int pp = px[key - T];
+      if (pp >= 0) rawrow[pp] = raw;
+    }
+  }
+  float l = 0.f, o[32];
+#pragma unroll
+  for (int dd = 0; dd < 32; ++dd) o[dd] = 0.f;
+  for (int key = 0; key < N; ++key) {
+    float raw;
+    const float pv = expf(logit(key, raw) - mx);
+    l += pv;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) o[dd] = fmaf(pv, vs[key * 33 + dd], o[dd]);
+  }
+  const float inv = 1.0f / l;
+  float* op = (float*)d.out + ((int64_t)win * N + query) * C + h * 32;
+#pragma unroll
+  for (int dd = 0; dd < 32; ++dd) op[dd] = o[dd] * inv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel attention: one workgroup per (b, t, window).  logits over the C feature channels in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chanattn_kernel(const mtt_chanattn_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lg_ = (float*)smem_raw;                   // [C] logits -> probabilities
+  __shared__ float qs[1024];                       // the window's queries (<= ce elements)
+  __shared__ float bk[1024], bv[1024];             // the k / v bias of those elements
+  __shared__ int es[1024];                         // their element index in the ce dimension
+  __shared__ float red[8];
+  const int nwin = d.nh * d.nw;
+  const int win = blockIdx.x % nwin, t = (blockIdx.x / nwin) % d.T, b = blockIdx.x / (nwin * d.T);
+  const int r = (int)(sqrtf((float)d.ce) + 0.5f);
+  const int wh = r / d.nh, ww = r / d.nw, P = wh * ww;
+  const int wy = win / d.nw, wx = win % d.nw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < P; e += 256) {
+    const int el = (wy * wh + e / ww) * r + wx * ww + e % ww;
+    es[e] = el;
+    qs[e] = d.q[((int64_t)b * d.T + t) * d.ce + el];
+    bk[e] = d.kvbias ? d.kvbias[el] : 0.f;
+    bv[e] = d.kvbias ? d.kvbias[d.ce + el] : 0.f;
+  }
+  __syncthreads();
+  const int64_t kvb = (int64_t)b * 2 * d.ce * d.ldk;
+  float mx = -INFINITY;
+  for (int c = tid; c < d.C; c += 256) {
+    float a = 0.f;
+    for (int e = 0; e < P; ++e) a = fmaf(qs[e], ld_elem(d.kvT, kvb + (int64_t)es[e] * d.ldk + c, d.kv_dtype) + bk[e], a);
+    d.rawchan[(((int64_t)b * d.T + t) * nwin + win) * d.C + c] = a;
+    const float v = a * d.scale;
+    lg_[c] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float l = 0.f;
+  for (int c = tid; c < d.C; c += 256) {
+    const float pv = expf(lg_[c] - mx);
+    lg_[c] = pv;
+    l += pv;
+  }
+  l = wave_sum(l);
+  if (lane == 0) red[4 + wave] = l;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int e = wave; e < P; e += 4) {
+    float a = 0.f;
+    const int64_t vrow = kvb + (int64_t)(d.ce + es[e]) * d.ldk;
+    for (int c = lane; c < d.C; c += 64) a = fmaf(lg_[c], ld_elem(d.kvT, vrow + c, d.kv_dtype), a);
+    a = wave_sum(a);
+    if (lane == 0) d.cx[((int64_t)b * d.T + t) * d.ce + es[e]] = a * inv + bv[e];     // sum_c p_c = 1
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-2 pad-1 convolution on small-channel fp32 maps: one thread per output element.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3s2_kernel(const mtt_conv3s2_desc d) {
+  const int Ho = d.H / 2, Wo = d.W / 2;
+  const int64_t total = (int64_t)d.B * d.Co * Ho * Wo;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int xo = (int)(t % Wo), yo = (int)((t / Wo) % Ho), co = (int)((t / ((int64_t)Wo * Ho)) % d.Co);
+    const int64_t b = t / ((int64_t)Wo * Ho * d.Co);
+    float a = d.bias ? d.bias[co] : 0.f;
+    for (int ci = 0; ci < d.Ci; ++ci) {
+      const float* xp = d.x + b * d.x_bs + (int64_t)ci * d.x_cs + d.x_off;
+      const float* wp = d.w + ((int64_t)co * d.Ci + ci) * 9;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = 2 * yo - 1 + ky;
+        if (yy < 0 || yy >= d.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = 2 * xo - 1 + kx;
+          if (xx < 0 || xx >= d.W) continue;
+          a = fmaf(xp[(int64_t)yy * d.W + xx], wp[ky * 3 + kx], a);
+        }
+      }
+    }
+    d.y[b * d.y_bs + (int64_t)co * d.y_cs + d.y_off + (int64_t)yo * Wo + xo] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear resize of fp32 planes (align_corners = False): the img_ds_ratio input resize (taskprompter_swin.py:666-667).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_nchw_kernel(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout) {
+  const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+  const int64_t total = (int64_t)planes * Hout * Wout;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int xo = (int)(t % Wout), yo = (int)((t / Wout) % Hout);
+    const int64_t pl = t / ((int64_t)Wout * Hout);
+    float fy = ((float)yo + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = ((float)xo + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float* p = in + pl * Hin * Win;
+    const float top = p[(int64_t)y0 * Win + x0] * (1.f - wx) + p[(int64_t)y0 * Win + x1] * wx;
+    const float bot = p[(int64_t)y1 * Win + x0] * (1.f - wx) + p[(int64_t)y1 * Win + x1] * wx;
+    out[t] = top * (1.f - wy) + bot * wy;
+  }
+}
+
+int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 65535 * 4 ? 65535 * 4 : g));
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int mtt_patchify(const float* img, void* cols, int B, int H, int W, int P, int64_t ldc, int out_dtype, void* stream) {
+  if (!img || !cols || B <= 0 || P <= 0 || (H % P) || (W % P) || ldc < 3 * P * P) return MTT_E_BADARG;
+  const int64_t n = (int64_t)B * (H / P) * (W / P) * (3 * P + 1);
+  if (P == 2) hipLaunchKernelGGL(patchify_p_kernel<2>, dim3(grid_for(n)), dim3(256), 0, S_, img, cols, B, H, W, ldc, out_dtype);
+  else if (P == 4) hipLaunchKernelGGL(patchify_p_kernel<4>, dim3(grid_for(n)), dim3(256), 0, S_, img, cols, B, H, W, ldc, out_dtype);
+  else if (P == 8) hipLaunchKernelGGL(patchify_p_kernel<8>, dim3(grid_for(n)), dim3(256), 0, S_, img, cols, B, H, W, ldc, out_dtype);
+  else return MTT_E_UNSUPPORTED;
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_resize_nchw(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, void* stream) {
+  if (!in || !out || planes <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return MTT_E_BADARG;
+  hipLaunchKernelGGL(resize_nchw_kernel, dim3(grid_for((int64_t)planes * Hout * Wout)), dim3(256), 0, S_, in, out, planes, Hin, Win, Hout, Wout);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_gather_rows(const mtt_gather_desc* d, void* stream) {
+  if (!d || !d->src || !d->dst || !d->idx || d->rows <= 0 || d->B <= 0 || d->C <= 0 || (d->C % 8)) return MTT_E_BADARG;
+  if ((d->ld_src % 8) || (d->ld_dst % 8) || (d->src_bs % 8) || (d->dst_bs % 8) || ((uintptr_t)d->src & 15) || ((uintptr_t)d->dst & 15)) return MTT_E_ALIGN;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)d->B * d->rows * (d->C / 8))), dim3(256), 0, S_, *d);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_winattn_fwd(const mtt_winattn_desc* d, void* stream) {
+  if (!d || !d->qkv || !d->out || !d->bias || !d->pix || d->nwin <= 0 || d->nW <= 0 || d->nH <= 0 || d->T < 0 || d->ws2 <= 0) return MTT_E_BADARG;
+  if (d->nwin % d->nW) return MTT_E_BADARG;
+  const int N = d->T + d->ws2;
+  if (N > 160 || d->T > 16) return MTT_E_UNSUPPORTED;
+  const dim3 grid((unsigned)(d->nwin * d->nH));
+  if (d->dtype == MTT_F32) {
+    const int smem = N * 33 * 4 * 2;
+    hipLaunchKernelGGL(winattn_f32_kernel, grid, dim3(256), smem, S_, *d);
+    return (int)hipGetLastError();
+  }
+  if (((uintptr_t)d->qkv & 15) || ((uintptr_t)d->out & 7)) return MTT_E_ALIGN;
+  if (N <= 32) hipLaunchKernelGGL(winattn_bf16_kernel<2>, grid, dim3(256), 0, S_, *d);
+  else if (N <= 64) hipLaunchKernelGGL(winattn_bf16_kernel<4>, grid, dim3(256), 0, S_, *d);
+  else if (N <= 96) hipLaunchKernelGGL(winattn_bf16_kernel<6>, grid, dim3(256), 0, S_, *d);
+  else hipLaunchKernelGGL(winattn_bf16_kernel<10>, grid, dim3(256), 0, S_, *d);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_chanattn_fwd(const mtt_chanattn_desc* d, void* stream) {
+  if (!d || !d->q || !d->kvT || !d->rawchan || !d->cx || d->B <= 0 || d->T <= 0 || d->C <= 0 || d->ce <= 0 || d->nh <= 0 || d->nw <= 0) return MTT_E_BADARG;
+  const int r = (int)(sqrt((double)d->ce) + 0.5);
+  if (r * r != d->ce || (r % d->nh) || (r % d->nw) || (r / d->nh) * (r / d->nw) > 1024 || d->C > 16384) return MTT_E_BADARG;
+  hipLaunchKernelGGL(chanattn_kernel, dim3((unsigned)(d->B * d->T * d->nh * d->nw)), dim3(256), d->C * 4, S_, *d);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_conv3s2_nchw(const mtt_conv3s2_desc* d, void* stream) {
+  if (!d || !d->x || !d->w || !d->y || d->B <= 0 || d->Ci <= 0 || d->Co <= 0 || d->H <= 0 || d->W <= 0 || (d->H % 2) || (d->W % 2)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(conv3s2_kernel, dim3(grid_for((int64_t)d->B * d->Co * (d->H / 2) * (d->W / 2))), dim3(256), 0, S_, *d);
+  return (int)hipGetLastError();
+}

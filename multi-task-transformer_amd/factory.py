@@ -56,6 +56,18 @@ def get_backbone(p):
     elif p['backbone'] == 'TaskPrompter_vitB':
         backbone = tp.taskprompter_vit_base_patch16_384(p=p, pretrained=False, drop_path_rate=p.get('drop_path_rate', 0.15),
                                                         img_size=p.TRAIN.SCALE)
+    elif p['backbone'] == 'TaskPrompter_swinB' or isinstance(p['backbone'], dict):
+        # TaskPrompter/utils/common_config.py:34-41; a dict(patch_size=, window_size=, embed_dim=, depths=, num_heads=) builds other sizes
+        from . import taskprompter_swin as sw
+        kw = dict(p['backbone']) if isinstance(p['backbone'], dict) else dict(patch_size=4, window_size=12, embed_dim=128,
+                                                                              depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32))
+        e = kw['embed_dim']
+        p.backbone_channels = [2 * e, 4 * e, 8 * e, 8 * e]
+        img_h, img_w = p.TRAIN.SCALE
+        p.ori_spatial_dim = [[img_h // st, img_w // st] for st in (8, 16, 32, 32)]
+        backbone = sw.taskprompter_create_swin_transformer('swin', pretrained=False, p=p, drop_path_rate=p.get('drop_path_rate', 0.15),
+                                                           img_size=p.TRAIN.SCALE, **kw)
+        return backbone, p.final_embed_dim
     elif isinstance(p['backbone'], (tuple, list)):       # (embed_dim, depth, heads, select_list): miniature / ViT-S variants
         C, depth, nH, select = p['backbone']
         backbone = tp._create_task_prompter('custom', p=p, select_list=list(select), patch_size=16, embed_dim=C, depth=depth,

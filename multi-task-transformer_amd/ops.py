@@ -318,13 +318,13 @@ def chan_logits(cq, xn, B, T, N, C, grid, nwin_hw):
     return rawchan
 
 
-def modulate(x, x_ld, x_bs, rawlog, rawchan, B, T, N, C, grid, nwin_hw, prec):
+def modulate(x, x_ld, x_bs, rawlog, rawchan, B, T, N, C, grid, nwin_hw, prec, hg=0):
     """x: fp32 base view of the patch rows ([B, hw, C] with row pitch x_ld, batch stride x_bs).
     -> [2T, B*hw, C] activation dtype (spatially- then channel-modulated copy per task)."""
     hw = grid[0] * grid[1]
     out = torch.empty(2 * T, B * hw, C, dtype=prec.adt, device=x.device)
     call("modulate", x=x, x_ld=x_ld, x_bs=x_bs, rawlog=rawlog, rawchan=rawchan, out=out, B=B, T=T, N=N, C=C,
-         h=grid[0], w=grid[1], nh=nwin_hw[0], nw=nwin_hw[1], out_dtype=dtype_code(out))
+         h=grid[0], w=grid[1], nh=nwin_hw[0], nw=nwin_hw[1], out_dtype=dtype_code(out), hg=hg)
     return out
 
 

@@ -513,7 +513,8 @@ class TaskPrompterWrapper(nn.Module):
         target = tuple(self.target_size) if self.target_size is not None else img_size
         bb = self.backbone
         B = x.shape[0]
-        h4, w4 = bb.resolution[0] * 4, bb.resolution[1] * 4
+        # the grid the heads run on: the ViT backbone's x4-upsampled patch grid, or what the backbone says (Swin: first level x2)
+        h4, w4 = getattr(bb, 'feature_hw', None) or (bb.resolution[0] * 4, bb.resolution[1] * 4)
         F = bb.p.final_embed_dim
         out = {}
         groups = {'conv': [], 'deconv': [], 'other': []}
@@ -522,7 +523,7 @@ class TaskPrompterWrapper(nn.Module):
             groups['conv' if isinstance(hd, ConvHead) else ('deconv' if isinstance(hd, DEConvHead) else 'other')].append(i)
         # ConvHeads take the backbone's h x w sums and fuse its x4 resize into their 3x3 conv (taskprompter.py:420 -> :692, taps first);
         # the upsampled stack [T, B*4h*4w, Fp] is only built if some other head needs it
-        fuse = self.fuse_upsample and bool(groups['conv'])
+        fuse = self.fuse_upsample and bool(groups['conv']) and getattr(bb, 'fusable_upsample', True)
         lo = bb.forward_nhwc(x, upsample=not fuse)
         fea = None if fuse else lo
         for kind in ('conv', 'deconv'):

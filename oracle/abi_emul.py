@@ -291,7 +291,8 @@ def chan_logits(**kw):
 
 def modulate(**kw):
     B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
-    hw, nH, nwin = h * w, Cn // 64, nh * nw
+    hg = kw.get("hg") or 64
+    hw, nH, nwin = h * w, Cn // hg, nh * nw
     xi = torch.arange(B)[:, None, None] * kw["x_bs"] + torch.arange(hw)[None, :, None] * kw["x_ld"] + torch.arange(Cn)[None, None, :]
     x = _rd(kw["x"], xi)
     f, o = flat(kw["rawlog"])
@@ -302,7 +303,7 @@ def modulate(**kw):
     win = (yy // (h // nh)) * nw + (xx // (w // nw))
     outs = []
     for t in range(T):
-        a = rl[:, :, t, T:].transpose(1, 2).repeat_interleave(64, dim=2)     # [B,hw,C]
+        a = rl[:, :, t, T:].transpose(1, 2).repeat_interleave(hg, dim=2)     # [B,hw,C]
         outs.append(x * (1 + a))
         outs.append(x * (1 + rc[:, t][:, win]))
     y = torch.stack(outs, 0).reshape(-1)
@@ -813,7 +814,103 @@ def upconv4_gather(**kw):
     _wr(kw["z"], torch.arange(dz.numel()), dz.reshape(-1))
 
 
-_TABLE = dict(gemm=gemm, upconv4_expand=upconv4_expand, upconv4_gather=upconv4_gather, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
+# ---- TaskPrompter-Swin forward entry points ---------------------------------------------------------------------------------
+def patchify(args):
+    img, cols, B, H, W, P, ldc, odt = args[:8]
+    gh, gw = H // P, W // P
+    x = img.double().reshape(B, 3, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, 3 * P * P)
+    out = torch.zeros(B * gh * gw, ldc, dtype=torch.float64)
+    out[:, :3 * P * P] = x
+    _wr(cols, torch.arange(out.numel()), out.reshape(-1))
+
+
+def resize_nchw(args):
+    src, dst, planes, Hin, Win, Hout, Wout = args[:7]
+    x = _rd(src, torch.arange(planes * Hin * Win)).view(1, planes, Hin, Win)
+    y = torch.nn.functional.interpolate(x, (Hout, Wout), mode="bilinear", align_corners=False)
+    _wr(dst, torch.arange(planes * Hout * Wout), y.reshape(-1))
+
+
+def gather_rows(**kw):
+    B, rows, Cn = kw["B"], kw["rows"], kw["C"]
+    idx = kw["idx"]
+    fi, oi = flat(idx)
+    b = torch.arange(B)[:, None, None]
+    r = torch.arange(rows)[None, :, None]
+    c = torch.arange(Cn)[None, None, :]
+    src_row = fi[oi + b * (kw.get("idx_bs") or 0) + r].long()                      # [B, rows, 1]
+    ok = (src_row >= 0).expand(B, rows, Cn)
+    v = _rd(kw["src"], b * (kw.get("src_bs") or 0) + src_row * kw["ld_src"] + c, ok)
+    _wr(kw["dst"], (b * (kw.get("dst_bs") or 0) + r * kw["ld_dst"] + c).reshape(-1), v.reshape(-1))
+
+
+def winattn_fwd(**kw):
+    nwin, nW, nH, T, ws2 = (kw[k] for k in ("nwin", "nW", "nH", "T", "ws2"))
+    N, Cn = T + ws2, nH * 32
+    qkv = _rd(kw["qkv"], torch.arange(nwin * N * 3 * Cn)).view(nwin, N, 3, nH, 32)
+    if kw.get("dtype", F32) == BF16:
+        qkv = _bf16_round(qkv)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))                # [nwin, nH, N, 32]
+    raw = q @ k.transpose(-1, -2)
+    S = raw * kw["scale"]
+    bias = _rd(kw["bias"], torch.arange(nH * ws2 * ws2)).view(1, nH, ws2, ws2)
+    S[:, :, T:, T:] += bias
+    if kw.get("mask") is not None:
+        mask = _rd(kw["mask"], torch.arange(nW * ws2 * ws2)).view(nW, 1, ws2, ws2)
+        S[:, :, T:, T:] += mask.repeat(nwin // nW, 1, 1, 1)
+    o = (torch.softmax(S, -1) @ v).permute(0, 2, 1, 3).reshape(nwin * N * Cn)
+    _wr(kw["out"], torch.arange(nwin * N * Cn), o)
+    if kw.get("rawmap") is not None:
+        fp, op = flat(kw["pix"])
+        pix = fp[op:op + nW * ws2].long().view(nW, ws2)
+        w = torch.arange(nwin)
+        px = pix[w % nW]                                                          # [nwin, ws2]
+        b = (w // nW)[:, None, None, None]
+        h = torch.arange(nH)[None, :, None, None]
+        t = torch.arange(T)[None, None, :, None]
+        dst = ((b * nH + h) * T + t) * kw["map_ld"] + kw.get("map_off", 0) + px[:, None, None, :]
+        ok = (px >= 0)[:, None, None, :].expand(nwin, nH, T, ws2)
+        _wr(kw["rawmap"], dst[ok], raw[:, :, :T, T:][ok])
+
+
+def chanattn_fwd(**kw):
+    B, T, Cn, ce, nh, nw = (kw[k] for k in ("B", "T", "C", "ce", "nh", "nw"))
+    ldk = kw["ldk"]
+    q = _rd(kw["q"], torch.arange(B * T * ce)).view(B, T, ce)
+    rows = torch.arange(B * 2 * ce)[:, None] * ldk + torch.arange(Cn)[None, :]
+    kv = _rd(kw["kvT"], rows).view(B, 2, ce, Cn)
+    if kw.get("kvbias") is not None:
+        kv = kv + _rd(kw["kvbias"], torch.arange(2 * ce)).view(1, 2, ce, 1)
+    kT, vT = kv[:, 0], kv[:, 1]
+    r = math.isqrt(ce)
+    wh, ww = r // nh, r // nw
+
+    def split(t):                                                                  # [B, X, ce] -> [B, nwin, X, wh*ww]
+        return t.view(B, t.shape[1], nh, wh, nw, ww).permute(0, 2, 4, 1, 3, 5).reshape(B, nh * nw, t.shape[1], wh * ww)
+    q_, k_, v_ = split(q), split(kT.transpose(1, 2)), split(vT.transpose(1, 2))    # k_: [B, nwin, C, P]
+    raw = q_ @ k_.transpose(-1, -2)                                                # [B, nwin, T, C]
+    cx = torch.softmax(raw * kw["scale"], -1) @ v_                                 # [B, nwin, T, P]
+    cx = cx.view(B, nh, nw, T, wh, ww).permute(0, 3, 1, 4, 2, 5).reshape(B * T * ce)
+    _wr(kw["rawchan"], torch.arange(B * T * nh * nw * Cn), raw.permute(0, 2, 1, 3).reshape(-1))
+    _wr(kw["cx"], torch.arange(B * T * ce), cx)
+
+
+def conv3s2_nchw(**kw):
+    B, Ci, Co, H, W = (kw[k] for k in ("B", "Ci", "Co", "H", "W"))
+    g = lambda k: kw.get(k) or 0
+    b = torch.arange(B)[:, None, None]
+    c = torch.arange(Ci)[None, :, None]
+    pxl = torch.arange(H * W)[None, None, :]
+    x = _rd(kw["x"], b * g("x_bs") + c * g("x_cs") + g("x_off") + pxl).view(B, Ci, H, W)
+    w = _rd(kw["w"], torch.arange(Co * Ci * 9)).view(Co, Ci, 3, 3)
+    bias = _rd(kw["bias"], torch.arange(Co)) if kw.get("bias") is not None else None
+    y = torch.nn.functional.conv2d(x, w, bias, stride=2, padding=1)
+    co = torch.arange(Co)[None, :, None]
+    po = torch.arange((H // 2) * (W // 2))[None, None, :]
+    _wr(kw["y"], (b * g("y_bs") + co * g("y_cs") + g("y_off") + po).reshape(-1), y.reshape(-1))
+
+
+_TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, chanattn_fwd=chanattn_fwd, conv3s2_nchw=conv3s2_nchw, gemm=gemm, upconv4_expand=upconv4_expand, upconv4_gather=upconv4_gather, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
               bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply,
@@ -822,7 +919,7 @@ _TABLE = dict(gemm=gemm, upconv4_expand=upconv4_expand, upconv4_gather=upconv4_g
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
               loss_fwd=loss_fwd, loss_bwd=loss_bwd)
-_POS = dict(patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
+_POS = dict(patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
             transpose_pad_sum=transpose_pad_sum)
 
 

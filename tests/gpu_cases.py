@@ -590,5 +590,76 @@ def upconv_cases():
     return cases
 
 
+def swin_cases():
+    """TaskPrompter-Swin forward entry points: patchify (P = 2 / 4 / 8, padded K), NCHW resize (down / up), row gather (shifted + padded
+    window partition with prompts, its inverse, column-offset destination as in patch merging, dtype conversion), window attention
+    (bf16 MFMA kernel at 2 / 4 / 6 / 10 key tiles and the exact fp32 kernel; with / without shift mask; padding pixels; 2 and 3 prompts;
+    several windows per image and several images), channel attention (1 and 4 windows, kv bias, bf16 / fp32 kv), the stride-2 map conv
+    and the modulation with 32-channel heads."""
+    import importlib
+    sw = importlib.import_module("multi-task-transformer_amd.taskprompter_swin")
+    cases = []
+    g = torch.Generator().manual_seed(31)
+    for P, (B, H, W) in ((4, (2, 16, 24)), (2, (1, 8, 6)), (8, (1, 16, 16))):
+        Kp = (3 * P * P + 7) // 8 * 8
+        for dt in (F32, BF16):
+            cases.append((f"patchify_P{P}_{dt}", "patchify", dict(args=[rnd(g, B, 3, H, W), torch.full((B * (H // P) * (W // P), Kp), 7.0, dtype=DT[dt]),
+                                                                        B, H, W, P, Kp, dt]), TOL_ROW))
+    for (pl, Hin, Win, Hout, Wout) in ((6, 16, 24, 12, 18), (3, 9, 7, 18, 14), (2, 32, 64, 24, 48)):
+        cases.append((f"resize_nchw_{Hin}x{Win}_to_{Hout}x{Wout}", "resize_nchw",
+                      dict(args=[rnd(g, pl, Hin, Win), torch.full((pl, Hout, Wout), 7.0), pl, Hin, Win, Hout, Wout]), TOL_ROW))
+    # gather: the real window tables (shift 2 of window 5 on a 7 x 9 map -> padded to 10 x 10), 3 prompts
+    for (res, window, shifted, T, C, B) in (((7, 9), 5, True, 3, 40, 2), ((8, 12), 4, True, 2, 64, 3), ((8, 12), 4, False, 2, 16, 1)):
+        ws, shift, Hp, Wp = sw.block_geometry(res, window, shifted)
+        part, pix, rev = sw.window_tables(res, ws, shift, Hp, Wp, T, "cpu")
+        N, Nw, nW = T + res[0] * res[1], T + ws * ws, (Hp // ws) * (Wp // ws)
+        for sdt, ddt in ((F32, BF16), (BF16, BF16), (F32, F32)):
+            src = rnd(g, B, N, C, dtype=DT[sdt])
+            kw = dict(src=src, dst=torch.full((B, nW * Nw, C), 7.0, dtype=DT[ddt]), idx=part, rows=nW * Nw, C=C, ld_src=C, ld_dst=C,
+                      src_dtype=sdt, dst_dtype=ddt, B=B, src_bs=N * C, dst_bs=nW * Nw * C, idx_bs=0)
+            cases.append((f"gather_partition_{res[0]}x{res[1]}_w{window}_s{shift}_{sdt}{ddt}", "gather_rows", kw, TOL_ROW))
+        win = rnd(g, B, nW * Nw, C, dtype=torch.bfloat16)
+        dst = torch.full((B, N, C + 8), 7.0)
+        kw = dict(src=win, dst=dst[:, T:, 8:], idx=rev, rows=res[0] * res[1], C=C, ld_src=C, ld_dst=C + 8, src_dtype=BF16, dst_dtype=F32,
+                  B=B, src_bs=nW * Nw * C, dst_bs=N * (C + 8), idx_bs=0)
+        cases.append((f"gather_reverse_{res[0]}x{res[1]}_w{window}_s{shift}", "gather_rows", kw, TOL_ROW))
+    # window attention
+    for (res, window, shifted, T, nH, B, dts) in (((8, 12), 4, True, 2, 2, 2, (BF16, F32)), ((7, 9), 5, True, 3, 1, 2, (BF16, F32)),
+                                                  ((7, 14), 7, False, 2, 3, 1, (BF16, F32)), ((9, 9), 9, False, 3, 2, 2, (BF16,)),
+                                                  ((24, 24), 12, True, 2, 4, 1, (BF16, F32)), ((12, 24), 12, False, 3, 2, 2, (BF16,))):
+        ws, shift, Hp, Wp = sw.block_geometry(res, window, shifted)
+        part, pix, rev = sw.window_tables(res, ws, shift, Hp, Wp, T, "cpu")
+        mask = sw.shift_attn_mask(Hp, Wp, ws, shift)
+        ws2, nW = ws * ws, (Hp // ws) * (Wp // ws)
+        N, Nw, Cc = T + res[0] * res[1], T + ws * ws, nH * 32
+        for dt in dts:
+            qkv = rnd(g, B * nW, Nw, 3 * Cc, scale=0.7).to(DT[dt])
+            kw = dict(qkv=qkv, out=torch.full((B * nW, Nw, Cc), 7.0, dtype=DT[dt]), rawmap=torch.full((B, nH, T, N), 3.0),
+                      bias=rnd(g, nH, ws2, ws2, scale=0.5), mask=mask, pix=pix, nwin=B * nW, nW=nW, nH=nH, T=T, ws2=ws2, dtype=dt,
+                      scale=32 ** -0.5, map_ld=N, map_off=T)
+            cases.append((f"winattn_{res[0]}x{res[1]}_w{window}_s{shift}_T{T}_h{nH}_{dt}", "winattn_fwd", kw, dict(f32=2e-5 if dt == F32 else 6e-3, bf16=1.5e-2)))
+    # channel attention
+    for (B, T, C, ce, nwin, kdt, has_b) in ((2, 2, 64, 16, 1, F32, True), (1, 3, 136, 64, 2, F32, True), (2, 2, 256, 256, 1, BF16, False), (1, 2, 1024, 256, 2, F32, True)):
+        Cp = (C + 7) // 8 * 8
+        kw = dict(q=rnd(g, B, T, ce, scale=0.3), kvT=rnd(g, B, 2 * ce, Cp, scale=0.5).to(DT[kdt]), rawchan=torch.full((B, T, nwin * nwin, C), 7.0),
+                  cx=torch.full((B, T, ce), 7.0), B=B, T=T, C=C, ce=ce, nh=nwin, nw=nwin, kv_dtype=kdt, ldk=Cp, scale=ce ** -0.5,
+                  kvbias=rnd(g, 2 * ce, scale=0.2) if has_b else None)
+        cases.append((f"chanattn_B{B}T{T}C{C}ce{ce}w{nwin}_{kdt}", "chanattn_fwd", kw, TOL_ROW))
+    # 3x3 stride-2 conv of the attention maps, in the [B, nH*T, T + hw] layout of the raw prompt logits
+    for (B, Ci, H, W, T) in ((2, 4, 8, 12, 2), (1, 24, 6, 10, 3)):
+        N, N2 = T + H * W, T + (H // 2) * (W // 2)
+        kw = dict(x=rnd(g, B, Ci, N), w=rnd(g, Ci, Ci, 3, 3, scale=0.3), bias=rnd(g, Ci), y=torch.full((B, Ci, N2), 7.0), B=B, Ci=Ci, Co=Ci, H=H, W=W,
+                  x_bs=Ci * N, x_cs=N, x_off=T, y_bs=Ci * N2, y_cs=N2, y_off=T)
+        cases.append((f"conv3s2_{B}x{Ci}x{H}x{W}", "conv3s2_nchw", kw, TOL_ROW))
+    # modulation with 32-channel heads (last Swin stage)
+    B, T, h, w, C, hg = 2, 2, 4, 6, 64, 32
+    N = T + h * w
+    xt = rnd(g, B, N, C)
+    kw = dict(x=xt[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // hg, T, N), rawchan=rnd(g, B, T, 4, C), out=torch.full((2 * T, B * h * w, C), 7.0, dtype=torch.bfloat16),
+              B=B, T=T, N=N, C=C, h=h, w=w, nh=2, nw=2, out_dtype=BF16, hg=hg)
+    cases.append(("modulate_hg32", "modulate", kw, TOL_ROW))
+    return cases
+
+
 def all_cases():
-    return gemm_cases() + attn_cases() + row_cases() + invpt_cases() + upconv_cases()
+    return gemm_cases() + attn_cases() + row_cases() + invpt_cases() + upconv_cases() + swin_cases()

@@ -25,6 +25,8 @@ def report(kind, **fields):
 
 
 def get_cfg(name):
+    if "swin" in name:
+        return configs.swin(name)
     return configs.invpt(name) if name.startswith("cfg4") or name in ("cfg1", "mini", "mini8") else configs.taskprompter(name)
 
 
@@ -46,6 +48,9 @@ def oracle_eval(name, B, seed=0):
             if cfg["model"] == "TransformerNet":
                 from oracle import invpt_oracle as ipo
                 ref = ipo.forward(sd, cfg, x)
+            elif cfg["model"] == "TaskPrompterSwin":
+                from oracle import swin_oracle as swo
+                ref = swo.forward(sd, cfg, x)
             else:
                 from oracle import taskprompter_oracle as tpo
                 ref = tpo.forward(sd, cfg, x)

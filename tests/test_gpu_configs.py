@@ -6,6 +6,7 @@
   cfg3  TaskPrompter ViT-L, NYUD-4, 448x576 (non-square), 768 / 768, windows, no ctr       B = 1
   cfg4  InvPT ViT-L, PASCAL-5 + depth, 512x512 (BASELINE's 8-GPU config)                    B = 1
   cfg5  TaskPrompter ViT-L, Cityscapes (semseg + depth), 1024x2048, N = 8194, DEConvHead    B = 1
+  cs_swinB  TaskPrompter Swin-B (cs_swinB_taskprompter.yml without 3ddet), 1024x2048 x 0.75, window 12, DEConvHead (forward path)  B = 1
 
 x3 (fp32-class: split-bf16 x 3 MFMA) must meet north_star's 1e-3 per head; bf16 (the throughput mode) is measured, reported
 (PARITY lines / gpurun_out/parity_report.jsonl) and bounded.  Weights are the deterministic synthetic state dict of oracle/weights.py
@@ -18,7 +19,7 @@ import parity_util as pu
 
 X3_TOL = 1e-3
 BF16_BOUND = 4e-2          # measured values are reported; see DESIGN.md for the numbers of this round
-CASES = [("ns6", 2), ("cfg2", 1), ("cfg3", 1), ("cfg4_6", 1), ("cfg5", 1)]
+CASES = [("ns6", 2), ("cfg2", 1), ("cfg3", 1), ("cfg4_6", 1), ("cfg5", 1), ("cs_swinB", 1)]
 
 
 @pytest.mark.gpu
@@ -29,7 +30,8 @@ def test_baseline_config_forward_matches_oracle(name, B, prec):
         pytest.skip("no GPU")
     cfg, sd, x, ref = pu.oracle_eval(name, B)
     model = conftest.build_product_model(cfg, prec, "cuda")
-    model.load_state_dict(sd, strict=True)
+    res = model.load_state_dict(sd, strict=False)          # geometry-derived buffers (Swin index / mask tables) are not synthesised
+    assert not res.unexpected_keys and all(k.rsplit(".", 1)[-1] in ("relative_position_index", "attn_mask") for k in res.missing_keys)
     model.eval()
     with torch.no_grad():
         out = model(x.cuda())

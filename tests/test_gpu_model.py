@@ -83,3 +83,27 @@ def test_invpt_forward_matches_reference_golden(prec, tol):
     model = conftest.build_product_model(cfg, prec, "cuda")
     model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=True)
     _invpt_outputs_vs_golden(model, cfg, meta, gold, tol, device="cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mini_swin", "mini_swin_pad"])
+@pytest.mark.parametrize("prec,tol", [("x3", REL_TOL_X3), ("bf16", 5e-2)])
+def test_swin_forward_matches_reference_golden(name, prec, tol):
+    """TaskPrompter-Swin forward (shifted / padded windows with prompts, channel attention, patch merging, multi-scale fusion, Conv and
+    DEConv heads) through the HIP kernels against the unmodified reference's outputs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = configs.swin(name)
+    meta, gold = conftest.load_golden(name)
+    model = conftest.build_product_model(cfg, prec, "cuda")
+    model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=False)
+    model.eval()
+    x = weights.synth_images(meta["batch"], cfg["img_size"], 1).cuda()
+    with torch.no_grad():
+        out = model(x)
+    es = meta["eval_stride"]
+    for t, n in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        e = _rel(out[t].cpu()[:, :, ::es, ::es], g)
+        print(f"PARITY swin {name} {prec} {t} {e:.3e}")
+        assert e < tol, (t, e)

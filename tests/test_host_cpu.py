@@ -4,6 +4,7 @@
   * the nn.Module wiring (descriptor construction, strides, padding) on the ABI emulator reproduces the
     golden outputs of the unmodified reference
   * the product refuses to run its kernels on CPU tensors (no fallback)"""
+import math
 import os
 import re
 
@@ -384,3 +385,57 @@ def test_fused_upsample_conv_matches_the_materialised_path(emulated):
             den = float(b[k].norm())
             if den > floor:
                 assert float((a[k] - b[k]).norm()) / den < 2e-4, (part, k)
+
+
+# ---- TaskPrompter-Swin (forward path) -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mini_swin", "mini_swin_pad"])
+@pytest.mark.parametrize("prec,tol", [("x3", 1e-4), ("bf16", 5e-2)])
+def test_swin_wiring_matches_reference_golden(emulated, name, prec, tol):
+    """The product's TaskPrompterSwin schedule (window tables, gathers, window / channel attention descriptors, patch merging, commuted
+    1x1 convs, multi-scale accumulation, heads) on the ABI emulator against the UNMODIFIED reference's outputs; the state-dict contract
+    (names, shapes, order, geometry-derived buffers) must be the reference's."""
+    from oracle import swin_oracle as swo
+    cfg = configs.swin(name)
+    meta, gold = conftest.load_golden(name)
+    model = conftest.build_product_model(cfg, prec)
+    assert [(k, list(v.shape)) for k, v in model.state_dict().items()] == [(k, list(s)) for k, s in meta["contract"]]
+    res = model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=False)
+    assert not res.unexpected_keys and all(k.rsplit(".", 1)[-1] in weights.DERIVED_BUFFERS for k in res.missing_keys)
+    for k, v in model.state_dict().items():                     # the derived buffers are what the (pinned) oracle computes
+        if k.endswith("relative_position_index"):
+            assert torch.equal(v, swo.relative_position_index(math.isqrt(v.shape[0])))
+    model.eval()
+    with torch.no_grad():
+        out = model(weights.synth_images(meta["batch"], cfg["img_size"], 1))
+    es = meta["eval_stride"]
+    for t, n in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        assert out[t].dtype == torch.float32 and tuple(out[t].shape[-2:]) == tuple(cfg["img_size"])
+        e = float((out[t][:, :, ::es, ::es] - g).norm() / g.norm())
+        assert e < tol, (t, prec, e)
+
+
+def test_swin_is_forward_only_for_now():
+    """Training the Swin variant is not built: it must say so instead of silently running without gradients."""
+    cfg = configs.swin("mini_swin")
+    model = conftest.build_product_model(cfg, "bf16")
+    with pytest.raises(NotImplementedError):
+        model(weights.synth_images(1, cfg["img_size"], 1))
+
+
+def test_swin_window_tables_are_consistent():
+    """part / rev / pix are mutually inverse views of one permutation-with-padding, and equal roll + pad + window_partition."""
+    import mtt_amd
+    sw = mtt_amd.taskprompter_swin
+    for res, window, shifted, T in (((7, 9), 5, True, 3), ((8, 12), 4, True, 2), ((4, 6), 4, True, 2), ((12, 24), 12, False, 1)):
+        ws, shift, Hp, Wp = sw.block_geometry(res, window, shifted)
+        part, pix, rev = sw.window_tables(res, ws, shift, Hp, Wp, T, "cpu")
+        H, W = res
+        Nw = T + ws * ws
+        assert torch.equal(part.view(-1, Nw)[:, T:][pix >= 0].long() - T, pix[pix >= 0].long())
+        assert torch.equal(part[rev.long()].long(), T + torch.arange(H * W))                 # every pixel sits where rev says
+        x = torch.arange(H * W, dtype=torch.float32).view(1, H, W, 1) + 1
+        xp = torch.nn.functional.pad(x, (0, 0, 0, Wp - W, 0, Hp - H))
+        xs = torch.roll(xp, (-shift, -shift), (1, 2)) if shift else xp
+        win = xs.view(1, Hp // ws, ws, Wp // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
+        assert torch.equal(torch.where(pix >= 0, pix + 1, torch.zeros_like(pix)).float(), win)
