@@ -419,6 +419,17 @@ typedef struct {
 } mtt_conv3s2_desc;
 int mtt_conv3s2_nchw(const mtt_conv3s2_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Bird's-eye-view rotated boxes [x1, y1, x2, y2, ry] of the 3-D detection branch (TaskPrompter/detection_toolbox/iou3d: iou3d_kernel.cu
+ * :241-275 pairwise kernels, :277-377 NMS mask kernels, iou3d.cpp:103-203 greedy reduction).
+ *   mtt_boxes_overlap_bev: out fp32 [na, nb] = overlap area (iou = 0) or IoU (iou = 1) of every pair
+ *   mtt_nms_bev          : boxes [n, 5] ALREADY sorted by descending score; rotated = 1 (nms_gpu) / 0 (nms_normal_gpu: axis-aligned IoU);
+ *                          keep int64 [n] <- kept indices in score order, *num_out <- their count, both on the DEVICE (no host round trip:
+ *                          the reference copies the suppression masks to the host and reduces there); ws >= mtt_nms_ws_bytes(n) bytes. */
+int mtt_boxes_overlap_bev(const float* boxes_a, int na, const float* boxes_b, int nb, float* out, int iou, void* stream);
+size_t mtt_nms_ws_bytes(int n);
+int mtt_nms_bev(const float* boxes, int n, float thresh, int rotated, long long* keep, int* num_out, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmtt_hip.so")
-SOURCES = ["gemm.hip", "attn.hip", "attn_fast.hip", "attn_bwd.hip", "rowops.hip", "invpt_ops.hip", "optim.hip", "loss.hip", "upconv.hip", "swin_ops.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "attn_fast.hip", "attn_bwd.hip", "rowops.hip", "invpt_ops.hip", "optim.hip", "loss.hip", "upconv.hip", "swin_ops.hip", "iou3d.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

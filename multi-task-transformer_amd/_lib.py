@@ -188,6 +188,8 @@ POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "patchify": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int, ptr],
     "resize_nchw": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
+    "boxes_overlap_bev": [ptr, C.c_int, ptr, C.c_int, ptr, C.c_int, ptr],
+    "nms_bev": [ptr, C.c_int, f32, C.c_int, ptr, ptr, ptr, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
@@ -213,7 +215,7 @@ DESC_EXTRA = {
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
 
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats", "mtt_nms_ws_bytes"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 

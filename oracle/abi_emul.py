@@ -910,6 +910,21 @@ def conv3s2_nchw(**kw):
     _wr(kw["y"], (b * g("y_bs") + co * g("y_cs") + g("y_off") + po).reshape(-1), y.reshape(-1))
 
 
+def boxes_overlap_bev(args):
+    from . import iou3d_oracle
+    a, na, b, nb, out, iou = args[:6]
+    r = iou3d_oracle.pairwise(a.reshape(na, 5).numpy(), b.reshape(nb, 5).numpy(), bool(iou))
+    _wr(out, torch.arange(na * nb), torch.from_numpy(r).reshape(-1))
+
+
+def nms_bev(args):
+    from . import iou3d_oracle
+    boxes, n, thresh, rotated, keep, num_out, ws = args[:7]
+    k = iou3d_oracle.nms(boxes.reshape(n, 5).numpy(), thresh, bool(rotated))
+    _wr(keep, torch.arange(len(k)), torch.from_numpy(k))
+    _wr(num_out, torch.arange(1), torch.tensor([len(k)]))
+
+
 _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, chanattn_fwd=chanattn_fwd, conv3s2_nchw=conv3s2_nchw, gemm=gemm, upconv4_expand=upconv4_expand, upconv4_gather=upconv4_gather, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
@@ -919,7 +934,7 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, chanattn_fwd=cha
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
               loss_fwd=loss_fwd, loss_bwd=loss_bwd)
-_POS = dict(patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
+_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
             transpose_pad_sum=transpose_pad_sum)
 
 
