@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const mtt_gather_desc 
 // Q / K fragments are 16-byte global loads (rows are 64 contiguous bytes; K is re-read from L2 by the 10 query tiles).
 // NKT = number of 16-key tiles (even): N <= 16 NKT.
 // ------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };     // 16-byte load that only promises 4-byte alignment
+
 template <int NKT>
 __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_desc d) {
   constexpr int NP = NKT * 16, PITCH = NP + 8;     // V^T rows: NP keys (+ 8 bf16 of padding: 2-way instead of 8-way bank conflicts)
@@ -131,24 +133,37 @@ __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_des
           }
         }
     }
-    // scale, bias, mask, softmax over the keys of this lane's query
+    // scale, bias, mask, softmax over the keys of this lane's query.  A lane's 4 keys of a tile are consecutive, so bias / mask come as
+    // one (4-byte aligned) 16-byte load per tile wherever the 4 keys are all window positions; scalar loads at the edges.
     const bool qwin = query >= T && query < N;
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < NKT; ++j)
+    for (int j = 0; j < NKT; ++j) {
+      const int kb = j * 16 + lg * 4;
+      float add[4] = {0.f, 0.f, 0.f, 0.f};
+      if (qwin && kb >= T && kb + 3 < N) {
+        const int64_t o = (int64_t)(query - T) * ws2 + (kb - T);
+        const F4u bb = *(const F4u*)(bias_h + o);
+        add[0] = bb.x; add[1] = bb.y; add[2] = bb.z; add[3] = bb.w;
+        if (mask_w) { const F4u mm = *(const F4u*)(mask_w + o); add[0] += mm.x; add[1] += mm.y; add[2] += mm.z; add[3] += mm.w; }
+      } else if (qwin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + r;
+          if (key >= T && key < N) {
+            const int64_t o = (int64_t)(query - T) * ws2 + (key - T);
+            add[r] = bias_h[o] + (mask_w ? mask_w[o] : 0.f);
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = j * 16 + lg * 4 + r;
-        float v = s[j][r] * d.scale;
-        if (qwin && key >= T && key < N) {
-          const int64_t o = (int64_t)(query - T) * ws2 + (key - T);
-          v += bias_h[o];
-          if (mask_w) v += mask_w[o];
-        }
-        if (key >= N) v = -INFINITY;
+        float v = s[j][r] * d.scale + add[r];
+        if (kb + r >= N) v = -INFINITY;
         s[j][r] = v;
         mx = fmaxf(mx, v);
       }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float l = 0.f;
@@ -253,59 +268,73 @@ __global__ __launch_bounds__(256) void winattn_f32_kernel(const mtt_winattn_desc
 }
 
 // ------------------------------------------------------------------------------------------------
-// Channel attention: one workgroup per (b, t, window).  logits over the C feature channels in LDS.
+// Channel attention in two kernels (the first version ran everything of a (b, t, window) in ONE workgroup: 8 workgroups on the chip,
+// 267 us per call = 10 % of the Swin-B forward, profiles/r02_prof_swin_q_forward_b4_first.txt):
+//   logits: grid (C / 256, B*T*nwin) — a thread owns one feature channel c (coalesced kT rows), loops over the window's elements;
+//   mix   : grid (P / 32,  B*T*nwin) — every workgroup recomputes the softmax statistics over the C logits (a few KB from L2), then
+//           its 4 waves take 8 window elements each: lanes stride over c, wave reduction.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chanattn_kernel(const mtt_chanattn_desc d) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* lg_ = (float*)smem_raw;                   // [C] logits -> probabilities
-  __shared__ float qs[1024];                       // the window's queries (<= ce elements)
-  __shared__ float bk[1024], bv[1024];             // the k / v bias of those elements
-  __shared__ int es[1024];                         // their element index in the ce dimension
-  __shared__ float red[8];
+struct ChanWin { int b, t, win, r, wh, ww, wy, wx, P; };
+MTT_DEV ChanWin chan_win(const mtt_chanattn_desc& d, int id) {
+  ChanWin w;
   const int nwin = d.nh * d.nw;
-  const int win = blockIdx.x % nwin, t = (blockIdx.x / nwin) % d.T, b = blockIdx.x / (nwin * d.T);
-  const int r = (int)(sqrtf((float)d.ce) + 0.5f);
-  const int wh = r / d.nh, ww = r / d.nw, P = wh * ww;
-  const int wy = win / d.nw, wx = win % d.nw;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < P; e += 256) {
-    const int el = (wy * wh + e / ww) * r + wx * ww + e % ww;
+  w.win = id % nwin; w.t = (id / nwin) % d.T; w.b = id / (nwin * d.T);
+  w.r = (int)(sqrtf((float)d.ce) + 0.5f);
+  w.wh = w.r / d.nh; w.ww = w.r / d.nw; w.P = w.wh * w.ww;
+  w.wy = w.win / d.nw; w.wx = w.win % d.nw;
+  return w;
+}
+MTT_DEV int chan_elem(const ChanWin& w, int e) { return (w.wy * w.wh + e / w.ww) * w.r + w.wx * w.ww + e % w.ww; }
+
+__global__ __launch_bounds__(256) void chanattn_logits_kernel(const mtt_chanattn_desc d) {
+  __shared__ float qs[1024], bk[1024];
+  __shared__ int es[1024];
+  const ChanWin w = chan_win(d, blockIdx.y);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < w.P; e += 256) {
+    const int el = chan_elem(w, e);
     es[e] = el;
-    qs[e] = d.q[((int64_t)b * d.T + t) * d.ce + el];
+    qs[e] = d.q[((int64_t)w.b * d.T + w.t) * d.ce + el];
     bk[e] = d.kvbias ? d.kvbias[el] : 0.f;
-    bv[e] = d.kvbias ? d.kvbias[d.ce + el] : 0.f;
   }
   __syncthreads();
-  const int64_t kvb = (int64_t)b * 2 * d.ce * d.ldk;
+  const int c = blockIdx.x * 256 + tid;
+  if (c >= d.C) return;
+  const int64_t kvb = (int64_t)w.b * 2 * d.ce * d.ldk;
+  float a = 0.f;
+  for (int e = 0; e < w.P; ++e) a = fmaf(qs[e], ld_elem(d.kvT, kvb + (int64_t)es[e] * d.ldk + c, d.kv_dtype) + bk[e], a);
+  d.rawchan[(((int64_t)w.b * d.T + w.t) * (d.nh * d.nw) + w.win) * d.C + c] = a;
+}
+
+__global__ __launch_bounds__(256) void chanattn_mix_kernel(const mtt_chanattn_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* pr = (float*)smem_raw;                    // [C] probabilities (unnormalised)
+  __shared__ float red[8];
+  const ChanWin w = chan_win(d, blockIdx.y);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* raw = d.rawchan + (((int64_t)w.b * d.T + w.t) * (d.nh * d.nw) + w.win) * d.C;
   float mx = -INFINITY;
-  for (int c = tid; c < d.C; c += 256) {
-    float a = 0.f;
-    for (int e = 0; e < P; ++e) a = fmaf(qs[e], ld_elem(d.kvT, kvb + (int64_t)es[e] * d.ldk + c, d.kv_dtype) + bk[e], a);
-    d.rawchan[(((int64_t)b * d.T + t) * nwin + win) * d.C + c] = a;
-    const float v = a * d.scale;
-    lg_[c] = v;
-    mx = fmaxf(mx, v);
-  }
+  for (int c = tid; c < d.C; c += 256) { const float v = raw[c] * d.scale; pr[c] = v; mx = fmaxf(mx, v); }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float l = 0.f;
-  for (int c = tid; c < d.C; c += 256) {
-    const float pv = expf(lg_[c] - mx);
-    lg_[c] = pv;
-    l += pv;
-  }
+  for (int c = tid; c < d.C; c += 256) { const float pv = expf(pr[c] - mx); pr[c] = pv; l += pv; }
   l = wave_sum(l);
   if (lane == 0) red[4 + wave] = l;
   __syncthreads();
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  for (int e = wave; e < P; e += 4) {
+  const int64_t kvb = (int64_t)w.b * 2 * d.ce * d.ldk;
+  for (int k = 0; k < 8; ++k) {
+    const int e = blockIdx.x * 32 + wave * 8 + k;
+    if (e >= w.P) break;
+    const int el = chan_elem(w, e);
+    const int64_t vrow = kvb + (int64_t)(d.ce + el) * d.ldk;
     float a = 0.f;
-    const int64_t vrow = kvb + (int64_t)(d.ce + es[e]) * d.ldk;
-    for (int c = lane; c < d.C; c += 64) a = fmaf(lg_[c], ld_elem(d.kvT, vrow + c, d.kv_dtype), a);
+    for (int c = lane; c < d.C; c += 64) a = fmaf(pr[c], ld_elem(d.kvT, vrow + c, d.kv_dtype), a);
     a = wave_sum(a);
-    if (lane == 0) d.cx[((int64_t)b * d.T + t) * d.ce + es[e]] = a * inv + bv[e];     // sum_c p_c = 1
+    if (lane == 0) d.cx[((int64_t)w.b * d.T + w.t) * d.ce + el] = a * inv + (d.kvbias ? d.kvbias[d.ce + el] : 0.f);     // sum_c p_c = 1
   }
 }
 
@@ -414,7 +443,9 @@ extern "C" int mtt_chanattn_fwd(const mtt_chanattn_desc* d, void* stream) {
   if (!d || !d->q || !d->kvT || !d->rawchan || !d->cx || d->B <= 0 || d->T <= 0 || d->C <= 0 || d->ce <= 0 || d->nh <= 0 || d->nw <= 0) return MTT_E_BADARG;
   const int r = (int)(sqrt((double)d->ce) + 0.5);
   if (r * r != d->ce || (r % d->nh) || (r % d->nw) || (r / d->nh) * (r / d->nw) > 1024 || d->C > 16384) return MTT_E_BADARG;
-  hipLaunchKernelGGL(chanattn_kernel, dim3((unsigned)(d->B * d->T * d->nh * d->nw)), dim3(256), d->C * 4, S_, *d);
+  const int groups = d->B * d->T * d->nh * d->nw, P = (r / d->nh) * (r / d->nw);
+  hipLaunchKernelGGL(chanattn_logits_kernel, dim3((unsigned)((d->C + 255) / 256), (unsigned)groups), dim3(256), 0, S_, *d);
+  hipLaunchKernelGGL(chanattn_mix_kernel, dim3((unsigned)((P + 31) / 32), (unsigned)groups), dim3(256), d->C * 4, S_, *d);
   return (int)hipGetLastError();
 }
 

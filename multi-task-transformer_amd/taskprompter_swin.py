@@ -367,11 +367,15 @@ class TaskPrompterSwin(nn.Module):
         q = self._lin(chan_p, blk.chan_q, tag + ('cq',), out_dtype=torch.float32)[0]                     # [B*T, ce]
         Wkv = ops.pack_linear([blk.chan_kv.weight], prec, tag + ('ckv',))                                # [1, 2ce, pad8(HW)]
         Cp = ops.pad8(C)
-        kvT = torch.empty(B, 2 * ce, Cp, dtype=torch.float32, device=dev)
         pov = po.view(B, N, C)[:, T:]
-        ops.call("gemm", A=Wkv, B=pov, D=kvT, M=2 * ce, N=C, K=H * W, a_op=OP_K, b_op=OP_R, a_dtype=dtype_code(Wkv), b_dtype=dtype_code(po),
-                 d_dtype=F32, prec=prec.code, lda=Wkv.shape[-1], ldb=C, ldd=Cp, batch=B, batch_inner=1, a_zo=0, b_zo=N * C, d_zo=2 * ce * Cp,
-                 alpha=1.0, n_store=Cp)
+        K = H * W
+        Ks = _split_k(K)                                                        # the reduction axis is the pixel count (73 728 at the first
+        S = K // Ks                                                             # Swin-B stage) and M x N is tiny: split it over workgroups
+        slabs = torch.empty(B, S, 2 * ce, Cp, dtype=torch.float32, device=dev)
+        ops.call("gemm", A=Wkv, B=pov, D=slabs, M=2 * ce, N=C, K=Ks, a_op=OP_K, b_op=OP_R, a_dtype=dtype_code(Wkv), b_dtype=dtype_code(po),
+                 d_dtype=F32, prec=prec.code, lda=Wkv.shape[-1], ldb=C, ldd=Cp, batch=B * S, batch_inner=S, a_zo=0, a_zi=Ks, b_zo=N * C,
+                 b_zi=Ks * C, d_zo=S * 2 * ce * Cp, d_zi=2 * ce * Cp, alpha=1.0, n_store=Cp)
+        kvT = slabs.sum(1) if S > 1 else slabs.view(B, 2 * ce, Cp)
         rawchan = torch.empty(B, T, nwin * nwin, C, dtype=torch.float32, device=dev)
         cx = torch.empty(B * T, ce, dtype=torch.float32, device=dev)
         ops.call("chanattn_fwd", q=q, kvT=kvT, rawchan=rawchan, cx=cx, B=B, T=T, C=C, ce=ce, nh=nwin, nw=nwin, kv_dtype=F32, ldk=Cp,
@@ -453,6 +457,15 @@ class TaskPrompterSwin(nn.Module):
             y1 = ops.conv3x3(y0, Wc, F, F, B, 2 * h, 2 * w, prec, bias=sh, colscale=sc, act=ACT_GELU)
         W4 = ops.pack_conv3([m[4].weight for m in ff], prec, ('swf4', il))
         return ops.conv3x3(y1, W4, F, F, B, 2 * h, 2 * w, prec, bias=ops.stack_vec([m[4].bias for m in ff], ('swf4b', il)))
+
+
+def _split_k(K, target=1152):
+    """Largest divisor of K that is a multiple of 8 and <= target (K itself when there is none): the K slice of one workgroup batch."""
+    best = K
+    for ks in range(8, min(K, target) + 1, 8):
+        if K % ks == 0:
+            best = ks
+    return best if best <= target else K
 
 
 def taskprompter_create_swin_transformer(variant, pretrained=False, default_cfg=None, **kwargs):
