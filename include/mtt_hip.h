@@ -382,6 +382,7 @@ typedef struct {
   const void* src; void* dst; const int32_t* idx;
   int64_t rows; int32_t C; int64_t ld_src, ld_dst; int32_t src_dtype, dst_dtype;
   int32_t B; int64_t src_bs, dst_bs, idx_bs;
+  int32_t skip_neg;              /* 1: rows with idx < 0 are left untouched instead of zero-filled (scatter-style adjoints) */
 } mtt_gather_desc;
 int mtt_gather_rows(const mtt_gather_desc* d, void* stream);
 
@@ -398,6 +399,10 @@ typedef struct {
   int32_t nwin, nW, nH, T, ws2, dtype; float scale; int64_t map_ld, map_off;
 } mtt_winattn_desc;
 int mtt_winattn_fwd(const mtt_winattn_desc* d, void* stream);
+/* backward (d as in the forward, d->out = the forward's output): dout (dtype) [nwin, N, nH*32]; drawmap fp32 = gradient of rawmap (same
+ * layout; NULL = none) -> dqkv (dtype) [nwin, N, 3*nH*32] (written), dS_out fp32 [nwin, nH, ws2, ws2] = dS of the window x window
+ * part (written when not NULL; the relative-position-bias gradient is its sum over the windows). */
+int mtt_winattn_bwd(const mtt_winattn_desc* d, const void* dout, const float* drawmap, void* dqkv, float* dS_out, void* stream);
 
 /* Channel attention of the prompts over the feature channels (taskprompter_swin.py:391-409), windows over the sqrt(ce) x sqrt(ce) grid
  * of the channel-embedding dimension:

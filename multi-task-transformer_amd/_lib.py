@@ -149,7 +149,7 @@ class LossDesc(C.Structure):
 
 class GatherDesc(C.Structure):
     _fields_ = [("src", ptr), ("dst", ptr), ("idx", ptr), ("rows", i64), ("C", i32), ("ld_src", i64), ("ld_dst", i64),
-                ("src_dtype", i32), ("dst_dtype", i32), ("B", i32), ("src_bs", i64), ("dst_bs", i64), ("idx_bs", i64)]
+                ("src_dtype", i32), ("dst_dtype", i32), ("B", i32), ("src_bs", i64), ("dst_bs", i64), ("idx_bs", i64), ("skip_neg", i32)]
 
 
 class WinAttnDesc(C.Structure):
@@ -206,6 +206,7 @@ DESC_EXTRA = {
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr]),
     "attn_bwd": (AttnDesc, [ptr, ptr, ptr, ptr]),
+    "winattn_bwd": (WinAttnDesc, [ptr, ptr, ptr, ptr]),
     "grad_sqnorm": (AdamDesc, [ptr]),
     "adam_step": (AdamDesc, [ptr]),
     "loss_label_stats": (LossDesc, [ptr]),

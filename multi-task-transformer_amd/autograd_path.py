@@ -424,8 +424,9 @@ class ModulateFn(Function):
 
     @staticmethod
     def forward(ctx, xsrc, rawlog, rawchan, geo, prec):
-        B, N, T, C, h, w, nwin = geo
-        mod = ops.modulate(xsrc.view(B, N, C)[:, T:], C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec)
+        B, N, T, C, h, w, nwin = geo[:7]
+        hg = geo[7] if len(geo) > 7 else 0               # channels per attention head (0 = 64; the Swin stages pass theirs)
+        mod = ops.modulate(xsrc.view(B, N, C)[:, T:], C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec, hg=hg)
         ctx.save_for_backward(xsrc, rawlog, rawchan)
         ctx.geo = geo
         return mod
@@ -433,12 +434,13 @@ class ModulateFn(Function):
     @staticmethod
     def backward(ctx, dmod):
         xsrc, rawlog, rawchan = ctx.saved_tensors
-        B, N, T, C, h, w, nwin = ctx.geo
+        B, N, T, C, h, w, nwin = ctx.geo[:7]
+        hg = ctx.geo[7] if len(ctx.geo) > 7 else 0
         dmod = dmod.contiguous()
         dx = torch.zeros_like(xsrc)
         dl, dc = torch.zeros_like(rawlog), torch.zeros_like(rawchan)
         ops.call("modulate_bwd", x=xsrc.view(B, N, C)[:, T:], x_ld=C, x_bs=N * C, rawlog=rawlog, rawchan=rawchan, out=None,
-                 B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin, out_dtype=dtype_code(dmod),
+                 B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin, out_dtype=dtype_code(dmod), hg=hg,
                  xargs=[dmod, dx.view(B, N, C)[:, T:], dl, dc])
         return dx, dl, dc, None, None
 

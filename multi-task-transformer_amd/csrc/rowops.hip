@@ -831,7 +831,8 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const void* src, float* d
 __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_desc d, const void* dout, float* dx,
                                                            float* drawlog, float* drawchan, int tbase) {
   const int nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw, P = wh * ww, hw = d.h * d.w;
-  const int nH = d.C >> 6;
+  const int hg = d.hg > 0 ? d.hg : 64;             // 64 or 32 channels per head (host-checked)
+  const int nH = d.C / hg;
   const int b = blockIdx.z / nwin, win = blockIdx.z % nwin;
   const int wy = win / d.nw, wx = win % d.nw;
   const int cl = threadIdx.x & 31, plane = threadIdx.x >> 5;
@@ -846,7 +847,8 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
   const int per = (P + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * per, p1 = p0 + per < P ? p0 + per : P;
-  const int head = (cchunk * 8) >> 6;
+  const int head = (cchunk * 8) / hg;
+  const int lanes_per_head = hg >> 3;              // 8 (or 4) consecutive lanes hold the chunks of one head
   for (int pi0 = p0; pi0 < p1; pi0 += 8) {
     const int pi = pi0 + plane;
     const bool pok = pi < p1 && cok;
@@ -879,9 +881,10 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
           dl += gs[j] * xv[j];
           acc[t][j] += gc[j] * xv[j];
         }
-        // the 8 chunks of one head are 8 consecutive lanes
-        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
-        if (pok && (cl & 7) == 0) drawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + pix] = dl;
+        // the chunks of one head are consecutive lanes
+        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64);
+        if (lanes_per_head == 8) dl += __shfl_xor(dl, 4, 64);
+        if (pok && (cl & (lanes_per_head - 1)) == 0) drawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + pix] = dl;
       }
     }
     if (pok && tbase == 0) {
@@ -1323,8 +1326,9 @@ extern "C" int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t c
 }
 
 extern "C" int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, void* stream) {
-  if (!d || !d->x || !d->rawlog || !d->rawchan || !dout || !dx || !drawlog || !drawchan || (d->C % 64)) return MTT_E_BADARG;
-  if (d->hg != 0 && d->hg != 64) return MTT_E_UNSUPPORTED;      /* the head reduction of drawlog is written for 64-channel heads */
+  if (!d || !d->x || !d->rawlog || !d->rawchan || !dout || !dx || !drawlog || !drawchan || (d->C % 32)) return MTT_E_BADARG;
+  if (d->hg != 0 && d->hg != 64 && d->hg != 32) return MTT_E_UNSUPPORTED;      /* the head reduction of drawlog: 8 or 4 lanes */
+  if (d->C % (d->hg > 0 ? d->hg : 64)) return MTT_E_BADARG;
   if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw)) return MTT_E_BADARG;
   const int P = (d->h / d->nh) * (d->w / d->nw);
   int splits = P / 64; if (splits < 1) splits = 1; if (splits > 32) splits = 32;

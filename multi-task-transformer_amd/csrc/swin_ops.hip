@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const mtt_gather_desc 
     const int64_t r = (t / chunks) % d.rows;
     const int64_t b = t / ((int64_t)chunks * d.rows);
     const int src_row = d.idx[b * d.idx_bs + r];
+    if (src_row < 0 && d.skip_neg) continue;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (src_row >= 0) ld8g(d.src, b * d.src_bs + (int64_t)src_row * d.ld_src + ch * 8, d.src_dtype, v);
     st8g(d.dst, b * d.dst_bs + r * d.ld_dst + ch * 8, d.dst_dtype, v);
@@ -268,6 +269,110 @@ __global__ __launch_bounds__(256) void winattn_f32_kernel(const mtt_winattn_desc
 }
 
 // ------------------------------------------------------------------------------------------------
+// Window attention backward (first version: exact fp32 VALU arithmetic for both storage dtypes; one workgroup per (window, head), the
+// five [N][32] operands Q, K, V, dO, O staged in LDS).  With P = softmax(S), D_i = dO_i . O_i:
+//   dS_ij = P_ij (dO_i . v_j - D_i);  g_ij = scale dS_ij + draw_ij   (draw = gradient of the raw prompt-row logits, image layout)
+//   dq_i = sum_j g_ij k_j   (phase 1, a thread per query: row max / sum first)      dk_j = sum_i g_ij q_i,  dv_j = sum_i P_ij dO_i
+//   (phase 2, a thread per key);  dS of the window x window part goes to dS_out [nwin, nH, ws2, ws2] when given (the relative-position
+//   bias gradient is its sum over windows, gathered by the host through relative_position_index).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void winattn_bwd_kernel(const mtt_winattn_desc d, const void* dout, const float* drawmap, void* dqkv, float* dS_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nH = d.nH, T = d.T, ws2 = d.ws2, N = T + ws2, C = nH * 32, ld = 3 * C;
+  float* qs = (float*)smem_raw;                    // [N][33] each
+  float* ks = qs + N * 33;
+  float* vs = ks + N * 33;
+  float* gs = vs + N * 33;                         // dO
+  float* os = gs + N * 33;                         // O
+  float* mrow = os + N * 33;                       // [N] row max, [N] 1 / row sum, [N] D
+  float* linv = mrow + N;
+  float* Drow = linv + N;
+  const int win = blockIdx.x / nH, h = blockIdx.x % nH;
+  const int wl = win % d.nW, b = win / d.nW;
+  const int64_t base = (int64_t)win * N * ld + h * 32, obase = (int64_t)win * N * C + h * 32;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < N * 32; e += 256) {
+    const int row = e >> 5, dd = e & 31;
+    qs[row * 33 + dd] = ld_elem(d.qkv, base + (int64_t)row * ld + dd, d.dtype);
+    ks[row * 33 + dd] = ld_elem(d.qkv, base + C + (int64_t)row * ld + dd, d.dtype);
+    vs[row * 33 + dd] = ld_elem(d.qkv, base + 2 * C + (int64_t)row * ld + dd, d.dtype);
+    gs[row * 33 + dd] = ld_elem(dout, obase + (int64_t)row * C + dd, d.dtype);
+    os[row * 33 + dd] = ld_elem(d.out, obase + (int64_t)row * C + dd, d.dtype);
+  }
+  __syncthreads();
+  const float* bias_h = d.bias + (int64_t)h * ws2 * ws2;
+  const float* mask_w = d.mask ? d.mask + (int64_t)wl * ws2 * ws2 : nullptr;
+  const int32_t* px = d.pix + (int64_t)wl * ws2;
+  auto logit = [&](int i, int j) {
+    float a = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) a = fmaf(qs[i * 33 + dd], ks[j * 33 + dd], a);
+    float v = a * d.scale;
+    if (i >= T && j >= T) {
+      const int64_t o = (int64_t)(i - T) * ws2 + (j - T);
+      v += bias_h[o];
+      if (mask_w) v += mask_w[o];
+    }
+    return v;
+  };
+  auto draw = [&](int i, int j) {                  // gradient of the raw logit (i < T prompt row, j >= T window pixel), else 0
+    if (!drawmap || i >= T || j < T) return 0.f;
+    const int pp = px[j - T];
+    return pp >= 0 ? drawmap[(((int64_t)b * nH + h) * T + i) * d.map_ld + d.map_off + pp] : 0.f;
+  };
+  // ---- phase 1: a thread per query ----
+  if (tid < N) {
+    const int i = tid;
+    float mx = -INFINITY;
+    for (int j = 0; j < N; ++j) mx = fmaxf(mx, logit(i, j));
+    float l = 0.f;
+    for (int j = 0; j < N; ++j) l += expf(logit(i, j) - mx);
+    float D = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) D = fmaf(gs[i * 33 + dd], os[i * 33 + dd], D);
+    mrow[i] = mx; linv[i] = 1.0f / l; Drow[i] = D;
+    float dq[32];
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) dq[dd] = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float pv = expf(logit(i, j) - mx) / l;
+      float dp = 0.f;
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) dp = fmaf(gs[i * 33 + dd], vs[j * 33 + dd], dp);
+      const float g = d.scale * pv * (dp - D) + draw(i, j);
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) dq[dd] = fmaf(g, ks[j * 33 + dd], dq[dd]);
+    }
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) st_elem(dqkv, base + (int64_t)i * ld + dd, d.dtype, dq[dd]);
+  }
+  __syncthreads();
+  // ---- phase 2: a thread per key ----
+  if (tid < N) {
+    const int j = tid;
+    float dk[32], dv[32];
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) { dk[dd] = 0.f; dv[dd] = 0.f; }
+    for (int i = 0; i < N; ++i) {
+      const float pv = expf(logit(i, j) - mrow[i]) * linv[i];
+      float dp = 0.f;
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) dp = fmaf(gs[i * 33 + dd], vs[j * 33 + dd], dp);
+      const float ds = pv * (dp - Drow[i]);
+      const float g = d.scale * ds + draw(i, j);
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) { dk[dd] = fmaf(g, qs[i * 33 + dd], dk[dd]); dv[dd] = fmaf(pv, gs[i * 33 + dd], dv[dd]); }
+      if (dS_out && i >= T && j >= T) dS_out[(((int64_t)win * nH + h) * ws2 + (i - T)) * ws2 + (j - T)] = ds;
+    }
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) {
+      st_elem(dqkv, base + C + (int64_t)j * ld + dd, d.dtype, dk[dd]);
+      st_elem(dqkv, base + 2 * C + (int64_t)j * ld + dd, d.dtype, dv[dd]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Channel attention in two kernels (the first version ran everything of a (b, t, window) in ONE workgroup: 8 workgroups on the chip,
 // 267 us per call = 10 % of the Swin-B forward, profiles/r02_prof_swin_q_forward_b4_first.txt):
 //   logits: grid (C / 256, B*T*nwin) — a thread owns one feature channel c (coalesced kT rows), loops over the window's elements;
@@ -436,6 +541,18 @@ extern "C" int mtt_winattn_fwd(const mtt_winattn_desc* d, void* stream) {
   else if (N <= 64) hipLaunchKernelGGL(winattn_bf16_kernel<4>, grid, dim3(256), 0, S_, *d);
   else if (N <= 96) hipLaunchKernelGGL(winattn_bf16_kernel<6>, grid, dim3(256), 0, S_, *d);
   else hipLaunchKernelGGL(winattn_bf16_kernel<10>, grid, dim3(256), 0, S_, *d);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_winattn_bwd(const mtt_winattn_desc* d, const void* dout, const float* drawmap, void* dqkv, float* dS_out, void* stream) {
+  if (!d || !d->qkv || !d->out || !d->bias || !d->pix || !dout || !dqkv || d->nwin <= 0 || d->nW <= 0 || d->nH <= 0 || d->T < 0 || d->ws2 <= 0) return MTT_E_BADARG;
+  if (d->nwin % d->nW) return MTT_E_BADARG;
+  const int N = d->T + d->ws2;
+  if (N > 160) return MTT_E_UNSUPPORTED;
+  const int smem = (5 * N * 33 + 3 * N) * 4;
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)winattn_bwd_kernel, smem, done)) return e;
+  hipLaunchKernelGGL(winattn_bwd_kernel, dim3((unsigned)(d->nwin * d->nH)), dim3(256), smem, S_, *d, dout, drawmap, dqkv, dS_out);
   return (int)hipGetLastError();
 }
 

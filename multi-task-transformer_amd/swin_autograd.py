@@ -1,0 +1,349 @@
+"""Training (autograd) path of TaskPrompterSwin: the forward of taskprompter_swin.py as a graph of autograd Functions.
+
+First version — correct, not yet fast.  The heavy operators are the HIP building blocks of the ViT variant (LayerNormFn, BLinearFn,
+MlpHalfFn, ModulateFn, Conv3x3Fn, BnActStackFn, BilinearFn) plus four new Functions: window gather (forward and adjoint through the same
+mtt_gather_rows kernel with the inverse tables), window attention (mtt_winattn_fwd / mtt_winattn_bwd; the relative-position-bias
+gradient is the window sum of the kernel's dS, index-added into the table), channel attention (HIP forward; its backward — a few
+hundred thousand elements — is recomputed with torch autograd) and the 3x3 stride-2 convolution of the attention maps (HIP forward,
+torch backward on the 8..96-channel maps).  Residual adds, prompt / pixel row concatenations and the transposed copy feeding chan_kv
+are torch ops here (the inference path has none of them): listed in DESIGN.md as the next things to fuse.  DropPath must be 0
+(the reference draws several independent masks per block, taskprompter_swin.py:412-414; not reproduced yet).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import ACT_GELU, dtype_code
+from .autograd_path import (BilinearFn, BLinearFn, Conv3x3Fn, LayerNormFn, MlpHalfFn, ModulateFn, _bn_act)
+
+
+def _gather(src, dst, idx, rows, C, ld_src, ld_dst, B, src_bs, dst_bs, skip_neg=0):
+    ops.call("gather_rows", src=src, dst=dst, idx=idx, rows=rows, C=C, ld_src=ld_src, ld_dst=ld_dst, src_dtype=dtype_code(src),
+             dst_dtype=dtype_code(dst), B=B, src_bs=src_bs, dst_bs=dst_bs, idx_bs=0, skip_neg=skip_neg)
+
+
+class WindowGatherFn(Function):
+    """to_windows=True : image token rows [B*N, C] -> window tokens [B*nW*Nw, C] (shift, zero padding, the T prompts joined to every window)
+       to_windows=False: window rows -> image rows [B*N, C]; the T prompt rows are the MEAN over the windows (taskprompter_swin.py:208).
+    Each direction's adjoint is the other direction's gather (prompt rows summed / spread by hand)."""
+
+    @staticmethod
+    def forward(ctx, x, to_windows, part, rev, geo):
+        B, N, T, nW, Nw, C = geo
+        ctx.tables, ctx.geo, ctx.to_windows = (part, rev), geo, to_windows
+        if to_windows:
+            out = torch.empty(B * nW * Nw, C, dtype=x.dtype, device=x.device)
+            _gather(x, out, part, nW * Nw, C, C, C, B, N * C, nW * Nw * C)
+        else:
+            out = torch.empty(B * N, C, dtype=x.dtype, device=x.device)
+            _gather(x, out.view(B, N, C)[:, T:], rev, N - T, C, C, C, B, nW * Nw * C, N * C)
+            out.view(B, N, C)[:, :T] = x.view(B, nW, Nw, C)[:, :, :T].float().mean(1).to(x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, T, nW, Nw, C = ctx.geo
+        part, rev = ctx.tables
+        dy = dy.contiguous()
+        if ctx.to_windows:                       # dy: window rows -> d image rows
+            dx = torch.empty(B * N, C, dtype=dy.dtype, device=dy.device)
+            _gather(dy, dx.view(B, N, C)[:, T:], rev, N - T, C, C, C, B, nW * Nw * C, N * C)
+            dx.view(B, N, C)[:, :T] = dy.view(B, nW, Nw, C)[:, :, :T].float().sum(1).to(dy.dtype)
+        else:                                    # dy: image rows -> d window rows (padding positions get zero)
+            dx = torch.empty(B * nW * Nw, C, dtype=dy.dtype, device=dy.device)
+            _gather(dy, dx, part, nW * Nw, C, C, C, B, N * C, nW * Nw * C)
+            dx.view(B, nW, Nw, C)[:, :, :T] *= 1.0 / nW
+        return dx, None, None, None, None
+
+
+class MergeGatherFn(Function):
+    """PatchMerging's 2x2 concatenation (taskprompter_swin.py:450-456): pixel rows of XT [B*N, C] fp32 -> [B*(N2-T), 4C]."""
+
+    @staticmethod
+    def forward(ctx, XT, tables, inv_tables, geo):
+        B, N, N2, T, C = geo
+        ctx.inv, ctx.geo = inv_tables, geo
+        cat = torch.empty(B * (N2 - T), 4 * C, dtype=torch.float32, device=XT.device)
+        for k, idx in enumerate(tables):
+            _gather(XT, cat[:, k * C:], idx, N2 - T, C, C, 4 * C, B, N * C, (N2 - T) * 4 * C)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        B, N, N2, T, C = ctx.geo
+        dcat = dcat.contiguous()
+        dXT = torch.zeros(B * N, C, dtype=torch.float32, device=dcat.device)
+        for k, inv in enumerate(ctx.inv):        # every pixel receives from exactly one (row, column block): 4 disjoint scatter-style gathers
+            _gather(dcat[:, k * C:], dXT.view(B, N, C)[:, T:], inv, N - T, C, 4 * C, C, B, (N2 - T) * 4 * C, N * C, skip_neg=1)
+        return dXT, None, None, None
+
+
+class WinAttnFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, table, rel_index, mask, pix, geo):
+        B, nW, nH, T, ws2, N = geo
+        Nw, C = T + ws2, nH * 32
+        bias = table.detach()[rel_index.view(-1)].view(ws2, ws2, nH).permute(2, 0, 1).contiguous().float()
+        out = torch.empty(B * nW * Nw, C, dtype=qkv.dtype, device=qkv.device)
+        rawlog = torch.zeros(B, nH, T, N, dtype=torch.float32, device=qkv.device)
+        kw = dict(qkv=qkv, out=out, bias=bias, mask=mask, pix=pix, nwin=B * nW, nW=nW, nH=nH, T=T, ws2=ws2, dtype=dtype_code(qkv),
+                  scale=32 ** -0.5, map_ld=N, map_off=T)
+        ops.call("winattn_fwd", rawmap=rawlog, **kw)
+        ctx.kw, ctx.geo, ctx.rel_index = kw, geo, rel_index
+        ctx.save_for_backward(table)
+        return out, rawlog
+
+    @staticmethod
+    def backward(ctx, dout, drawlog):
+        B, nW, nH, T, ws2, N = ctx.geo
+        (table,) = ctx.saved_tensors
+        kw = ctx.kw
+        qkv = kw["qkv"]
+        dqkv = torch.empty_like(qkv)
+        dS = torch.empty(B * nW, nH, ws2, ws2, dtype=torch.float32, device=qkv.device)
+        dout = dout.contiguous()
+        ops.call("winattn_bwd", rawmap=None, xargs=[dout, drawlog.contiguous() if drawlog is not None else None, dqkv, dS], **kw)
+        dbias = dS.sum(0).permute(1, 2, 0).reshape(ws2 * ws2, nH)
+        dtable = torch.zeros_like(table).index_add_(0, ctx.rel_index.view(-1), dbias)
+        return dqkv, dtable, None, None, None, None
+
+
+def _chan_split(t, B, nh, nw, wh, ww):          # [B, X, ce] -> [B, nwin, X, wh*ww]   ('b t (nh h nw w) -> b (nh nw) t (h w)')
+    return t.view(B, t.shape[1], nh, wh, nw, ww).permute(0, 2, 4, 1, 3, 5).reshape(B, nh * nw, t.shape[1], wh * ww)
+
+
+class ChanAttnFn(Function):
+    """q [B*T, ce] fp32, kv [B, C, 2ce] fp32 (k | v per channel, biases included) -> rawchan [B, T, nwin, C], cx [B*T, ce]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, geo):
+        B, T, C, ce, nwin = geo
+        Cp = ops.pad8(C)
+        kvT = torch.zeros(B, 2 * ce, Cp, dtype=torch.float32, device=q.device)
+        kvT[:, :, :C] = kv.transpose(1, 2)
+        rawchan = torch.empty(B, T, nwin * nwin, C, dtype=torch.float32, device=q.device)
+        cx = torch.empty(B * T, ce, dtype=torch.float32, device=q.device)
+        ops.call("chanattn_fwd", q=q, kvT=kvT, rawchan=rawchan, cx=cx, B=B, T=T, C=C, ce=ce, nh=nwin, nw=nwin, kv_dtype=0, ldk=Cp,
+                 scale=ce ** -0.5, kvbias=None)
+        ctx.save_for_backward(q, kv)
+        ctx.geo = geo
+        return rawchan, cx
+
+    @staticmethod
+    def backward(ctx, drawchan, dcx):
+        q, kv = ctx.saved_tensors
+        B, T, C, ce, nwin = ctx.geo
+        r = math.isqrt(ce)
+        wh = ww = r // nwin
+        with torch.enable_grad():
+            q_ = q.detach().view(B, T, ce).requires_grad_(True)
+            kv_ = kv.detach().requires_grad_(True)
+            k, v = kv_[:, :, :ce], kv_[:, :, ce:]
+            qs, ks, vs = _chan_split(q_, B, nwin, nwin, wh, ww), _chan_split(k, B, nwin, nwin, wh, ww), _chan_split(v, B, nwin, nwin, wh, ww)
+            raw = qs @ ks.transpose(-1, -2)                                            # [B, nwin2, T, C]
+            cx = torch.softmax(raw * ce ** -0.5, -1) @ vs                              # [B, nwin2, T, P]
+            cx = cx.view(B, nwin, nwin, T, wh, ww).permute(0, 3, 1, 4, 2, 5).reshape(B * T, ce)
+            gq, gkv = torch.autograd.grad([raw.permute(0, 2, 1, 3), cx], [q_, kv_], [drawchan, dcx])
+        return gq.reshape(B * T, ce), gkv, None
+
+
+class Conv3s2Fn(Function):
+    """PatchMerging.spa_attn_ds on the raw prompt-logit maps [B, nH, T, T + H*W] -> [B, nH, T, T + H*W/4]."""
+
+    @staticmethod
+    def forward(ctx, rawlog, weight, bias, geo):
+        B, nH, T, H, W = geo
+        N, N2 = T + H * W, T + (H // 2) * (W // 2)
+        raw2 = torch.zeros(B, nH, T, N2, dtype=torch.float32, device=rawlog.device)
+        ops.call("conv3s2_nchw", x=rawlog, w=weight.detach().contiguous(), bias=bias.detach(), y=raw2, B=B, Ci=nH * T, Co=nH * T, H=H, W=W,
+                 x_bs=nH * T * N, x_cs=N, x_off=T, y_bs=nH * T * N2, y_cs=N2, y_off=T)
+        ctx.save_for_backward(rawlog, weight, bias)
+        ctx.geo = geo
+        return raw2
+
+    @staticmethod
+    def backward(ctx, draw2):
+        rawlog, weight, bias = ctx.saved_tensors
+        B, nH, T, H, W = ctx.geo
+        with torch.enable_grad():
+            x = rawlog.detach()[..., T:].reshape(B, nH * T, H, W).requires_grad_(True)
+            w_, b_ = weight.detach().requires_grad_(True), bias.detach().requires_grad_(True)
+            y = torch.nn.functional.conv2d(x, w_, b_, stride=2, padding=1)
+            g = draw2[..., T:].reshape(B, nH * T, H // 2, W // 2)
+            gx, gw, gb = torch.autograd.grad(y, [x, w_, b_], g)
+        dl = torch.zeros_like(rawlog)
+        dl[..., T:] = gx.reshape(B, nH, T, H * W)
+        return dl, gw, gb, None
+
+
+_zero_bias = {}
+
+
+def _lin(model, x, layer, tag, out_dtype=None):
+    """x [M, K] (activation dtype) @ layer.weight^T + bias through BLinearFn (bias-free layers get a constant zero vector)."""
+    bias = layer.bias
+    if bias is None:
+        key = (layer.weight.shape[0], str(x.device))
+        if key not in _zero_bias:
+            _zero_bias[key] = torch.zeros(layer.weight.shape[0], dtype=torch.float32, device=x.device)
+        bias = _zero_bias[key]
+    if x.shape[-1] % 8:                                   # reduction length not a multiple of 8 (chan_kv on a 6 x 9 map): zero columns
+        x = torch.nn.functional.pad(x, (0, 8 - x.shape[-1] % 8))
+    y = BLinearFn.apply(x, layer.weight.shape[0], 'plain', None, out_dtype, model.prec, tag, layer.weight, bias)
+    return y[0][:, :layer.weight.shape[0]]
+
+
+def _inverse_merge_tables(res, T, device):
+    """For k = (dy, dx) in PatchMerging's order: table over ALL H*W pixels, the merged row that holds the pixel in column block k, -1 else."""
+    H, W = res
+    yy = torch.arange(H)[:, None]
+    xx = torch.arange(W)[None, :]
+    row = (yy // 2) * (W // 2) + xx // 2
+    out = []
+    for dy, dx in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        ok = ((yy % 2) == dy) & ((xx % 2) == dx)
+        out.append(torch.where(ok, row, torch.full_like(row, -1)).reshape(-1).to(torch.int32).to(device))
+    return out
+
+
+def backbone_forward(model, img):
+    """Autograd twin of TaskPrompterSwin._forward_nograd -> [T, B*h0*w0, pad8(F)] task features."""
+    from . import taskprompter_swin as sw
+    p, prec = model.p, model.prec
+    adt = prec.adt
+    dev = img.device
+    B = img.shape[0]
+    assert all(l_.blocks[i].drop_path_rate == 0.0 for l_ in model.layers for i in range(len(l_.blocks))), \
+        "TaskPrompterSwin training: DropPath is not built yet (construct with drop_path_rate=0)"
+    img = img.float().contiguous()
+    if model.img_ds_ratio != 1:
+        Hs, Ws = model.patch_embed.img_size
+        small = torch.empty(B, 3, Hs, Ws, dtype=torch.float32, device=dev)
+        ops.call("resize_nchw", args=[img, small, B * 3, img.shape[-2], img.shape[-1], Hs, Ws])
+        img = small
+    T = model.prompts_len
+    ps = model.patch_embed.patch_size[0]
+    gh, gw = model.patch_grid
+    C = model.embed_dim
+    Kp = ops.pad8(3 * ps * ps)
+    cols = torch.empty(B * gh * gw, Kp, dtype=adt, device=dev)
+    ops.call("patchify", args=[img, cols, B, img.shape[-2], img.shape[-1], ps, Kp, dtype_code(cols)])
+    pe = _lin(model, cols, model.patch_embed.proj, 'swpe', torch.float32)
+    if isinstance(model.patch_embed.norm, torch.nn.LayerNorm):
+        nm = model.patch_embed.norm
+        pe = LayerNormFn.apply(pe.contiguous(), nm.weight, nm.bias, nm.eps, prec, torch.float32)
+    XT = torch.cat([model.task_prompts[None].expand(B, T, C), pe.reshape(B, gh * gw, C)], 1).reshape(B * (T + gh * gw), C)
+
+    fea_levels = []
+    rawlog = rawchan = None
+    nl = model.num_layers
+    for il, layer in enumerate(model.layers):
+        res = layer.input_resolution
+        for ib, blk in enumerate(layer.blocks):
+            XT, rawlog, rawchan = _block(model, blk, (il, ib), XT, B, T, res)
+        if layer.downsample is not None:
+            XT, rawlog, rawchan = _merge(model, layer.downsample, il, XT, rawlog, rawchan, B, T, res, layer.blocks[0].num_heads)
+            r2 = (res[0] // 2, res[1] // 2)
+            fea_levels.append(_task_features(model, XT, rawlog, rawchan, il, B, r2, 2 * layer.dim, 2 * layer.dim // layer.blocks[0].num_heads))
+    res = model.layers[-1].input_resolution
+    Cl = model.layers[-1].dim
+    xf = LayerNormFn.apply(XT, model.norm.weight, model.norm.bias, model.norm.eps, prec, torch.float32)
+    fea_levels.append(_task_features(model, xf, rawlog, rawchan, nl - 1, B, res, Cl, Cl // model.layers[-1].blocks[0].num_heads))
+    h0, w0 = model.feature_hw
+    Fp = fea_levels[0].shape[-1]
+    acc = None
+    for i, f in enumerate(fea_levels):
+        hi, wi = 2 * model.resolution[i][0], 2 * model.resolution[i][1]
+        up = BilinearFn.apply(f, (B, Fp, hi, wi, h0, w0), torch.float32, False)
+        acc = up if acc is None else acc + up
+    names = list(model.all_tasks)
+    F = p.final_embed_dim
+    accq = acc if adt == torch.float32 else acc.to(adt)
+    return Conv3x3Fn.apply(accq, (B, h0, w0, F, F), prec, 'swmsf', *[model.multi_scale_fuse[t].weight for t in names],
+                           *[model.multi_scale_fuse[t].bias for t in names])
+
+
+def _block(model, blk, tag, XT, B, T, res):
+    from . import taskprompter_swin as sw
+    prec = model.prec
+    adt = prec.adt
+    dev = XT.device
+    H, W = res
+    C, nH, ws, shift = blk.dim, blk.num_heads, blk.window_size, blk.shift_size
+    Hp, Wp = blk.padded
+    N, ws2 = T + H * W, ws * ws
+    Nw, nW = T + ws2, (Hp // ws) * (Wp // ws)
+    part, pix, rev = sw.window_tables(res, ws, shift, Hp, Wp, T, dev)
+    tag = ('swt',) + tag
+    a = blk.attn
+    xn = LayerNormFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, prec, None)
+    prompts = XT.view(B, N, C)[:, :T].reshape(B * T, C)
+    chan_p = _lin(model, prompts.to(adt), blk.token_trans, tag + ('tt',), torch.float32)              # [B*T, ce]
+    wtok = WindowGatherFn.apply(xn, True, part, rev, (B, N, T, nW, Nw, C))
+    qkv = _lin(model, wtok, a.qkv, tag + ('qkv',)).contiguous()
+    ao, rawlog = WinAttnFn.apply(qkv, a.relative_position_bias_table, a.relative_position_index, blk.attn_mask, pix, (B, nW, nH, T, ws2, N))
+    ao_img = WindowGatherFn.apply(ao, False, part, rev, (B, N, T, nW, Nw, C))
+    po = _lin(model, ao_img, a.proj, tag + ('proj',))                                                 # [B*N, C] activation dtype
+    XT2 = XT + po.float()
+    # channel attention: kv = chan_kv(x_attn^T) per image (taskprompter_swin.py:393-397)
+    ce = model.p.chan_embed_dim
+    nwin = int(math.isqrt(model.p.chan_nheads))
+    q = _lin(model, chan_p.to(adt), blk.chan_q, tag + ('cq',), torch.float32)
+    xT = po.view(B, N, C)[:, T:].transpose(1, 2).reshape(B * C, H * W)
+    kv = _lin(model, xT.contiguous(), blk.chan_kv, tag + ('ckv',), torch.float32).reshape(B, C, 2 * ce)
+    rawchan, cx = ChanAttnFn.apply(q.contiguous(), kv.contiguous(), (B, T, C, ce, nwin))
+    if not blk.last_block:
+        cp = _lin(model, cx.to(adt), blk.chan_proj, tag + ('cpj',), torch.float32)
+        tt1 = _lin(model, cp.to(adt), blk.token_trans1, tag + ('tt1',), torch.float32)                # [B*T, C]
+        v = XT2.view(B, N, C)
+        XT2 = torch.cat([v[:, :T] + tt1.reshape(B, T, C), v[:, T:]], 1).reshape(B * N, C)
+    XT3 = MlpHalfFn.apply(XT2.contiguous(), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                          blk.mlp.fc2.weight, blk.mlp.fc2.bias, None, (B, N, T), prec, tag)
+    return XT3, rawlog, rawchan
+
+
+def _merge(model, ds, il, XT, rawlog, rawchan, B, T, res, nH):
+    from . import taskprompter_swin as sw
+    prec = model.prec
+    adt = prec.adt
+    dev = XT.device
+    H, W = res
+    C = ds.dim
+    N, N2 = T + H * W, T + (H // 2) * (W // 2)
+    tag = ('swtm', il)
+    cat = MergeGatherFn.apply(XT, sw.merge_tables(res, T, dev), _inverse_merge_tables(res, T, dev), (B, N, N2, T, C))
+    catn = LayerNormFn.apply(cat, ds.norm.weight, ds.norm.bias, ds.norm.eps, prec, None)
+    red = _lin(model, catn, ds.reduction, tag + ('red',), torch.float32)                              # [B*(N2-T), 2C]
+    prompts = XT.view(B, N, C)[:, :T].reshape(B * T, C)
+    pr = _lin(model, prompts.to(adt), ds.task_prompts_up, tag + ('tpu',), torch.float32)
+    XT2 = torch.cat([pr.reshape(B, T, 2 * C), red.reshape(B, N2 - T, 2 * C)], 1).reshape(B * N2, 2 * C)
+    raw2 = Conv3s2Fn.apply(rawlog, ds.spa_attn_ds.weight, ds.spa_attn_ds.bias, (B, nH, T, H, W))
+    nwin2 = rawchan.shape[2]
+    rc2 = _lin(model, rawchan.reshape(B * T * nwin2, C).to(adt), ds.process_chan_attn, tag + ('pca',), torch.float32)
+    return XT2.contiguous(), raw2, rc2.reshape(B, T, nwin2, 2 * C).contiguous()
+
+
+def _task_features(model, xsrc, rawlog, rawchan, il, B, res, C, hg):
+    p, prec = model.p, model.prec
+    names = list(model.all_tasks)
+    T = len(names)
+    h, w = res
+    N = T + h * w
+    tar, F = p.level_embed_dim, p.final_embed_dim
+    tarp = ops.pad8(tar)
+    nwin = int(math.isqrt(p.chan_nheads))
+    mod = ModulateFn.apply(xsrc.contiguous(), rawlog, rawchan, (B, N, T, C, h, w, nwin, hg), prec)
+    dec_w, dec_b = [], []
+    for t in names:
+        dec_w += [model.fea_decode_spa[il][t][0].weight, model.fea_decode_chan[il][t][0].weight]
+        dec_b += [model.fea_decode_spa[il][t][0].bias, model.fea_decode_chan[il][t][0].bias]
+    cat = BLinearFn.apply(mod, tar, 'catpair', None, None, prec, ('swtdec', il), *dec_w, *dec_b)
+    ff = [model.fea_fuse[il][t] for t in names]
+    kmap = (2 * tarp, [(0, 0, tar), (tarp, tar, tar)])
+    y0 = BLinearFn.apply(cat, F, 'plain', kmap, None, prec, ('swtf0', il), *[m[0].weight for m in ff], *[m[0].bias for m in ff])
+    y0 = BilinearFn.apply(y0, (B, y0.shape[-1], h, w, 2 * h, 2 * w), prec.adt, False)
+    y1 = Conv3x3Fn.apply(y0, (B, 2 * h, 2 * w, F, F), prec, ('swtf1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
+    y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)
+    return Conv3x3Fn.apply(y1, (B, 2 * h, 2 * w, F, F), prec, ('swtf4', il), *[m[4].weight for m in ff], *[m[4].bias for m in ff])

@@ -2,8 +2,9 @@
 reference's constructor arguments and state_dict layout (so `load_state_dict(strict=True)` takes its checkpoints and the module drops
 into TaskPrompterWrapper / get_model), executed as a fused schedule on libmtt_hip.so.
 
-Status: FORWARD (inference) path only.  Calling it with gradients enabled raises NotImplementedError — the window-attention /
-channel-attention / gather kernels have no backward yet (the decoder half reuses the differentiable building blocks of the ViT variant).
+Status: the forward (inference) path below is the fused one; with gradients enabled `forward_nhwc` builds the autograd graph of
+swin_autograd.py (first, unoptimised training path: HIP kernels for the heavy operators, torch glue for residual adds and row
+concatenations, DropPath 0 only).
 
 Schedule of a SwinTransformerBlock (taskprompter_swin.py:324-414), per image a token buffer XT [T + H*W, C] fp32 with the T task
 prompts first (like the ViT variant):
@@ -254,7 +255,8 @@ class TaskPrompterSwin(nn.Module):
 
     def forward_nhwc(self, img, upsample=True):
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
-            raise NotImplementedError("TaskPrompterSwin: only the forward (inference) path is built; call under torch.no_grad()")
+            from . import swin_autograd
+            return swin_autograd.backbone_forward(self, img)
         return self._forward_nograd(img)
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------------

@@ -463,7 +463,8 @@ def add_rows(args):
 def modulate_bwd(**kw):
     dout, dx, drawlog, drawchan = kw["xargs"]
     B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
-    hw, nH, nwin = h * w, Cn // 64, nh * nw
+    hg = kw.get("hg") or 64
+    hw, nH, nwin = h * w, Cn // hg, nh * nw
     xi = torch.arange(B)[:, None, None] * kw["x_bs"] + torch.arange(hw)[None, :, None] * kw["x_ld"] + torch.arange(Cn)[None, None, :]
     x = _rd(kw["x"], xi)
     f, o = flat(kw["rawlog"]); rl = f[o:o + B * nH * T * N].double().view(B, nH, T, N)
@@ -475,9 +476,9 @@ def modulate_bwd(**kw):
     dl = torch.zeros(B, nH, T, N, dtype=torch.float64)
     dc = torch.zeros(B, T, nwin, Cn, dtype=torch.float64)
     for t in range(T):
-        a = rl[:, :, t, T:].transpose(1, 2).repeat_interleave(64, dim=2)
+        a = rl[:, :, t, T:].transpose(1, 2).repeat_interleave(hg, dim=2)
         dxv += g[t, 0] * (1 + a) + g[t, 1] * (1 + rc[:, t][:, win])
-        dl[:, :, t, T:] = (g[t, 0] * x).view(B, hw, nH, 64).sum(-1).transpose(1, 2)
+        dl[:, :, t, T:] = (g[t, 0] * x).view(B, hw, nH, hg).sum(-1).transpose(1, 2)
         dc[:, t].index_add_(1, win, g[t, 1] * x)
     _wr(dx, xi, _rd(dx, xi) + dxv)
     li = torch.arange(B * nH * T)[:, None] * N + torch.arange(T, N)[None, :]
@@ -841,7 +842,11 @@ def gather_rows(**kw):
     src_row = fi[oi + b * (kw.get("idx_bs") or 0) + r].long()                      # [B, rows, 1]
     ok = (src_row >= 0).expand(B, rows, Cn)
     v = _rd(kw["src"], b * (kw.get("src_bs") or 0) + src_row * kw["ld_src"] + c, ok)
-    _wr(kw["dst"], (b * (kw.get("dst_bs") or 0) + r * kw["ld_dst"] + c).reshape(-1), v.reshape(-1))
+    di = (b * (kw.get("dst_bs") or 0) + r * kw["ld_dst"] + c).expand(B, rows, Cn)
+    if kw.get("skip_neg"):
+        _wr(kw["dst"], di[ok], v[ok])
+    else:
+        _wr(kw["dst"], di.reshape(-1), v.reshape(-1))
 
 
 def winattn_fwd(**kw):
@@ -871,6 +876,38 @@ def winattn_fwd(**kw):
         dst = ((b * nH + h) * T + t) * kw["map_ld"] + kw.get("map_off", 0) + px[:, None, None, :]
         ok = (px >= 0)[:, None, None, :].expand(nwin, nH, T, ws2)
         _wr(kw["rawmap"], dst[ok], raw[:, :, :T, T:][ok])
+
+
+def winattn_bwd(**kw):
+    """autograd of the forward contract: dqkv, and dS of the window x window part (= gradient wrt a per-window additive term)."""
+    dout, drawmap, dqkv, dS_out = kw["xargs"]
+    nwin, nW, nH, T, ws2 = (kw[k] for k in ("nwin", "nW", "nH", "T", "ws2"))
+    N, Cn = T + ws2, nH * 32
+    qkv = _rd(kw["qkv"], torch.arange(nwin * N * 3 * Cn)).view(nwin, N, 3, nH, 32).clone().requires_grad_(True)
+    extra = torch.zeros(nwin, nH, ws2, ws2, dtype=torch.float64, requires_grad=True)
+    const = _rd(kw["bias"], torch.arange(nH * ws2 * ws2)).view(1, nH, ws2, ws2).expand(nwin, nH, ws2, ws2)
+    if kw.get("mask") is not None:
+        const = const + _rd(kw["mask"], torch.arange(nW * ws2 * ws2)).view(nW, 1, ws2, ws2).repeat(nwin // nW, 1, 1, 1)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    raw = q @ k.transpose(-1, -2)
+    S = raw * kw["scale"] + torch.nn.functional.pad(const + extra, (T, 0, T, 0))
+    o = (torch.softmax(S, -1) @ v).permute(0, 2, 1, 3)                                  # [nwin, N, nH, 32]
+    loss = (o * _rd(dout, torch.arange(nwin * N * Cn)).view(nwin, N, nH, 32)).sum()
+    if drawmap is not None:
+        fp, op = flat(kw["pix"])
+        pix = fp[op:op + nW * ws2].long().view(nW, ws2)
+        w = torch.arange(nwin)
+        px = pix[w % nW]
+        b = (w // nW)[:, None, None, None]
+        h = torch.arange(nH)[None, :, None, None]
+        t = torch.arange(T)[None, None, :, None]
+        src = ((b * nH + h) * T + t) * kw["map_ld"] + kw.get("map_off", 0) + px[:, None, None, :]
+        ok = (px >= 0)[:, None, None, :].expand(nwin, nH, T, ws2)
+        loss = loss + (raw[:, :, :T, T:] * _rd(drawmap, src, ok)).sum()
+    gq, gs = torch.autograd.grad(loss, [qkv, extra])
+    _wr(dqkv, torch.arange(nwin * N * 3 * Cn), gq.reshape(-1))
+    if dS_out is not None:
+        _wr(dS_out, torch.arange(nwin * nH * ws2 * ws2), gs.reshape(-1))
 
 
 def chanattn_fwd(**kw):
@@ -925,7 +962,7 @@ def nms_bev(args):
     _wr(num_out, torch.arange(1), torch.tensor([len(k)]))
 
 
-_TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, chanattn_fwd=chanattn_fwd, conv3s2_nchw=conv3s2_nchw, gemm=gemm, upconv4_expand=upconv4_expand, upconv4_gather=upconv4_gather, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
+_TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=winattn_bwd, chanattn_fwd=chanattn_fwd, conv3s2_nchw=conv3s2_nchw, gemm=gemm, upconv4_expand=upconv4_expand, upconv4_gather=upconv4_gather, attn_fwd=attn_fwd, softmax_fwd=softmax_fwd, softmax_bwd=softmax_bwd,
               layernorm_fwd=layernorm_fwd, layernorm_bwd=layernorm_bwd, chan_logits=chan_logits, modulate=modulate,
               ctr_mix=ctr_mix, bilinear_fwd=bilinear_fwd, bilinear_bwd=bilinear_bwd, bn_stats=bn_stats,
               bn_apply=bn_apply, bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply,
@@ -939,7 +976,7 @@ _POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patch
 
 
 def call(name, **kw):
-    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd", "upconv4_gather") else torch.no_grad():
+    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd", "upconv4_gather", "winattn_bwd") else torch.no_grad():
         if name in _POS:
             return _POS[name](kw["args"])
         return _TABLE[name](**kw)

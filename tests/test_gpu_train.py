@@ -88,3 +88,18 @@ def test_fused_losses_on_gpu():
         pytest.skip("no GPU")
     from test_host_cpu import check_fused_losses
     check_fused_losses("cuda", 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mini_swin", "mini_swin_pad"])
+@pytest.mark.parametrize("prec,fwd_tol,med_tol,worst_tol", [("x3", 1e-3, 1e-3, 2e-2), ("bf16", 5e-2, 1e-1, 1.0)])
+def test_swin_training_gradients(name, prec, fwd_tol, med_tol, worst_tol):
+    """TaskPrompter-Swin training step on the HIP kernels vs the oracle's autograd (measured errors printed)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import train_check
+    fwd, errs, dead = train_check.swin_grad_errors(name, prec, "cuda")
+    worst, med = train_check.summarize(errs)
+    print(f"PARITY swin-train {name} {prec} fwd {max(fwd.values()):.3e} grad median {med:.3e} worst {worst[0]:.3e} ({worst[1]})")
+    assert max(fwd.values()) < fwd_tol, fwd
+    assert med < med_tol and worst[0] < worst_tol, (med, worst)

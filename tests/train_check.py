@@ -105,3 +105,32 @@ def multi_step_check(name, prec, device, steps=3, lr=5e-3, seed=0):
         d = float((prm.detach().cpu() - params[k].detach()).norm() / params[k].detach().norm().clamp_min(1e-12))
         worst = max(worst, d)
     return losses, worst
+
+
+def swin_grad_errors(name, prec, device, seed=0):
+    """TaskPrompter-Swin: product training forward + backward (swin_autograd.py) vs the oracle's autograd (itself pinned against the
+    reference's gradient norms in tests/test_oracle_golden.py).  Parameters the reference leaves without a gradient must stay so."""
+    from oracle import swin_oracle as swo
+    cfg = configs.swin(name)
+    meta, _ = conftest.load_golden(name)
+    sd = weights.synth_state_dict(meta["contract"], seed)
+    model = conftest.build_product_model(cfg, prec, device)
+    model.load_state_dict({k: v.to(device) for k, v in sd.items()}, strict=False)
+    model.train()
+    x = weights.synth_images(2, cfg["img_size"], 2)
+    out = model(x.to(device))
+    loss_of({k: v.cpu() for k, v in out.items()}).backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    ref_out = swo.forward(dict(sd, **params), cfg, x, training=True)
+    loss_of(ref_out).backward()
+    fwd = {t: float((out[t].detach().cpu() - ref_out[t].detach()).norm() / ref_out[t].detach().norm()) for t in ref_out}
+    errs, dead = {}, []
+    for k, prm in model.named_parameters():
+        rg = params[k].grad
+        if rg is None or float(rg.abs().max()) == 0.0:
+            dead.append(k)
+            assert prm.grad is None or float(prm.grad.abs().max()) < 1e-12, f"{k}: dead in the reference but got a gradient"
+            continue
+        assert prm.grad is not None, f"{k}: no gradient"
+        errs[k] = (float((prm.grad.cpu() - rg).norm()), float(rg.norm()))
+    return fwd, errs, dead
