@@ -57,6 +57,11 @@ CONFIGS = {
              dict(tasks=["semseg", "depth"], backbone="TaskPrompter_vitL", head="deconv", embed_dim=300, final_embed_dim=350, chan_nheads=1,
                   use_ctr=True, num_output=dict(semseg=19)),
              (1024, 2048), 4, 12543.0),
+    "swinb": ("TaskPrompter Swin-B (taskprompter_swin_base_patch4_window12_384), Cityscapes semseg(19) + depth (cs_swinB_taskprompter.yml without "
+              "the 3ddet task), 1024x2048 x 0.75, window 12, level 256 / final 450, DEConvHead; SURVEY.md §8f rank 3",
+              dict(tasks=["semseg", "depth"], backbone="TaskPrompter_swinB", head="deconv", final_embed_dim=450, chan_nheads=1, img_ds_ratio=0.75,
+                   level_embed_dim=256, chan_embed_dim=256, prompt_len=1, num_output=dict(semseg=19)),
+              (1024, 2048), 2, 3678.8),
 }
 
 
@@ -138,9 +143,9 @@ def _cpu_baseline_worker(cfg_name, batch, threads, q):
     T.set_num_threads(threads)
     from oracle import configs, weights
     import mtt_amd
-    okey = {"ns6": "ns6", "cfg2": "cfg2", "cfg3": "cfg3", "cfg4": "cfg4_6", "cfg5": "cfg5"}[cfg_name]
-    invpt = cfg_name == "cfg4"
-    cfg = dict(configs.invpt(okey) if invpt else configs.taskprompter(okey))
+    okey = {"ns6": "ns6", "cfg2": "cfg2", "cfg3": "cfg3", "cfg4": "cfg4_6", "cfg5": "cfg5", "swinb": "cs_swinB"}[cfg_name]
+    invpt, swin = cfg_name == "cfg4", cfg_name == "swinb"
+    cfg = dict(configs.invpt(okey) if invpt else (configs.swin(okey) if swin else configs.taskprompter(okey)))
     p, model = build(cfg_name, "x3", mtt_amd)                     # only for the state-dict contract (names, shapes)
     contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
     del model
@@ -151,6 +156,8 @@ def _cpu_baseline_worker(cfg_name, batch, threads, q):
     gt = mtt_amd.losses.synthetic_targets(p, batch, cfg["img_size"][0], cfg["img_size"][1], "cpu")
     if invpt:
         from oracle import invpt_oracle as orc
+    elif swin:
+        from oracle import swin_oracle as orc
     else:
         from oracle import taskprompter_oracle as orc
     times = []

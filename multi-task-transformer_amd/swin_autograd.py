@@ -6,8 +6,9 @@ mtt_gather_rows kernel with the inverse tables), window attention (mtt_winattn_f
 gradient is the window sum of the kernel's dS, index-added into the table), channel attention (HIP forward; its backward — a few
 hundred thousand elements — is recomputed with torch autograd) and the 3x3 stride-2 convolution of the attention maps (HIP forward,
 torch backward on the 8..96-channel maps).  Residual adds, prompt / pixel row concatenations and the transposed copy feeding chan_kv
-are torch ops here (the inference path has none of them): listed in DESIGN.md as the next things to fuse.  DropPath must be 0
-(the reference draws several independent masks per block, taskprompter_swin.py:412-414; not reproduced yet).
+are torch ops here (the inference path has none of them): listed in DESIGN.md as the next things to fuse.  DropPath: the block's four
+independent per-sample draws (taskprompter_swin.py:408-413) scale the attention branch (pixels / prompts) and, through MlpHalfFn's
+row-scale epilogue, the MLP branch.
 """
 import math
 
@@ -215,8 +216,6 @@ def backbone_forward(model, img):
     adt = prec.adt
     dev = img.device
     B = img.shape[0]
-    assert all(l_.blocks[i].drop_path_rate == 0.0 for l_ in model.layers for i in range(len(l_.blocks))), \
-        "TaskPrompterSwin training: DropPath is not built yet (construct with drop_path_rate=0)"
     img = img.float().contiguous()
     if model.img_ds_ratio != 1:
         Hs, Ws = model.patch_embed.img_size
@@ -265,8 +264,23 @@ def backbone_forward(model, img):
                            *[model.multi_scale_fuse[t].bias for t in names])
 
 
+def _drop_scales(model, blk, tag, B, device):
+    """The block's 4 independent per-sample DropPath draws (taskprompter_swin.py:412-413, 408-409), already mask / keep: [4, B] in the
+    reference's call order x-attention, x-mlp, prompt-attention, prompt-mlp; None when inactive.  Tests inject the oracle's masks
+    through model._drop_override[(layer, block)]."""
+    override = getattr(model, "_drop_override", None)
+    if override is not None:
+        return override[tag].to(device)
+    rate = blk.drop_path_rate
+    if not model.training or rate <= 0.0:
+        return None
+    keep = 1.0 - rate
+    return torch.bernoulli(torch.full((4, B), keep, device=device)) / keep
+
+
 def _block(model, blk, tag, XT, B, T, res):
     from . import taskprompter_swin as sw
+    drops = _drop_scales(model, blk, tag, B, XT.device)
     prec = model.prec
     adt = prec.adt
     dev = XT.device
@@ -286,7 +300,13 @@ def _block(model, blk, tag, XT, B, T, res):
     ao, rawlog = WinAttnFn.apply(qkv, a.relative_position_bias_table, a.relative_position_index, blk.attn_mask, pix, (B, nW, nH, T, ws2, N))
     ao_img = WindowGatherFn.apply(ao, False, part, rev, (B, N, T, nW, Nw, C))
     po = _lin(model, ao_img, a.proj, tag + ('proj',))                                                 # [B*N, C] activation dtype
-    XT2 = XT + po.float()
+    branch = po.float()
+    if drops is not None and blk.last_block:     # the last block's prompt output is not used: only the pixel rows are scaled
+        branch = (branch.view(B, N, C) * torch.cat([drops[0].new_ones(B, T), drops[0][:, None].expand(B, N - T)], 1)[:, :, None]).reshape(B * N, C)
+    elif drops is not None:                      # pixels: draw 0; prompts: draw 2 (applied below together with the channel term)
+        v = branch.view(B, N, C)
+        branch = torch.cat([v[:, :T], v[:, T:] * drops[0][:, None, None]], 1).reshape(B * N, C)
+    XT2 = XT + branch if (drops is None or blk.last_block) else None
     # channel attention: kv = chan_kv(x_attn^T) per image (taskprompter_swin.py:393-397)
     ce = model.p.chan_embed_dim
     nwin = int(math.isqrt(model.p.chan_nheads))
@@ -297,10 +317,15 @@ def _block(model, blk, tag, XT, B, T, res):
     if not blk.last_block:
         cp = _lin(model, cx.to(adt), blk.chan_proj, tag + ('cpj',), torch.float32)
         tt1 = _lin(model, cp.to(adt), blk.token_trans1, tag + ('tt1',), torch.float32)                # [B*T, C]
-        v = XT2.view(B, N, C)
-        XT2 = torch.cat([v[:, :T] + tt1.reshape(B, T, C), v[:, T:]], 1).reshape(B * N, C)
+        if drops is None:
+            v = XT2.view(B, N, C)
+            XT2 = torch.cat([v[:, :T] + tt1.reshape(B, T, C), v[:, T:]], 1).reshape(B * N, C)
+        else:
+            xv, bv = XT.view(B, N, C), branch.view(B, N, C)
+            XT2 = torch.cat([xv[:, :T] + (bv[:, :T] + tt1.reshape(B, T, C)) * drops[2][:, None, None], xv[:, T:] + bv[:, T:]], 1).reshape(B * N, C)
+    rs_mlp = None if drops is None else torch.stack([drops[3], drops[1]], 1).contiguous()            # [B, 2]: prompt rows, pixel rows
     XT3 = MlpHalfFn.apply(XT2.contiguous(), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
-                          blk.mlp.fc2.weight, blk.mlp.fc2.bias, None, (B, N, T), prec, tag)
+                          blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp, (B, N, T), prec, tag)
     return XT3, rawlog, rawchan
 
 

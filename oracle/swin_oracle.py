@@ -77,7 +77,7 @@ def block_geometry(res, window, shift_flag):
     return ws, shift, Hp, Wp
 
 
-def swin_block(sd, pre, x, prompts, res, nH, window, shift_flag, last_block, p):
+def swin_block(sd, pre, x, prompts, res, nH, window, shift_flag, last_block, p, drop=None):
     """taskprompter_swin.py:324-414.  x [B, H*W, C], prompts [B, T, C] -> (x, (raw_spa [B,nH,T,H,W], raw_chan [B,T,C,nh,nw]), prompts)."""
     H, W = res
     B, L, C = x.shape
@@ -133,12 +133,15 @@ def swin_block(sd, pre, x, prompts, res, nH, window, shift_flag, last_block, p):
     cx = torch.softmax(raw_chan * ce ** -0.5, -1) @ v_                        # [B, nh*nw, T, wh*ww]
     cx = cx.view(B, nh, nw, T, wh, ww).permute(0, 3, 1, 4, 2, 5).reshape(B, T, ce)
     raw_chan = raw_chan.view(B, nh, nw, T, C).permute(0, 3, 4, 1, 2).contiguous()        # 'b (nh nw) t c -> b t c nh nw'
-    x = x + xo                                                                # drop_path = identity in eval (:412)
-    x = x + _mlp(sd, pre + ".mlp", _ln(x, sd, pre + ".norm2"))
+    # `drop` = optional 4 per-sample scale vectors [B] (already mask / keep) for the block's 4 independent DropPath draws in call order
+    # (:412-413, :408-409): x-attention, x-mlp, prompt-attention, prompt-mlp
+    dp = (lambda t, i: t) if drop is None else (lambda t, i: t * drop[i][:, None, None])
+    x = x + dp(xo, 0)
+    x = x + dp(_mlp(sd, pre + ".mlp", _ln(x, sd, pre + ".norm2")), 1)
     if not last_block:
         tp = new_prompts + _lin(_lin(cx, sd, pre + ".chan_proj"), sd, pre + ".token_trans1")
-        tp = prompts + tp
-        tp = tp + _mlp(sd, pre + ".mlp", _ln(tp, sd, pre + ".norm2"))
+        tp = prompts + dp(tp, 2)
+        tp = tp + dp(_mlp(sd, pre + ".mlp", _ln(tp, sd, pre + ".norm2")), 3)
     else:
         tp = new_prompts
     return x, (raw_spa, raw_chan), tp
@@ -191,7 +194,7 @@ def cal_task_feature(sd, x, attn, il, res, tasks, prompt_len, chans, training, b
     return out
 
 
-def backbone_forward(sd, cfg, img, training=False, bn_updates=None):
+def backbone_forward(sd, cfg, img, training=False, bn_updates=None, drop=None):
     """TaskPrompterSwin.forward (:664-713) -> {task: [B, F, H/4', W/4']} at the first level's (x2 upsampled) scale."""
     tasks = [t for t, _ in cfg["tasks"]]
     pl = cfg["prompt_len"]
@@ -215,7 +218,7 @@ def backbone_forward(sd, cfg, img, training=False, bn_updates=None):
         for ib in range(cfg["depths"][il]):
             last = il == nl - 1 and ib == cfg["depths"][il] - 1
             x, attn, prompts = swin_block(sd, f"backbone.layers.{il}.blocks.{ib}", x, prompts, res, cfg["heads"][il], cfg["window"],
-                                          ib % 2 == 1, last, pdict)
+                                          ib % 2 == 1, last, pdict, None if drop is None else drop[(il, ib)])
         if il < nl - 1:
             x, prompts, attn = patch_merging(sd, f"backbone.layers.{il}.downsample", x, prompts, attn, res)
             cur = cal_task_feature(sd, x, attn, il, res_out[il], tasks, pl, chans[il], training, bn_updates)
@@ -232,9 +235,9 @@ def backbone_forward(sd, cfg, img, training=False, bn_updates=None):
     return out
 
 
-def forward(sd, cfg, img, training=False, bn_updates=None, target_size=None):
-    """TaskPrompterWrapper.forward on the Swin backbone -> {task: [B, n_out, H, W]}."""
-    fea = backbone_forward(sd, cfg, img, training, bn_updates)
+def forward(sd, cfg, img, training=False, bn_updates=None, target_size=None, drop=None):
+    """TaskPrompterWrapper.forward on the Swin backbone -> {task: [B, n_out, H, W]}.  drop: {(layer, block): [4, B] DropPath scales}."""
+    fea = backbone_forward(sd, cfg, img, training, bn_updates, drop)
     tgt = target_size or tuple(img.shape[-2:])
     out = {}
     for t, _ in cfg["tasks"]:

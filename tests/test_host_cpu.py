@@ -428,12 +428,15 @@ def test_swin_training_gradients_on_emulator(emulated, name):
     assert not dead, dead[:5]
 
 
-def test_swin_training_requires_zero_droppath(emulated):
+def test_swin_training_with_droppath_masks(emulated):
+    """The block's four independent DropPath draws (pixels / prompts x attention / MLP), injected into product and oracle alike."""
+    import train_check
     cfg = configs.swin("mini_swin")
-    model = conftest.build_product_model(cfg, "x3", drop_path_rate=0.1)
-    model.train()
-    with pytest.raises(AssertionError):
-        model(weights.synth_images(1, cfg["img_size"], 1))
+    drop = train_check.swin_drop_masks(cfg, 2)
+    fwd, errs, dead = train_check.swin_grad_errors("mini_swin", "x3", "cpu", drop=drop)
+    assert max(fwd.values()) < 5e-5, fwd
+    worst, med = train_check.summarize(errs)
+    assert worst[0] < 1e-3 and med < 1e-4, (worst, med)
 
 
 def test_swin_window_tables_are_consistent():

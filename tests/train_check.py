@@ -107,21 +107,30 @@ def multi_step_check(name, prec, device, steps=3, lr=5e-3, seed=0):
     return losses, worst
 
 
-def swin_grad_errors(name, prec, device, seed=0):
+def swin_drop_masks(cfg, B, rate=0.3, seed=5):
+    """One [4, B] mask / keep table per block (the 4 DropPath draws), shared by the product (model._drop_override) and the oracle."""
+    g = torch.Generator().manual_seed(seed)
+    keep = 1.0 - rate
+    return {(il, ib): torch.bernoulli(torch.full((4, B), keep), generator=g) / keep for il, d in enumerate(cfg["depths"]) for ib in range(d)}
+
+
+def swin_grad_errors(name, prec, device, seed=0, drop=None):
     """TaskPrompter-Swin: product training forward + backward (swin_autograd.py) vs the oracle's autograd (itself pinned against the
     reference's gradient norms in tests/test_oracle_golden.py).  Parameters the reference leaves without a gradient must stay so."""
     from oracle import swin_oracle as swo
     cfg = configs.swin(name)
     meta, _ = conftest.load_golden(name)
     sd = weights.synth_state_dict(meta["contract"], seed)
-    model = conftest.build_product_model(cfg, prec, device)
+    model = conftest.build_product_model(cfg, prec, device, drop_path_rate=0.3 if drop is not None else 0.0)
     model.load_state_dict({k: v.to(device) for k, v in sd.items()}, strict=False)
     model.train()
     x = weights.synth_images(2, cfg["img_size"], 2)
+    if drop is not None:
+        model.backbone._drop_override = drop
     out = model(x.to(device))
     loss_of({k: v.cpu() for k, v in out.items()}).backward()
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
-    ref_out = swo.forward(dict(sd, **params), cfg, x, training=True)
+    ref_out = swo.forward(dict(sd, **params), cfg, x, training=True, drop=drop)
     loss_of(ref_out).backward()
     fwd = {t: float((out[t].detach().cpu() - ref_out[t].detach()).norm() / ref_out[t].detach().norm()) for t in ref_out}
     errs, dead = {}, []
