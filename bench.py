@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--no-ref-batch", action="store_true")
     ap.add_argument("--no-fuse-upsample", action="store_true",
                     help="A/B: materialise the x4-upsampled task features and run ConvHead's 3x3 conv on them (the reference's operation order)")
+    ap.add_argument("--measure-no-repack", action="store_true",
+                    help="MEASUREMENT ONLY (invalid training: the forward keeps using the step-0 weight packs): what the per-step re-packing costs")
     ap.add_argument("--gemm-variant", type=int, default=None,
                     help="A/B: mtt_gemm_desc.variant for every GEMM left at AUTO (12 = policy + persistent kernel, 14 = policy without it)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
@@ -230,6 +232,9 @@ def main():
         mtt_amd.taskprompter.TaskPrompterWrapper.fuse_upsample = False
     if a.gemm_variant is not None:
         mtt_amd.ops.GEMM_VARIANT = a.gemm_variant
+    if a.measure_no_repack:
+        mtt_amd.ops.bump_param_epoch = lambda: None
+        torch.autograd.graph.increment_version = lambda *x, **k: None
     torch.manual_seed(0)
     p, model = build(a.config, a.prec, mtt_amd)
     if world > 1:
@@ -308,8 +313,9 @@ def main():
                     kernel=("gemm_pdma_kernel<KIND> (persistent workgroups, K loop continuous across 256x256x64 tiles, bf16 MFMA 16x16x32, LDS-DMA "
                             "staging, staggered read / MFMA phases, per-wave epilogue) + gemm_dma_kernel<256> for the ineligible calls"
                             if pers else
-                            "gemm_dma_kernel<256, false, 0> (256x256x64 tile, bf16 MFMA 16x16x32, LDS-DMA staging, staggered read / MFMA phases, "
-                            "specialised interior-tile epilogue)") + ": every encoder Linear forward and input gradient of the step",
+                            "gemm_dma_kernel<256, false, 7> (256x256x64 tile, bf16 MFMA 16x16x32, LDS-DMA staging with wave-uniform base + 32-bit lane "
+                            "offset addressing, staggered read / MFMA phases, specialised interior-tile epilogue; <256, false, 0> = the same kernel with "
+                            "general addressing for calls with a K tail)") + ": every encoder Linear forward and input gradient of the step",
                     persistent_launches=gt_.persistent,
                     launches=n, kernel_ms_per_step=round(ms, 3), algorithmic_tflop_per_step=round(flops / 1e12, 2))
 
