@@ -58,6 +58,8 @@ enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DM
        MTT_GEMM_DMA256_PERSIST_V0 = 13 /* the same with block-by-block stores and the plain one-tile-ahead prefetch instead of deferred stores (A/B measurements) */,
        MTT_GEMM_DMA256_NONPERSIST = 14 /* AUTO policy without the persistent kernel (A/B) */,
        MTT_GEMM_DMA256_SLOWADDR = 18 /* AUTO policy, but the 256 x 256 kernel with general (K-tail capable, 64-bit) source addressing even where the fast form applies (A/B) */,
+       MTT_GEMM_DMA256_DIRECT = 19 /* AUTO policy, the 256 x 256 kernel with swapped-operand MFMAs + direct-store epilogue (no LDS staging) where eligible (A/B) */,
+       MTT_GEMM_DMA256_LDS_EPILOGUE = 20 /* AUTO policy, the 256 x 256 kernel with the LDS-staged epilogue even where the direct one is the default (A/B) */,
        MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE = 15, MTT_GEMM_PDMA_ABLATE_NO_STORES = 16, MTT_GEMM_PDMA_ABLATE_NO_BIAS = 17
        /* measurement-only ablations of the persistent kernel (bf16 output + bias calls): WRONG results by construction */ };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1 };

@@ -228,7 +228,9 @@ MTT_DEV void stager_init_b(S& s, const GemmP& p, const void* base, int row0) {
 // ---------------------------------------------------------------------------------------------
 // EPI_ABL (measurement only): 1 = everything but the global stores of the vector path, 2 = no LDS staging / barriers (stores of
 // register garbage at the right addresses).
-template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL, int EPI_ABL = 0>
+// SWP: the accumulators hold the TRANSPOSED MFMA result (acc[a][b][r] = D[(wm*MT + a)*16 + li][(wn*NTL + b)*16 + lg*4 + r], the layout of
+// gemm_dma_kernel's direct-store variant); only the staging writes differ.
+template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL, int EPI_ABL = 0, bool SWP = false>
 MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -270,6 +272,7 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (EPI_ABL == 2) asm volatile("" :: "v"(acc[a][b][r]));
+          else if (SWP) ep[((gt & 3) * 16 + li) * EP_LD + (wn * NTL + b) * 16 + lg * 4 + r] = acc[a][b][r];
           else ep[((gt & 3) * 16 + lg * 4 + r) * EP_LD + (wn * NTL + b) * 16 + li] = acc[a][b][r];
         }
     }
@@ -501,6 +504,113 @@ MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned 
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-store epilogue for the 256 x 256 / 8-wave kernels when the MFMAs were issued with SWAPPED operands (acc = B-fragment x
+// A-fragment): a lane then holds 4 consecutive COLUMNS of one row per 16 x 16 fragment, and one v_permlane16_swap per register between
+// the fragments b and b + 1 (lane rows 0 / 2 keep fragment b and receive the neighbouring row's 4 columns, rows 1 / 3 likewise for
+// b + 1; mapping measured in profiles/r02_probe_permlane_swap.txt) gives every lane 8 consecutive columns: exactly the per-thread work
+// item of gemm_epilogue_fast, without staging the tile through LDS and without its 8 workgroup barriers.  Interior tiles of the
+// specialised kinds only; everything else takes gemm_epilogue<..., SWP = true>.
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+MTT_DEV void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc)[8][4], int m0, int n0, int zo, int zi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const mtt_gemm_desc& d = p.d;
+  const int col0 = n0 + wn * 64 + (lg & 1) * 16 + (lg >> 1) * 8;      // + 32 * pair
+  float sh[2][8], cs[2][8];
+  {
+    const int64_t zcol = (int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi + col0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sh[q][j] = d.colshift ? d.colshift[zcol + q * 32 + j] : 0.0f;
+        cs[q][j] = d.colscale ? d.colscale[zcol + q * 32 + j] : 1.0f;
+      }
+  }
+  const int64_t zD = (int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi + col0;
+  const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + col0;
+  const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi + col0;
+  const int mbase = m0 + wm * 128 + li;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    // this half's residual / GELU' input rows, all issued before any store of the half (D and resid may alias)
+    float4 ra[4][2], rb[4][2];
+    u32x4 za[4][2];
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int64_t m = mbase + (half * 4 + aa) * 16;
+        if (KIND == 3) {
+          if (d.resid) { ra[aa][q] = *(const float4*)(d.resid + (zR + m * d.ldr + q * 32)); rb[aa][q] = *(const float4*)(d.resid + (zR + m * d.ldr + q * 32) + 4); }
+          else { ra[aa][q] = rb[aa][q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+        if (KIND == 4) za[aa][q] = *(const u32x4*)((const bf16_t*)d.aux_in + (zAux + m * d.ldaux + q * 32));
+      }
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+      const int a = half * 4 + aa;
+      const int64_t m = mbase + a * 16;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // inline asm, not __builtin_amdgcn_permlane16_swap: hipcc (ROCm 7.2) folds the four builtin calls of this unrolled loop into ONE
+          // swap and replicates its result (seen in the .s and in a 10-line reproducer); the s_nop covers the VALU-write -> permlane hazard
+          float lo = acc[a][2 * q][r], hi = acc[a][2 * q + 1][r];
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+          v[r] = fmaf(lo, cs[q][r], sh[q][r]);
+          v[4 + r] = fmaf(hi, cs[q][4 + r], sh[q][4 + r]);
+        }
+        if (KIND == 2) {
+          if (d.aux_out)
+            *(u32x4*)((bf16_t*)d.aux_out + (zAux + m * d.ldaux + q * 32)) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        }
+        if (KIND == 4) {
+          const u32x4 u = za[aa][q];
+          v[0] *= gelu_grad_f(lo_of(u.x)); v[1] *= gelu_grad_f(hi_of(u.x)); v[2] *= gelu_grad_f(lo_of(u.y)); v[3] *= gelu_grad_f(hi_of(u.y));
+          v[4] *= gelu_grad_f(lo_of(u.z)); v[5] *= gelu_grad_f(hi_of(u.z)); v[6] *= gelu_grad_f(lo_of(u.w)); v[7] *= gelu_grad_f(hi_of(u.w));
+        }
+        if (KIND == 3) {
+          if (d.rowscale) {
+            const uint32_t qq = fdiv((uint32_t)m, p.divDmb), rem = (uint32_t)m - qq * (uint32_t)d.d_mb;
+            const float rs = d.rowscale[qq * 2 + (rem >= (uint32_t)d.n_prompt ? 1 : 0)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= rs;
+          }
+          v[0] += ra[aa][q].x; v[1] += ra[aa][q].y; v[2] += ra[aa][q].z; v[3] += ra[aa][q].w;
+          v[4] += rb[aa][q].x; v[5] += rb[aa][q].y; v[6] += rb[aa][q].z; v[7] += rb[aa][q].w;
+        }
+        if (KIND == 1 || KIND == 3) {
+          float* dp = (float*)d.D + (zD + m * d.ldd + q * 32);
+          *(float4*)dp = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(dp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *(u32x4*)((bf16_t*)d.D + (zD + m * d.ldd + q * 32)) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        }
+      }
+    }
+  }
+}
+
+template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+MTT_DEV void gemm_epilogue_auto_swapped(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
+  static_assert(TBN == 256 && WAVES_M == 2 && WAVES_N == 4 && MT == 8 && NTL == 4, "direct epilogue: 256 x 256 tile, 2 x 4 waves");
+  const int kind = fast_epilogue_kind(p.d, m0, n0, 256, 256);
+  if (kind == 0) gemm_epilogue_direct<0>(p, acc, m0, n0, zo, zi);
+  else if (kind == 1) gemm_epilogue_direct<1>(p, acc, m0, n0, zo, zi);
+  else if (kind == 2) gemm_epilogue_direct<2>(p, acc, m0, n0, zo, zi);
+  else if (kind == 3) gemm_epilogue_direct<3>(p, acc, m0, n0, zo, zi);
+  else if (kind == 4) gemm_epilogue_direct<4>(p, acc, m0, n0, zo, zi);
+  else gemm_epilogue<TBN, WAVES_M, WAVES_N, MT, NTL, 0, true>(p, acc, smem, m0, n0, zo, zi);
 }
 
 // epilogue dispatch (workgroup-uniform): specialised path for interior tiles of the hot call sites, general path otherwise
@@ -910,7 +1020,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   // wave-uniform base (advanced by the K offset on the scalar unit) + a constant 32-bit per-lane byte offset, and there is no K tail,
   // so a piece costs one 64-bit add instead of two adds, a compare and two selects (58 -> 32 VALU instructions per K step; measured
   // on the persistent kernel's identical loop: 1 469 vs 1 395 TFLOP/s at 8192^3 without epilogue, profiles/r02_gemm_ablate_o_*.log)
-  constexpr bool FASTADDR = SCHED == 7 && !CONV;
+  constexpr bool FASTADDR = (SCHED == 7 || SCHED == 8) && !CONV;
+  constexpr bool SWAPPED = SCHED == 8 && BN_ == 256 && !CONV;      // MFMAs with swapped operands + the direct-store epilogue
   uint32_t aoff32[4], boff32[B_GLDS];
   if constexpr (FASTADDR) {
 #pragma unroll
@@ -1040,7 +1151,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
 #pragma unroll
           for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+            for (int b = 0; b < NT; ++b) acc[a][b] = SWAPPED ? mfma16(fb[b], fa[a], acc[a][b]) : mfma16(fa[a], fb[b], acc[a][b]);
           if (SCHED == 1 && kh == 1 && LATE && CONV && kt + 2 < nk) issueA(kt & 1, kt + 2);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1063,7 +1174,10 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   }
   if constexpr (SCHED == 5 || SCHED == 6 || SCHED == 3)
     gemm_epilogue<BN_, WAVES_M, WAVES_N, MT, NT, (SCHED == 5 ? 1 : (SCHED == 6 ? 2 : 0))>(p, acc, smem, m0, n0, zo, zi);
-  else
+  else if constexpr (SWAPPED) {
+    if (p.d.variant == MTT_GEMM_GENERAL_EPILOGUE) gemm_epilogue<BN_, WAVES_M, WAVES_N, MT, NT, 0, true>(p, acc, smem, m0, n0, zo, zi);
+    else gemm_epilogue_auto_swapped<BN_, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  } else
     gemm_epilogue_auto<BN_, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
 }
 
@@ -1660,6 +1774,8 @@ static bool pdma_eligible(const mtt_gemm_desc& d) {
 }
 // AUTO policy switch for the persistent kernel (set after the A/B on MI355X: tools/gemm_bench.py, profiles/r02_gemm_bench_m_*)
 constexpr bool PDMA_BY_DEFAULT = false;
+// AUTO policy switch for the swapped-MFMA / direct-store epilogue form of the 256 x 256 kernel (set after the A/B on MI355X)
+constexpr bool DIRECT_EPILOGUE_BY_DEFAULT = false;
 static int gemm_variant_for(const mtt_gemm_desc& d) {
   // 6: token-major weight-gradient kernel (gemm_tn_kernel): both operands MTT_OP_R (B may be the implicit im2col^T), bf16
   const bool tn = d.prec == MTT_PREC_BF16 && d.a_op == MTT_OP_R && (d.b_op == MTT_OP_R || d.b_op == MTT_OP_CONV_R) &&
@@ -1749,7 +1865,9 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_DMA256_SKEW) return launch_dma<256, false, 4>(p, s);
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STORES) return launch_dma<256, false, 5>(p, s);
     if (v == 3 && !conv_a && d.variant == MTT_GEMM_ABLATE_NO_STAGING) return launch_dma<256, false, 6>(p, s);
-    if (v == 3 && !conv_a && d.variant != MTT_GEMM_DMA256_S1 && d.variant != MTT_GEMM_DMA256_SLOWADDR && dma_fastaddr_ok(d)) return launch_dma<256, false, 7>(p, s);
+    if (v == 3 && !conv_a && d.variant != MTT_GEMM_DMA256_S1 && d.variant != MTT_GEMM_DMA256_SLOWADDR && dma_fastaddr_ok(d))
+      return (DIRECT_EPILOGUE_BY_DEFAULT ? d.variant != MTT_GEMM_DMA256_LDS_EPILOGUE : d.variant == MTT_GEMM_DMA256_DIRECT)
+                 ? launch_dma<256, false, 8>(p, s) : launch_dma<256, false, 7>(p, s);
     if (v == 3) return conv_a ? launch_dma<256, true, 0>(p, s) : (d.variant == MTT_GEMM_DMA256_S1 ? launch_dma<256, false, 1>(p, s) : launch_dma<256, false, 0>(p, s));
     if (v == 4) return conv_a ? launch_dma<128, true, 0>(p, s) : launch_dma<128, false, 0>(p, s);
     if (v == 7 && epilogue_kind_of(d) == 0 && d.variant >= MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE && d.variant <= MTT_GEMM_PDMA_ABLATE_NO_BIAS)

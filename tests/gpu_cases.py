@@ -187,7 +187,9 @@ def gemm_cases():
     # 1e'. persistent 256 x 256 kernel (variant 12 = deferred stores + two-tile prefetch across the seam; 13 = block-by-block stores):
     #      more than 256 tiles so that workgroups walk several tiles (K loop continuous across the seam, per-wave epilogue), ragged M,
     #      2 .. 17 K tiles, every epilogue kind, task batches (flat tile index over z); K = 8 is ineligible (falls back to the one-tile kernel)
-    for v in (12, 13):
+    #      variant 19 = the one-tile kernel with swapped-operand MFMAs + direct-store epilogue (v_permlane16_swap instead of LDS staging):
+    #      the same shapes exercise its interior tiles (direct) and its ragged last row of tiles (general epilogue on the swapped layout)
+    for v in (12, 13, 19):
         for (M, N, K) in ((8498, 2048, 192), (20000, 1024, 1088), (33 * 256, 2048, 128), (9000, 2048, 8)):
             cases.append((f"gemm_pdma_v{v}_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0, variant=v, colshift=rnd(g, N), n_store=N), TOL_BF))
         M, N, K = 8498, 2048, 256

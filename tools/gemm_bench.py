@@ -19,7 +19,7 @@ prec = ops.Prec("bf16")
 M63 = 63 * 1030
 SHAPES = [("qkv", M63, 3072, 1024, 0), ("proj", M63, 1024, 1024, 0), ("proj+resid", M63, 1024, 1024, 2), ("fc1+gelu", M63, 4096, 1024, 1),
           ("fc2", M63, 1024, 4096, 0), ("fc2+resid", M63, 1024, 4096, 2), ("fc2 dgrad*gelu'", M63, 4096, 1024, 3), ("big", 8192, 8192, 8192, 0)]
-KERNELS = [(14, "one tile / workgroup"), (12, "persistent, deferred stores"), (13, "persistent, immediate stores")]
+KERNELS = [(20, "LDS-staged epilogue"), (19, "swapped MFMA + direct-store epilogue"), (13, "persistent, immediate stores")]
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 
 
@@ -70,7 +70,7 @@ b = torch.randn(1, N, device="cuda")
 ref = torch.empty(1, M, N, device="cuda", dtype=torch.bfloat16)
 FORCE["v"] = 14
 ops.linear(x, w, N, prec, bias=b, act=1, out=ref)
-for v in (12, 13):
+for v in (12, 13, 19):
     FORCE["v"] = v
     bad = 0
     for i in range(30):
