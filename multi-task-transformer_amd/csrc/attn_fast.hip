@@ -9,6 +9,7 @@
 //     staged K / V^T tile.
 // The fp32-parity (x3) mode keeps the straightforward kernel in attn.hip.
 #include "mtt_device.h"
+#include <type_traits>
 
 namespace {
 
@@ -29,7 +30,12 @@ MTT_DEV u32x4 perm_frag(const unsigned char* tile, int row, int ks, int lg) {
 // Workgroup = 128 query rows, 32 per wave (two B fragments of Q per K / V^T fragment read); 64-key tiles.
 // (A key-split variant — all waves share 64 query rows, each wave owns 32 keys of a 128-key tile, partials merged in LDS —
 // measured 5 % slower on MI355X: the kernel is bound by VALU issue (softmax, staging address math), not by LDS traffic.)
-__global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
+// VER >= 1 (mtt_attn_desc.variant = MTT_ATTN_FAST2 / _FAST3 / _FAST4): the KV loop is unrolled by the two LDS stages (compile-time stage
+// offsets: the fragment reads take immediate offsets instead of a per-read address add), full key tiles are staged without per-key
+// predicates (the `key < N` selects only run for the sequence's last tile), and the MFMA clusters run at raised wave priority.
+// VER 2 / 3 additionally ask the compiler for 3 / 4 workgroups per CU (<= 168 / 128 VGPRs) instead of 2.
+template <int VER>
+__global__ __launch_bounds__(256, VER == 3 ? 4 : (VER == 2 ? 3 : 2)) void attn_fwd_fast_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 2 * KTILE;                  // K, V^T
   const mtt_attn_desc& d = p.d;
@@ -66,6 +72,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   const int kq = tid & 15, rb = (tid >> 4) & 7;
   const int kt_ = tid - 128;
   auto stage_load = [&](int kv0) {
+    if (VER >= 1 && kv0 + KV <= N) {                 // block-uniform: a full tile needs no per-key selects
+      okm = 0xfu;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = kt_ + 128 * i;
+        const int key = isV ? kv0 + kq * 4 + i : kv0 + (idx >> 3);
+        const int col = isV ? 2 * C + rb * 8 : C + (idx & 7) * 8;
+        raw[i].r0 = *(const u32x4*)(qkv + ((tok0 + key) * 3 * C + col + h * HD));
+      }
+      return;
+    }
     okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -79,8 +96,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   };
   auto stage_store = [&](unsigned char* st) {
     u32x4 sh[4];
+    if (VER >= 1 && okm == 0xfu) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cvt8<false, false>((okm >> i) & 1u, raw[i], sh[i], dummy);
+      for (int i = 0; i < 4; ++i) sh[i] = raw[i].r0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cvt8<false, false>((okm >> i) & 1u, raw[i], sh[i], dummy);
+    }
     if (isV) {
       u32x2 piece[8];
       transpose4x8(sh, piece);
@@ -109,15 +131,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   stage_store(smem);
   __syncthreads();
 
-  for (int j = 0; j < nkv; ++j) {
+  auto tile = [&](auto stage_tag, int j) {
+    constexpr int ST = decltype(stage_tag)::value;   // -1: run-time stage (VER 0)
     const bool more = j + 1 < nkv;
     if (more) stage_load((j + 1) * KV);
-    const unsigned char* Kh = smem + (j & 1) * STAGE;
+    const unsigned char* Kh = smem + (ST < 0 ? (j & 1) : ST) * STAGE;
     const unsigned char* Vt = Kh + KTILE;
     const int kv0 = j * KV;
     if (active) {
       // ---- S^T = K Q^T : s[sub][kt][r] = S[q = li][key = kv0 + 16 kt + 4 lg + r] ------------------------------
       f32x4 s[2][4];
+      if (VER >= 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         s[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -129,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
           s[1][kt] = mfma16(kf, qf[1][kh], s[1][kt]);
         }
       }
+      if (VER >= 1) __builtin_amdgcn_s_setprio(0);
       if (write_raw) {
         float* rl = d.rawlog + (((int64_t)b * d.nH + h) * d.T + li) * N;
 #pragma unroll
@@ -186,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
                                 pack2(s[sub][2 * ks + 1][0], s[sub][2 * ks + 1][1]), pack2(s[sub][2 * ks + 1][2], s[sub][2 * ks + 1][3])};
       }
       // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------
+      if (VER >= 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if (kv0 + 32 * ks >= N) continue;              // block-uniform: nothing valid in this half of the last tile (P = 0)
@@ -196,9 +222,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
           o[1][dt] = mfma16(vf, pb[1][ks], o[1][dt]);
         }
       }
+      if (VER >= 1) __builtin_amdgcn_s_setprio(0);
     }
-    if (more) stage_store(smem + ((j + 1) & 1) * STAGE);
+    if (more) stage_store(smem + (ST < 0 ? ((j + 1) & 1) : (1 - ST)) * STAGE);
     __syncthreads();
+  };
+  if (VER >= 1) {
+    for (int j = 0; j < nkv; j += 2) {
+      tile(std::integral_constant<int, 0>{}, j);
+      if (j + 1 < nkv) tile(std::integral_constant<int, 1>{}, j + 1);
+    }
+  } else {
+    for (int j = 0; j < nkv; ++j) tile(std::integral_constant<int, -1>{}, j);
   }
 
   // ---- epilogue: o[sub][dt][r] = O[q = li][d = 16 dt + 4 lg + r] ---------------------------------------------------
@@ -226,6 +261,9 @@ int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s) {
   constexpr int smem = 2 * 2 * KTILE;
   AttnP p; p.d = *dd;
   dim3 grid((unsigned)(((dd->N + 127) / 128) * dd->nH * dd->B));
-  hipLaunchKernelGGL(attn_fwd_fast_kernel, grid, dim3(256), smem, s, p);
+  if (dd->variant == MTT_ATTN_FAST2) hipLaunchKernelGGL(attn_fwd_fast_kernel<1>, grid, dim3(256), smem, s, p);
+  else if (dd->variant == MTT_ATTN_FAST3) hipLaunchKernelGGL(attn_fwd_fast_kernel<2>, grid, dim3(256), smem, s, p);
+  else if (dd->variant == MTT_ATTN_FAST4) hipLaunchKernelGGL(attn_fwd_fast_kernel<3>, grid, dim3(256), smem, s, p);
+  else hipLaunchKernelGGL(attn_fwd_fast_kernel<0>, grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }

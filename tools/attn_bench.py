@@ -12,9 +12,9 @@ from mtt_amd import ops  # noqa: E402
 B, N, nH, T = [int(a) for a in sys.argv[1:5]] + [40, 1030, 16, 6][len(sys.argv) - 1:]
 C = nH * 64
 prec = ops.Prec("bf16")
-if os.environ.get("MTT_ATTN_PLAIN") == "1":
-    _call = ops.call
-    ops.call = lambda name, **kw: _call(name, **(dict(kw, variant=1) if name == "attn_fwd" else kw))
+_call = ops.call
+FORCE = {"v": 1 if os.environ.get("MTT_ATTN_PLAIN") == "1" else 0}
+ops.call = lambda name, **kw: _call(name, **(dict(kw, variant=FORCE["v"]) if name == "attn_fwd" else kw))
 dev = torch.device("cuda")
 qkv = (torch.randn(B * N, 3 * C, device=dev) * 1.0).to(torch.bfloat16)
 dao = torch.randn(B * N, C, device=dev).to(torch.bfloat16)
@@ -36,6 +36,21 @@ def timed(fn, iters=10):
 
 ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
 t_f = timed(lambda: ops.attention(qkv, B, N, nH, T, prec, want_lse=True))
+if FORCE["v"] == 0:                                    # A/B of the forward variants (mtt_attn_desc.variant), interleaved, + bitwise comparison
+    import statistics
+    VARS = (0, 2, 3, 4)
+    res = {v: [] for v in VARS}
+    for _ in range(5):
+        for v in VARS:
+            FORCE["v"] = v
+            res[v].append(timed(lambda: ops.attention(qkv, B, N, nH, T, prec, want_lse=True), 5))
+    eq = {}
+    for v in VARS[1:]:
+        FORCE["v"] = v
+        ao2, rawlog2, lse2 = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
+        eq[v] = bool(torch.equal(ao, ao2) and torch.equal(lse, lse2) and (not T or torch.equal(rawlog, rawlog2)))
+    FORCE["v"] = 0
+    print("forward A/B (us, median of 5): " + ", ".join(f"variant {v}: {statistics.median(res[v]) * 1e3:.0f}" for v in VARS) + f"; bitwise equal to variant 0: {eq}")
 dqkv = torch.empty_like(qkv)
 dsum = torch.empty(B, nH, 2, (N + 3) // 4 * 4, device=dev)
 
