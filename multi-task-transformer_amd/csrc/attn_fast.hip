@@ -30,12 +30,14 @@ MTT_DEV u32x4 perm_frag(const unsigned char* tile, int row, int ks, int lg) {
 // Workgroup = 128 query rows, 32 per wave (two B fragments of Q per K / V^T fragment read); 64-key tiles.
 // (A key-split variant — all waves share 64 query rows, each wave owns 32 keys of a 128-key tile, partials merged in LDS —
 // measured 5 % slower on MI355X: the kernel is bound by VALU issue (softmax, staging address math), not by LDS traffic.)
-// VER >= 1 (mtt_attn_desc.variant = MTT_ATTN_FAST2 / _FAST3 / _FAST4): the KV loop is unrolled by the two LDS stages (compile-time stage
-// offsets: the fragment reads take immediate offsets instead of a per-read address add), full key tiles are staged without per-key
-// predicates (the `key < N` selects only run for the sequence's last tile), and the MFMA clusters run at raised wave priority.
-// VER 2 / 3 additionally ask the compiler for 3 / 4 workgroups per CU (<= 168 / 128 VGPRs) instead of 2.
+// VER 1 (the default; VER 0 = the previous form, mtt_attn_desc.variant = MTT_ATTN_FAST_V0, kept for A/B): the KV loop is unrolled by the two
+// LDS stages (compile-time stage offsets: the fragment reads take immediate offsets instead of a per-read address add), full key tiles
+// are staged without per-key predicates (the `key < N` selects only run for the sequence's last tile), and the MFMA clusters run at
+// raised wave priority: 650 -> 605 us per layer at B = 63, N = 1030 and 2 004 -> 1 844 us at N = 8194, bitwise identical outputs
+// (tools/attn_bench.py).  Asking the compiler for 3 / 4 workgroups per CU (<= 168 / 128 VGPRs) instead of 2 spills and is much slower
+// (806 / 1 669 us), and taking the softmax denominators out of the matrix pipe (an A fragment of ones) changed nothing: measured, dropped.
 template <int VER>
-__global__ __launch_bounds__(256, VER == 3 ? 4 : (VER == 2 ? 3 : 2)) void attn_fwd_fast_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 2 * KTILE;                  // K, V^T
   const mtt_attn_desc& d = p.d;
@@ -261,9 +263,7 @@ int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s) {
   constexpr int smem = 2 * 2 * KTILE;
   AttnP p; p.d = *dd;
   dim3 grid((unsigned)(((dd->N + 127) / 128) * dd->nH * dd->B));
-  if (dd->variant == MTT_ATTN_FAST2) hipLaunchKernelGGL(attn_fwd_fast_kernel<1>, grid, dim3(256), smem, s, p);
-  else if (dd->variant == MTT_ATTN_FAST3) hipLaunchKernelGGL(attn_fwd_fast_kernel<2>, grid, dim3(256), smem, s, p);
-  else if (dd->variant == MTT_ATTN_FAST4) hipLaunchKernelGGL(attn_fwd_fast_kernel<3>, grid, dim3(256), smem, s, p);
-  else hipLaunchKernelGGL(attn_fwd_fast_kernel<0>, grid, dim3(256), smem, s, p);
+  if (dd->variant == MTT_ATTN_FAST_V0) hipLaunchKernelGGL(attn_fwd_fast_kernel<0>, grid, dim3(256), smem, s, p);
+  else hipLaunchKernelGGL(attn_fwd_fast_kernel<1>, grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }

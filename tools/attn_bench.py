@@ -38,7 +38,7 @@ ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
 t_f = timed(lambda: ops.attention(qkv, B, N, nH, T, prec, want_lse=True))
 if FORCE["v"] == 0:                                    # A/B of the forward variants (mtt_attn_desc.variant), interleaved, + bitwise comparison
     import statistics
-    VARS = (0, 2, 3, 4)
+    VARS = (0, 2)        # 0 = default, 2 = MTT_ATTN_FAST_V0 (the previous forward kernel)
     res = {v: [] for v in VARS}
     for _ in range(5):
         for v in VARS:
@@ -55,12 +55,27 @@ dqkv = torch.empty_like(qkv)
 dsum = torch.empty(B, nH, 2, (N + 3) // 4 * 4, device=dev)
 
 
+BV = {"v": 0}
+
+
 def bwd():
-    ops.call("attn_bwd", qkv=qkv, out=ao, rawlog=None, lse=lse, B=B, N=N, nH=nH, T=T, dtype=1, prec=0, scale=0.125,
-             xargs=[dao, drawlog, dqkv, dsum])
+    _call("attn_bwd", qkv=qkv, out=ao, rawlog=None, lse=lse, B=B, N=N, nH=nH, T=T, dtype=1, prec=0, scale=0.125, variant=BV["v"],
+          xargs=[dao, drawlog, dqkv, dsum])
 
 
 t_b = timed(bwd)
+import statistics as _st
+rb = {0: [], 2: []}
+for _ in range(5):
+    for v in (0, 2):
+        BV["v"] = v
+        rb[v].append(timed(bwd, 5))
+BV["v"] = 0
+bwd(); ref = dqkv.clone()
+BV["v"] = 2
+bwd(); same = torch.equal(ref, dqkv)
+BV["v"] = 0
+print(f"backward A/B (us, median of 5): default {_st.median(rb[0]) * 1e3:.0f}, MTT_ATTN_FAST_V0 {_st.median(rb[2]) * 1e3:.0f}; dqkv bitwise equal: {same}")
 gf = 4.0 * N * N * 64 * nH * B / 1e9
 print(f"attention B={B} N={N} nH={nH} T={T} plain={os.environ.get('MTT_ATTN_PLAIN', '0')}: fwd {t_f * 1e3:.0f} us = {gf / t_f:.0f} TFLOP/s (2 GEMMs);"
       f"  bwd {t_b * 1e3:.0f} us = {2.5 * gf / t_b:.0f} TFLOP/s (5 GEMMs algorithmic)")
