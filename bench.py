@@ -287,6 +287,18 @@ def main():
     value = batch * world * a.steps / dt
     peak_gb = torch.cuda.max_memory_allocated() / 2**30
 
+    def host_share(fn):
+        """host time to ENQUEUE one step (python + ctypes + launches, no sync) against the step's wall time: far below 1 = GPU-bound."""
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        fn()
+        h1 = time.perf_counter()
+        torch.cuda.synchronize()
+        h2 = time.perf_counter()
+        return dict(enqueue_ms=round((h1 - h0) * 1e3, 2), step_ms=round((h2 - h0) * 1e3, 2))
+
+    host = host_share(step)
+
     # forward-only latency (the metric's second half), same process
     model.eval()
     with torch.no_grad():
@@ -331,7 +343,7 @@ def main():
             s2()
         torch.cuda.synchronize()
         ms2 = (time.perf_counter() - t2) / 5 * 1e3
-        ref_batch = dict(per_gpu_batch=2, images_per_s=round(2e3 / ms2, 2), ms_per_step=round(ms2, 2))
+        ref_batch = dict(per_gpu_batch=2, images_per_s=round(2e3 / ms2, 2), ms_per_step=round(ms2, 2), host=host_share(s2))
 
     parity = None
     if not a.no_parity and rank == 0:
@@ -379,7 +391,7 @@ def main():
                                 optimizer="clip_grad_norm 10 + Adam (mtt_grad_sqnorm / mtt_adam_step)", loss=float(loss.detach()),
                                 grad_comm=a.grad_comm if world > 1 else None, bucket_mb=a.bucket_mb if world > 1 else None,
                                 rccl_ranks=world if world > 1 else None),
-                    fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(peak_gb, 1),
+                    fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(peak_gb, 1), host=host,
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                       fwd=round(gflop_fwd / fwd_ms_img, 1), fwd_frac_of_bf16_peak=round(gflop_fwd / fwd_ms_img / MFMA_BF16_PEAK_TFLOPS, 4),
                                       gflop_fwd_per_img=gflop_fwd, gflop_fwd_executed_per_img=round(gflop_exec, 1),

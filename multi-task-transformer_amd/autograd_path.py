@@ -143,6 +143,22 @@ def _wgrad_fast(dy, x, N, Kp, prec, colsum=None):
     return _gemm(dyT, xT, dW, N, Kp, Mp, prec, lda=Mp, ldb=Mp, ldd=Kp)
 
 
+N_CUS = 256                 # one 256 x 256 weight-gradient tile occupies a whole CU (128 KiB of LDS)
+
+
+def _tn_splits(tiles, rows, max_splits=32):
+    """Reduction slices for a weight-gradient GEMM with `tiles` 256 x 256 output tiles over `rows` tokens.  The launch takes
+    ceil(tiles * S / 256) rounds of workgroups that each reduce rows / S tokens (~4.7 TFLOP/s per CU), and every slice costs one fp32
+    slab written and read back (~4 TB/s): pick the S with the smallest modelled time (48 tiles: S = 5 -> 240 workgroups in ONE round,
+    where ceil(256 / 48) = 6 needs two rounds for 288 workgroups)."""
+    best, cost = 2, None
+    for S in range(2, max_splits + 1):
+        t = -(-tiles * S // N_CUS) / S * rows * 131072 / 4.7e12 + S * tiles * 65536 * 8 / 4e12
+        if cost is None or t < cost:
+            best, cost = S, t
+    return best
+
+
 WGRAD_TN = os.environ.get("MTT_WGRAD_TN", "1") != "0"     # host-side A/B switch: 0 = round-1 path (transposing copies + K-contiguous GEMM)
 
 
@@ -154,7 +170,7 @@ def _wgrad_tn(dy, x, N, Kp, prec):
     lda, ldb = dy.stride(0), x.stride(0)
     tiles = -(-N // 256) * -(-Kp // 256)
     if tiles < 192 and rows >= 4096:
-        S = max(2, min(32, -(-256 // tiles)))
+        S = _tn_splits(tiles, rows)
         c = (rows // S) // 64 * 64
         if c >= 512:
             nz = rows // c

@@ -27,6 +27,47 @@ MTT_DEV u32x4 perm_frag(const unsigned char* tile, int row, int ks, int lg) {
   return (u32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
+// ---- VER 2 staging: HBM -> LDS by LDS-DMA (no staging registers, no register transposes) --------------------------------------------
+// K tile: [64 keys][8 chunks], the usual lds_off swizzle, applied to the SOURCE chunk of each DMA lane (the LDS image of a
+// global_load_lds is lane-linear: lane l of a 1-KiB piece fills bytes 16 l .. 16 l + 15 = row l >> 3, position l & 7).
+// V tile: [64 keys][4 units of 32 B] as it sits in memory (NOT transposed): the V^T fragments of O^T += V^T P^T come from
+// ds_read_b64_tr_b16 (inside a 16-lane group, lane r pointing at row k0 + (r >> 2), columns c0 + 4 (r & 3) receives rows k0 .. k0 + 3 of
+// column c0 + r: profiles/r02_probe_ds_read_b64_tr_b16.txt); 32-byte units are XOR-ed with (key >> 1) & 3 so that the 8 rows a 32-lane
+// half touches land on 8 different bank octets.
+__device__ __attribute__((aligned(32))) const unsigned g_attn_zero_page[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+MTT_DEV void attn_glds16(const bf16_t* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int OFF>
+MTT_DEV u32x2 attn_ds_read_tr16(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+// all-reduce steps across the 4 lane groups without the LDS pipe (__shfl_xor compiles to ds_bpermute_b32 + a full lgkmcnt wait):
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper
+// 32 lanes of the first with the lower 32 of the second (profiles/r02_probe_permlane_swap.txt), so with both operands = x the two results
+// hold x and its xor-16 (xor-32) partner.  Inline asm: hipcc folds repeated calls of the builtins.
+MTT_DEV void xor16_pair(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+MTT_DEV void xor32_pair(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+MTT_DEV float groups_max(float x) {
+  float a, b;
+  xor16_pair(x, a, b); x = fmaxf(a, b);
+  xor32_pair(x, a, b); return fmaxf(a, b);
+}
+MTT_DEV float groups_sum(float x) {
+  float a, b;
+  xor16_pair(x, a, b); x = a + b;
+  xor32_pair(x, a, b); return a + b;
+}
+
 // Workgroup = 128 query rows, 32 per wave (two B fragments of Q per K / V^T fragment read); 64-key tiles.
 // (A key-split variant — all waves share 64 query rows, each wave owns 32 keys of a 128-key tile, partials merged in LDS —
 // measured 5 % slower on MI355X: the kernel is bound by VALU issue (softmax, staging address math), not by LDS traffic.)
@@ -37,7 +78,7 @@ MTT_DEV u32x4 perm_frag(const unsigned char* tile, int row, int ks, int lg) {
 // (tools/attn_bench.py).  Asking the compiler for 3 / 4 workgroups per CU (<= 168 / 128 VGPRs) instead of 2 spills and is much slower
 // (806 / 1 669 us), and taking the softmax denominators out of the matrix pipe (an A fragment of ones) changed nothing: measured, dropped.
 template <int VER>
-__global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, VER == 3 ? 3 : 2) void attn_fwd_fast_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 2 * KTILE;                  // K, V^T
   const mtt_attn_desc& d = p.d;
@@ -119,6 +160,54 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
     }
   };
 
+  // VER 2: wave w moves key rows [16 w, 16 w + 16) of the K and of the V tile as two 1-KiB pieces each
+  int dma_off[4];                                    // element offsets from (token kv0 of this image, column 0 of this head): K piece 0/1, V piece 0/1
+  int dma_row[2];
+  uint64_t zpage = 0;
+  if (VER >= 2) {
+    zpage = (uint64_t)(uintptr_t)g_attn_zero_page;
+    asm volatile("" : "+s"(zpage));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = wave * 16 + i * 8 + (lane >> 3), pc = lane & 7;
+      dma_row[i] = r;
+      dma_off[i] = r * 3 * C + C + ((pc ^ (r >> 1)) & 7) * 8;                  // K swizzle of VER 2: chunk ^ ((row >> 1) & 7), the same for every 16-key tile
+      dma_off[2 + i] = r * 3 * C + 2 * C + (((((pc >> 1) ^ (r >> 1)) & 3) << 1) | (pc & 1)) * 8;
+    }
+  }
+  auto dma_issue = [&](unsigned char* st, int kv0) {
+    const bf16_t* base = qkv + ((tok0 + kv0) * 3 * C + h * HD);
+    unsigned char* dK = st + wave * 2048;
+    unsigned char* dV = st + KTILE + wave * 2048;
+    if (kv0 + KV <= N) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) attn_glds16(base + dma_off[i], dK + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) attn_glds16(base + dma_off[2 + i], dV + i * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = kv0 + dma_row[i] < N;
+        attn_glds16((const bf16_t*)(uintptr_t)(ok ? (uint64_t)(uintptr_t)(base + dma_off[i]) : zpage), dK + i * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = kv0 + dma_row[i] < N;
+        attn_glds16((const bf16_t*)(uintptr_t)(ok ? (uint64_t)(uintptr_t)(base + dma_off[2 + i]) : zpage), dV + i * 1024);
+      }
+    }
+  };
+  // V^T fragment addresses (stage 0, ks = 0, dt = 0, first 4-key half): row 4 lg + (li >> 2), 8 bytes at column 4 (li & 3) of unit dt ^ f(row)
+  const int vrow = 4 * lg + (li >> 2);
+  const int vf_ = (vrow >> 1) & 3;                   // f(row); rows + 16 / + 32 / + 48 keep it
+  unsigned vaddr[4];                                 // per d tile; stage, 32-key half and 4-key half are immediate offsets
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vaddr[dt] = (unsigned)(uintptr_t)smem + (unsigned)(KTILE + vrow * 128 + (li & 3) * 8 + ((dt ^ vf_) & 3) * 32);
+  // K fragment addresses of VER 2 (row 16 kt + li, chunk 4 kh + lg): two per-lane bases, the key tile and the stage are immediates
+  const unsigned char* kaddr[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) kaddr[kh] = smem + li * 128 + (((kh * 4 + lg) ^ (li >> 1)) & 7) * 16;
+
   f32x4 o[2][4];
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub)
@@ -129,20 +218,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   const bool write_raw = d.rawlog != nullptr && d.T > 0 && qb == 0 && wave == 0 && li < d.T;
 
   const int nkv = (N + KV - 1) / KV;
-  stage_load(0);
-  stage_store(smem);
+  if (VER >= 2) {
+    dma_issue(smem, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    stage_load(0);
+    stage_store(smem);
+  }
   __syncthreads();
 
   auto tile = [&](auto stage_tag, int j) {
     constexpr int ST = decltype(stage_tag)::value;   // -1: run-time stage (VER 0)
     const bool more = j + 1 < nkv;
-    if (more) stage_load((j + 1) * KV);
+    if (more) {
+      if (VER >= 2) dma_issue(smem + (1 - ST) * STAGE, (j + 1) * KV);
+      else stage_load((j + 1) * KV);
+    }
     const unsigned char* Kh = smem + (ST < 0 ? (j & 1) : ST) * STAGE;
     const unsigned char* Vt = Kh + KTILE;
     const int kv0 = j * KV;
     if (active) {
       // ---- S^T = K Q^T : s[sub][kt][r] = S[q = li][key = kv0 + 16 kt + 4 lg + r] ------------------------------
       f32x4 s[2][4];
+      if constexpr (VER >= 2) {
+        u32x4 kf[4][2];                                // all 8 fragment reads in flight before the first MFMA
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) kf[kt][kh] = *(const u32x4*)(kaddr[kh] + ST * STAGE + kt * 2048);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          s[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          s[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) {
+            s[0][kt] = mfma16(kf[kt][kh], qf[0][kh], s[0][kt]);
+            s[1][kt] = mfma16(kf[kt][kh], qf[1][kh], s[1][kt]);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+      } else {
       if (VER >= 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -156,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
         }
       }
       if (VER >= 1) __builtin_amdgcn_s_setprio(0);
+      }
       if (write_raw) {
         float* rl = d.rawlog + (((int64_t)b * d.nH + h) * d.T + li) * N;
 #pragma unroll
@@ -185,8 +302,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (VER >= 2) {
+          mx = groups_max(mx);
+        } else {
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
         const float m_new = fmaxf(m_run[sub], mx * sc2);
         if (__builtin_amdgcn_ballot_w64(m_new != m_run[sub]) != 0) {      // wave-uniform: rescale only when a max moved
           const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new);
@@ -213,6 +334,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
                                 pack2(s[sub][2 * ks + 1][0], s[sub][2 * ks + 1][1]), pack2(s[sub][2 * ks + 1][2], s[sub][2 * ks + 1][3])};
       }
       // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------
+      if constexpr (VER >= 2) {
+        // the 16 transpose reads of the tile are issued up front (the asm loads are invisible to the compiler's wait counting: the waits
+        // below name every destination as an in/out operand, so no use can move above them); half 1 lands under half 0's MFMAs
+        const bool half1 = kv0 + 32 < N;               // block-uniform: the second 32 keys of the last tile may be all padding (P = 0)
+        u32x2 v0l[4], v0h[4], v1l[4], v1h[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          v0l[dt] = attn_ds_read_tr16<ST * STAGE>(vaddr[dt]);
+          v0h[dt] = attn_ds_read_tr16<ST * STAGE + 16 * 128>(vaddr[dt]);
+        }
+#define ATW(x) "+v"(x)
+        if (half1) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            v1l[dt] = attn_ds_read_tr16<ST * STAGE + 32 * 128>(vaddr[dt]);
+            v1h[dt] = attn_ds_read_tr16<ST * STAGE + 48 * 128>(vaddr[dt]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(8)" : ATW(v0l[0]), ATW(v0l[1]), ATW(v0l[2]), ATW(v0l[3]), ATW(v0h[0]), ATW(v0h[1]), ATW(v0h[2]), ATW(v0h[3]) :: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : ATW(v0l[0]), ATW(v0l[1]), ATW(v0l[2]), ATW(v0l[3]), ATW(v0h[0]), ATW(v0h[1]), ATW(v0h[2]), ATW(v0h[3]) :: "memory");
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const u32x4 vf = (u32x4){v0l[dt][0], v0l[dt][1], v0h[dt][0], v0h[dt][1]};
+          o[0][dt] = mfma16(vf, pb[0][0], o[0][dt]);
+          o[1][dt] = mfma16(vf, pb[1][0], o[1][dt]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (half1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : ATW(v1l[0]), ATW(v1l[1]), ATW(v1l[2]), ATW(v1l[3]), ATW(v1h[0]), ATW(v1h[1]), ATW(v1h[2]), ATW(v1h[3]) :: "memory");
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const u32x4 vf = (u32x4){v1l[dt][0], v1l[dt][1], v1h[dt][0], v1h[dt][1]};
+            o[0][dt] = mfma16(vf, pb[0][1], o[0][dt]);
+            o[1][dt] = mfma16(vf, pb[1][1], o[1][dt]);
+          }
+          __builtin_amdgcn_s_setprio(0);
+        }
+#undef ATW
+      } else {
       if (VER >= 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -225,8 +388,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
         }
       }
       if (VER >= 1) __builtin_amdgcn_s_setprio(0);
+      }
     }
-    if (more) stage_store(smem + (ST < 0 ? ((j + 1) & 1) : (1 - ST)) * STAGE);
+    if (more) {
+      if (VER >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else stage_store(smem + (ST < 0 ? ((j + 1) & 1) : (1 - ST)) * STAGE);
+    }
     __syncthreads();
   };
   if (VER >= 1) {
@@ -243,8 +410,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
     float l = l_part[sub];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    if (VER >= 2) {
+      l = groups_sum(l);
+    } else {
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const int qrow = q0 + sub * 16 + li;
     if (qrow >= N) continue;
     const float inv = 1.0f / l;
@@ -264,6 +435,8 @@ int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s) {
   AttnP p; p.d = *dd;
   dim3 grid((unsigned)(((dd->N + 127) / 128) * dd->nH * dd->B));
   if (dd->variant == MTT_ATTN_FAST_V0) hipLaunchKernelGGL(attn_fwd_fast_kernel<0>, grid, dim3(256), smem, s, p);
+  else if (dd->variant == MTT_ATTN_FAST_DMA) hipLaunchKernelGGL(attn_fwd_fast_kernel<2>, grid, dim3(256), smem, s, p);
+  else if (dd->variant == MTT_ATTN_FAST_DMA3) hipLaunchKernelGGL(attn_fwd_fast_kernel<3>, grid, dim3(256), smem, s, p);
   else hipLaunchKernelGGL(attn_fwd_fast_kernel<1>, grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }

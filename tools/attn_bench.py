@@ -38,7 +38,7 @@ ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
 t_f = timed(lambda: ops.attention(qkv, B, N, nH, T, prec, want_lse=True))
 if FORCE["v"] == 0:                                    # A/B of the forward variants (mtt_attn_desc.variant), interleaved, + bitwise comparison
     import statistics
-    VARS = (0, 2)        # 0 = default, 2 = MTT_ATTN_FAST_V0 (the previous forward kernel)
+    VARS = (0, 2, 3, 4)  # 0 = default, 2 = MTT_ATTN_FAST_V0 (the first forward kernel), 3 / 4 = LDS-DMA staging at 2 / 3 workgroups per CU
     res = {v: [] for v in VARS}
     for _ in range(5):
         for v in VARS:
