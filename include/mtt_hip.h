@@ -62,9 +62,9 @@ enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DM
        MTT_GEMM_DMA256_LDS_EPILOGUE = 20 /* AUTO policy, the 256 x 256 kernel with the LDS-staged epilogue even where the direct one is the default (A/B) */,
        MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE = 15, MTT_GEMM_PDMA_ABLATE_NO_STORES = 16, MTT_GEMM_PDMA_ABLATE_NO_BIAS = 17
        /* measurement-only ablations of the persistent kernel (bf16 output + bias calls): WRONG results by construction */ };
-enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1, MTT_ATTN_FAST_V0 = 2 /* the flash forward before its stage unrolling / predicate-free staging (A/B) */,
-       MTT_ATTN_FAST_DMA = 3 /* forward with LDS-DMA staging + transpose reads of V (A/B) */,
-       MTT_ATTN_FAST_DMA3 = 4 /* the same, compiled for 3 workgroups per CU (A/B) */ };
+enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1,
+       MTT_ATTN_FAST_V0 = 2 /* A/B: the first flash kernels (run-time LDS stage, predicated register staging) */,
+       MTT_ATTN_FAST_V1 = 3 /* A/B: register-staged tiles, unrolled stages (AUTO = LDS-DMA staging + transpose reads) */ };
 
 /* 3x3 (dilated) "same" convolution geometry for MTT_OP_CONV_* operands; stride 1, pad = dil. */
 typedef struct {

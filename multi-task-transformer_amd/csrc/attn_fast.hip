@@ -71,14 +71,17 @@ MTT_DEV float groups_sum(float x) {
 // Workgroup = 128 query rows, 32 per wave (two B fragments of Q per K / V^T fragment read); 64-key tiles.
 // (A key-split variant — all waves share 64 query rows, each wave owns 32 keys of a 128-key tile, partials merged in LDS —
 // measured 5 % slower on MI355X: the kernel is bound by VALU issue (softmax, staging address math), not by LDS traffic.)
-// VER 1 (the default; VER 0 = the previous form, mtt_attn_desc.variant = MTT_ATTN_FAST_V0, kept for A/B): the KV loop is unrolled by the two
-// LDS stages (compile-time stage offsets: the fragment reads take immediate offsets instead of a per-read address add), full key tiles
-// are staged without per-key predicates (the `key < N` selects only run for the sequence's last tile), and the MFMA clusters run at
-// raised wave priority: 650 -> 605 us per layer at B = 63, N = 1030 and 2 004 -> 1 844 us at N = 8194, bitwise identical outputs
-// (tools/attn_bench.py).  Asking the compiler for 3 / 4 workgroups per CU (<= 168 / 128 VGPRs) instead of 2 spills and is much slower
-// (806 / 1 669 us), and taking the softmax denominators out of the matrix pipe (an A fragment of ones) changed nothing: measured, dropped.
+// VER 2 (the default): K / V tiles go HBM -> LDS by LDS-DMA (no staging registers, no register transposes, no ds_write), the V^T fragments
+// come from ds_read_b64_tr_b16, all 8 K fragment reads of a tile are in flight before its first MFMA, and the two cross-group reductions
+// of the softmax use v_permlane16/32_swap instead of __shfl_xor (= ds_bpermute_b32 + a full LDS wait, 4 per tile on the critical path).
+// 162 VGPRs -> 3 workgroups per CU.  B = 63, N = 1030, 16 heads: 605 -> 417 us per layer (656 TFLOP/s), N = 8194: 1 838 -> 1 306 us
+// (842 TFLOP/s), outputs bitwise identical to VER 1 / VER 0 on every shape of tools/attn_variants_check.py (profiles/r02_attn_bench_w_*).
+// VER 1 (mtt_attn_desc.variant = MTT_ATTN_FAST_V1): register-staged tiles (global loads -> 4x8 register transposes -> ds_write), KV loop
+// unrolled by the two LDS stages, full tiles staged without per-key predicates, MFMA clusters at raised wave priority (650 -> 605 us over
+// VER 0 = MTT_ATTN_FAST_V0).  Dead ends: forcing 3 / 4 workgroups per CU on VER 1 spills (806 / 1 669 us); softmax denominators on the
+// matrix pipe (an A fragment of ones) changed nothing.
 template <int VER>
-__global__ __launch_bounds__(256, VER == 3 ? 3 : 2) void attn_fwd_fast_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE = 2 * KTILE;                  // K, V^T
   const mtt_attn_desc& d = p.d;
@@ -335,26 +338,26 @@ __global__ __launch_bounds__(256, VER == 3 ? 3 : 2) void attn_fwd_fast_kernel(co
       }
       // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------
       if constexpr (VER >= 2) {
-        // the 16 transpose reads of the tile are issued up front (the asm loads are invisible to the compiler's wait counting: the waits
-        // below name every destination as an in/out operand, so no use can move above them); half 1 lands under half 0's MFMAs
-        const bool half1 = kv0 + 32 < N;               // block-uniform: the second 32 keys of the last tile may be all padding (P = 0)
+        // the 16 transpose reads of the tile are issued up front, unconditionally and with NO control flow before their waits: the asm loads
+        // are invisible to the compiler's wait counting, so a register copy it places between a read and its wait (e.g. a phi move at a
+        // branch merge) would copy a register still in flight.  The waits name every destination as an in/out operand: no use can move
+        // above them.  Half 1 lands under half 0's MFMAs.
+        const bool half1 = kv0 + 32 < N;               // block-uniform: the second 32 keys of the last tile may be all padding (P = 0, V = 0)
         u32x2 v0l[4], v0h[4], v1l[4], v1h[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           v0l[dt] = attn_ds_read_tr16<ST * STAGE>(vaddr[dt]);
           v0h[dt] = attn_ds_read_tr16<ST * STAGE + 16 * 128>(vaddr[dt]);
         }
-#define ATW(x) "+v"(x)
-        if (half1) {
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            v1l[dt] = attn_ds_read_tr16<ST * STAGE + 32 * 128>(vaddr[dt]);
-            v1h[dt] = attn_ds_read_tr16<ST * STAGE + 48 * 128>(vaddr[dt]);
-          }
-          asm volatile("s_waitcnt lgkmcnt(8)" : ATW(v0l[0]), ATW(v0l[1]), ATW(v0l[2]), ATW(v0l[3]), ATW(v0h[0]), ATW(v0h[1]), ATW(v0h[2]), ATW(v0h[3]) :: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : ATW(v0l[0]), ATW(v0l[1]), ATW(v0l[2]), ATW(v0l[3]), ATW(v0h[0]), ATW(v0h[1]), ATW(v0h[2]), ATW(v0h[3]) :: "memory");
+        for (int dt = 0; dt < 4; ++dt) {
+          v1l[dt] = attn_ds_read_tr16<ST * STAGE + 32 * 128>(vaddr[dt]);
+          v1h[dt] = attn_ds_read_tr16<ST * STAGE + 48 * 128>(vaddr[dt]);
         }
+#define ATW(x) "+v"(x)
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : ATW(v0l[0]), ATW(v0l[1]), ATW(v0l[2]), ATW(v0l[3]), ATW(v0h[0]), ATW(v0h[1]), ATW(v0h[2]), ATW(v0h[3]),
+                       ATW(v1l[0]), ATW(v1l[1]), ATW(v1l[2]), ATW(v1l[3]), ATW(v1h[0]), ATW(v1h[1]), ATW(v1h[2]), ATW(v1h[3]) :: "memory");
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -362,18 +365,16 @@ __global__ __launch_bounds__(256, VER == 3 ? 3 : 2) void attn_fwd_fast_kernel(co
           o[0][dt] = mfma16(vf, pb[0][0], o[0][dt]);
           o[1][dt] = mfma16(vf, pb[1][0], o[1][dt]);
         }
-        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : ATW(v1l[0]), ATW(v1l[1]), ATW(v1l[2]), ATW(v1l[3]), ATW(v1h[0]), ATW(v1h[1]), ATW(v1h[2]), ATW(v1h[3]) :: "memory");
         if (half1) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : ATW(v1l[0]), ATW(v1l[1]), ATW(v1l[2]), ATW(v1l[3]), ATW(v1h[0]), ATW(v1h[1]), ATW(v1h[2]), ATW(v1h[3]) :: "memory");
-          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
             const u32x4 vf = (u32x4){v1l[dt][0], v1l[dt][1], v1h[dt][0], v1h[dt][1]};
             o[0][dt] = mfma16(vf, pb[0][1], o[0][dt]);
             o[1][dt] = mfma16(vf, pb[1][1], o[1][dt]);
           }
-          __builtin_amdgcn_s_setprio(0);
         }
+        __builtin_amdgcn_s_setprio(0);
 #undef ATW
       } else {
       if (VER >= 1) __builtin_amdgcn_s_setprio(1);
@@ -435,8 +436,7 @@ int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s) {
   AttnP p; p.d = *dd;
   dim3 grid((unsigned)(((dd->N + 127) / 128) * dd->nH * dd->B));
   if (dd->variant == MTT_ATTN_FAST_V0) hipLaunchKernelGGL(attn_fwd_fast_kernel<0>, grid, dim3(256), smem, s, p);
-  else if (dd->variant == MTT_ATTN_FAST_DMA) hipLaunchKernelGGL(attn_fwd_fast_kernel<2>, grid, dim3(256), smem, s, p);
-  else if (dd->variant == MTT_ATTN_FAST_DMA3) hipLaunchKernelGGL(attn_fwd_fast_kernel<3>, grid, dim3(256), smem, s, p);
-  else hipLaunchKernelGGL(attn_fwd_fast_kernel<1>, grid, dim3(256), smem, s, p);
+  else if (dd->variant == MTT_ATTN_FAST_V1) hipLaunchKernelGGL(attn_fwd_fast_kernel<1>, grid, dim3(256), smem, s, p);
+  else hipLaunchKernelGGL(attn_fwd_fast_kernel<2>, grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }

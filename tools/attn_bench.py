@@ -38,7 +38,7 @@ ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
 t_f = timed(lambda: ops.attention(qkv, B, N, nH, T, prec, want_lse=True))
 if FORCE["v"] == 0:                                    # A/B of the forward variants (mtt_attn_desc.variant), interleaved, + bitwise comparison
     import statistics
-    VARS = (0, 2, 3, 4)  # 0 = default, 2 = MTT_ATTN_FAST_V0 (the first forward kernel), 3 / 4 = LDS-DMA staging at 2 / 3 workgroups per CU
+    VARS = (0, 2, 3)  # 0 = default, 2 = MTT_ATTN_FAST_V0 (the first forward kernel), 3 = MTT_ATTN_FAST_V1 (register-staged tiles)
     res = {v: [] for v in VARS}
     for _ in range(5):
         for v in VARS:
@@ -65,17 +65,19 @@ def bwd():
 
 t_b = timed(bwd)
 import statistics as _st
-rb = {0: [], 2: []}
+rb = {0: [], 3: [], 2: []}
 for _ in range(5):
-    for v in (0, 2):
+    for v in rb:
         BV["v"] = v
         rb[v].append(timed(bwd, 5))
 BV["v"] = 0
 bwd(); ref = dqkv.clone()
-BV["v"] = 2
-bwd(); same = torch.equal(ref, dqkv)
+same = {}
+for v in (3, 2):
+    BV["v"] = v
+    bwd(); same[v] = torch.equal(ref, dqkv)
 BV["v"] = 0
-print(f"backward A/B (us, median of 5): default {_st.median(rb[0]) * 1e3:.0f}, MTT_ATTN_FAST_V0 {_st.median(rb[2]) * 1e3:.0f}; dqkv bitwise equal: {same}")
+print(f"backward A/B (us, median of 5): default (LDS-DMA) {_st.median(rb[0]) * 1e3:.0f}, MTT_ATTN_FAST_V1 {_st.median(rb[3]) * 1e3:.0f}, MTT_ATTN_FAST_V0 {_st.median(rb[2]) * 1e3:.0f}; dqkv bitwise equal to default: {same}")
 gf = 4.0 * N * N * 64 * nH * B / 1e9
 print(f"attention B={B} N={N} nH={nH} T={T} plain={os.environ.get('MTT_ATTN_PLAIN', '0')}: fwd {t_f * 1e3:.0f} us = {gf / t_f:.0f} TFLOP/s (2 GEMMs);"
       f"  bwd {t_b * 1e3:.0f} us = {2.5 * gf / t_b:.0f} TFLOP/s (5 GEMMs algorithmic)")
