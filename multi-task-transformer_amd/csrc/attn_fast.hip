@@ -45,29 +45,6 @@ MTT_DEV u32x2 attn_ds_read_tr16(unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
   return r;
 }
-// all-reduce steps across the 4 lane groups without the LDS pipe (__shfl_xor compiles to ds_bpermute_b32 + a full lgkmcnt wait):
-// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper
-// 32 lanes of the first with the lower 32 of the second (profiles/r02_probe_permlane_swap.txt), so with both operands = x the two results
-// hold x and its xor-16 (xor-32) partner.  Inline asm: hipcc folds repeated calls of the builtins.
-MTT_DEV void xor16_pair(float x, float& a, float& b) {
-  a = x; b = x;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-MTT_DEV void xor32_pair(float x, float& a, float& b) {
-  a = x; b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-MTT_DEV float groups_max(float x) {
-  float a, b;
-  xor16_pair(x, a, b); x = fmaxf(a, b);
-  xor32_pair(x, a, b); return fmaxf(a, b);
-}
-MTT_DEV float groups_sum(float x) {
-  float a, b;
-  xor16_pair(x, a, b); x = a + b;
-  xor32_pair(x, a, b); return a + b;
-}
-
 // Workgroup = 128 query rows, 32 per wave (two B fragments of Q per K / V^T fragment read); 64-key tiles.
 // (A key-split variant — all waves share 64 query rows, each wave owns 32 keys of a 128-key tile, partials merged in LDS —
 // measured 5 % slower on MI355X: the kernel is bound by VALU issue (softmax, staging address math), not by LDS traffic.)

@@ -151,6 +151,29 @@ MTT_DEV void transpose4x8(const u32x4 (&in)[4], u32x2 (&out)[8]) {
   }
 }
 
+// ---- all-reduce steps across the 4 lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48) without the LDS pipe (__shfl_xor compiles to ds_bpermute_b32 + a full lgkmcnt wait):
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper
+// 32 lanes of the first with the lower 32 of the second (profiles/r02_probe_permlane_swap.txt), so with both operands = x the two results
+// hold x and its xor-16 (xor-32) partner.  Inline asm: hipcc folds repeated calls of the builtins.
+MTT_DEV void xor16_pair(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+MTT_DEV void xor32_pair(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+MTT_DEV float groups_max(float x) {
+  float a, b;
+  xor16_pair(x, a, b); x = fmaxf(a, b);
+  xor32_pair(x, a, b); return fmaxf(a, b);
+}
+MTT_DEV float groups_sum(float x) {
+  float a, b;
+  xor16_pair(x, a, b); x = a + b;
+  xor32_pair(x, a, b); return a + b;
+}
+
 MTT_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

@@ -165,8 +165,7 @@ __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_des
         mx = fmaxf(mx, v);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = groups_max(mx);
     float l = 0.f;
 #pragma unroll
     for (int j = 0; j < NKT; ++j)
@@ -176,8 +175,7 @@ __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_des
         s[j][r] = pv;
         l += pv;
       }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = groups_sum(l);
     // O^T += V^T P^T over 32-key chunks
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll

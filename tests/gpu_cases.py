@@ -352,6 +352,20 @@ def attn_cases():
                   xargs=[rnd(g, B * N, C, dtype=DT[BF16]), rnd(g, B, nH, T, N) * 0.05 if T else None,
                          torch.zeros(B * N, 3 * C, dtype=DT[BF16]), torch.zeros(B, nH, 2, (N + 3) // 4 * 4)])
         cases.append((f"attn_bwd_B{B}N{N}T{T}", "attn_bwd", kw, dict(f32=5e-3, bf16=1.5e-2)))
+    # the A/B variants of the flash kernels (mtt_attn_desc.variant 3 = register-staged tiles, 2 = the first form) stay covered
+    for variant in (3, 2):
+        B, N, nH, T = 2, 150, 2, 6
+        C = nH * 64
+        kw = dict(qkv=rnd(g, B * N, 3 * C, dtype=DT[BF16]), out=torch.zeros(B * N, C, dtype=DT[BF16]), rawlog=torch.zeros(B, nH, T, N),
+                  lse=torch.zeros(B, nH, N), B=B, N=N, nH=nH, T=T, dtype=BF16, prec=0, scale=0.125, variant=variant)
+        cases.append((f"attn_B{B}N{N}T{T}_bf16_variant{variant}", "attn_fwd", kw, dict(f32=2e-3, bf16=6e-3)))
+        fw = dict(kw, rawlog=None, T=0, out=torch.zeros(B * N, C, dtype=DT[BF16]), lse=torch.zeros(B, nH, N))
+        fw.pop("variant")
+        abi_emul.call("attn_fwd", **fw)
+        kb = dict(qkv=kw["qkv"], out=fw["out"], rawlog=None, lse=fw["lse"], B=B, N=N, nH=nH, T=T, dtype=BF16, prec=0, scale=0.125, variant=variant,
+                  xargs=[rnd(g, B * N, C, dtype=DT[BF16]), rnd(g, B, nH, T, N) * 0.05, torch.zeros(B * N, 3 * C, dtype=DT[BF16]),
+                         torch.zeros(B, nH, 2, (N + 3) // 4 * 4)])
+        cases.append((f"attn_bwd_B{B}N{N}T{T}_variant{variant}", "attn_bwd", kb, dict(f32=5e-3, bf16=1.5e-2)))
     # softmax spike (forces large running-max jumps across tiles)
     B, N, nH, T = 1, 200, 1, 2
     q = rnd(g, B * N, 3 * 64)

@@ -15,3 +15,17 @@ def test_entry_point_matches_emulator(case):
     cname, entry, kw, tol = case
     r = gpu_cases.run_case(entry, kw, None, tol)
     assert r["ok"], f"{cname}: {r['errs']}"
+
+
+@pytest.mark.gpu
+def test_attention_variants_are_bitwise_identical_and_repeatable():
+    """tools/attn_variants_check.py: the LDS-DMA flash kernels (default) against both register-staged variants on ragged shapes, forward and
+    backward, with repeats (a staging race shows as run-to-run differences)."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_variants_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
