@@ -344,6 +344,26 @@ def main():
         torch.cuda.synchronize()
         ms2 = (time.perf_counter() - t2) / 5 * 1e3
         ref_batch = dict(per_gpu_batch=2, images_per_s=round(2e3 / ms2, 2), ms_per_step=round(ms2, 2), host=host_share(s2))
+        # the same iteration recorded once in a hipGraph and replayed (graphs.GraphedTrainStep): at this batch the eager step is bound by
+        # the host's launch rate, not by the GPU
+        try:
+            x2, gt2 = x[:2].contiguous(), {k: v[:2].contiguous() for k, v in gt.items()}
+            gopt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=2e-5, weight_decay=1e-6, max_norm=10.0, capturable=True)
+            gstep = mtt_amd.graphs.GraphedTrainStep(model, crit, gopt, x2, gt2, warmup=2)
+            for _ in range(3):
+                gstep(x2, gt2)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(10):
+                gl = gstep(x2, gt2)
+            torch.cuda.synchronize()
+            ms3 = (time.perf_counter() - t3) / 10 * 1e3
+            ref_batch["graphed"] = dict(images_per_s=round(2e3 / ms3, 2), ms_per_step=round(ms3, 2), loss=float(gl),
+                                        what="forward + criterion + backward + clip + Adam + weight re-packing replayed from one hipGraph")
+            del gstep, gopt
+            mtt_amd.graphs.clear()
+        except Exception as e:  # noqa: BLE001
+            ref_batch["graphed"] = dict(error=repr(e)[:300])
 
     parity = None
     if not a.no_parity and rank == 0:

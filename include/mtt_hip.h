@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 4
+#define MTT_ABI_VERSION 5
 
 enum { MTT_F32 = 0, MTT_BF16 = 1 };
 enum { MTT_PREC_BF16 = 0, MTT_PREC_X3 = 1 };
@@ -345,6 +345,8 @@ typedef struct {
   const void* const* grads; float* const* params; float* const* exp_avg; float* const* exp_avg_sq; const int64_t* numel;
   const int32_t* chunk_tensor; const int64_t* chunk_off; int32_t n_chunks;
   float max_norm, step_size, beta1, beta2, eps, weight_decay, inv_sqrt_bc2;
+  const float* hyper;  /* optional DEVICE pair {step_size, inv_sqrt_bc2}: when non-NULL it replaces the two by-value fields, so that a step
+                          captured in a hipGraph can be replayed with the next step count / learning rate (graphs.py) */
 } mtt_adam_desc;
 int mtt_adam_chunk(void);
 int mtt_grad_sqnorm(const mtt_adam_desc* d, float* out_sq, void* stream);

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, BF16 = 0, 1
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -139,7 +139,7 @@ class AdamDesc(C.Structure):
     _fields_ = [("grads", ptr), ("params", ptr), ("exp_avg", ptr), ("exp_avg_sq", ptr), ("numel", ptr),
                 ("chunk_tensor", ptr), ("chunk_off", ptr), ("n_chunks", i32),
                 ("max_norm", f32), ("step_size", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32),
-                ("inv_sqrt_bc2", f32)]
+                ("inv_sqrt_bc2", f32), ("hyper", ptr)]
 
 
 class LossDesc(C.Structure):

@@ -38,13 +38,14 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const mtt_adam_desc d,
   if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
-MTT_DEV void adam1(float g, float& p, float& m, float& v, const mtt_adam_desc& d, float coef) {
+struct AdamHyper { float step_size, inv_sqrt_bc2; };
+MTT_DEV void adam1(float g, float& p, float& m, float& v, const mtt_adam_desc& d, float coef, AdamHyper hy) {
   g *= coef;
   if (d.weight_decay != 0.f) g = fmaf(d.weight_decay, p, g);
   m = fmaf(d.beta1, m, (1.0f - d.beta1) * g);
   v = fmaf(d.beta2, v, (1.0f - d.beta2) * g * g);
-  const float denom = sqrtf(v) * d.inv_sqrt_bc2 + d.eps;
-  p -= d.step_size * (m / denom);
+  const float denom = sqrtf(v) * hy.inv_sqrt_bc2 + d.eps;
+  p -= hy.step_size * (m / denom);
 }
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const mtt_adam_desc d, const float* total_sq) {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const mtt_adam_desc d, c
     coef = d.max_norm / (sqrtf(*total_sq) + 1e-6f);
     coef = coef < 1.0f ? coef : 1.0f;
   }
+  const AdamHyper hy = d.hyper ? AdamHyper{d.hyper[0], d.hyper[1]} : AdamHyper{d.step_size, d.inv_sqrt_bc2};
   const bool vec = (((uintptr_t)g | (uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
   int done = 0;
   if (vec) {
@@ -68,13 +70,13 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const mtt_adam_desc d, c
     for (int i = threadIdx.x; i < n4; i += 256) {
       const float4 gv = ((const float4*)g)[i];
       float4 pv = ((float4*)p)[i], mv = ((float4*)m)[i], vv = ((float4*)v)[i];
-      adam1(gv.x, pv.x, mv.x, vv.x, d, coef); adam1(gv.y, pv.y, mv.y, vv.y, d, coef);
-      adam1(gv.z, pv.z, mv.z, vv.z, d, coef); adam1(gv.w, pv.w, mv.w, vv.w, d, coef);
+      adam1(gv.x, pv.x, mv.x, vv.x, d, coef, hy); adam1(gv.y, pv.y, mv.y, vv.y, d, coef, hy);
+      adam1(gv.z, pv.z, mv.z, vv.z, d, coef, hy); adam1(gv.w, pv.w, mv.w, vv.w, d, coef, hy);
       ((float4*)p)[i] = pv; ((float4*)m)[i] = mv; ((float4*)v)[i] = vv;
     }
     done = n4 << 2;
   }
-  for (int i = done + threadIdx.x; i < n; i += 256) adam1(g[i], p[i], m[i], v[i], d, coef);
+  for (int i = done + threadIdx.x; i < n; i += 256) adam1(g[i], p[i], m[i], v[i], d, coef, hy);
 }
 
 }  // namespace

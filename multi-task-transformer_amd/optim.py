@@ -17,9 +17,16 @@ class FusedClipAdam(torch.optim.Optimizer):
     """Adam (torch.optim.Adam semantics: L2 weight decay added to the gradient, bias-corrected moments, no amsgrad) preceded by
     global-norm gradient clipping.  `step()` returns the total gradient norm before clipping (like clip_grad_norm_)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0, capturable=False):
+        """capturable=True: the step-dependent scalars (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)) are read by the kernel from a device
+        pair (`mtt_adam_desc.hyper`) instead of being launch constants, so that a step captured in a hipGraph (graphs.GraphedTrainStep) can be
+        replayed with the next step count and learning rate; `prepare_replay()` advances them."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_norm = float(max_norm)
+        self.capturable = bool(capturable)
+        self._hyper = {}           # (group, part) -> device fp32 [2]
+        self._hyper_pinned = {}    # (group, part, slot) -> pinned fp32 [2]
+        self._captured = None      # work list of the captured step: [(group index, part, params)]
         self._tables = {}
         self._pinned = {}          # (group, slot) -> pinned int64 staging buffer of gradient pointers (rotated: copies are asynchronous)
         self._slot = 0
@@ -30,7 +37,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         n = len(grads)
         if dev.type != "cuda":
             return torch.from_numpy(np.array([g.data_ptr() for g in grads], dtype=np.int64))
-        key = (gi, self._slot % 4)
+        key = (gi, "captured" if self._capturing(dev) else self._slot % 4)     # a captured copy re-reads ITS host buffer on every replay
         buf = self._pinned.get(key)
         if buf is None or buf.numel() != n:
             buf = torch.empty(n, dtype=torch.int64).pin_memory()
@@ -71,6 +78,48 @@ class FusedClipAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._tables.clear()
 
+    @staticmethod
+    def _capturing(dev):
+        return dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+    def _set_hyper(self, key, dev, group, t):
+        """-> device pair {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} of one launch group, refreshed by a stream-ordered copy from a ring of
+        pinned host pairs (never while a stream is capturing: a captured copy would re-read the same host pair on every replay)."""
+        hy = self._hyper.get(key)
+        if hy is None:
+            hy = self._hyper[key] = torch.zeros(2, dtype=torch.float32, device=dev)
+        if self._capturing(dev):
+            return hy
+        b1, b2 = group["betas"]
+        vals = (group["lr"] / (1.0 - b1 ** t), 1.0 / math.sqrt(1.0 - b2 ** t))
+        if dev.type != "cuda":
+            hy.copy_(torch.tensor(vals, dtype=torch.float32))
+            return hy
+        pk = key + (self._slot % 4,)
+        buf = self._hyper_pinned.get(pk)
+        if buf is None:
+            buf = self._hyper_pinned[pk] = torch.empty(2, dtype=torch.float32).pin_memory()
+        buf[0], buf[1] = vals
+        hy.copy_(buf, non_blocking=True)
+        return hy
+
+    def prepare_replay(self):
+        """Before replaying a captured step: advance every captured parameter's step count and enqueue the new step-dependent scalars
+        (and whatever the learning-rate scheduler set in `param_groups`) on the current stream."""
+        if self._captured is None:
+            raise RuntimeError("FusedClipAdam.prepare_replay: no captured step (call step() under stream capture with capturable=True first)")
+        self._slot += 1
+        for gi, part, plist in self._captured:
+            steps = [self.state[p]["step"] for p in plist]
+            torch._foreach_add_(steps, 1)
+            self._set_hyper((gi, part), plist[0].device, self.param_groups[gi], float(steps[0]))
+
+    def after_replay(self):
+        """After a replay: the graph wrote the parameters behind torch's back — same bookkeeping as the end of step()."""
+        for _, _, plist in self._captured:
+            torch.autograd.graph.increment_version(plist)
+        ops.bump_param_epoch()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -95,26 +144,34 @@ class FusedClipAdam(torch.optim.Optimizer):
                 tab = self._group_tables(gi, part, plist)
                 grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
                 gp = self._grad_ptrs((gi, part), grads, plist[0].device)
-                work.append((group, plist, tab, grads, gp, t0 + 1.0))
+                work.append((group, plist, tab, grads, gp, t0 + 1.0, (gi, part)))
         if not work:
             return loss
         self._slot += 1
         dev = work[0][1][0].device
+        capturing = self._capturing(dev)
+        if capturing:
+            if not self.capturable:
+                raise RuntimeError("FusedClipAdam: construct with capturable=True to capture step() in a graph")
+            self._captured = [(key[0], key[1], plist) for _, plist, _, _, _, _, key in work]
         total_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         base = dict(max_norm=0.0, step_size=0.0, beta1=0.0, beta2=0.0, eps=0.0, weight_decay=0.0, inv_sqrt_bc2=0.0)
-        for group, plist, tab, grads, gp, t in work:
+        for group, plist, tab, grads, gp, t, key in work:
             ops.call("grad_sqnorm", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
                      chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], xargs=[total_sq], **base)
-        for group, plist, tab, grads, gp, t in work:
-            torch._foreach_add_([self.state[p]["step"] for p in plist], 1)
+        for group, plist, tab, grads, gp, t, key in work:
+            if not capturing:                                     # a capture records the launch; nothing is executed, no step is taken
+                torch._foreach_add_([self.state[p]["step"] for p in plist], 1)
             b1, b2 = group["betas"]
-            ops.call("adam_step", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
+            hyper = self._set_hyper(key, dev, group, t) if self.capturable else None
+            ops.call("adam_step", hyper=hyper, grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
                      chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], max_norm=self.max_norm,
                      step_size=group["lr"] / (1.0 - b1 ** t), beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
                      inv_sqrt_bc2=1.0 / math.sqrt(1.0 - b2 ** t), xargs=[total_sq if self.max_norm > 0 else None])
             # the kernel wrote the parameters through raw pointers: tell torch (autograd's saved-tensor checks, any cache keyed
             # on `_version`) and the pack cache of ops.py that they changed
-            torch.autograd.graph.increment_version(plist)
+            if not capturing:
+                torch.autograd.graph.increment_version(plist)
         ops.bump_param_epoch()
         self.last_grad_norm = total_sq.sqrt()
         return loss if loss is not None else self.last_grad_norm

@@ -668,12 +668,15 @@ def adam_step(**kw):
     coef = 1.0
     if kw["max_norm"] > 0 and total is not None:
         coef = min(1.0, kw["max_norm"] / (float(_rd(total, torch.arange(1))[0]) ** 0.5 + 1e-6))
+    step_size, inv_sqrt_bc2 = float(np.float32(kw["step_size"])), float(np.float32(kw["inv_sqrt_bc2"]))      # f32 descriptor fields
+    if kw.get("hyper") is not None:                      # device pair that replaces the by-value fields (graph-capturable step)
+        step_size, inv_sqrt_bc2 = (float(v) for v in _rd(kw["hyper"], torch.arange(2)))
     for g, p, m, v, n in zip(grads, params, ms, vs, numel):
         ga, pa, ma, va = (_raw_f32(a, n) for a in (g, p, m, v))
         gg = ga.astype("float64") * coef + kw["weight_decay"] * pa.astype("float64")
         mm = kw["beta1"] * ma.astype("float64") + (1 - kw["beta1"]) * gg
         vv = kw["beta2"] * va.astype("float64") + (1 - kw["beta2"]) * gg * gg
-        pa[:] = (pa.astype("float64") - kw["step_size"] * mm / (np.sqrt(vv) * kw["inv_sqrt_bc2"] + kw["eps"])).astype("float32")
+        pa[:] = (pa.astype("float64") - step_size * mm / (np.sqrt(vv) * inv_sqrt_bc2 + kw["eps"])).astype("float32")
         ma[:] = mm.astype("float32")
         va[:] = vv.astype("float32")
 

@@ -82,6 +82,59 @@ def test_fused_clip_adam_matches_torch_on_gpu():
 
 
 @pytest.mark.gpu
+def test_graphed_train_step_matches_eager_steps():
+    """graphs.GraphedTrainStep (the whole iteration recorded in one hipGraph, FusedClipAdam(capturable=True)) against the same iterations
+    launched eagerly: identical parameters after 3 further steps on changing inputs (DropPath off: the graph draws from its own Philox
+    offsets), optimizer step counts advanced, weight packs invalidated for the eager forward that follows."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import copy
+    import mtt_amd
+    dev = torch.device("cuda")
+    H = W = 64
+    torch.manual_seed(0)
+    p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (H, W), backbone="TaskPrompter_vitB", head="conv", embed_dim=48, final_embed_dim=56,
+                               chan_nheads=1, use_ctr=True, prec="bf16", drop_path_rate=0.0)
+    model_a = mtt_amd.factory.get_model(p).to(dev).train()
+    model_b = copy.deepcopy(model_a)
+    crit = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES).to(dev)
+    xs = [torch.randn(2, 3, H, W, device=dev) for _ in range(6)]
+    gts = [mtt_amd.losses.synthetic_targets(p, 2, H, W, dev, seed=i) for i in range(6)]
+    oa = mtt_amd.optim.FusedClipAdam(model_a.parameters(), lr=1e-3, weight_decay=1e-6, max_norm=10.0)
+    ob = mtt_amd.optim.FusedClipAdam(model_b.parameters(), lr=1e-3, weight_decay=1e-6, max_norm=10.0, capturable=True)
+
+    def eager(model, opt, x, gt):
+        loss = crit(model(x), gt)["total"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    # the recorder runs 2 eager warm-up iterations on (xs[0], gts[0]) before capturing
+    for _ in range(2):
+        eager(model_a, oa, xs[0], gts[0])
+    step = mtt_amd.graphs.GraphedTrainStep(model_b, crit, ob, xs[0], gts[0], warmup=2)
+    for q, r in zip(model_a.parameters(), model_b.parameters()):
+        assert float((q.detach() - r.detach()).abs().max()) <= 1e-6        # recording executes nothing (a third step would move them by ~1e-3)
+    losses = []
+    for i in range(1, 4):
+        la = eager(model_a, oa, xs[i], gts[i])
+        lb = step(xs[i], gts[i])
+        losses.append((float(la), float(lb)))
+    worst = max(float((q.detach() - r.detach()).abs().max()) for q, r in zip(model_a.parameters(), model_b.parameters()))
+    print(f"graphed vs eager: losses {losses}, worst parameter difference after 3 steps {worst:.3e}")
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(a)) for a, b in losses), losses
+    assert worst <= 1e-6, worst            # the gradient norm is accumulated with float atomics (order-dependent last bits)
+    st = ob.state[next(iter(model_b.parameters()))]
+    assert float(st["step"]) == 5.0
+    model_a.eval(), model_b.eval()
+    with torch.no_grad():
+        ya, yb = model_a(xs[4]), model_b(xs[4])                            # eager forward after replays: packs must have been rebuilt
+    for t in ya:
+        assert float((ya[t].float() - yb[t].float()).abs().max()) <= 1e-3 * float(ya[t].float().abs().max()) + 1e-6, t
+
+
+@pytest.mark.gpu
 def test_fused_losses_on_gpu():
     """mtt_loss_label_stats / mtt_loss_fwd / mtt_loss_bwd vs the torch restatement of the reference criterion (CPU, fp32)."""
     if not torch.cuda.is_available():

@@ -210,6 +210,30 @@ def test_fused_clip_adam_matches_torch_adam_with_clipping(emulated, monkeypatch)
     o_ref.load_state_dict(sd)                                                     # layouts are interchangeable
 
 
+def test_fused_clip_adam_capturable_reads_step_scalars_from_memory(emulated, monkeypatch):
+    """capturable=True (mtt_adam_desc.hyper: the bias corrections / learning rate come from a memory pair) takes the same steps as the
+    launch-constant form, with a learning-rate schedule in between."""
+    import mtt_amd
+    monkeypatch.setattr(mtt_amd.ops, "adam_chunk", lambda: 65536)
+    torch.manual_seed(1)
+    shapes = [(3000,), (33, 17)]
+    a = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    b = [torch.nn.Parameter(q.detach().clone()) for q in a]
+    oa = mtt_amd.optim.FusedClipAdam(a, lr=3e-3, weight_decay=1e-2, max_norm=2.0)
+    ob = mtt_amd.optim.FusedClipAdam(b, lr=3e-3, weight_decay=1e-2, max_norm=2.0, capturable=True)
+    sa, sb = mtt_amd.optim.PolynomialLR(oa, max_iterations=10), mtt_amd.optim.PolynomialLR(ob, max_iterations=10)
+    for it in range(3):
+        for q, r in zip(a, b):
+            g = torch.randn(q.shape)
+            q.grad, r.grad = g.clone(), g.clone()
+        oa.step(), ob.step()
+        sa.step(), sb.step()
+        for q, r in zip(a, b):
+            assert torch.equal(q.detach(), r.detach()), it
+    with pytest.raises(RuntimeError):
+        ob.prepare_replay()                                  # nothing was captured
+
+
 def _loss_case(device, B=2, H=12, W=10):
     import mtt_amd
     p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (H, W))
