@@ -88,6 +88,7 @@ def parse():
                     help="MEASUREMENT ONLY (invalid training: the forward keeps using the step-0 weight packs): what the per-step re-packing costs")
     ap.add_argument("--gemm-variant", type=int, default=None,
                     help="A/B: mtt_gemm_desc.variant for every GEMM left at AUTO (12 = policy + persistent kernel, 14 = policy without it)")
+    ap.add_argument("--graphed-worker", action="store_true", help="(internal) the subprocess leg of ref_batch.graphed")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
     return ap.parse_args()
@@ -215,8 +216,50 @@ def _pmc_traffic(kernel_substr):
     return rec.get("hbm_bytes_per_launch"), rec.get("source")
 
 
+def _graphed_worker(cfg_name, prec):
+    """(subprocess) the reference-batch iteration recorded once in a hipGraph and replayed (graphs.GraphedTrainStep); prints one JSON object."""
+    import mtt_amd
+    dev = torch.device("cuda", 0)
+    _, _, (H, W), _, _ = CONFIGS[cfg_name]
+    torch.manual_seed(0)
+    p, model = build(cfg_name, prec, mtt_amd)
+    model = model.to(dev).train()
+    crit = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES).to(dev)
+    opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=2e-5, weight_decay=1e-6, max_norm=10.0, capturable=True)
+    x = torch.randn(2, 3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    gt = mtt_amd.losses.synthetic_targets(p, 2, H, W, dev, seed=0)
+    step = mtt_amd.graphs.GraphedTrainStep(model, crit, opt, x, gt, warmup=2)
+    for _ in range(3):
+        step(x, gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        loss = step(x, gt)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    print(json.dumps(dict(images_per_s=round(2e3 / ms, 2), ms_per_step=round(ms, 2), loss=float(loss), steps=10,
+                          what="forward + criterion + backward + clip + Adam + weight re-packing replayed from ONE hipGraph "
+                               "(graphs.GraphedTrainStep), measured in its own process")), flush=True)
+
+
+def graphed_ref_batch(cfg_name, prec, limit_s=240):
+    """Runs _graphed_worker in a subprocess (a failed stream capture can leave the HIP runtime unusable; the bench line must survive it)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graphed-worker", "--config", cfg_name, "--prec", prec],
+                           capture_output=True, text=True, timeout=limit_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return dict(error=f"worker exit {r.returncode}: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200])
+    except Exception as e:  # noqa: BLE001
+        return dict(error=repr(e)[:200])
+
+
 def main():
     a = parse()
+    if a.graphed_worker:
+        return _graphed_worker(a.config, a.prec)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -344,26 +387,7 @@ def main():
         torch.cuda.synchronize()
         ms2 = (time.perf_counter() - t2) / 5 * 1e3
         ref_batch = dict(per_gpu_batch=2, images_per_s=round(2e3 / ms2, 2), ms_per_step=round(ms2, 2), host=host_share(s2))
-        # the same iteration recorded once in a hipGraph and replayed (graphs.GraphedTrainStep): at this batch the eager step is bound by
-        # the host's launch rate, not by the GPU
-        try:
-            x2, gt2 = x[:2].contiguous(), {k: v[:2].contiguous() for k, v in gt.items()}
-            gopt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=2e-5, weight_decay=1e-6, max_norm=10.0, capturable=True)
-            gstep = mtt_amd.graphs.GraphedTrainStep(model, crit, gopt, x2, gt2, warmup=2)
-            for _ in range(3):
-                gstep(x2, gt2)
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            for _ in range(10):
-                gl = gstep(x2, gt2)
-            torch.cuda.synchronize()
-            ms3 = (time.perf_counter() - t3) / 10 * 1e3
-            ref_batch["graphed"] = dict(images_per_s=round(2e3 / ms3, 2), ms_per_step=round(ms3, 2), loss=float(gl),
-                                        what="forward + criterion + backward + clip + Adam + weight re-packing replayed from one hipGraph")
-            del gstep, gopt
-            mtt_amd.graphs.clear()
-        except Exception as e:  # noqa: BLE001
-            ref_batch["graphed"] = dict(error=repr(e)[:300])
+        ref_batch["graphed"] = graphed_ref_batch(a.config, a.prec)
 
     parity = None
     if not a.no_parity and rank == 0:

@@ -40,8 +40,13 @@ class FusedClipAdam(torch.optim.Optimizer):
         key = (gi, "captured" if self._capturing(dev) else self._slot % 4)     # a captured copy re-reads ITS host buffer on every replay
         buf = self._pinned.get(key)
         if buf is None or buf.numel() != n:
+            if self._capturing(dev):
+                raise RuntimeError("FusedClipAdam: run at least one eager step() with the same gradients before capturing (pinned staging "
+                                   "buffers cannot be allocated while a stream is capturing)")
             buf = torch.empty(n, dtype=torch.int64).pin_memory()
             self._pinned[key] = buf
+        if self.capturable and (gi, "captured") not in self._pinned:
+            self._pinned[(gi, "captured")] = torch.empty(n, dtype=torch.int64).pin_memory()      # host allocations are illegal while capturing
         buf.numpy()[:] = [g.data_ptr() for g in grads]
         return buf.to(dev, non_blocking=True)
 
