@@ -237,7 +237,7 @@ def _graphed_worker(cfg_name, prec):
         loss = step(x, gt)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 10 * 1e3
-    print(json.dumps(dict(images_per_s=round(2e3 / ms, 2), ms_per_step=round(ms, 2), loss=float(loss), steps=10,
+    print(json.dumps(dict(images_per_s=round(2e3 / ms, 2), ms_per_step=round(ms, 2), loss=float(loss.detach()), steps=10,
                           what="forward + criterion + backward + clip + Adam + weight re-packing replayed from ONE hipGraph "
                                "(graphs.GraphedTrainStep), measured in its own process")), flush=True)
 
