@@ -234,6 +234,16 @@ def test_fused_clip_adam_capturable_reads_step_scalars_from_memory(emulated, mon
         ob.prepare_replay()                                  # nothing was captured
 
 
+def test_graphed_train_step_refuses_what_it_cannot_record():
+    import mtt_amd
+    w = torch.nn.Parameter(torch.zeros(4))
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(ValueError, match="capturable"):
+        mtt_amd.graphs.GraphedTrainStep(None, None, mtt_amd.optim.FusedClipAdam([w]), x, {})
+    with pytest.raises(ValueError, match="GPU"):
+        mtt_amd.graphs.GraphedTrainStep(None, None, mtt_amd.optim.FusedClipAdam([w], capturable=True), x, {})
+
+
 def _loss_case(device, B=2, H=12, W=10):
     import mtt_amd
     p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (H, W))
