@@ -310,33 +310,51 @@ __global__ __launch_bounds__(256) void dwconv3s2_bwd_dx_kernel(const mtt_dwconv_
     st8(dx, ((((int64_t)z * d.B + b) * d.H + iy) * d.W + ix) * d.ld + c8 * 8, d.dtype, acc);
   }
 }
-// dw[z,tap,c] = sum_{b,oy,ox} x[z,b,2oy-1+ky,2ox-1+kx,c] * dy[z,b,oy,ox,c]     (one thread per (z, tap, 8 channels))
+// dw[z,tap,c] = sum_{b,oy,ox} x[z,b,2oy-1+ky,2ox-1+kx,c] * dy[z,b,oy,ox,c].
+// One workgroup per (z, tap, group of 64 channels): 8 chunk lanes (8 channels = 16 B each: a pixel's 128 contiguous bytes) x 32 pixel lanes
+// that stride over the B * Ho * Wo output pixels; fixed-order reduction (xor shuffles over the 8 pixel lanes of a wave, then the 4 waves
+// through LDS): deterministic, no atomics, no workspace.  (Round 1 looped over ALL pixels in one thread per (z, tap, 8 channels): 12 ms per
+// call at the InvPT ViT-L sizes, 7.7 % of the cfg4 training step, profiles/r02_train_cfg4_b32_z.txt.)
 __global__ __launch_bounds__(256) void dwconv3s2_bwd_dw_kernel(const mtt_dwconv_desc d, const void* dy, float* dw) {
-  const int C8 = d.ld >> 3;
+  const int C8 = (int)(d.ld >> 3);
   const int Ho = (d.H - 1) / 2 + 1, Wo = (d.W - 1) / 2 + 1;
-  const int64_t total = (int64_t)d.Z * 9 * C8;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int c8 = (int)(t % C8), tap = (int)((t / C8) % 9), z = (int)(t / (9 * C8));
+  const int groups = (C8 + 7) >> 3;
+  const int grp = blockIdx.x % groups, tap = (blockIdx.x / groups) % 9, z = blockIdx.x / (groups * 9);
   const int ky = tap / 3, kx = tap % 3;
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;            // chunk lane, pixel lane (0..31)
+  const int c8 = grp * 8 + cl;
+  const bool cok = c8 < C8;
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int b = 0; b < d.B; ++b)
-    for (int oy = 0; oy < Ho; ++oy) {
-      const int iy = 2 * oy - 1 + ky;
-      if (iy < 0 || iy >= d.H) continue;
-      for (int ox = 0; ox < Wo; ++ox) {
-        const int ix = 2 * ox - 1 + kx;
-        if (ix < 0 || ix >= d.W) continue;
-        float xv[8], g[8];
-        ld8(d.x, ((((int64_t)z * d.B + b) * d.H + iy) * d.W + ix) * d.ld + c8 * 8, d.dtype, xv);
-        ld8(dy, ((((int64_t)z * d.B + b) * Ho + oy) * Wo + ox) * d.ld + c8 * 8, d.dtype, g);
+  const int npix = d.B * Ho * Wo;
+  if (cok) {
+    for (int p = pl; p < npix; p += 32) {
+      const int ox = p % Wo, t = p / Wo;
+      const int oy = t % Ho, b = t / Ho;
+      const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+      if (iy < 0 || iy >= d.H || ix < 0 || ix >= d.W) continue;
+      float xv[8], g[8];
+      ld8(d.x, ((((int64_t)z * d.B + b) * d.H + iy) * d.W + ix) * d.ld + c8 * 8, d.dtype, xv);
+      ld8(dy, ((int64_t)z * npix + p) * d.ld + c8 * 8, d.dtype, g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += xv[j] * g[j];
-      }
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], g[j], acc[j]);
     }
-  st8(dw, ((int64_t)z * 9 + tap) * d.ld + c8 * 8, MTT_F32, acc);
+  }
+  __shared__ float red[4][8][8];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc[j];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if ((threadIdx.x & 63) < 8) red[wave][cl][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x >> 3, j = threadIdx.x & 7;
+    if (grp * 8 + c < C8)
+      dw[((int64_t)z * 9 + tap) * d.ld + (grp * 8 + c) * 8 + j] = (red[0][c][j] + red[1][c][j]) + (red[2][c][j] + red[3][c][j]);
+  }
 }
 // average-pool backward: dx[b,y,x,c] = dy[b, y/k, x/k, c] / (#in-bounds elements of that window)
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const mtt_pool_desc d, const void* dy, void* dx) {
@@ -429,7 +447,7 @@ extern "C" int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream) {
 extern "C" int mtt_dwconv3x3s2_bwd(const mtt_dwconv_desc* d, const void* dy, void* dx, float* dw, void* stream) {
   if (!d || !d->x || !d->w || !dy || d->Z <= 0 || d->B <= 0 || (d->ld % 8)) return MTT_E_BADARG;
   if (dx) hipLaunchKernelGGL(dwconv3s2_bwd_dx_kernel, dim3(grid_for((int64_t)d->Z * d->B * d->H * d->W * (d->ld / 8))), dim3(256), 0, S_, *d, dy, dx);
-  if (dw) hipLaunchKernelGGL(dwconv3s2_bwd_dw_kernel, dim3((unsigned)(((int64_t)d->Z * 9 * (d->ld / 8) + 255) / 256)), dim3(256), 0, S_, *d, dy, dw);
+  if (dw) hipLaunchKernelGGL(dwconv3s2_bwd_dw_kernel, dim3((unsigned)((int64_t)d->Z * 9 * ((d->ld / 8 + 7) / 8))), dim3(256), 0, S_, *d, dy, dw);
   return (int)hipGetLastError();
 }
 extern "C" int mtt_avgpool_ceil_bwd(const mtt_pool_desc* d, const void* dy, void* dx, void* stream) {

@@ -563,6 +563,10 @@ def invpt_cases():
         kw = dict(x=rnd(g, Z, B * H * W, ld, dtype=DT[dt]), w=rnd(g, Z, 9, ld), y=None, scale=None, shift=None, Z=Z, B=B, H=H, W=W, ld=ld, dtype=dt,
                   xargs=[rnd(g, Z, B * 3 * 2, ld, dtype=DT[dt]), torch.zeros(Z, B * H * W, ld, dtype=DT[dt]), torch.zeros(Z, 9, ld)])
         cases.append((f"dwconv_bwd_{dt}", "dwconv3x3s2_bwd", kw, dict(f32=2e-5, bf16=6e-3)))
+        Z, B, H, W, ld = 3, 3, 9, 7, 136                     # odd map, more than one 64-channel group with a ragged last one, > 32 pixels per lane set
+        kw = dict(x=rnd(g, Z, B * H * W, ld, dtype=DT[dt]), w=rnd(g, Z, 9, ld), y=None, scale=None, shift=None, Z=Z, B=B, H=H, W=W, ld=ld, dtype=dt,
+                  xargs=[rnd(g, Z, B * 5 * 4, ld, dtype=DT[dt]), torch.zeros(Z, B * H * W, ld, dtype=DT[dt]), torch.zeros(Z, 9, ld)])
+        cases.append((f"dwconv_bwd_ragged_{dt}", "dwconv3x3s2_bwd", kw, dict(f32=2e-5, bf16=6e-3)))
         kw = dict(x=None, y=None, B=2, H=5, W=7, k=4, ld=16, dtype=dt, xargs=[rnd(g, 2 * 2 * 2, 16, dtype=DT[dt]), torch.zeros(2 * 35, 16, dtype=DT[dt])])
         cases.append((f"avgpool_bwd_{dt}", "avgpool_ceil_bwd", kw, TOL_ROW))
         kw = dict(yall=None, out=None, bias=None, B=2, H=3, W=4, Cop=16, dtype=dt, out_dtype=dt,
