@@ -234,6 +234,22 @@ def test_fused_clip_adam_capturable_reads_step_scalars_from_memory(emulated, mon
         ob.prepare_replay()                                  # nothing was captured
 
 
+def test_weight_gradient_slice_count_fills_one_round_of_cus():
+    """autograd_path._tn_splits: 256 x 256 weight-gradient tiles occupy a whole CU, so the slice count must not spill a few workgroups into a
+    second round (48 tiles: 5 slices = 240 workgroups, not ceil(256 / 48) = 6 -> 288), and few-tile outputs still get many slices."""
+    import mtt_amd
+    from mtt_amd import autograd_path
+    ts = autograd_path._tn_splits
+    rows = 63 * 1030
+    assert ts(48, rows) == 5 and ts(64, rows) == 4 and ts(16, rows) == 16
+    for tiles in (1, 3, 9, 12, 36, 48, 64, 100, 150, 191):
+        S = ts(tiles, rows)
+        assert 2 <= S <= 32
+        rounds = -(-tiles * S // 256)
+        assert tiles * S > 256 * (rounds - 1) + 0.5 * 256 or rounds == 1, (tiles, S)      # the last round is at least half full
+    assert ts(4, 8240) < ts(4, rows)                                                        # short reductions take fewer slabs
+
+
 def test_graphed_train_step_refuses_what_it_cannot_record():
     import mtt_amd
     w = torch.nn.Parameter(torch.zeros(4))
