@@ -356,6 +356,8 @@ def main():
     model.train()
 
     roof = None
+    if not a.no_roofline and rank != 0:
+        step()                                   # every rank takes the instrumented step: under DDP its gradient all-reduce is a collective
     if not a.no_roofline and rank == 0:
         with GemmTimer(mtt_amd.ops, mtt_amd._lib.gemm_variant) as gt_:
             step()
@@ -444,6 +446,7 @@ def main():
                     roofline=roof, parity=parity, ref_batch=ref_batch, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                            # rank 0's extra legs (parity twin, JSON line) end before any rank tears the group down
         dist.destroy_process_group()
 
 
