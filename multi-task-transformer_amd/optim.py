@@ -80,8 +80,20 @@ class FusedClipAdam(torch.optim.Optimizer):
         return tab
 
     def load_state_dict(self, state_dict):
+        """torch's loader REPLACES the moment tensors.  A captured step (graphs.GraphedTrainStep) holds their addresses, so when one exists
+        the loaded values are copied INTO the tensors the graph updates and those stay in place; otherwise only the pointer tables are dropped."""
+        if self._captured is None:
+            super().load_state_dict(state_dict)
+            self._tables.clear()
+            return
+        pinned = {p: (self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for _, _, plist in self._captured for p in plist}
         super().load_state_dict(state_dict)
-        self._tables.clear()
+        with torch.no_grad():
+            for p, (m, v) in pinned.items():
+                st = self.state[p]
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                st["exp_avg"], st["exp_avg_sq"] = m, v
 
     @staticmethod
     def _capturing(dev):

@@ -250,6 +250,28 @@ def test_weight_gradient_slice_count_fills_one_round_of_cus():
     assert ts(4, 8240) < ts(4, rows)                                                        # short reductions take fewer slabs
 
 
+def test_load_state_dict_keeps_the_moment_tensors_a_captured_step_updates(emulated, monkeypatch):
+    """After a capture the graph holds the addresses of exp_avg / exp_avg_sq: load_state_dict must fill THOSE tensors instead of replacing them."""
+    import mtt_amd
+    monkeypatch.setattr(mtt_amd.ops, "adam_chunk", lambda: 65536)
+    torch.manual_seed(2)
+    a = [torch.nn.Parameter(torch.randn(50)), torch.nn.Parameter(torch.randn(7, 3))]
+    b = [torch.nn.Parameter(q.detach().clone()) for q in a]
+    oa = mtt_amd.optim.FusedClipAdam(a, lr=1e-2, capturable=True)
+    ob = mtt_amd.optim.FusedClipAdam(b, lr=1e-2, capturable=True)
+    for q, r in zip(a, b):
+        q.grad = torch.randn(q.shape)
+        r.grad = torch.randn(r.shape)
+    oa.step(), ob.step()
+    ob._captured = [(0, 0, list(b))]                       # what step() records under stream capture
+    held = [(ob.state[r]["exp_avg"], ob.state[r]["exp_avg_sq"]) for r in b]
+    ob.load_state_dict(oa.state_dict())
+    for q, r, (m, v) in zip(a, b, held):
+        assert ob.state[r]["exp_avg"] is m and ob.state[r]["exp_avg_sq"] is v
+        assert torch.equal(m, oa.state[q]["exp_avg"]) and torch.equal(v, oa.state[q]["exp_avg_sq"])
+        assert float(ob.state[r]["step"]) == float(oa.state[q]["step"])
+
+
 def test_graphed_train_step_refuses_what_it_cannot_record():
     import mtt_amd
     w = torch.nn.Parameter(torch.zeros(4))
