@@ -22,6 +22,8 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep needs FusedClipAdam(..., capturable=True)")
         if not x.is_cuda:
             raise ValueError("GraphedTrainStep records a HIP graph: inputs must live on the GPU")
+        if isinstance(model, torch.nn.parallel.DistributedDataParallel):
+            raise ValueError("GraphedTrainStep is single-process: DistributedDataParallel's bucketed all-reduce is not captured")
         self.model, self.criterion, self.optimizer, self.loss_key = model, criterion, optimizer, loss_key
         self.x = x.clone()
         self.targets = {k: v.clone() for k, v in targets.items()}
