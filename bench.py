@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-ref-batch", action="store_true")
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg (the oracle's torch ops on the GPU)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the tolerance-compliant sub-record (parity_mode)")
+    ap.add_argument("--torch-baseline-worker", default=None, help="(internal) subprocess leg of torch_rocm_baseline: 'fp32' or 'bf16'")
     ap.add_argument("--no-fuse-upsample", action="store_true",
                     help="A/B: materialise the x4-upsampled task features and run ConvHead's 3x3 conv on them (the reference's operation order)")
     ap.add_argument("--measure-no-repack", action="store_true",
@@ -194,6 +197,89 @@ def cpu_baseline(cfg_name, batch, threads=16, limit_s=240):
                        f"step ({warm:.1f} s): {dt:.1f} s on {threads} of {os.cpu_count()} host threads")
 
 
+def _torch_baseline_worker(cfg_name, mode):
+    """(subprocess) STOCK PyTorch-ROCm on this GPU: the oracle's torch ops (the reference's op graph: hipBLASLt / rocBLAS GEMMs, MIOpen
+    convs, ATen softmax / LayerNorm / GELU kernels) run on cuda:0, fp32 like the reference or under bf16 autocast — forward + criterion +
+    backward + torch.optim.Adam + clip_grad_norm_.  BASELINE ONLY: the number a user gets for free on this chip, next to the hand-written path."""
+    import torch as T
+    from oracle import configs, weights
+    import mtt_amd
+    okey = {"ns6": "ns6", "cfg2": "cfg2", "cfg3": "cfg3", "cfg4": "cfg4_6", "cfg5": "cfg5", "swinb": "cs_swinB"}[cfg_name]
+    invpt, swin = cfg_name == "cfg4", cfg_name == "swinb"
+    cfg = dict(configs.invpt(okey) if invpt else (configs.swin(okey) if swin else configs.taskprompter(okey)))
+    p, model = build(cfg_name, "x3", mtt_amd)
+    contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+    del model
+    dev = T.device("cuda", 0)
+    sd = {k: v.to(dev) for k, v in weights.synth_state_dict(contract, 0).items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    if invpt:
+        from oracle import invpt_oracle as orc
+    elif swin:
+        from oracle import swin_oracle as orc
+    else:
+        from oracle import taskprompter_oracle as orc
+    crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)
+    opt = T.optim.Adam(list(params.values()), lr=2e-5, weight_decay=1e-6)
+    H, W = cfg["img_size"]
+    res = {}
+    for batch in (2, 16):
+        try:
+            x = weights.synth_images(batch, cfg["img_size"], 1).to(dev)
+            gt = mtt_amd.losses.synthetic_targets(p, batch, H, W, dev)
+
+            def step():
+                with T.autocast("cuda", dtype=T.bfloat16, enabled=(mode == "bf16")):
+                    out = orc.forward(dict(sd, **params), cfg, x, training=True)
+                out = {k: (v.float() if T.is_tensor(v) else {kk: vv.float() for kk, vv in v.items()}) for k, v in out.items()}
+                loss = crit(out, gt)["total"]
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                T.nn.utils.clip_grad_norm_(list(params.values()), 10.0)
+                opt.step()
+                return loss
+            step()
+            T.cuda.synchronize()
+            n = 3 if batch <= 8 else 2
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            T.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            res[str(batch)] = dict(images_per_s=round(batch * 1e3 / ms, 2), ms_per_step=round(ms, 1),
+                                   peak_hbm_gb=round(T.cuda.max_memory_allocated() / 2**30, 1))
+            print(json.dumps(dict(partial=res)), flush=True)
+        except Exception as e:  # noqa: BLE001  (out of memory at the larger batches ends the sweep)
+            res[str(batch)] = dict(error=repr(e)[:160])
+            break
+        finally:
+            x = gt = None
+            T.cuda.empty_cache()
+    print(json.dumps(dict(result=res)), flush=True)
+
+
+def torch_rocm_baseline(cfg_name, limit_s=150):
+    """Both legs (fp32 = the reference's arithmetic; bf16 autocast) in subprocesses, bounded; the last complete / partial result is kept."""
+    import subprocess
+    out = dict(what="stock PyTorch-ROCm (torch %s) on the same GPU: the CPU oracle's torch op graph = the reference's (hipBLASLt / MIOpen / ATen "
+                    "kernels), training step = fwd + criterion + bwd + clip_grad_norm_ + torch.optim.Adam, synthetic batch resident in HBM; "
+                    "per-GPU batch -> images/s.  Baseline only." % torch.__version__)
+    for mode in ("fp32", "bf16"):
+        stdout, err = "", "timeout"
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-baseline-worker", mode, "--config", cfg_name],
+                               capture_output=True, text=True, timeout=limit_s)
+            stdout, err = r.stdout, (r.stderr.strip().splitlines() or ["?"])[-1][:200]
+        except subprocess.TimeoutExpired as e:
+            stdout = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:200]
+        recs = [json.loads(ln) for ln in stdout.splitlines() if ln.startswith("{")]
+        fin = [x["result"] for x in recs if "result" in x] or [x["partial"] for x in recs if "partial" in x]
+        out[mode] = fin[-1] if fin else dict(error="no result: " + err)
+    return out
+
+
 def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -260,12 +346,17 @@ def main():
     a = parse()
     if a.graphed_worker:
         return _graphed_worker(a.config, a.prec)
+    if a.torch_baseline_worker:
+        return _torch_baseline_worker(a.config, a.torch_baseline_worker)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # launched by torch.distributed.run (RANK / MASTER_ADDR in the env): RCCL process group + DDP even at world size 1, so that a
+    # one-GPU box exercises the same communicator / bucketed all-reduce code path the 8-GPU run takes
+    ddp_mode = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if ddp_mode:
         dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
     import mtt_amd
 
@@ -280,11 +371,11 @@ def main():
         torch.autograd.graph.increment_version = lambda *x, **k: None
     torch.manual_seed(0)
     p, model = build(a.config, a.prec, mtt_amd)
-    if world > 1:
+    if ddp_mode:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)          # TaskPrompter/main.py:92
     model = model.to(dev).train()
     net = model
-    if world > 1:
+    if ddp_mode:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=a.config == "cfg4",
                                                         gradient_as_bucket_view=True, bucket_cap_mb=a.bucket_mb)
         if a.grad_comm == "bf16":
@@ -414,6 +505,11 @@ def main():
         except Exception as e:  # noqa: BLE001
             parity["error"] = repr(e)
 
+    torch_base = None
+    if rank == 0 and world == 1 and not a.no_torch_baseline:
+        torch.cuda.empty_cache()
+        torch_base = torch_rocm_baseline(a.config)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -435,17 +531,17 @@ def main():
                     vs_baseline=None, dtype="bf16" if a.prec == "bf16" else "f32(bf16x3)", data="synthetic",
                     config=dict(workload=desc, name=a.config, per_gpu_batch=batch, global_batch=batch * world, parallelism=f"dp{world}",
                                 optimizer="clip_grad_norm 10 + Adam (mtt_grad_sqnorm / mtt_adam_step)", loss=float(loss.detach()),
-                                grad_comm=a.grad_comm if world > 1 else None, bucket_mb=a.bucket_mb if world > 1 else None,
-                                rccl_ranks=world if world > 1 else None),
+                                grad_comm=a.grad_comm if ddp_mode else None, bucket_mb=a.bucket_mb if ddp_mode else None,
+                                rccl_ranks=world if ddp_mode else None),
                     fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(peak_gb, 1), host=host,
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                       fwd=round(gflop_fwd / fwd_ms_img, 1), fwd_frac_of_bf16_peak=round(gflop_fwd / fwd_ms_img / MFMA_BF16_PEAK_TFLOPS, 4),
                                       gflop_fwd_per_img=gflop_fwd, gflop_fwd_executed_per_img=round(gflop_exec, 1),
                                       convention="FLOPs of the reference's operation order; 'executed' subtracts what the taps-first "
                                                  "ConvHead (upsample x4 + 3x3 conv commuted) does not compute"),
-                    roofline=roof, parity=parity, ref_batch=ref_batch, cpu_baseline=cpu)
+                    roofline=roof, parity=parity, ref_batch=ref_batch, torch_rocm_baseline=torch_base, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if ddp_mode:
         dist.barrier()                            # rank 0's extra legs (parity twin, JSON line) end before any rank tears the group down
         dist.destroy_process_group()
 

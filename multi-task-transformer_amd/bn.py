@@ -3,7 +3,7 @@
 
 Statistics are centred (mean, M2 = sum (x - mean)^2) from the deterministic two-level reduction mtt_bn_stats, like the
 reference's nn.BatchNorm2d (never E[x^2] - E[x]^2).  Under SyncBatchNorm + an initialised process group ALL Z maps of a stage
-exchange their (mean, M2, count) triplets in ONE all_gather (forward) and their backward sums in ONE all_reduce, and the
+exchange their (mean, M2, count) triplets in ONE collective (forward: an all_reduce of a rank-slotted table) and their backward sums in ONE all_reduce, and the
 per-rank triplets are merged exactly (Chan), so ranks may hold different numbers of rows.
 """
 import torch
@@ -29,10 +29,12 @@ def train_stats(x, C, bns):
     mean, m2 = ops.bn_stats(x, C)
     world = _world(bns)
     if world > 1:
-        pack = torch.cat([mean, m2, torch.full((Z, 1), float(rows), dtype=torch.float32, device=x.device)], 1).contiguous()
-        parts = [torch.empty_like(pack) for _ in range(world)]
-        dist.all_gather(parts, pack)                                   # one collective for the whole stage
-        allp = torch.stack(parts, 0)                                   # [W, Z, 2C+1]
+        # one collective for the whole stage: every rank fills its own slot of a zero [W, Z, 2C+1] table and the table is all-reduced
+        # (sum with zeros is exact).  An all_reduce rather than an all_gather because it is the one collective every backend offers
+        # on device tensors (gloo has no device all_gather; RCCL has both) — the table is a few KB.
+        allp = torch.zeros(world, Z, 2 * C + 1, dtype=torch.float32, device=x.device)
+        allp[dist.get_rank()] = torch.cat([mean, m2, torch.full((Z, 1), float(rows), dtype=torch.float32, device=x.device)], 1)
+        dist.all_reduce(allp)
         cnt = allp[:, :, 2 * C:]
         n = cnt.sum(0)                                                 # [Z, 1]
         mean = (allp[:, :, :C] * cnt).sum(0) / n

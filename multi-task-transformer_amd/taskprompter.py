@@ -44,6 +44,22 @@ def _prec_of(p):
     return ops.Prec(p.get('mtt_prec', 'bf16') if hasattr(p, 'get') else getattr(p, 'mtt_prec', 'bf16'))
 
 
+PREC_GROUPS = ('enc', 'attn', 'side', 'fuse', 'heads')
+
+
+def _group_precs(p, base):
+    """Per-group OPERAND precision for the error-attribution runs (tools/prec_attribution.py): `p.mtt_prec_groups` maps a group
+    of PREC_GROUPS to 'bf16' | 'x3'.  Storage stays fp32 (requires mtt_prec == 'x3'); a 'bf16' group rounds its GEMM / attention
+    operands to bf16 exactly where the bf16 mode does (weights packed bf16, activations converted while staged), so the table
+    isolates which part of the path the bf16 mode's error comes from.  Inference path only."""
+    g = p.get('mtt_prec_groups', None) if hasattr(p, 'get') else getattr(p, 'mtt_prec_groups', None)
+    if not g:
+        return None
+    assert base.name == 'x3', "mtt_prec_groups needs fp32 storage (mtt_prec = 'x3')"
+    assert set(g) <= set(PREC_GROUPS), g
+    return {k: ops.Prec(g.get(k, 'x3')) for k in PREC_GROUPS}
+
+
 class PatchEmbed(nn.Module):
     """Parameter holder with timm's PatchEmbed attribute surface (proj, grid_size, num_patches)."""
 
@@ -163,6 +179,11 @@ class TaskPrompter(nn.Module):
         trunc_normal_(self.pos_embed, std=.02)
         self.apply(_init_vit_weights)
         self.prec = _prec_of(p)
+        self.gprec = _group_precs(p, self.prec)
+
+    def _gp(self, group):
+        """compute precision of a group (== the model's, unless an attribution run overrides it)"""
+        return self.gprec[group] if self.gprec else self.prec
 
     @torch.jit.ignore
     def no_weight_decay(self):
@@ -218,8 +239,9 @@ class TaskPrompter(nn.Module):
         XT = torch.empty(B * N, C, dtype=torch.float32, device=dev)
         XT.view(B, N, C)[:, :T] = self.task_prompts.detach()
         cols = ops.patchify(img.float(), prec)
-        wpe = ops.pack_linear([self.patch_embed.proj.weight], prec, 'pe')
-        ops.linear(cols, wpe, C, prec, bias=self.patch_embed.proj.bias.detach()[None], out=XT.view(B, N, C)[:, T:],
+        pe = self._gp('enc')
+        wpe = ops.pack_linear([self.patch_embed.proj.weight], pe, 'pe')
+        ops.linear(cols, wpe, C, pe, bias=self.patch_embed.proj.bias.detach()[None], out=XT.view(B, N, C)[:, T:],
                    d_rows=(hw, N * C, C), resid=self.pos_embed.detach()[0, 1:], r_rows=(hw, 0, C), M=B * hw)
 
         acc = None
@@ -235,34 +257,43 @@ class TaskPrompter(nn.Module):
 
     def _block(self, blk, i, XT, B, N, T, grid, nwin):
         prec, C, nH = self.prec, self.embed_dim, self.num_heads
+        pe, pa, ps = self._gp('enc'), self._gp('attn'), self._gp('side')
+        adt = prec.adt                                              # storage dtype (a group override only changes operand rounding)
         hw = grid[0] * grid[1]
         a = blk.attn
         tag = ('blk', i)
         xn, _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec)
-        qkv = ops.linear(xn, ops.pack_linear([a.qkv.weight], prec, tag + ('qkv',)), 3 * C, prec,
-                         bias=a.qkv.bias.detach()[None])[0]
-        ao, rawlog, _ = ops.attention(qkv, B, N, nH, T, prec)
+        qkv = ops.linear(xn, ops.pack_linear([a.qkv.weight], pe, tag + ('qkv',)), 3 * C, pe,
+                         bias=a.qkv.bias.detach()[None], out_dtype=adt)[0]
+        if pa.adt != qkv.dtype:                                      # attribution: bf16 attention inside an fp32-storage run
+            q16 = ops.cast2d(qkv, qkv.shape[0], 3 * C, 3 * C, pa.adt, ldd=3 * C)
+            ao16, rawlog, _ = ops.attention(q16, B, N, nH, T, pa)
+            ao = ops.cast2d(ao16, ao16.shape[0], C, C, adt, ldd=C)
+        else:
+            ao, rawlog, _ = ops.attention(qkv, B, N, nH, T, pa)
         XT2 = torch.empty_like(XT)
-        ops.linear(ao, ops.pack_linear([a.proj.weight], prec, tag + ('proj',)), C, prec, bias=a.proj.bias.detach()[None],
+        ops.linear(ao, ops.pack_linear([a.proj.weight], pe, tag + ('proj',)), C, pe, bias=a.proj.bias.detach()[None],
                    out=XT2, resid=XT)
         # channel attention: queries token_trans(norm1(prompts)), keys norm1(x)^T, windowed (:216-250)
-        cq = ops.linear(xn, ops.pack_linear([a.token_trans.weight], prec, tag + ('tt',)), hw, prec,
-                        bias=a.token_trans.bias.detach()[None], a_rows=(T, N * C, C), M=B * T)[0]
-        rawchan = ops.chan_logits(cq, xn, B, T, N, C, grid, (nwin, nwin))
+        cq = ops.linear(xn, ops.pack_linear([a.token_trans.weight], ps, tag + ('tt',)), hw, ps,
+                        bias=a.token_trans.bias.detach()[None], a_rows=(T, N * C, C), M=B * T, out_dtype=ps.adt)[0]
+        xnc = xn if ps.adt == xn.dtype else ops.cast2d(xn, xn.shape[0], C, C, ps.adt, ldd=C)
+        rawchan = ops.chan_logits(cq, xnc, B, T, N, C, grid, (nwin, nwin))
         pr = XT2.view(B, N, C)[:, :T]
-        ops.linear(cq, ops.pack_linear([a.token_trans1.weight], prec, tag + ('tt1',)), C, prec,
+        ops.linear(cq, ops.pack_linear([a.token_trans1.weight], ps, tag + ('tt1',)), C, ps,
                    bias=a.token_trans1.bias.detach()[None], out=pr, d_rows=(T, N * C, C), resid=pr, M=B * T)
         xn2, _, _ = ops.layernorm(XT2, blk.norm2.weight.detach(), blk.norm2.bias.detach(), blk.norm2.eps, prec)
-        hmid = ops.linear(xn2, ops.pack_linear([blk.mlp.fc1.weight], prec, tag + ('fc1',)), 4 * C, prec,
-                          bias=blk.mlp.fc1.bias.detach()[None], act=ACT_GELU)[0]
+        hmid = ops.linear(xn2, ops.pack_linear([blk.mlp.fc1.weight], pe, tag + ('fc1',)), 4 * C, pe,
+                          bias=blk.mlp.fc1.bias.detach()[None], act=ACT_GELU, out_dtype=adt)[0]
         XT3 = torch.empty_like(XT)
-        ops.linear(hmid, ops.pack_linear([blk.mlp.fc2.weight], prec, tag + ('fc2',)), C, prec,
+        ops.linear(hmid, ops.pack_linear([blk.mlp.fc2.weight], pe, tag + ('fc2',)), C, pe,
                    bias=blk.mlp.fc2.bias.detach()[None], out=XT3, resid=XT2)
         return XT3, rawlog, rawchan
 
     # ---- cal_task_feature (taskprompter.py:424-487), all tasks at once -----------------------------
     def _decoder_packs(self, il):
-        p, prec = self.p, self.prec
+        p = self.p
+        prec, pf = self._gp('side'), self._gp('fuse')          # fea_decode_* belong to 'side', fea_fuse to 'fuse' (== self.prec unless attributing)
         names = p.TASKS.NAMES
         tar, F = p.embed_dim, p.final_embed_dim
         tarp = ops.pad8(tar)
@@ -281,12 +312,12 @@ class TaskPrompter(nn.Module):
                     w2 = wt.detach().reshape(F, 2 * tar)
                     buf[i, :, :tar] = w2[:, :tar]
                     buf[i, :, tarp:tarp + tar] = w2[:, tar:]
-                return buf.to(prec.adt)
-        W0 = ops._cached(('f0', il, prec.name, tuple(id(q) for q in f0)), f0, build_f0)
+                return buf.to(pf.adt)
+        W0 = ops._cached(('f0', il, pf.name, tuple(id(q) for q in f0)), f0, build_f0)
         b0 = ops.stack_vec([self.fea_fuse[il][t][0].bias for t in names], ('f0b', il))
-        Wc = ops.pack_conv3([self.fea_fuse[il][t][1].weight for t in names], prec, ('f1', il))
+        Wc = ops.pack_conv3([self.fea_fuse[il][t][1].weight for t in names], pf, ('f1', il))
         bc = ops.stack_vec([self.fea_fuse[il][t][1].bias for t in names], ('f1b', il))
-        W4 = ops.pack_linear([self.fea_fuse[il][t][4].weight for t in names], prec, ('f4', il))
+        W4 = ops.pack_linear([self.fea_fuse[il][t][4].weight for t in names], pf, ('f4', il))
         b4 = ops.stack_vec([self.fea_fuse[il][t][4].bias for t in names], ('f4b', il))
         return Wdec, bdec, W0, b0, Wc, bc, W4, b4
 
@@ -313,6 +344,7 @@ class TaskPrompter(nn.Module):
 
     def _task_features(self, xsrc, xview, rawlog, rawchan, il, B, acc):
         p, prec = self.p, self.prec
+        ps, pf, adt = self._gp('side'), self._gp('fuse'), self.prec.adt
         names = p.TASKS.NAMES
         T, C = len(names), self.embed_dim
         h, w = self.resolution
@@ -323,17 +355,17 @@ class TaskPrompter(nn.Module):
         Wdec, bdec, W0, b0, Wc, bc, W4, b4 = self._decoder_packs(il)
         mod = ops.modulate(xview, C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec)
         cat = torch.empty(T, B * hw, 2 * tarp, dtype=prec.adt, device=xsrc.device)
-        ops.linear(mod, Wdec, tar, prec, bias=bdec, out=cat, batch_inner=2, d_z=(B * hw * 2 * tarp, tarp), ldd=2 * tarp,
+        ops.linear(mod, Wdec, tar, ps, bias=bdec, out=cat, batch_inner=2, d_z=(B * hw * 2 * tarp, tarp), ldd=2 * tarp,
                    n_store=tarp)
-        y0 = ops.linear(cat, W0, F, prec, bias=b0)
+        y0 = ops.linear(cat, W0, F, pf, bias=b0, out_dtype=adt)
         bns = [self.fea_fuse[il][t][2] for t in names]
         if self.training:
-            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, prec, bias=bc)
+            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, pf, bias=bc, out_dtype=adt)
             y1 = self._bn_train(y1, bns, F, ACT_GELU)
         else:
             sc, sh = self._bn_fold(bns, [self.fea_fuse[il][t][1].bias for t in names], ('f2', il))
-            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, prec, bias=sh, colscale=sc, act=ACT_GELU)
-        fea = ops.linear(y1, W4, F, prec, bias=b4)
+            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, pf, bias=sh, colscale=sc, act=ACT_GELU, out_dtype=adt)
+        fea = ops.linear(y1, W4, F, pf, bias=b4, out_dtype=adt)
         wmix = self._ctr_weights(rawlog, il, B, T).detach()
         return ops.ctr_mix(fea, wmix, B, F, acc)
 
@@ -535,7 +567,8 @@ class TaskPrompterWrapper(nn.Module):
                 fea = bb.upsample4(lo, B)                                   # [T, B*4h*4w, Fp]
             src = lo if lowres else fea
             sub = src if len(idx) == len(self.tasks) else src[idx]
-            preds = run_heads(kind, [self.heads[self.tasks[i]] for i in idx], sub, B, h4, w4, target, bb.prec, self.training, lowres)
+            hprec = bb._gp('heads') if hasattr(bb, '_gp') else bb.prec
+            preds = run_heads(kind, [self.heads[self.tasks[i]] for i in idx], sub, B, h4, w4, target, hprec, self.training, lowres)
             for i, pr in zip(idx, preds):
                 out[self.tasks[i]] = pr
         if groups['other'] and fea is None:

@@ -69,11 +69,13 @@ def _worker_body(rank, world, port, case, q):
             m._mtt_sync = True
     n_coll = {"gather": 0}
     ag = dist.all_gather
+    ar = dist.all_reduce
 
-    def counted_gather(*a, **k):
-        n_coll["gather"] += 1
-        return ag(*a, **k)
-    dist.all_gather = counted_gather
+    def counted_reduce(t, *a, **k):
+        if t.dim() == 3 and t.shape[0] == world and t.shape[-1] % 2 == 1:   # the rank-slotted [W, Z, 2C+1] statistics table of bn.train_stats
+            n_coll["gather"] += 1
+        return ar(t, *a, **k)
+    dist.all_reduce = counted_reduce
     ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=(kind == "IP"))
     n_total = sum(len(s) for s in shares)
     rows = shares[rank]
