@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0,
                     help="per-GPU batch (weak scaling); 0 = the config's default.  ns6: 63*1030 token rows = 254 row tiles of 256, so the "
                          "N=1024/3072/4096 encoder GEMMs launch 3.97/11.9/15.9 full rounds of the 256 CUs; 93 GB of HBM")
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "x3"])
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "x3", "x3f"])
     ap.add_argument("--bucket-mb", type=int, default=100, help="DDP gradient bucket size (MB)")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="gradient all-reduce payload: fp32 (reference semantics) or bf16-compressed (halves the xGMI bytes)")

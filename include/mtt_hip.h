@@ -13,10 +13,11 @@
  *     of 8 the elements K..pad8(K)-1 of every row must exist and be zero (ld >= pad8(K))
  *   - activations are token-major / NHWC: a feature map is a row-major [rows = B*H*W, channels]
  *     matrix with a leading dimension (ld, in elements) that is a multiple of 8; 16-byte aligned
- *   - dtype codes: MTT_F32 = 0, MTT_BF16 = 1
- *   - prec: MTT_PREC_BF16 = 0 (bf16 MFMA, fp32 accumulate — the throughput path)
+ *   - dtype codes: MTT_F32 = 0, MTT_BF16 = 1, MTT_SPLIT = 2 (hi / lo bf16 planes, see below)
+ *   - prec: MTT_PREC_BF16 = 0 (bf16 MFMA, fp32 accumulate — the throughput path; fp32 operands are rounded while staged)
  *           MTT_PREC_X3   = 1 (operands split hi+lo bf16, 3 MFMAs — fp32-class accuracy, the
- *                              1e-3 parity gate; operands must be MTT_F32)
+ *                              1e-3 parity gate; operands MTT_F32 (split while staged) or both MTT_SPLIT (pre-split planes
+ *                              streamed by LDS-DMA))
  *
  * Each entry names the reference code it replaces (paths relative to /root/reference).
  */
@@ -30,9 +31,13 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 5
+#define MTT_ABI_VERSION 6
 
-enum { MTT_F32 = 0, MTT_BF16 = 1 };
+/* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+ * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
+ * an ordinary bf16 tensor — which is what lets a training step run its forward in fp32-class arithmetic (3 MFMAs per product on the
+ * LDS-DMA kernel, MTT_PREC_X3) and its backward in bf16 on the very same buffers. */
+enum { MTT_F32 = 0, MTT_BF16 = 1, MTT_SPLIT = 2 };
 enum { MTT_PREC_BF16 = 0, MTT_PREC_X3 = 1 };
 enum { MTT_E_BADARG = -1, MTT_E_ALIGN = -2, MTT_E_UNSUPPORTED = -3 };
 
@@ -46,22 +51,12 @@ enum {
 enum { MTT_ACT_NONE = 0, MTT_ACT_GELU = 1, MTT_ACT_RELU = 2, MTT_ACT_GELU_BWD = 3, MTT_ACT_RELU_BWD = 4 };
 enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
 /* kernel selection of mtt_gemm / mtt_attn_fwd: AUTO = the library's policy (a pure function of the descriptor); the other values
- * force one kernel where it is applicable (benchmarks, A/B measurements).  There is no process-global switch and no environment
- * variable: the library keeps no mutable state that affects results. */
-enum { MTT_GEMM_AUTO = 0, MTT_GEMM_GENERAL = 1, MTT_GEMM_DMA128 = 2, MTT_GEMM_DMA256 = 3, MTT_GEMM_DMA256_V1 = 4,
-       MTT_GEMM_DMA256_S1 = 5 /* phased kernel with the balanced LDS-DMA schedule (A/B measurements) */,
-       MTT_GEMM_ABLATE_NO_EPILOGUE = 6, MTT_GEMM_ABLATE_NO_KLOOP = 7 /* measurement-only: WRONG results by construction */,
-       MTT_GEMM_DMA256_SKEW = 8 /* phased kernel with first-round workgroups started 0..7 x 1.5 us apart (experiment) */,
-       MTT_GEMM_ABLATE_NO_STORES = 9, MTT_GEMM_ABLATE_NO_STAGING = 10 /* measurement-only epilogue ablations */,
-       MTT_GEMM_GENERAL_EPILOGUE = 11 /* policy kernel, but always the general (run-time configured) epilogue: A/B of the specialised one */,
-       MTT_GEMM_DMA256_PERSIST = 12 /* AUTO policy, with the persistent 256 x 256 LDS-DMA kernel (K loop continuous across tiles, per-wave epilogue) wherever the policy picks the 256 x 256 kernel and the call is eligible */,
-       MTT_GEMM_DMA256_PERSIST_V0 = 13 /* the same with block-by-block stores and the plain one-tile-ahead prefetch instead of deferred stores (A/B measurements) */,
-       MTT_GEMM_DMA256_NONPERSIST = 14 /* AUTO policy without the persistent kernel (A/B) */,
-       MTT_GEMM_DMA256_SLOWADDR = 18 /* AUTO policy, but the 256 x 256 kernel with general (K-tail capable, 64-bit) source addressing even where the fast form applies (A/B) */,
-       MTT_GEMM_DMA256_DIRECT = 19 /* AUTO policy, the 256 x 256 kernel with swapped-operand MFMAs + direct-store epilogue (no LDS staging) where eligible (A/B) */,
-       MTT_GEMM_DMA256_LDS_EPILOGUE = 20 /* AUTO policy, the 256 x 256 kernel with the LDS-staged epilogue even where the direct one is the default (A/B) */,
-       MTT_GEMM_PDMA_ABLATE_NO_EPILOGUE = 15, MTT_GEMM_PDMA_ABLATE_NO_STORES = 16, MTT_GEMM_PDMA_ABLATE_NO_BIAS = 17
-       /* measurement-only ablations of the persistent kernel (bf16 output + bias calls): WRONG results by construction */ };
+ * force one kernel where it is applicable (tests of a kernel on small shapes, A/B measurements).  There is no process-global switch and
+ * no environment variable: the library keeps no mutable state that affects results. */
+enum { MTT_GEMM_AUTO = 0,
+       MTT_GEMM_GENERAL = 1           /* the register-staged 128 x 128 kernel (any layout / dtype / precision) */,
+       MTT_GEMM_DMA256 = 3            /* the 256 x 256 LDS-DMA kernel (or, for two MTT_OP_R operands, the token-major weight-gradient kernel) on any shape it supports */,
+       MTT_GEMM_GENERAL_EPILOGUE = 11 /* policy kernel, but always the general (run-time configured) epilogue: A/B of the specialised one */ };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1,
        MTT_ATTN_FAST_V0 = 2 /* A/B: the first flash kernels (run-time LDS stage, predicated register staging) */,
        MTT_ATTN_FAST_V1 = 3 /* A/B: register-staged tiles, unrolled stages (AUTO = LDS-DMA staging + transpose reads) */ };
@@ -91,7 +86,9 @@ typedef struct {
  *   aux_out[m,n] = pre-activation value (optional, training)
  *   v *= rowscale[(m / d_mb)*2 + ((m % d_mb) >= n_prompt)]   (DropPath per-sample scale, optional)
  *   v += resid[m,n] (fp32, own row mapping; may alias D)
- *   store D (dtype d_dtype); columns N <= n < n_store are written as zeros (channel padding).
+ *   store D (dtype d_dtype; MTT_SPLIT: hi plane at D, lo plane at D_lo); columns N <= n < n_store are written as zeros (channel padding).
+ * Operand dtypes: MTT_PREC_BF16 takes bf16 or fp32 operands in any mix (fp32 is rounded to bf16 while staged); MTT_PREC_X3 takes
+ * fp32 operands (general kernel) or A and B both MTT_SPLIT with a_op = b_op = MTT_OP_K, K % 64 == 0 (LDS-DMA kernel).
  */
 typedef struct {
   const void* A; const void* B; void* D;
@@ -115,6 +112,7 @@ typedef struct {
   int32_t store_mode;            /* MTT_STORE_PIXSHUF2: n = (dy*2+dx)*Co + co, D is [B,2H,2W,ldd] (ConvTranspose2d k=s=2, taskprompter.py:705) */
   int32_t ps_H, ps_W, ps_Co;
   int32_t variant;               /* MTT_GEMM_* (0 = AUTO) */
+  const void* A_lo; const void* B_lo; void* D_lo;   /* lo planes of MTT_SPLIT operands / output (same layout, strides and batch offsets as the hi plane) */
 } mtt_gemm_desc;
 
 int mtt_abi_version(void);
@@ -122,9 +120,9 @@ int mtt_abi_version(void);
  * 10 dwconv, 11 pool, 12 lnmt, 13 attnmsg, 14 convt, 17 upconv */
 size_t mtt_desc_size(int which);
 int mtt_gemm(const mtt_gemm_desc* d, void* stream);
-/* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128 (general), 1 LDS-DMA 128x128 ring, 3 / 4 phased
- * LDS-DMA 256x256 / 256x128 (gemm_dma_kernel), 5 lock-step LDS-DMA 256x256 (round-1 kernel, forced only), 6 token-major weight-gradient
- * kernel (gemm_tn_kernel: both operands MTT_OP_R, LDS-DMA + LDS transpose reads) */
+/* which kernel mtt_gemm dispatches this descriptor to: 0 register-staged 128x128 (general), 3 phased LDS-DMA 256x256
+ * (gemm_dma_kernel), 6 token-major weight-gradient kernel (gemm_tn_kernel: both operands MTT_OP_R, LDS-DMA + LDS transpose reads),
+ * 8 gemm_dma_kernel on MTT_SPLIT operands (K-concatenated x3 product) */
 int mtt_gemm_variant(const mtt_gemm_desc* d);
 
 /*
@@ -140,6 +138,7 @@ typedef struct {
   int32_t dtype, prec;
   float scale;
   int32_t variant;   /* MTT_ATTN_* (0 = AUTO: the swapped-product flash kernel for bf16 storage, the plain kernel otherwise) */
+  const void* qkv_lo; void* out_lo;   /* dtype == MTT_SPLIT (forward, MTT_PREC_X3): lo planes of qkv / out, same layout as the hi planes */
 } mtt_attn_desc;
 int mtt_attn_fwd(const mtt_attn_desc* d, void* stream);
 /* Flash backward of mtt_attn_fwd (autograd of taskprompter.py:201-210 / vit.py:184-191), bf16 storage + MTT_PREC_BF16 only
@@ -172,6 +171,8 @@ typedef struct {
   int64_t rows; int32_t C; int64_t ldx, ldy; int32_t y_dtype; float eps;
   const float* dx_in;
   float* ws;
+  void* y_lo;                    /* fwd, y_dtype == MTT_SPLIT: lo plane of y (same pitch ldy) */
+  float* y32; int64_t ldy32;     /* fwd, optional: an additional fp32 copy of y (consumers that want the exact rows next to the split planes) */
 } mtt_ln_desc;
 size_t mtt_layernorm_bwd_ws_floats(int64_t rows, int32_t C);
 int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream);
@@ -245,6 +246,9 @@ int mtt_bn_stats(const mtt_bn_desc* d, float* ws, void* stream);
 int mtt_bn_apply(const mtt_bn_desc* d, void* stream);
 int mtt_bn_bwd_reduce(const mtt_bn_desc* d, float* ws, void* stream);
 int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream);
+
+/* fp32 [rows, cols] (pitch lds) -> MTT_SPLIT planes hi / lo [rows, ldd] (bf16; columns cols..ldd-1 zero): hi = bf16(x), lo = bf16(x - hi) */
+int mtt_split_cast(const float* src, void* hi, void* lo, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, void* stream);
 
 /* Small utilities: dtype cast / strided 2-D copy, column sums (bias gradients), axpy-style accumulate. */
 int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,

@@ -16,13 +16,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 5
-F32, BF16 = 0, 1
+ABI_VERSION = 6
+F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 STORE_ROWS, STORE_PIXSHUF2 = 0, 1
-GEMM_AUTO, GEMM_GENERAL, GEMM_DMA128, GEMM_DMA256, GEMM_DMA256_V1 = 0, 1, 2, 3, 4
+GEMM_AUTO, GEMM_GENERAL, GEMM_DMA256, GEMM_GENERAL_EPILOGUE = 0, 1, 3, 11
 ATTN_AUTO, ATTN_PLAIN = 0, 1
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -54,13 +54,14 @@ class GemmDesc(C.Structure):
         ("n_store", i32), ("store_mode", i32),
         ("ps_H", i32), ("ps_W", i32), ("ps_Co", i32),
         ("variant", i32),
+        ("A_lo", ptr), ("B_lo", ptr), ("D_lo", ptr),
     ]
 
 
 class AttnDesc(C.Structure):
     _fields_ = [("qkv", ptr), ("out", ptr), ("rawlog", ptr), ("lse", ptr),
                 ("B", i32), ("N", i32), ("nH", i32), ("T", i32), ("dtype", i32), ("prec", i32), ("scale", f32),
-                ("variant", i32)]
+                ("variant", i32), ("qkv_lo", ptr), ("out_lo", ptr)]
 
 
 class SoftmaxDesc(C.Structure):
@@ -72,7 +73,8 @@ class SoftmaxDesc(C.Structure):
 class LnDesc(C.Structure):
     _fields_ = [("x", ptr), ("y", ptr), ("gamma", ptr), ("beta", ptr), ("mean", ptr), ("rstd", ptr),
                 ("dy", ptr), ("dx", ptr), ("dgamma", ptr), ("dbeta", ptr),
-                ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32), ("dx_in", ptr), ("ws", ptr)]
+                ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32), ("dx_in", ptr), ("ws", ptr),
+                ("y_lo", ptr), ("y32", ptr), ("ldy32", i64)]
 
 
 class ChanLogitDesc(C.Structure):
@@ -191,6 +193,7 @@ POSITIONAL = {
     "boxes_overlap_bev": [ptr, C.c_int, ptr, C.c_int, ptr, C.c_int, ptr],
     "nms_bev": [ptr, C.c_int, f32, C.c_int, ptr, ptr, ptr, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
+    "split_cast": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
@@ -282,8 +285,8 @@ def _stream():
 
 
 def gemm_variant(**kw):
-    """Kernel mtt_gemm would dispatch these descriptor fields to (0 general, 1 LDS-DMA 128 ring, 3 / 4 phased LDS-DMA 256x256 / 256x128,
-    5 lock-step LDS-DMA 256x256)."""
+    """Kernel mtt_gemm would dispatch these descriptor fields to (0 general 128x128, 3 LDS-DMA 256x256, 6 token-major weight gradient,
+    8 LDS-DMA 256x256 on split operands; < 0: no kernel takes them)."""
     lib = load()
     desc = GemmDesc()
     for k, v in kw.items():

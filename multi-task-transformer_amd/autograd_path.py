@@ -299,12 +299,23 @@ class AttnHalfFn(Function):
         B, N, nH, T, h, w, nwin = geo
         C, hw = nH * 64, h * w
         chan = Wtt is not None
-        xn, mean, rstd = ops.layernorm(XT, g1, b1, eps, prec, save_stats=True)
-        wq = ops.pack_linear([Wqkv], prec, tag + ('qkv',))
-        wp = ops.pack_linear([Wproj], prec, tag + ('proj',))
-        qkv = ops.linear(xn, wq, 3 * C, prec, bias=bqkv[None])[0]
-        flash = FLASH_BWD and prec.name == "bf16" and qkv.dtype == torch.bfloat16
-        ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=flash)
+        split = prec.split                       # x3f: x3 products on pre-split planes (LDS-DMA kernel), bf16 backward on the hi planes
+        if split:
+            xn, mean, rstd = ops.layernorm(XT, g1, b1, eps, prec, save_stats=True, out_dtype="split", want32=chan)
+            xs, xn32 = xn if chan else (xn, None)
+            wq = ops.pack_linear_split([Wqkv], tag + ('qkv',))
+            wp = ops.pack_linear_split([Wproj], tag + ('proj',))
+            qkv = ops.linear(xs, wq, 3 * C, prec, bias=bqkv[None], out_dtype="split")[0]
+            ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
+            xn_b, xn_c = xs.hi, xn32                # backward operands: bf16 hi plane (weight gradients), fp32 rows (channel attention)
+        else:
+            xn, mean, rstd = ops.layernorm(XT, g1, b1, eps, prec, save_stats=True)
+            wq = ops.pack_linear([Wqkv], prec, tag + ('qkv',))
+            wp = ops.pack_linear([Wproj], prec, tag + ('proj',))
+            qkv = ops.linear(xn, wq, 3 * C, prec, bias=bqkv[None])[0]
+            flash = FLASH_BWD and prec.name == "bf16" and qkv.dtype == torch.bfloat16
+            ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=flash)
+            xn_b = xn_c = xn
         XT2 = torch.empty_like(XT)
         ops.linear(ao, wp, C, prec, bias=bproj[None], out=XT2, resid=XT, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
                    M=B * N)
@@ -312,12 +323,13 @@ class AttnHalfFn(Function):
         if chan:
             wt = ops.pack_linear([Wtt], prec, tag + ('tt',))
             wt1 = ops.pack_linear([Wtt1], prec, tag + ('tt1',))
-            cq = ops.linear(xn, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
-            rawchan = ops.chan_logits(cq, xn, B, T, N, C, (h, w), (nwin, nwin))
+            cq = ops.linear(xn_c, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
+            rawchan = ops.chan_logits(cq, xn_c, B, T, N, C, (h, w), (nwin, nwin))
             pr = XT2.view(B, N, C)[:, :T]
             ops.linear(cq, wt1, C, prec, bias=btt1[None], out=pr, d_rows=(T, N * C, C), resid=pr, rowscale=rowscale, n_prompt=T,
                        M=B * T)
-        ctx.save_for_backward(XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1)
+        ctx.save_for_backward(XT, g1, mean, rstd, xn_b, ops._hi(qkv), ops._hi(ao), ops._hi(wq), ops._hi(wp), rowscale, lse, cq, wt, wt1,
+                              xn_c if chan and split else None)
         ctx.geo, ctx.prec, ctx.eps, ctx.chan = geo, prec, eps, chan
         ctx.params = (Wqkv, Wproj)
         z = torch.zeros(0, device=XT.device)
@@ -325,10 +337,11 @@ class AttnHalfFn(Function):
 
     @staticmethod
     def backward(ctx, dXT2, drawlog, drawchan):
-        XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1 = ctx.saved_tensors
+        XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1, xn32 = ctx.saved_tensors
         Wqkv_, Wproj_ = ctx.params
         B, N, nH, T, h, w, nwin = ctx.geo
-        prec, C, M, hw = ctx.prec, nH * 64, B * N, h * w
+        prec, C, M, hw = ctx.prec.bwd, nH * 64, B * N, h * w
+        xn_c = xn32 if xn32 is not None else xn                    # the rows the channel attention read (fp32 in the x3f mode)
         dXT2 = dXT2.contiguous()
         # ---- spatial attention ---------------------------------------------------------------------------------
         g = _scaled(dXT2, rowscale, N, T, prec)
@@ -353,10 +366,10 @@ class AttnHalfFn(Function):
             dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
             if drawchan is not None and drawchan.numel():
                 dq2 = torch.zeros(B * T, hwp, dtype=torch.float32, device=xn.device)
-                ops.call("chan_logits_bwd", q=cq, xn=xn, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
-                         dtype=dtype_code(xn), ldq=hwp, xargs=[drawchan.contiguous(), dq2, F32, dxn])
+                ops.call("chan_logits_bwd", q=cq, xn=xn_c, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
+                         dtype=dtype_code(xn_c), ldq=hwp, xargs=[drawchan.contiguous(), dq2, F32, dxn])
                 dcq = dcq + dq2                                                # [B*T, hwp] fp32 (tiny)
-            xnp = xn.view(B, N, C)[:, :T].reshape(B * T, C)
+            xnp = xn_c.view(B, N, C)[:, :T].reshape(B * T, C)
             dWtt = _wgrad(dcq, xnp, hw, C, prec)[:, :C]
             dbtt = _colsum(dcq, hw)
             dp = dxn.view(B, N, C)[:, :T]
@@ -374,15 +387,16 @@ class MlpHalfFn(Function):
     def forward(ctx, XT2, g2, b2n, eps, W1, b1, W2, b2, rowscale, geo, prec, tag):
         B, N, T = geo
         C, Hd = W1.shape[1], W1.shape[0]
-        xn2, mean, rstd = ops.layernorm(XT2, g2, b2n, eps, prec, save_stats=True)
-        w1 = ops.pack_linear([W1], prec, tag + ('fc1',))
-        w2 = ops.pack_linear([W2], prec, tag + ('fc2',))
-        z = torch.empty(B * N, Hd, dtype=prec.adt, device=XT2.device)
-        hmid = ops.linear(xn2, w1, Hd, prec, bias=b1[None], act=ACT_GELU, aux_out=z)[0]
+        split = prec.split and C % 64 == 0 and Hd % 64 == 0          # LDS-DMA x3 GEMM: whole 64-deep K tiles (else the register-staged x3 kernels)
+        xn2, mean, rstd = ops.layernorm(XT2, g2, b2n, eps, prec, save_stats=True, out_dtype="split" if split else None)
+        w1 = ops.pack_linear_split([W1], tag + ('fc1',)) if split else ops.pack_linear([W1], prec, tag + ('fc1',))
+        w2 = ops.pack_linear_split([W2], tag + ('fc2',)) if split else ops.pack_linear([W2], prec, tag + ('fc2',))
+        z = torch.empty(B * N, Hd, dtype=prec.bwd.adt, device=XT2.device)          # pre-activation for GELU' (bf16 when the backward is bf16)
+        hmid = ops.linear(xn2, w1, Hd, prec, bias=b1[None], act=ACT_GELU, aux_out=z, out_dtype="split" if split else None)[0]
         XT3 = torch.empty_like(XT2)
         ops.linear(hmid, w2, C, prec, bias=b2[None], out=XT3, resid=XT2, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
                    M=B * N)
-        ctx.save_for_backward(XT2, g2, mean, rstd, xn2, z, hmid, w1, w2, rowscale)
+        ctx.save_for_backward(XT2, g2, mean, rstd, ops._hi(xn2), z, ops._hi(hmid), ops._hi(w1), ops._hi(w2), rowscale)
         ctx.geo, ctx.prec, ctx.eps = geo, prec, eps
         ctx.params = (W1, W2)
         return XT3
@@ -391,7 +405,7 @@ class MlpHalfFn(Function):
     def backward(ctx, dXT3):
         XT2, g2, mean, rstd, xn2, z, hmid, w1, w2, rowscale = ctx.saved_tensors
         B, N, T = ctx.geo
-        prec, M = ctx.prec, B * N
+        prec, M = ctx.prec.bwd, B * N
         C, Hd = xn2.shape[1], z.shape[1]
         dXT3 = dXT3.contiguous()
         g = _scaled(dXT3, rowscale, N, T, prec)
@@ -428,7 +442,7 @@ class PatchEmbedFn(Function):
         C = ctx.wshape[0]
         d3 = dXT.contiguous().view(B, N, C)
         dpatch = d3[:, T:].reshape(B * hw, C)
-        dW = _wgrad(dpatch, cols, C, 768, ctx.prec).view(ctx.wshape)
+        dW = _wgrad(dpatch, cols, C, 768, ctx.prec.bwd).view(ctx.wshape)
         db = _colsum(dpatch, C)
         dpos = torch.zeros(1, hw + 1, C, dtype=torch.float32, device=dXT.device)
         dpos[0, 1:] = d3[:, T:].sum(0)
@@ -501,6 +515,7 @@ class BLinearFn(Function):
     def backward(ctx, dy):
         x, wpack = ctx.saved_tensors
         Z, N, layout, kmap, prec, wshapes = ctx.meta
+        prec = prec.bwd
         dy = dy.contiguous()
         M, Np, Kp = x.shape[-2], pad8(N), wpack.shape[-1]
         if layout == 'catpair':
@@ -569,6 +584,7 @@ class Conv3x3Fn(Function):
     def backward(ctx, dy):
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         (B, H, W, Co, Ci, dil), prec, tag, Z, has_bias = ctx.meta
+        prec = prec.bwd
         dy = dy.contiguous()
         rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
         wd = ops.pack_conv3(list(ws), prec, tag, transpose=True)                     # [Z, Ci, 9*Cop]
@@ -616,6 +632,7 @@ class UpConv3x3Fn(Function):
     def backward(ctx, dy):
         xa, w9 = ctx.saved_tensors
         (B, h, w, Co, Ci), prec, Z, xdtype = ctx.meta
+        prec = prec.bwd
         dy = dy.contiguous()
         M, Kp, N9 = xa.shape[1], xa.shape[2], w9.shape[1]
         dz = ops.upconv4_gather(dy, Co, B, h, w)                         # [Z, M, N9]
@@ -696,6 +713,7 @@ class TaskHeadsFn(Function):
     def backward(ctx, *dps):
         y, packs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         prec, wshapes = ctx.meta
+        prec = prec.bwd
         Z, rows, ld = y.shape
         dy = torch.empty_like(y)
         dws, dbs = [], []
@@ -754,6 +772,7 @@ class Deconv2x2Fn(Function):
     def backward(ctx, dy):
         x, Wd = ctx.saved_tensors
         (B, H, W), prec, Ci, Co = ctx.meta
+        prec = prec.bwd
         N4, N4p = 4 * Co, pad8(4 * Co)
         # pixel-unshuffle of the gradient (pure re-indexing): g4[(b,y,x), (dy*2+dx)*Co + co] = dy[b, 2y+dy, 2x+dx, co]
         g4 = torch.zeros(B * H * W, N4p, dtype=dy.dtype, device=dy.device)

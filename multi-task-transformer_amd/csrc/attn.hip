@@ -18,9 +18,22 @@ constexpr int KTILE = KV * HD * 2;   // 8 KiB per bf16 plane
 
 struct AttnP { mtt_attn_desc d; };
 
-// F32: storage dtype of qkv / out (compile time); X3 implies F32
-template <bool X3, bool F32>
+// SRC: storage of qkv / out (compile time): 0 bf16, 1 fp32, 2 MTT_SPLIT (hi / lo bf16 planes: the x3 operands are read as stored, and
+// the output is written as planes for the LDS-DMA proj GEMM); X3 implies SRC >= 1
+template <int SRC> struct RawQ { Raw8<SRC == 1> a; u32x4 l; };
+template <int SRC>
+MTT_DEV void load_q8(const mtt_attn_desc& d, int64_t idx, bool ok, RawQ<SRC>& r) {
+  load8_raw<SRC == 1>(d.qkv, idx, ok, r.a);
+  if constexpr (SRC == 2) r.l = *(const u32x4*)((const bf16_t*)d.qkv_lo + (ok ? idx : 0));
+}
+template <bool X3, int SRC>
+MTT_DEV void cvt_q8(bool ok, const RawQ<SRC>& r, u32x4& hi, u32x4& lo) {
+  cvt8<X3 && SRC == 1, SRC == 1>(ok, r.a, hi, lo);
+  if constexpr (SRC == 2) lo = ok ? r.l : (u32x4){0u, 0u, 0u, 0u};
+}
+template <bool X3, int SRC>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
+  constexpr bool F32 = SRC == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPL = X3 ? 2 : 1;
   constexpr int STAGE = KTILE * 2 * NPL;            // K planes, then Vt planes
@@ -43,15 +56,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     const int qrow = qb * QB + wave * 16 + li;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      Raw8<F32> rq;
-      load8_raw<F32>(d.qkv, (tok0 + qrow) * 3 * C + h * HD + kh * 32 + lg * 8, qrow < N, rq);
-      cvt8<X3, F32>(qrow < N, rq, qh[kh], ql[kh]);
+      RawQ<SRC> rq;
+      load_q8<SRC>(d, (tok0 + qrow) * 3 * C + h * HD + kh * 32 + lg * 8, qrow < N, rq);
+      cvt_q8<X3, SRC>(qrow < N, rq, qh[kh], ql[kh]);
     }
   }
 
   // ---- staging roles: waves 0,1 transpose V, waves 2,3 copy K --------------------------------
   const bool isV = tid < 128;
-  Raw8<F32> raw[4];
+  RawQ<SRC> raw[4];
   unsigned okm = 0;
   const int kq = tid & 15, rb = (tid >> 4) & 7;     // V: 4 keys x 8 d unit
   const int kt_ = tid - 128;                        // K: chunk id base
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
       const int col = isV ? 2 * C + rb * 8 : C + (idx & 7) * 8;
       const bool ok = key < N;
       okm |= (ok ? 1u : 0u) << i;
-      load8_raw<F32>(d.qkv, (tok0 + key) * 3 * C + col + h * HD, ok, raw[i]);
+      load_q8<SRC>(d, (tok0 + key) * 3 * C + col + h * HD, ok, raw[i]);
     }
   };
   auto stage_store = [&](unsigned char* st) {
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     unsigned char* Vh = st + KTILE * NPL;
     u32x4 sh[4], sl[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cvt8<X3, F32>((okm >> i) & 1u, raw[i], sh[i], sl[i]);
+    for (int i = 0; i < 4; ++i) cvt_q8<X3, SRC>((okm >> i) & 1u, raw[i], sh[i], sl[i]);
     if (isV) {
       u32x2 piece[8];
       transpose4x8(sh, piece);
@@ -230,21 +243,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     if (qrow >= N) continue;
     const float inv = 1.0f / l_run[r];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      st_elem(d.out, (tok0 + qrow) * C + h * HD + dt * 16 + li, F32 ? MTT_F32 : MTT_BF16, o[dt][r] * inv);
+    for (int dt = 0; dt < 4; ++dt) {
+      const int64_t oi = (tok0 + qrow) * C + h * HD + dt * 16 + li;
+      const float ov = o[dt][r] * inv;
+      if constexpr (SRC == 2) {
+        const bf16_t hv = f2bf(ov);
+        ((bf16_t*)d.out)[oi] = hv;
+        ((bf16_t*)d.out_lo)[oi] = f2bf(ov - bf2f(hv));
+      } else st_elem(d.out, oi, F32 ? MTT_F32 : MTT_BF16, ov);
+    }
     if (d.lse && li == 0)
       d.lse[((int64_t)b * d.nH + h) * N + qrow] = (m_run[r] + log2f(l_run[r])) * 0.6931471805599453f;
   }
 }
 
-template <bool X3, bool F32>
+template <bool X3, int SRC>
 int launch_attn(const AttnP& p, hipStream_t s) {
   constexpr int NPL = X3 ? 2 : 1;
   constexpr int smem = 2 * (KTILE * 2 * NPL) + 4 * (16 * KV * 2) * NPL;
   static std::atomic<unsigned long long> done{0};
-  if (int e = mtt_ensure_dyn_lds((const void*)attn_fwd_kernel<X3, F32>, smem, done)) return e;
+  if (int e = mtt_ensure_dyn_lds((const void*)attn_fwd_kernel<X3, SRC>, smem, done)) return e;
   dim3 grid((unsigned)(((p.d.N + QB - 1) / QB) * p.d.nH * p.d.B));
-  hipLaunchKernelGGL((attn_fwd_kernel<X3, F32>), grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<X3, SRC>), grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }
 
@@ -255,11 +275,12 @@ int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s);     // attn_fast.
 extern "C" int mtt_attn_fwd(const mtt_attn_desc* dd, void* stream) {
   if (!dd || !dd->qkv || !dd->out) return MTT_E_BADARG;
   if (dd->B <= 0 || dd->N <= 0 || dd->nH <= 0 || dd->T < 0 || dd->T > 16) return MTT_E_BADARG;
-  if (dd->prec == MTT_PREC_X3 && dd->dtype != MTT_F32) return MTT_E_UNSUPPORTED;
+  if (dd->prec == MTT_PREC_X3 && dd->dtype != MTT_F32 && dd->dtype != MTT_SPLIT) return MTT_E_UNSUPPORTED;
+  if (dd->dtype == MTT_SPLIT && (dd->prec != MTT_PREC_X3 || !dd->qkv_lo || !dd->out_lo || ((uintptr_t)dd->qkv_lo & 15))) return MTT_E_BADARG;
   if ((uintptr_t)dd->qkv & 15) return MTT_E_ALIGN;
   if (dd->variant != MTT_ATTN_PLAIN && dd->prec == MTT_PREC_BF16 && dd->dtype == MTT_BF16 && !((uintptr_t)dd->out & 15))
     return mtt_attn_fwd_fast(dd, (hipStream_t)stream);
   AttnP p; p.d = *dd;
-  if (dd->prec == MTT_PREC_X3) return launch_attn<true, true>(p, (hipStream_t)stream);
-  return dd->dtype == MTT_F32 ? launch_attn<false, true>(p, (hipStream_t)stream) : launch_attn<false, false>(p, (hipStream_t)stream);
+  if (dd->prec == MTT_PREC_X3) return dd->dtype == MTT_SPLIT ? launch_attn<true, 2>(p, (hipStream_t)stream) : launch_attn<true, 1>(p, (hipStream_t)stream);
+  return dd->dtype == MTT_F32 ? launch_attn<false, 1>(p, (hipStream_t)stream) : launch_attn<false, 0>(p, (hipStream_t)stream);
 }

@@ -55,7 +55,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const mtt_ln_desc d) {
     const float y2 = (v.z - mean) * rstd * g.z + bb.z, y3 = (v.w - mean) * rstd * g.w + bb.w;
     const int64_t o = row * d.ldy + (int64_t)c * 4;
     if (d.y_dtype == MTT_F32) *(float4*)((float*)d.y + o) = make_float4(y0, y1, y2, y3);
-    else *(u32x2*)((bf16_t*)d.y + o) = (u32x2){pack2(y0, y1), pack2(y2, y3)};
+    else {
+      const u32x2 hi = (u32x2){pack2(y0, y1), pack2(y2, y3)};
+      *(u32x2*)((bf16_t*)d.y + o) = hi;
+      if (d.y_dtype == MTT_SPLIT)          // x = hi + lo: the lo plane carries the bf16 rounding residual (fp32-class operand for the LDS-DMA x3 GEMM)
+        *(u32x2*)((bf16_t*)d.y_lo + o) = (u32x2){pack2(y0 - lo_of(hi.x), y1 - hi_of(hi.x)), pack2(y2 - lo_of(hi.y), y3 - hi_of(hi.y))};
+    }
+    if (d.y32) *(float4*)(d.y32 + row * d.ldy32 + (int64_t)c * 4) = make_float4(y0, y1, y2, y3);
   }
 }
 
@@ -811,6 +817,24 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const void* src, void* dst,
   }
 }
 
+// fp32 -> split planes, 8 columns per lane (cols padded to ldd with zeros)
+__global__ __launch_bounds__(256) void split_cast_kernel(const float* src, bf16_t* hi, bf16_t* lo, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd) {
+  const int64_t c8n = ldd >> 3, total = rows * c8n;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / c8n, c = (t - r * c8n) * 8;
+    float v[8];
+    if (c + 8 <= cols && (lds_ & 3) == 0) ld8(src, r * lds_ + c, MTT_F32, v);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = c + j < cols ? src[r * lds_ + c + j] : 0.f;
+    }
+    const u32x4 h = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    *(u32x4*)(hi + r * ldd + c) = h;
+    *(u32x4*)(lo + r * ldd + c) = (u32x4){pack2(v[0] - lo_of(h.x), v[1] - hi_of(h.x)), pack2(v[2] - lo_of(h.y), v[3] - hi_of(h.y)),
+                                         pack2(v[4] - lo_of(h.z), v[5] - hi_of(h.z)), pack2(v[6] - lo_of(h.w), v[7] - hi_of(h.w))};
+  }
+}
+
 __global__ __launch_bounds__(256) void add_rows_kernel(const void* src, float* dst, int64_t rows, int cols, int64_t lds_, int64_t ldd,
                                                        int sdt, float alpha) {
   const int64_t total = rows * cols;
@@ -1140,6 +1164,8 @@ int grid_for(int64_t work_items) {
 extern "C" int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream) {
   if (!d || !d->x || !d->y || !d->gamma || !d->beta || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
   if ((d->C % 4) || (d->ldx % 4) || (d->ldy % 4)) return MTT_E_ALIGN;
+  if (d->y_dtype == MTT_SPLIT && !d->y_lo) return MTT_E_BADARG;
+  if (d->y32 && (d->ldy32 % 4)) return MTT_E_ALIGN;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }
@@ -1311,6 +1337,12 @@ extern "C" int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream) {
   return LAUNCH_OK();
 }
 
+extern "C" int mtt_split_cast(const float* src, void* hi, void* lo, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, void* stream) {
+  if (!src || !hi || !lo || rows <= 0 || cols <= 0 || ldd < cols) return MTT_E_BADARG;
+  if ((ldd % 8) || ((uintptr_t)hi & 15) || ((uintptr_t)lo & 15) || ((uintptr_t)src & 15)) return MTT_E_ALIGN;
+  hipLaunchKernelGGL(split_cast_kernel, dim3(grid_for(rows * (ldd / 8))), dim3(256), 0, S_, src, (bf16_t*)hi, (bf16_t*)lo, rows, cols, lds_, ldd);
+  return LAUNCH_OK();
+}
 extern "C" int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd,
                           int src_dtype, int dst_dtype, int zero_pad_cols, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;

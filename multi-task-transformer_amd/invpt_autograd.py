@@ -46,7 +46,7 @@ class VitEmbedFn(Function):
         C = ctx.wshape[0]
         d3 = dXT.contiguous().view(B, N, C)
         dpatch = d3[:, 1:].reshape(B * hw, C)
-        dW = _wgrad(dpatch, cols, C, 768, ctx.prec).view(ctx.wshape)
+        dW = _wgrad(dpatch, cols, C, 768, ctx.prec.bwd).view(ctx.wshape)
         db = _colsum(dpatch, C)
         dpos = d3.sum(0, keepdim=True)
         return None, dW, db, dpos, d3[:, :1].sum(0, keepdim=True), None, None
@@ -82,6 +82,7 @@ class ConvT3x3s2Fn(Function):
     def backward(ctx, dout):
         x, wall = ctx.saved_tensors
         (B, H, W), prec, C, Co, Cop = ctx.meta
+        prec = prec.bwd
         dout = dout.contiguous()
         dyall = torch.empty(B * H * W, 9 * Cop, dtype=dout.dtype, device=dout.device)
         ops.call("convt3x3s2_gather_bwd", yall=None, out=None, bias=None, B=B, H=H, W=W, Cop=Cop, dtype=dtype_code(dyall),
@@ -164,6 +165,7 @@ class ScoresFn(Function):
     def backward(ctx, dS):
         q, k = ctx.saved_tensors
         heads, alpha, prec = ctx.meta
+        prec = prec.bwd
         B, Q, D = q.shape
         K = k.shape[1]
         hd, Kp = D // heads, pad8(K)
@@ -219,7 +221,7 @@ class PVFn(Function):
     @staticmethod
     def backward(ctx, do):
         P, v = ctx.saved_tensors
-        prec = ctx.prec
+        prec = ctx.prec.bwd
         B, heads, Q, Kp = P.shape
         K, D = v.shape[1], v.shape[2]
         hd = D // heads

@@ -14,8 +14,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, OP_CONV_K, OP_CONV_R, OP_K, OP_R, PREC_BF16, PREC_X3,
-                   dtype_code)
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, OP_CONV_K, OP_CONV_R, OP_K, OP_R, PREC_BF16, PREC_X3, SPLIT)
 
 
 def pad8(n):
@@ -23,16 +22,69 @@ def pad8(n):
 
 
 class Prec:
-    """Arithmetic mode: name in {'bf16', 'x3'}."""
+    """Arithmetic mode: name in {'bf16', 'x3', 'x3f'}.
+
+    bf16 — bf16 storage + bf16 MFMA (throughput).  x3 — fp32 storage, every product as 3 bf16 MFMAs on split operands, forward AND
+    backward (fp32-class everywhere; register-staged kernels).  x3f — the x3 FORWARD arithmetic (same 3-MFMA products, 1e-3 per-head
+    parity with the reference's fp32 forward) with the encoder's GEMM operands stored as pre-split hi / lo bf16 planes (`Split`) so
+    that they stream through the LDS-DMA GEMM kernel, and a bf16 BACKWARD on the hi planes (`.bwd`): mixed-precision training whose
+    forward outputs match the reference."""
 
     def __init__(self, name):
-        assert name in ("bf16", "x3")
+        assert name in ("bf16", "x3", "x3f")
         self.name = name
         self.code = PREC_BF16 if name == "bf16" else PREC_X3
         self.adt = torch.bfloat16 if name == "bf16" else torch.float32
+        self.split = name == "x3f"                       # encoder operands as Split planes (LDS-DMA x3 GEMM)
+        self.bwd = Prec("bf16") if name == "x3f" else self   # arithmetic of the backward pass
 
     def __repr__(self):
         return f"Prec({self.name})"
+
+
+class Split:
+    """An fp32-class activation / weight as two bf16 planes x = hi + lo (MTT_SPLIT) of identical shape and strides: hi = bf16(x),
+    lo = bf16(x - hi).  The hi plane alone is an ordinary bf16 tensor — what the bf16 backward of the x3f mode reads; the planes are
+    separate allocations so that saving `hi` for the backward does not keep `lo` alive."""
+
+    def __init__(self, hi, lo):
+        assert hi.dtype == torch.bfloat16 and lo.dtype == torch.bfloat16 and hi.shape == lo.shape and hi.stride() == lo.stride()
+        self.hi, self.lo = hi, lo
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    @property
+    def device(self):
+        return self.hi.device
+
+    @staticmethod
+    def empty(shape, device):
+        return Split(torch.empty(tuple(shape), dtype=torch.bfloat16, device=device), torch.empty(tuple(shape), dtype=torch.bfloat16, device=device))
+
+    def __getitem__(self, idx):
+        return Split(self.hi[idx], self.lo[idx])
+
+    def float(self):
+        return self.hi.float() + self.lo.float()
+
+
+def dtype_code(t):
+    return SPLIT if isinstance(t, Split) else _lib.dtype_code(t)
+
+
+def _hi(t):
+    return t.hi if isinstance(t, Split) else t
+
+
+def split_cast(x2d, cols=None):
+    """fp32 [rows, ld] -> Split [rows, pad8(cols)] (mtt_split_cast)."""
+    rows = x2d.shape[0]
+    cols = cols or x2d.shape[1]
+    out = Split.empty((rows, pad8(cols)), x2d.device)
+    call("split_cast", args=[x2d, out.hi, out.lo, rows, cols, x2d.stride(0), pad8(cols)])
+    return out
 
 
 GEMM_VARIANT = None            # A/B hook (bench.py --gemm-variant): mtt_gemm_desc.variant for every call that leaves it at AUTO
@@ -105,6 +157,21 @@ def pack_linear(weights, prec, tag):
     return _cached((tag, prec.name, tuple(id(w) for w in weights)), weights, build)
 
 
+def pack_linear_split(weights, tag):
+    """List of Z parameters [N, K] -> Split [Z, N, pad8(K)]: pre-split weight planes for the LDS-DMA x3 GEMM (x3f mode)."""
+    def build():
+        with torch.no_grad():
+            mats = [w.detach().reshape(w.shape[0], -1).float() for w in weights]
+            N, K = mats[0].shape
+            buf = torch.zeros(2, len(mats), N, pad8(K), dtype=torch.bfloat16, device=mats[0].device)
+            for z, m in enumerate(mats):
+                hi = m.to(torch.bfloat16)
+                buf[0, z, :, :K] = hi
+                buf[1, z, :, :K] = (m - hi.float()).to(torch.bfloat16)
+            return Split(buf[0], buf[1])
+    return _cached((tag, 'split', tuple(id(w) for w in weights)), weights, build)
+
+
 def pack_conv3(weights, prec, tag, transpose=False):
     """List of Z conv weights [Co, Ci, 3, 3] -> [Z, Co, 9*Cip] with k = tap*Cip + ci (taps row-major).
     transpose=True packs the dgrad operand [Z, Ci, 9*Cop] with k = tap*Cop + co."""
@@ -162,11 +229,14 @@ def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=No
     default = D's); may alias `out`."""
     Z, Nw, Kp = wpack.shape
     assert N <= Nw
+    x_split = isinstance(x, Split)
+    assert x_split == isinstance(wpack, Split), "split planes: both operands or neither"
     if a_rows is not None:
         a_mb, a_bs, lda = a_rows
         a_z = 0
     else:
-        xv = x if x.dim() == 3 else x[None]
+        xh = _hi(x)
+        xv = xh if xh.dim() == 3 else xh[None]
         if M is None:
             M = xv.shape[1]
         a_mb, a_bs, lda = 0, 0, xv.shape[2]
@@ -174,25 +244,31 @@ def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=No
         assert xv.shape[0] in (1, Z) and lda >= Kp
     Np = pad8(N)
     if out is None:
-        out = torch.empty(Z, M, Np, dtype=out_dtype or prec.adt, device=x.device)
+        out = Split.empty((Z, M, Np), x.device) if out_dtype == "split" else torch.empty(Z, M, Np, dtype=out_dtype or prec.adt, device=x.device)
+    oh = _hi(out)
     if d_rows is not None:
         d_mb, d_bs, ldd_ = d_rows
         dz = 0
         nst = N
     else:
         d_mb, d_bs = 0, 0
-        ldd_ = ldd if ldd is not None else out.shape[-1]
-        dz = out.stride(0) if out.dim() == 3 else 0
+        ldd_ = ldd if ldd is not None else oh.shape[-1]
+        dz = oh.stride(0) if oh.dim() == 3 else 0
         nst = min(Np, ldd_)
     if n_store is not None:
         nst = n_store
-    kw = dict(A=x, B=wpack, D=out, M=M, N=N, K=Kp, a_op=OP_K, b_op=OP_K,
+    wh = _hi(wpack)
+    kw = dict(A=_hi(x), B=wh, D=oh, M=M, N=N, K=Kp, a_op=OP_K, b_op=OP_K,
               a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
               lda=lda, ldb=Kp, ldd=ldd_, a_mb=a_mb, a_bs=a_bs, d_mb=d_mb, d_bs=d_bs,
               batch=Z, batch_inner=batch_inner, alpha=alpha, act=act, n_store=nst)
+    if x_split:
+        kw.update(A_lo=x.lo, B_lo=wpack.lo)
+    if isinstance(out, Split):
+        kw.update(D_lo=out.lo)
     # batch offsets: linear in z for A / B / bias; D may be two-level (d_z)
     kw.update(a_zo=a_z * batch_inner, a_zi=a_z if batch_inner > 1 else 0,
-              b_zo=wpack.stride(0) * batch_inner, b_zi=wpack.stride(0) if batch_inner > 1 else 0)
+              b_zo=wh.stride(0) * batch_inner, b_zi=wh.stride(0) if batch_inner > 1 else 0)
     if d_z is not None:
         kw.update(d_zo=d_z[0], d_zi=d_z[1])
     else:
@@ -280,25 +356,36 @@ def deconv2x2(x, wpack, Co, Ci, B, H, W, prec, *, bias4=None, out_dtype=None):
 # ---------------------------------------------------------------------------------------------
 # row ops
 # ---------------------------------------------------------------------------------------------
-def layernorm(x, gamma, beta, eps, prec, save_stats=False, out_dtype=None):
-    """x fp32 [rows, C] -> y [rows, C] (activation dtype unless out_dtype).  Returns (y, mean, rstd)."""
+def layernorm(x, gamma, beta, eps, prec, save_stats=False, out_dtype=None, want32=False):
+    """x fp32 [rows, C] -> y [rows, C] (activation dtype unless out_dtype; "split": a Split, and with want32 also the fp32 rows —
+    then y is the pair (Split, fp32 tensor)).  Returns (y, mean, rstd)."""
     rows, C = x.shape
-    y = torch.empty(rows, C, dtype=out_dtype or prec.adt, device=x.device)
+    split = out_dtype == "split"
+    y = Split.empty((rows, C), x.device) if split else torch.empty(rows, C, dtype=out_dtype or prec.adt, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    call("layernorm_fwd", x=x, y=y, gamma=gamma, beta=beta, mean=mean, rstd=rstd, rows=rows, C=C,
-         ldx=x.stride(0), ldy=C, y_dtype=dtype_code(y), eps=eps)
-    return y, mean, rstd
+    kw = {}
+    y32 = None
+    if split:
+        kw.update(y_lo=y.lo)
+        if want32:
+            y32 = torch.empty(rows, C, dtype=torch.float32, device=x.device)
+            kw.update(y32=y32, ldy32=C)
+    call("layernorm_fwd", x=x, y=_hi(y), gamma=gamma, beta=beta, mean=mean, rstd=rstd, rows=rows, C=C,
+         ldx=x.stride(0), ldy=C, y_dtype=dtype_code(y), eps=eps, **kw)
+    return ((y, y32) if want32 else y), mean, rstd
 
 
 def attention(qkv, B, N, nH, T, prec, want_lse=False):
     """qkv [B*N, 3*nH*64] -> (out [B*N, nH*64], rawlog fp32 [B, nH, T, N] or None, lse or None)."""
     C = nH * 64
-    out = torch.empty(B * N, C, dtype=qkv.dtype, device=qkv.device)
+    split = isinstance(qkv, Split)
+    out = Split.empty((B * N, C), qkv.device) if split else torch.empty(B * N, C, dtype=qkv.dtype, device=qkv.device)
     rawlog = torch.empty(B, nH, T, N, dtype=torch.float32, device=qkv.device) if T > 0 else None
     lse = torch.empty(B, nH, N, dtype=torch.float32, device=qkv.device) if want_lse else None
-    call("attn_fwd", qkv=qkv, out=out, rawlog=rawlog, lse=lse, B=B, N=N, nH=nH, T=T,
-         dtype=dtype_code(qkv), prec=prec.code, scale=64 ** -0.5)
+    kw = dict(qkv_lo=qkv.lo, out_lo=out.lo) if split else {}
+    call("attn_fwd", qkv=_hi(qkv), out=_hi(out), rawlog=rawlog, lse=lse, B=B, N=N, nH=nH, T=T,
+         dtype=dtype_code(qkv), prec=prec.code, scale=64 ** -0.5, **kw)
     return out, rawlog, lse
 
 

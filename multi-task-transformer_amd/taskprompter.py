@@ -262,6 +262,8 @@ class TaskPrompter(nn.Module):
         hw = grid[0] * grid[1]
         a = blk.attn
         tag = ('blk', i)
+        if prec.split and self.gprec is None:
+            return self._block_split(blk, tag, XT, B, N, T, grid, nwin)
         xn, _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec)
         qkv = ops.linear(xn, ops.pack_linear([a.qkv.weight], pe, tag + ('qkv',)), 3 * C, pe,
                          bias=a.qkv.bias.detach()[None], out_dtype=adt)[0]
@@ -287,6 +289,32 @@ class TaskPrompter(nn.Module):
                           bias=blk.mlp.fc1.bias.detach()[None], act=ACT_GELU, out_dtype=adt)[0]
         XT3 = torch.empty_like(XT)
         ops.linear(hmid, ops.pack_linear([blk.mlp.fc2.weight], pe, tag + ('fc2',)), C, pe,
+                   bias=blk.mlp.fc2.bias.detach()[None], out=XT3, resid=XT2)
+        return XT3, rawlog, rawchan
+
+    def _block_split(self, blk, tag, XT, B, N, T, grid, nwin):
+        """the block in the x3f mode (inference): the same x3 products, the four big Linears on the LDS-DMA kernel over pre-split
+        hi / lo planes (ops.Split) written by the producing kernels (LayerNorm, qkv / fc1 epilogues, attention)."""
+        prec, C, nH = self.prec, self.embed_dim, self.num_heads
+        hw = grid[0] * grid[1]
+        a = blk.attn
+        (xs, xn32), _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec, out_dtype="split", want32=True)
+        qkv = ops.linear(xs, ops.pack_linear_split([a.qkv.weight], tag + ('qkv',)), 3 * C, prec, bias=a.qkv.bias.detach()[None],
+                         out_dtype="split")[0]
+        ao, rawlog, _ = ops.attention(qkv, B, N, nH, T, prec)
+        XT2 = torch.empty_like(XT)
+        ops.linear(ao, ops.pack_linear_split([a.proj.weight], tag + ('proj',)), C, prec, bias=a.proj.bias.detach()[None], out=XT2, resid=XT)
+        cq = ops.linear(xn32, ops.pack_linear([a.token_trans.weight], prec, tag + ('tt',)), hw, prec,
+                        bias=a.token_trans.bias.detach()[None], a_rows=(T, N * C, C), M=B * T)[0]
+        rawchan = ops.chan_logits(cq, xn32, B, T, N, C, grid, (nwin, nwin))
+        pr = XT2.view(B, N, C)[:, :T]
+        ops.linear(cq, ops.pack_linear([a.token_trans1.weight], prec, tag + ('tt1',)), C, prec,
+                   bias=a.token_trans1.bias.detach()[None], out=pr, d_rows=(T, N * C, C), resid=pr, M=B * T)
+        xs2, _, _ = ops.layernorm(XT2, blk.norm2.weight.detach(), blk.norm2.bias.detach(), blk.norm2.eps, prec, out_dtype="split")
+        hmid = ops.linear(xs2, ops.pack_linear_split([blk.mlp.fc1.weight], tag + ('fc1',)), 4 * C, prec,
+                          bias=blk.mlp.fc1.bias.detach()[None], act=ACT_GELU, out_dtype="split")[0]
+        XT3 = torch.empty_like(XT)
+        ops.linear(hmid, ops.pack_linear_split([blk.mlp.fc2.weight], tag + ('fc2',)), C, prec,
                    bias=blk.mlp.fc2.bias.detach()[None], out=XT3, resid=XT2)
         return XT3, rawlog, rawchan
 

@@ -11,7 +11,7 @@ import math
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, SPLIT = 0, 1, 2        # SPLIT: x = hi + lo, two bf16 planes (main pointer = hi, *_lo = lo)
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 
@@ -71,6 +71,9 @@ def gemm(**kw):
     m = torch.arange(M)[:, None]
     n = torch.arange(N)[:, None]
     k = torch.arange(K)[None, :]
+    a_split, b_split, d_split = g("a_dtype") == SPLIT, g("b_dtype") == SPLIT, g("d_dtype") == SPLIT
+    if a_split or b_split:
+        assert a_split and b_split and prec == 1 and a_op == OP_K and b_op == OP_K and K % 64 == 0, "split operands: x3, both split, OP_K, K % 64 == 0"
 
     def conv_taps(idx_tap, flip):
         ty, tx = idx_tap // 3, idx_tap % 3
@@ -86,6 +89,8 @@ def gemm(**kw):
         # ---- A [M, K] ----
         if a_op == OP_K:
             Am = _rd(A, za + _rowoff(m, g("a_mb"), g("a_bs"), lda) + k)
+            if a_split:
+                Am = Am + _rd(kw["A_lo"], za + _rowoff(m, g("a_mb"), g("a_bs"), lda) + k)
         elif a_op == OP_R:
             Am = _rd(A, za + k * lda + m)
         elif a_op == OP_CONV_K:
@@ -100,6 +105,8 @@ def gemm(**kw):
         # ---- B [N, K] ----
         if b_op == OP_K:
             Bm = _rd(B, zb + n * ldb + k)
+            if b_split:
+                Bm = Bm + _rd(kw["B_lo"], zb + n * ldb + k)
         elif b_op == OP_R:
             Bm = _rd(B, zb + k * ldb + n)
         elif b_op == OP_CONV_R:
@@ -155,10 +162,13 @@ def gemm(**kw):
         else:
             didx = zd + _rowoff(mrow, d_mb, d_bs, ldd)[:, None] + ncol[None, :]
             _wr(D, didx, v)
+            if d_split:
+                _wr(kw["D_lo"], didx, v - _bf16_round(v))
             n_store = g("n_store")
             if n_store and n_store > N:
                 pad = torch.arange(N, n_store)
-                _wr(D, zd + _rowoff(mrow, d_mb, d_bs, ldd)[:, None] + pad[None, :], torch.zeros(M, n_store - N, dtype=torch.float64))
+                for Dp in ([D, kw["D_lo"]] if d_split else [D]):
+                    _wr(Dp, zd + _rowoff(mrow, d_mb, d_bs, ldd)[:, None] + pad[None, :], torch.zeros(M, n_store - N, dtype=torch.float64))
 
 
 def attn_fwd(**kw):
@@ -167,6 +177,10 @@ def attn_fwd(**kw):
     C = nH * 64
     f, o = flat(qkv)
     x = f[o:o + B * N * 3 * C].double().view(B, N, 3, nH, 64)
+    split = kw.get("dtype") == SPLIT
+    if split:
+        fl, ol = flat(kw["qkv_lo"])
+        x = x + fl[ol:ol + B * N * 3 * C].double().view(B, N, 3, nH, 64)
     if kw.get("prec", 0) == 0 and ROUND_BF16_OPERANDS:
         x = _bf16_round(x)
     q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
@@ -178,6 +192,8 @@ def attn_fwd(**kw):
         _wr(kw["lse"], torch.arange(B * nH * N), torch.logsumexp(s, dim=-1).reshape(-1))
     y = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(-1)
     _wr(out, torch.arange(B * N * C), y)
+    if split:
+        _wr(kw["out_lo"], torch.arange(B * N * C), y - _bf16_round(y))
 
 
 def attn_bwd(**kw):
@@ -243,6 +259,10 @@ def layernorm_fwd(**kw):
     rstd = torch.rsqrt(var + kw["eps"])
     y = (x - mean) * rstd * _rd(kw["gamma"], c) + _rd(kw["beta"], c)
     _wr(kw["y"], r * kw["ldy"] + c, y)
+    if kw.get("y_dtype") == SPLIT:
+        _wr(kw["y_lo"], r * kw["ldy"] + c, y - _bf16_round(y))
+    if kw.get("y32") is not None:
+        _wr(kw["y32"], r * kw["ldy32"] + c, y)
     if kw.get("mean") is not None:
         _wr(kw["mean"], torch.arange(rows), mean[:, 0])
     if kw.get("rstd") is not None:
@@ -444,6 +464,17 @@ def cast2d(args):
     _wr(dst, r * ldd + c, _rd(src, r * lds + c))
     if zp and ldd > cols:
         _wr(dst, r * ldd + torch.arange(cols, ldd)[None, :], torch.zeros(rows, ldd - cols, dtype=torch.float64))
+
+
+def split_cast(args):
+    src, hi, lo, rows, cols, lds, ldd = args[:7]
+    r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+    x = _rd(src, r * lds + c)
+    _wr(hi, r * ldd + c, x)
+    _wr(lo, r * ldd + c, x - _bf16_round(x))
+    if ldd > cols:
+        for t in (hi, lo):
+            _wr(t, r * ldd + torch.arange(cols, ldd)[None, :], torch.zeros(rows, ldd - cols, dtype=torch.float64))
 
 
 def colsum(args):
@@ -974,7 +1005,7 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=wina
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
               loss_fwd=loss_fwd, loss_bwd=loss_bwd)
-_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
+_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
             transpose_pad_sum=transpose_pad_sum)
 
 

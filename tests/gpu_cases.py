@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 
 from oracle import abi_emul  # noqa: E402
 
-F32, BF16 = 0, 1
+F32, BF16, SPLIT = 0, 1, 2
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
 DT = {0: torch.float32, 1: torch.bfloat16}
 
@@ -63,6 +63,21 @@ def run_case(name, kw, outputs, tol):
     torch.cuda.synchronize()
     abi_emul.call(name, **kw)
     errs, ok = {}, True
+    # MTT_SPLIT outputs (hi / lo bf16 planes): the lo plane alone is ill-conditioned (a 1-ulp flip of hi moves lo by a whole ulp), so
+    # the pair is judged by its SUM (fp32-class: tol["split"]); the hi plane is still compared on its own as a bf16 storage
+    pairs = [(kw[h], kw[l], gpu_kw[h], gpu_kw[l], f"{h}+{l}") for h, l in tol.get("split_pairs", ())]
+    if "split_args" in tol:
+        ih, il = tol["split_args"]
+        pairs.append((kw["args"][ih], kw["args"][il], gpu_kw["args"][ih], gpu_kw["args"][il], "args"))
+    for ch, cl, gh, gl, hk in pairs:
+        lk = ""
+        skip.add(cl.untyped_storage().data_ptr())
+        a = gh.float().cpu().double() + gl.float().cpu().double()
+        b = ch.double() + cl.double()
+        e = float((a - b).norm()) / (float(b.norm()) + 1e-30)
+        errs[f"split({hk}{lk})"] = (e, float((a - b).abs().max()))
+        if not (e <= tol["split"]):
+            ok = False
     for key, (gflat, cflat) in gpu_store.items():
         if key in skip:
             continue
@@ -85,6 +100,7 @@ def run_case(name, kw, outputs, tol):
 TOL_X3 = dict(f32=2e-5, bf16=5e-3)
 TOL_BF = dict(f32=2e-5, bf16=5e-3)        # emulator rounds operands to bf16 too -> only accumulation order differs
 TOL_ROW = dict(f32=1e-5, bf16=5e-3)
+TOL_SPLIT_D = dict(f32=2e-5, bf16=5e-3, split=2e-5, split_pairs=[("D", "D_lo")])      # a split-plane GEMM output: hi as bf16, hi + lo as fp32-class
 
 
 def gemm_cases():
@@ -138,26 +154,14 @@ def gemm_cases():
               alpha=1.0, colshift=rnd(g, N), resid=XT[:, 3:], ldr=1032, r_mb=Mb, r_bs=(Mb + 3) * 1032,
               rowscale=torch.rand(Bn, 2, generator=g), n_prompt=5, n_store=1032)
     cases.append(("gemm_fast256_rowgroups_resid", "gemm", kw, TOL_BF))
-    # 1d. phased LDS-DMA kernels forced on small shapes (variant = 3: 256 x 256 or 256 x 128 by N): K tails (K % 64 != 0 -> zero page),
-    #     ragged M / N, one and many K tiles, both tile widths; then the implicit-GEMM 3x3 conv through the same kernels
+    # 1d. the LDS-DMA kernel forced on small shapes (variant = 3): K tails (K % 64 != 0 -> general addressing, zero page), ragged M / N,
+    #     one and many K tiles
     for (M, N, K) in ((300, 260, 200), (70, 700, 64), (513, 350, 1096), (256, 128, 8), (1000, 300, 72)):
         kw = base(M, N, K, BF16, BF16, BF16, 0, variant=3, colshift=rnd(g, N), act=1)
         cases.append((f"gemm_dma_forced_{M}x{N}x{K}", "gemm", kw, TOL_BF))
-    for dil, flip, (Bn, H, W, Ci, Co) in ((1, 0, (2, 9, 7, 20, 30)), (2, 0, (2, 9, 7, 20, 30)), (1, 1, (2, 9, 7, 20, 30)), (1, 0, (3, 20, 17, 44, 300)),
-                                          (2, 1, (1, 33, 40, 72, 130))):
-        Cp, Cop = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
-        X = rnd(g, 2, Bn * H * W, Cp, dtype=torch.bfloat16); X[..., Ci:] = 0
-        Wt = rnd(g, 2, Co, 9, Cp, dtype=torch.bfloat16); Wt[..., Ci:] = 0
-        kw = dict(A=X, B=Wt, D=torch.zeros(2, Bn * H * W, Cop, dtype=torch.bfloat16), M=Bn * H * W, N=Co, K=9 * Cp,
-                  a_op=OP_CONV_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=Cp, ldb=9 * Cp, ldd=Cop,
-                  batch=2, batch_inner=1, a_zo=Bn * H * W * Cp, b_zo=Co * 9 * Cp, d_zo=Bn * H * W * Cop,
-                  conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, colshift=rnd(g, 2, Co), col_zo=Co, act=1, n_store=Cop, variant=3)
-        cases.append((f"gemm_dma_conv3_d{dil}f{flip}_{Bn}x{H}x{W}x{Ci}to{Co}", "gemm", kw, TOL_BF))
-    # balanced LDS-DMA schedule of the phased kernel (variant = 5) and many K tiles / both parities of the tile count under the default one
-    for (M, N, K, v) in ((300, 520, 200, 5), (513, 600, 1096, 5), (520, 700, 1152, 3), (300, 512, 1088, 3), (256, 256, 64, 3), (256, 256, 128, 3)):
+    # many K tiles / both parities of the tile count (fast addressing: K % 64 == 0) and K tails (general addressing)
+    for (M, N, K, v) in ((300, 520, 200, 3), (513, 600, 1096, 3), (520, 700, 1152, 3), (300, 512, 1088, 3), (256, 256, 64, 3), (256, 256, 128, 3)):
         cases.append((f"gemm_dma_sched{v}_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0, variant=v, colshift=rnd(g, N)), TOL_BF))
-    # the round-1 lock-step 256 x 256 kernel stays reachable (variant = 4) for A/B measurements
-    cases.append(("gemm_dma256_v1_forced", "gemm", base(300, 260, 192, BF16, BF16, BF16, 0, variant=4), TOL_BF))
     # 1e. specialised interior-tile epilogues (KIND 0..4 of gemm_epilogue_fast) on the DMA kernel (variant 3) and the general kernel
     #     (variant 1), next to edge tiles that take the general epilogue in the same launch; variant 11 = general epilogue everywhere
     for v in (3, 1, 11):
@@ -184,45 +188,55 @@ def gemm_cases():
                                                                           resid=rnd(g, M, 520), ldr=520, n_store=N), TOL_BF))
         cases.append((f"gemm_epi_kind4_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528, act=3,
                                                                aux_in=rnd(g, M, 536, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
-    # 1e'. persistent 256 x 256 kernel (variant 12 = deferred stores + two-tile prefetch across the seam; 13 = block-by-block stores):
-    #      more than 256 tiles so that workgroups walk several tiles (K loop continuous across the seam, per-wave epilogue), ragged M,
-    #      2 .. 17 K tiles, every epilogue kind, task batches (flat tile index over z); K = 8 is ineligible (falls back to the one-tile kernel)
-    #      variant 19 = the one-tile kernel with swapped-operand MFMAs + direct-store epilogue (v_permlane16_swap instead of LDS staging):
-    #      the same shapes exercise its interior tiles (direct) and its ragged last row of tiles (general epilogue on the swapped layout)
-    for v in (12, 13, 19):
-        for (M, N, K) in ((8498, 2048, 192), (20000, 1024, 1088), (33 * 256, 2048, 128), (9000, 2048, 8)):
-            cases.append((f"gemm_pdma_v{v}_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0, variant=v, colshift=rnd(g, N), n_store=N), TOL_BF))
-        M, N, K = 8498, 2048, 256
-        A16 = rnd(g, M, K, dtype=torch.bfloat16)
-        B16 = rnd(g, N, K, dtype=torch.bfloat16)
-        common = dict(A=A16, B=B16, M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, prec=0, lda=K, ldb=K,
-                      batch=1, batch_inner=1, alpha=1.0, variant=v, n_store=N)
-        cases.append((f"gemm_pdma_kind1_v{v}", "gemm", dict(common, D=torch.full((M, N + 8), 7.0), d_dtype=F32, ldd=N + 8), TOL_BF))
-        cases.append((f"gemm_pdma_kind2_v{v}", "gemm", dict(common, D=torch.full((M, N + 8), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=N + 8,
-                                                                colshift=rnd(g, N), colscale=rnd(g, N).abs() + 0.5, act=1,
-                                                                aux_out=torch.full((M, N + 16), 3.0, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=N + 16), TOL_BF))
-        cases.append((f"gemm_pdma_kind2_noaux_v{v}", "gemm", dict(common, D=torch.full((M, N + 8), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=N + 8,
-                                                                      colshift=rnd(g, N), act=1), TOL_BF))
-        XT = rnd(g, M, N + 8)
-        cases.append((f"gemm_pdma_kind3_v{v}", "gemm", dict(common, D=XT, d_dtype=F32, ldd=N + 8, d_mb=607, d_bs=607 * (N + 8), colshift=rnd(g, N),
-                                                                resid=XT, ldr=N + 8, r_mb=607, r_bs=607 * (N + 8), rowscale=torch.rand(14, 2, generator=g),
-                                                                n_prompt=7), TOL_BF))
-        cases.append((f"gemm_pdma_kind3_norowscale_v{v}", "gemm", dict(common, D=torch.zeros(M, N + 8), d_dtype=F32, ldd=N + 8, colshift=rnd(g, N),
-                                                                           resid=rnd(g, M, N), ldr=N), TOL_BF))
-        cases.append((f"gemm_pdma_kind4_v{v}", "gemm", dict(common, D=torch.full((M, N + 8), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=N + 8, act=3,
-                                                                aux_in=rnd(g, M, N + 16, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=N + 16), TOL_BF))
-        Z, M, N, K = 3, 6000, 1024, 320
-        kw = dict(A=rnd(g, Z, M, K, dtype=torch.bfloat16), B=rnd(g, Z, N, K, dtype=torch.bfloat16), D=torch.zeros(Z, M, N, dtype=torch.bfloat16),
-                  M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=N, batch=Z, batch_inner=1,
-                  a_zo=M * K, b_zo=N * K, d_zo=M * N, alpha=1.0, colshift=rnd(g, Z, N), col_zo=N, n_store=N, variant=v)
-        cases.append((f"gemm_pdma_batched_v{v}", "gemm", kw, TOL_BF))
-        # a_mb row groups on the A side (prompt rows skipped), as the encoder's patch-only GEMMs address the token buffer
-        Bn, Mb, K, N = 18, 517, 192, 1024
-        XA = rnd(g, Bn, Mb + 3, K, dtype=torch.bfloat16)
-        kw = dict(A=XA[:, 3:], B=rnd(g, N, K, dtype=torch.bfloat16), D=torch.zeros(Bn * Mb, N, dtype=torch.bfloat16), M=Bn * Mb, N=N, K=K,
-                  a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=N, a_mb=Mb, a_bs=(Mb + 3) * K,
-                  batch=1, batch_inner=1, alpha=1.0, colshift=rnd(g, N), n_store=N, variant=v)
-        cases.append((f"gemm_pdma_rowgroups_v{v}", "gemm", kw, TOL_BF))
+    # 1e'. MTT_SPLIT operands (x = hi + lo bf16 planes) on the LDS-DMA kernel: the fp32-class product as one K-concatenated bf16 GEMM
+    #      (gemm_dma_kernel<2>); D fp32 / split planes, every epilogue kind it serves (1, 3, 5, 6 + the general one on ragged tiles),
+    #      row groups on A, task batches; K = 64 .. 1088 (both parities of 3 K / 64).  The emulator reads hi + lo in fp64.
+    def planes(t):
+        hi = t.to(torch.bfloat16)
+        return hi, (t - hi.float()).to(torch.bfloat16)
+    for (M, N, K) in ((300, 260, 64), (600, 520, 192), (257, 300, 1088), (1000, 1024, 256)):
+        Ah, Al = planes(rnd(g, M, K + 8)); Bh, Bl = planes(rnd(g, N, K + 16))
+        common = dict(A=Ah, A_lo=Al, B=Bh, B_lo=Bl, M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=SPLIT, b_dtype=SPLIT, prec=1, lda=K + 8, ldb=K + 16,
+                      batch=1, batch_inner=1, alpha=1.0)
+        ldd = (N + 7) // 8 * 8 + 8
+        cases.append((f"gemm_split_f32out_{M}x{N}x{K}", "gemm", dict(common, D=torch.full((M, ldd), 7.0), d_dtype=F32, ldd=ldd, colshift=rnd(g, N)), TOL_X3))
+        cases.append((f"gemm_split_splitout_{M}x{N}x{K}", "gemm", dict(common, D=torch.full((M, ldd), 7.0, dtype=torch.bfloat16),
+                                                                          D_lo=torch.full((M, ldd), 5.0, dtype=torch.bfloat16), d_dtype=SPLIT, ldd=ldd,
+                                                                          colshift=rnd(g, N), n_store=(N + 7) // 8 * 8), TOL_SPLIT_D))
+        cases.append((f"gemm_split_gelu_aux_{M}x{N}x{K}", "gemm", dict(common, D=torch.full((M, ldd), 7.0, dtype=torch.bfloat16),
+                                                                        D_lo=torch.full((M, ldd), 5.0, dtype=torch.bfloat16), d_dtype=SPLIT, ldd=ldd,
+                                                                        colshift=rnd(g, N), act=1, aux_out=torch.full((M, ldd + 8), 3.0, dtype=torch.bfloat16),
+                                                                        aux_dtype=BF16, ldaux=ldd + 8), TOL_SPLIT_D))
+        XT = rnd(g, M, ldd)
+        cases.append((f"gemm_split_resid_{M}x{N}x{K}", "gemm", dict(common, D=XT, d_dtype=F32, ldd=ldd, d_mb=100, d_bs=100 * ldd, colshift=rnd(g, N),
+                                                                     resid=XT, ldr=ldd, r_mb=100, r_bs=100 * ldd, rowscale=torch.rand(M // 100 + 1, 2, generator=g),
+                                                                     n_prompt=7), TOL_X3))
+    Bn, Mb, K, N = 5, 117, 128, 520
+    XAh, XAl = planes(rnd(g, Bn, Mb + 3, K))
+    Bh, Bl = planes(rnd(g, N, K))
+    kw = dict(A=XAh[:, 3:], A_lo=XAl[:, 3:], B=Bh, B_lo=Bl, D=torch.zeros(Bn * Mb, N), M=Bn * Mb, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=SPLIT,
+              b_dtype=SPLIT, d_dtype=F32, prec=1, lda=K, ldb=K, ldd=N, a_mb=Mb, a_bs=(Mb + 3) * K, batch=1, batch_inner=1, alpha=1.0, colshift=rnd(g, N))
+    cases.append(("gemm_split_rowgroups", "gemm", kw, TOL_X3))
+    Z, M, N, K = 3, 300, 264, 192
+    Ah, Al = planes(rnd(g, Z, M, K)); Bh, Bl = planes(rnd(g, Z, N, K))
+    kw = dict(A=Ah, A_lo=Al, B=Bh, B_lo=Bl, D=torch.zeros(Z, M, N), M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=SPLIT, b_dtype=SPLIT, d_dtype=F32, prec=1,
+              lda=K, ldb=K, ldd=N, batch=Z, batch_inner=1, a_zo=M * K, b_zo=N * K, d_zo=M * N, alpha=1.0, colshift=rnd(g, Z, N), col_zo=N)
+    cases.append(("gemm_split_batched", "gemm", kw, TOL_X3))
+    # 1e''. bf16 arithmetic on fp32-STORED operands (rounded while staged: general kernel MODE 3 = f32 x f32, MODE 4 = bf16 x f32), in the
+    #       layouts the bf16 backward of the x3-forward training mode uses them: dgrad (OP_K x OP_R), wgrad (OP_R x OP_R), conv dgrad / wgrad
+    for tag, adt, bdt in (("f32f32", F32, F32), ("bf16f32", BF16, F32)):
+        cases.append((f"gemm_bf16prec_{tag}_plain", "gemm", base(200, 150, 136, adt, bdt, F32, 0), TOL_BF))
+        kw = dict(A=rnd(g, 90, 72, dtype=DT[adt]), B=rnd(g, 72, 136, dtype=DT[bdt]), D=torch.zeros(90, 136), M=90, N=136, K=72,
+                  a_op=OP_K, b_op=OP_R, a_dtype=adt, b_dtype=bdt, d_dtype=F32, prec=0, lda=72, ldb=136, ldd=136, batch=1, batch_inner=1, alpha=1.0)
+        cases.append((f"gemm_bf16prec_{tag}_dgrad", "gemm", kw, TOL_BF))
+        kw = dict(A=rnd(g, 203, 72, dtype=DT[adt]), B=rnd(g, 203, 40, dtype=DT[bdt]), D=torch.zeros(72, 40), M=72, N=40, K=203, a_op=OP_R, b_op=OP_R,
+                  a_dtype=adt, b_dtype=bdt, d_dtype=F32, prec=0, lda=72, ldb=40, ldd=40, batch=1, batch_inner=1, alpha=1.0)
+        cases.append((f"gemm_bf16prec_{tag}_wgrad", "gemm", kw, TOL_BF))
+        Bn, H, W, Ci, Co = 2, 9, 7, 24, 40
+        X = rnd(g, Bn * H * W, Ci, dtype=DT[bdt]); dY = rnd(g, Bn * H * W, Co, dtype=DT[adt])
+        kw = dict(A=dY, B=X, D=torch.full((Co, 9 * Ci), 5.0), M=Co, N=9 * Ci, K=Bn * H * W, a_op=OP_R, b_op=OP_CONV_R, a_dtype=adt, b_dtype=bdt,
+                  d_dtype=F32, prec=0, lda=Co, ldb=Ci, ldd=9 * Ci, batch=1, batch_inner=1, conv=dict(H=H, W=W, C=Ci, Cp=Ci, dil=1, flip=0), alpha=1.0)
+        cases.append((f"gemm_bf16prec_{tag}_conv_wgrad", "gemm", kw, TOL_BF))
     # 1f. token-major weight-gradient kernel (gemm_tn_kernel, forced by variant 3 on small shapes): ragged M / N / K, several K tiles of
     #     both parities, batch slabs (split K), asymmetric operands (an M <-> N swap or a k permutation cannot pass), then the 3x3 conv
     #     weight gradient (implicit im2col^T on the B side; halo, dilation, channel padding)
@@ -366,6 +380,15 @@ def attn_cases():
                   xargs=[rnd(g, B * N, C, dtype=DT[BF16]), rnd(g, B, nH, T, N) * 0.05, torch.zeros(B * N, 3 * C, dtype=DT[BF16]),
                          torch.zeros(B, nH, 2, (N + 3) // 4 * 4)])
         cases.append((f"attn_bwd_B{B}N{N}T{T}_variant{variant}", "attn_bwd", kb, dict(f32=5e-3, bf16=1.5e-2)))
+    # x3 attention on split planes (qkv hi / lo in, out hi / lo + lse + raw prompt logits out): the x3f mode's forward
+    for (B, N, nH, T) in ((2, 150, 2, 6), (1, 257, 1, 0)):
+        C = nH * 64
+        q = rnd(g, B * N, 3 * C)
+        qh = q.to(torch.bfloat16)
+        kw = dict(qkv=qh, qkv_lo=(q - qh.float()).to(torch.bfloat16), out=torch.zeros(B * N, C, dtype=torch.bfloat16),
+                  out_lo=torch.zeros(B * N, C, dtype=torch.bfloat16), rawlog=torch.zeros(B, nH, max(T, 1), N) if T else None,
+                  lse=torch.zeros(B, nH, N), B=B, N=N, nH=nH, T=T, dtype=SPLIT, prec=1, scale=0.125)
+        cases.append((f"attn_B{B}N{N}T{T}_split", "attn_fwd", kw, dict(f32=3e-5, bf16=6e-3, split=3e-5, split_pairs=[("out", "out_lo")])))
     # softmax spike (forces large running-max jumps across tiles)
     B, N, nH, T = 1, 200, 1, 2
     q = rnd(g, B * N, 3 * 64)
@@ -379,6 +402,18 @@ def attn_cases():
 def row_cases():
     cases = []
     g = torch.Generator().manual_seed(13)
+    # LayerNorm writing split planes (+ the optional fp32 copy), and the fp32 -> split cast
+    for want32 in (False, True):
+        rows, C = 37, 128
+        kw = dict(x=rnd(g, rows, C + 4), y=torch.zeros(rows, C, dtype=torch.bfloat16), y_lo=torch.zeros(rows, C, dtype=torch.bfloat16),
+                  gamma=rnd(g, C), beta=rnd(g, C), mean=torch.zeros(rows), rstd=torch.zeros(rows), rows=rows, C=C, ldx=C + 4, ldy=C, y_dtype=SPLIT, eps=1e-6)
+        if want32:
+            kw.update(y32=torch.zeros(rows, C + 8), ldy32=C + 8)
+        cases.append((f"ln_fwd_split_{int(want32)}", "layernorm_fwd", kw, dict(f32=1e-5, bf16=5e-3, split=1e-5, split_pairs=[("y", "y_lo")])))
+    for (rows, cols, lds) in ((37, 128, 132), (50, 45, 45), (9, 300, 304)):
+        ldd = (cols + 7) // 8 * 8
+        args = [rnd(g, rows, lds), torch.full((rows, ldd), 3.0, dtype=torch.bfloat16), torch.full((rows, ldd), 3.0, dtype=torch.bfloat16), rows, cols, lds, ldd]
+        cases.append((f"split_cast_{rows}x{cols}", "split_cast", dict(args=args), dict(f32=1e-6, bf16=5e-3, split=1e-5, split_args=(1, 2))))
     for ydt in (F32, BF16):
         rows, C = 37, 128
         kw = dict(x=rnd(g, rows, C + 4), y=torch.zeros(rows, C, dtype=DT[ydt]), gamma=rnd(g, C), beta=rnd(g, C),

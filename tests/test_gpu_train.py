@@ -27,6 +27,31 @@ def test_gradients_bf16_are_bf16_accurate():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv"])
+def test_gradients_x3f_forward_exact_backward_bf16(name):
+    """x3f: the forward is the x3 arithmetic (1e-3 per head; split planes through the LDS-DMA kernel for the encoder Linears), the
+    backward is bf16 on the hi planes — gradients are bf16-accurate, computed from fp32-class activations."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fwd, errs = train_check.grad_errors(name, "x3f", "cuda")
+    assert max(fwd.values()) < 1e-3, fwd
+    worst, med = train_check.summarize(errs, floor=1e-4)
+    assert med < 3e-2, (worst, med)
+
+
+@pytest.mark.gpu
+def test_invpt_x3f_runs_and_matches_forward():
+    """InvPT under x3f: ViT encoder on split planes, decoder Linears whose width is not a multiple of 64 fall back to the register-staged
+    x3 kernels; bf16 backward everywhere."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fwd, errs, dead = train_check.invpt_grad_errors("mini8", "x3f", "cuda")
+    assert max(fwd.values()) < 1e-3, fwd
+    worst, med = train_check.summarize(errs, floor=1e-4)
+    assert med < 2e-1, (worst, med)
+
+
+@pytest.mark.gpu
 def test_gradients_with_droppath_masks():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

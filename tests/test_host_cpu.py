@@ -44,7 +44,7 @@ def test_state_dict_contract_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv"])
-@pytest.mark.parametrize("prec,tol", [("x3", 2e-5), ("bf16", 4e-2)])
+@pytest.mark.parametrize("prec,tol", [("x3", 2e-5), ("x3f", 5e-5), ("bf16", 4e-2)])
 def test_wiring_on_emulator_matches_golden(emulated, name, prec, tol):
     cfg = configs.taskprompter(name)
     meta, gold = conftest.load_golden(name)
@@ -88,6 +88,30 @@ def test_training_gradients_on_emulator(emulated, name):
     assert max(fwd.values()) < 5e-5
     worst, med = train_check.summarize(errs)
     assert worst[0] < 1e-3, worst
+
+
+def test_x3f_mode_forward_x3_on_split_planes_backward_bf16(emulated, monkeypatch):
+    """x3f: the four encoder Linears of every block (and the attention between them) run on MTT_SPLIT planes in x3 arithmetic, the
+    backward is the bf16 one (flash attention backward, bf16 weight / input gradients on the hi planes); outputs stay fp32-class,
+    gradients bf16-accurate."""
+    import mtt_amd
+    import train_check
+    seen = []
+    inner = mtt_amd.ops.call
+
+    def spy(name, **kw):
+        seen.append((name, kw.get("a_dtype"), kw.get("prec"), kw.get("dtype")))
+        return inner(name, **kw)
+    monkeypatch.setattr(mtt_amd.ops, "call", spy)
+    fwd, errs = train_check.grad_errors("mini_ctr", "x3f", "cpu")
+    assert max(fwd.values()) < 5e-5, fwd
+    worst, med = train_check.summarize(errs, floor=1e-4)
+    assert med < 3e-2, (worst, med)
+    n_blocks = 4
+    assert sum(1 for n, adt, pr, _ in seen if n == "gemm" and adt == 2 and pr == 1) == 4 * n_blocks          # qkv, proj, fc1, fc2 per block
+    assert sum(1 for n, _, pr, dt in seen if n == "attn_fwd" and dt == 2 and pr == 1) == n_blocks
+    assert sum(1 for n, *_ in seen if n == "attn_bwd") == n_blocks
+    assert not any(n == "gemm" and pr == 1 for n, _, pr, _ in seen[len(seen) // 2 + 40:]), "x3 GEMMs in the backward half"
 
 
 def test_bf16_training_uses_flash_attention_backward(emulated, monkeypatch):
