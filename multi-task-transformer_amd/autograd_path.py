@@ -528,7 +528,10 @@ class BLinearFn(Function):
         bi = az['batch_inner']
         dx = torch.empty(Z, M, Kp, dtype=x.dtype, device=x.device)
         if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and M >= FAST_MIN_ROWS and Kp >= 128:
-            # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T
+            # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T.  The reduction runs over pad8(N) columns of dy:
+            # the padding columns [N, pad8(N)) meet zero rows of W^T, but 0 * NaN is NaN, so they must hold FINITE values.  Invariant of
+            # this file: every producer of a task-stack gradient writes its padding channels as zeros (conv / linear dgrads through
+            # n_store = pitch, bn_bwd_apply, ctr_mix, upconv4_gather, cast2d with zero_pad) — never torch.empty garbage.
             wT = _pad_last(wpack.transpose(1, 2), Np)                  # [Z, Kp, pad8(N)]: a few MB, once per backward of this node
             _gemm(dy, wT, dx, M, Kp, Np, prec, lda=lda, ldb=Np, ldd=Kp, b_zo=wT.stride(0) * bi, b_zi=wT.stride(0) if bi > 1 else 0,
                   d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
@@ -664,7 +667,8 @@ class BnActStackFn(Function):
             y, mean, rstd, scale = bn_mod.train_forward(x, C, bns, act, gammas, betas)
         else:
             mean = torch.stack([bn.running_mean for bn in bns])
-            rstd = torch.rsqrt(torch.stack([bn.running_var for bn in bns]) + bns[0].eps)
+            eps = torch.tensor([bn.eps for bn in bns], dtype=torch.float32, device=x.device)[:, None] if len({bn.eps for bn in bns}) > 1 else bns[0].eps
+            rstd = torch.rsqrt(torch.stack([bn.running_var for bn in bns]) + eps)
             y, scale = ops.bn_apply(x, C, mean, rstd, gammas, betas, act), 1.0
         ctx.save_for_backward(x, mean, rstd, gammas, betas)
         ctx.meta = (C, act, training, scale, bns)

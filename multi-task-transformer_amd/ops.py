@@ -440,13 +440,21 @@ def bilinear(x, B, C, Hin, Win, Hout, Wout, out_dtype, nchw=False):
 
 
 _ws_cache = {}
+_ws_retired = []         # outgrown workspaces are kept alive: a captured hipGraph (graphs.GraphedTrainStep) has their raw addresses baked in
 
 
 def workspace(nfloats, device):
-    """Grow-only fp32 scratch buffer per device for the kernels' workspaces (launches are stream-ordered, so one buffer serves all)."""
+    """Grow-only fp32 scratch buffer per device for the kernels' workspaces (launches are stream-ordered, so one buffer serves all).
+    An outgrown buffer is never freed (a recorded graph may still write its partial sums there), and growing while a stream is
+    capturing is an error (the allocation would land in the graph's private pool and die with it)."""
     key = (device.type, device.index)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops.workspace: the kernel workspace must not grow during stream capture; run one eager iteration of the same "
+                               "shapes first (GraphedTrainStep's warm-up does)")
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(max(int(nfloats), 1 << 18), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf

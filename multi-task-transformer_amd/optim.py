@@ -29,7 +29,23 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._captured = None      # work list of the captured step: [(group index, part, params)]
         self._tables = {}
         self._pinned = {}          # (group, slot) -> pinned int64 staging buffer of gradient pointers (rotated: copies are asynchronous)
+        self._staged = {}          # pinned-buffer key -> event recorded after the stream-ordered copy that READS the buffer
         self._slot = 0
+
+    def _reuse(self, key):
+        """A pinned staging buffer is read by an ASYNCHRONOUS copy: before the host rewrites slot `key`, wait until the copy enqueued the
+        last time this slot was used has executed (the ring is 4 deep, the host can run further ahead than that — it queues whole
+        steps in about a millisecond and never synchronises)."""
+        ev = self._staged.get(key)
+        if ev is not None:
+            ev.synchronize()
+
+    def _staged_copy(self, key, buf, dst=None, dev=None):
+        out = buf.to(dev, non_blocking=True) if dst is None else dst.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._staged[key] = ev
+        return out
 
     def _grad_ptrs(self, gi, grads, dev):
         """Device array of the gradients' addresses.  The table is staged through a ring of pinned host buffers and copied with
@@ -47,8 +63,12 @@ class FusedClipAdam(torch.optim.Optimizer):
             self._pinned[key] = buf
         if self.capturable and (gi, "captured") not in self._pinned:
             self._pinned[(gi, "captured")] = torch.empty(n, dtype=torch.int64).pin_memory()      # host allocations are illegal while capturing
+        if self._capturing(dev):
+            buf.numpy()[:] = [g.data_ptr() for g in grads]
+            return buf.to(dev, non_blocking=True)
+        self._reuse(("ptr",) + key)
         buf.numpy()[:] = [g.data_ptr() for g in grads]
-        return buf.to(dev, non_blocking=True)
+        return self._staged_copy(("ptr",) + key, buf, dev=dev)
 
     def _group_tables(self, gi, part, plist):
         """Device pointer / chunk tables of one launch group.  The key covers the parameter AND the moment tensors' addresses:
@@ -91,9 +111,19 @@ class FusedClipAdam(torch.optim.Optimizer):
         with torch.no_grad():
             for p, (m, v) in pinned.items():
                 st = self.state[p]
-                m.copy_(st["exp_avg"])
-                v.copy_(st["exp_avg_sq"])
+                if "exp_avg" in st:                         # a fresh / partial optimizer state has no entry for p: zero moments, step 0
+                    m.copy_(st["exp_avg"])
+                    v.copy_(st["exp_avg_sq"])
+                else:
+                    m.zero_()
+                    v.zero_()
+                    st["step"] = torch.zeros((), dtype=torch.float32)
                 st["exp_avg"], st["exp_avg_sq"] = m, v
+        # the captured launches take ONE (step-dependent) scalar pair per partition: its parameters must share a step count
+        for _, _, plist in self._captured:
+            if len({float(self.state[p]["step"]) for p in plist}) > 1:
+                raise RuntimeError("FusedClipAdam.load_state_dict: parameters of one captured launch group carry different step counts; "
+                                   "re-capture the step (GraphedTrainStep) after loading this state")
 
     @staticmethod
     def _capturing(dev):
@@ -116,8 +146,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         buf = self._hyper_pinned.get(pk)
         if buf is None:
             buf = self._hyper_pinned[pk] = torch.empty(2, dtype=torch.float32).pin_memory()
+        self._reuse(("hyper",) + pk)
         buf[0], buf[1] = vals
-        hy.copy_(buf, non_blocking=True)
+        self._staged_copy(("hyper",) + pk, buf, dst=hy)
         return hy
 
     def prepare_replay(self):
