@@ -6,7 +6,8 @@
  * Conventions (all entry points):
  *   - return 0 on success, <0 = MTT_E_* argument error, >0 = hipError_t from the launch
  *   - asynchronous on the caller's stream; no allocation, no synchronisation (safe under hipGraph capture); every buffer,
- *     including kernel workspaces, is owned by the caller.  No environment variables and no process-global switches: which
+ *     including kernel workspaces, is owned by the caller.  No floating-point atomics: every cross-workgroup reduction writes
+ *     per-workgroup partials to a caller-owned workspace and sums them in a fixed order, so results are run-to-run reproducible.  No environment variables and no process-global switches: which
  *     kernel runs is a pure function of the descriptor.  The only process state is a per-device "already configured" bit per
  *     kernel for the one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) opt-in (idempotent, thread-safe)
  *   - reduction-contiguous GEMM operands (MTT_OP_K) are read in 8-element chunks: when K is not a multiple
@@ -187,7 +188,11 @@ int mtt_patchify16(const float* img, void* cols, int B, int H, int W, int out_dt
 typedef struct {
   const void* q; const void* xn; float* rawchan;
   int32_t B, T, N, C, h, w, nh, nw; int32_t dtype; int64_t ldq;
+  float* ws;                     /* forward: workspace of mtt_chan_logits_ws_floats(d) floats (may be NULL when that is 0) */
 } mtt_chanlogit_desc;
+/* rawchan is WRITTEN.  Reductions over the pixels of a window that are split across workgroups go through per-split partials in the
+ * caller-owned workspace and are summed in split order (deterministic; no atomics — as every reduction of this library since ABI 6). */
+size_t mtt_chan_logits_ws_floats(const mtt_chanlogit_desc* d);
 int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream);
 /* backward: dq[b,t,p] = sum_c drawchan*xn (written, dq_dtype, pitch ldq); dxn[b,T+p,c] += sum_t drawchan*q (fp32 [B,N,C]). */
 int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* drawchan, void* dq, int dq_dtype, float* dxn, void* stream);
@@ -202,8 +207,10 @@ typedef struct {
 } mtt_modulate_desc;
 int mtt_modulate(const mtt_modulate_desc* d, void* stream);
 /* backward: dout [2T, B*hw, C] (d->out_dtype) -> dx += (fp32, same addressing as x), drawlog[b,head,t,T+p] = (fp32 [B,nH,T,N],
- * caller zeroes the first T columns), drawchan += (fp32 [B,T,nwin,C], caller zeroes). */
-int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, void* stream);
+ * caller zeroes the first T columns), drawchan = (fp32 [B,T,nwin,C], WRITTEN: per-split partials in ws, mtt_modulate_bwd_ws_floats(d)
+ * floats, summed in split order). */
+size_t mtt_modulate_bwd_ws_floats(const mtt_modulate_desc* d);
+int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, float* ws, void* stream);
 
 /* Cross-task reweighting, taskprompter.py:478-485: w[b,t,s] from the per-head MLP on the prompt<->prompt
  * logits, then out[t][b,p,:] = sum_s w[b,t,s] * fea[s][b,p,:] (+= into acc when accumulate=1). */
@@ -212,8 +219,10 @@ typedef struct {
   int32_t T, B; int64_t rows_per_b, ld; int32_t C; int32_t fea_dtype; int32_t accumulate;
 } mtt_ctr_desc;
 int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream);
-/* dwmix[b,t,s] += sum_{rows of b, c} dout[t][row,c] * fea[s][row,c]   (dout fp32 [T, rows, ld], caller zeroes dwmix) */
-int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dwmix, void* stream);
+/* dwmix[b,t,s] = sum_{rows of b, c} dout[t][row,c] * fea[s][row,c]   (dout fp32 [T, rows, ld]; dwmix WRITTEN; ws: mtt_ctr_dw_ws_floats(d)
+ * floats of per-workgroup partials, summed in workgroup order) */
+size_t mtt_ctr_dw_ws_floats(const mtt_ctr_desc* d);
+int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dwmix, float* ws, void* stream);
 
 /* Bilinear resize, align_corners=False (F.interpolate at taskprompter.py:420, taskprompter_wrapper.py:36,
  * invpt.py:221,303,537, transformer_net.py:35-36).  NHWC in -> NHWC out or NCHW fp32 out.
@@ -256,13 +265,6 @@ int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t l
 /* dst[r,:] = rowscale[(r/mb)*2 + ((r%mb) >= n_prompt)] * src[r,:] with dtype cast (DropPath scale of a branch gradient) */
 int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
                       const float* rowscale, int32_t mb, int32_t n_prompt, void* stream);
-/* dst[c, r] = src[r, c] for r < rows, c < cols; dst is [cols, ldd] with columns rows..ldd-1 written as zeros (ldd >= rows). */
-int mtt_transpose_pad(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
-                      void* stream);
-/* same, and colsum[c] += sum_r src[r, c] (fp32 atomics; bf16 destination, 8-aligned shapes only): the bias gradient comes for
- * free with the transposing copy the fast weight-gradient GEMM needs anyway. */
-int mtt_transpose_pad_sum(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int src_dtype,
-                          int dst_dtype, float* colsum, void* stream);
 /* dst[c] = sum_r src[r, c] for c < cols (bias gradients; ld >= pad8(cols), columns up to pad8(cols) are read).  Deterministic two-stage
  * reduction through the caller-owned workspace ws (>= mtt_colsum_ws_floats(rows, cols) floats, contents unspecified afterwards). */
 size_t mtt_colsum_ws_floats(int64_t rows, int32_t cols);
@@ -307,9 +309,10 @@ typedef struct {
 } mtt_attnmsg_desc;
 int mtt_attn_msg(const mtt_attnmsg_desc* d, void* stream);
 /* backward of mtt_attn_msg (d->out unused): dcur, dup fp32 [B, heads, T*qh*qw, ldk] = gradients w.r.t. `cur` and w.r.t. the x2-upsampled
- * `prev` (the gradient of `prev` itself is mtt_bilinear_bwd of dup); dw [heads, 2*heads] and dbias [heads] are ACCUMULATED
- * (fp32 atomics; zeroed by the caller). */
-int mtt_attn_msg_bwd(const mtt_attnmsg_desc* d, const float* dout, float* dcur, float* dup, float* dw, float* dbias, void* stream);
+ * `prev` (the gradient of `prev` itself is mtt_bilinear_bwd of dup); dw [heads, 2*heads] and dbias [heads] are WRITTEN (per-workgroup
+ * partials in ws, mtt_attn_msg_bwd_ws_floats(d) floats, summed in workgroup order). */
+size_t mtt_attn_msg_bwd_ws_floats(const mtt_attnmsg_desc* d);
+int mtt_attn_msg_bwd(const mtt_attnmsg_desc* d, const float* dout, float* dcur, float* dup, float* dw, float* dbias, float* ws, void* stream);
 
 /* Gather half of nn.ConvTranspose2d(k=3, s=2, p=1, output_padding=1) (scale_embed[0], transformer_decoder.py:64):
  * yall [B*H*W, 9*Cop] = x @ Wall^T computed by mtt_gemm (column = tap*Cop + co) -> out [B*2H*2W, Cop] (+ bias[Cop]). */
@@ -351,6 +354,7 @@ typedef struct {
   float max_norm, step_size, beta1, beta2, eps, weight_decay, inv_sqrt_bc2;
   const float* hyper;  /* optional DEVICE pair {step_size, inv_sqrt_bc2}: when non-NULL it replaces the two by-value fields, so that a step
                           captured in a hipGraph can be replayed with the next step count / learning rate (graphs.py) */
+  float* ws;           /* mtt_grad_sqnorm: n_chunks floats of per-chunk partial sums (summed in chunk order: a deterministic clip norm) */
 } mtt_adam_desc;
 int mtt_adam_chunk(void);
 int mtt_grad_sqnorm(const mtt_adam_desc* d, float* out_sq, void* stream);
@@ -366,7 +370,9 @@ int mtt_adam_step(const mtt_adam_desc* d, const float* total_sq, void* stream);
 typedef struct {
   const float* pred; const float* label; float* dpred; float* loss; const float* stats;
   int64_t B, HW; int32_t C, Cl, kind; float ignore, pos_weight;
+  float* ws;           /* label_stats / fwd: mtt_loss_ws_floats(d) floats of per-workgroup partials (summed in workgroup order) */
 } mtt_loss_desc;
+size_t mtt_loss_ws_floats(const mtt_loss_desc* d);
 int mtt_loss_label_stats(const mtt_loss_desc* d, float* stats, void* stream);
 int mtt_loss_fwd(const mtt_loss_desc* d, void* stream);
 int mtt_loss_bwd(const mtt_loss_desc* d, const float* gout, void* stream);

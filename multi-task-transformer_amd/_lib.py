@@ -80,7 +80,7 @@ class LnDesc(C.Structure):
 class ChanLogitDesc(C.Structure):
     _fields_ = [("q", ptr), ("xn", ptr), ("rawchan", ptr),
                 ("B", i32), ("T", i32), ("N", i32), ("C", i32), ("h", i32), ("w", i32), ("nh", i32), ("nw", i32),
-                ("dtype", i32), ("ldq", i64)]
+                ("dtype", i32), ("ldq", i64), ("ws", ptr)]
 
 
 class ModulateDesc(C.Structure):
@@ -141,12 +141,12 @@ class AdamDesc(C.Structure):
     _fields_ = [("grads", ptr), ("params", ptr), ("exp_avg", ptr), ("exp_avg_sq", ptr), ("numel", ptr),
                 ("chunk_tensor", ptr), ("chunk_off", ptr), ("n_chunks", i32),
                 ("max_norm", f32), ("step_size", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32),
-                ("inv_sqrt_bc2", f32), ("hyper", ptr)]
+                ("inv_sqrt_bc2", f32), ("hyper", ptr), ("ws", ptr)]
 
 
 class LossDesc(C.Structure):
     _fields_ = [("pred", ptr), ("label", ptr), ("dpred", ptr), ("loss", ptr), ("stats", ptr), ("B", i64), ("HW", i64),
-                ("C", i32), ("Cl", i32), ("kind", i32), ("ignore", f32), ("pos_weight", f32)]
+                ("C", i32), ("Cl", i32), ("kind", i32), ("ignore", f32), ("pos_weight", f32), ("ws", ptr)]
 
 
 class GatherDesc(C.Structure):
@@ -197,17 +197,15 @@ POSITIONAL = {
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
-    "transpose_pad": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, ptr],
-    "transpose_pad_sum": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, ptr, ptr],
 }
 
 # descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)
 DESC_EXTRA = {
     "bn_stats": (BnDesc, [ptr]), "bn_bwd_reduce": (BnDesc, [ptr]),
-    "attn_msg_bwd": (AttnMsgDesc, [ptr, ptr, ptr, ptr, ptr]),
-    "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr]),
+    "attn_msg_bwd": (AttnMsgDesc, [ptr, ptr, ptr, ptr, ptr, ptr]),
+    "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr, ptr]),
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
-    "ctr_dw": (CtrDesc, [ptr, ptr]),
+    "ctr_dw": (CtrDesc, [ptr, ptr, ptr]),
     "attn_bwd": (AttnDesc, [ptr, ptr, ptr, ptr]),
     "winattn_bwd": (WinAttnDesc, [ptr, ptr, ptr, ptr]),
     "grad_sqnorm": (AdamDesc, [ptr]),
@@ -219,7 +217,9 @@ DESC_EXTRA = {
     "convt3x3s2_gather_bwd": (ConvtDesc, [ptr, ptr]),
 }
 
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats", "mtt_nms_ws_bytes"] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+# workspace-size queries mtt_<entry>_ws_floats(const desc*) of the entry points whose cross-workgroup reductions go through caller-owned partials
+WS_QUERIES = {"chan_logits": ChanLogitDesc, "modulate_bwd": ModulateDesc, "ctr_dw": CtrDesc, "attn_msg_bwd": AttnMsgDesc, "loss": LossDesc}
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats", "mtt_nms_ws_bytes"] + ["mtt_%s_ws_floats" % n for n in WS_QUERIES] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 
@@ -262,6 +262,18 @@ def load():
         fn.argtypes = [C.POINTER(st)] + extra + [ptr]
     _lib = lib
     return lib
+
+
+def ws_floats(entry, **fields):
+    """mtt_<entry>_ws_floats(desc) for the geometry in `fields` (ints only; pointer fields stay NULL)."""
+    lib = load()
+    desc = WS_QUERIES[entry]()
+    for k, v in fields.items():
+        setattr(desc, k, v)
+    fn = getattr(lib, "mtt_%s_ws_floats" % entry)
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.POINTER(WS_QUERIES[entry])]
+    return int(fn(C.byref(desc)))
 
 
 def dtype_code(t):

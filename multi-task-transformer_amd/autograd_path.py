@@ -8,7 +8,6 @@ attention backward materialises P per (batch, head) with the batched GEMM + row-
 (no N x N tensor ever leaves the backward), see DESIGN.md.
 """
 import math
-import os
 
 import torch
 import torch.distributed as dist
@@ -109,40 +108,6 @@ def _pad_last(t, width):
     return out
 
 
-def _transposed(x2d, cols, dtype=torch.bfloat16, colsum=None):
-    """[rows, ld] -> [cols, pad64(rows)] (zero padded): reduction-contiguous operand for the fast weight-gradient GEMM.
-    colsum (fp32 [cols], zero-initialised): also receives the column sums of x2d (the bias gradient) from the same pass."""
-    rows = x2d.shape[0]
-    Mp = (rows + 63) // 64 * 64
-    out = torch.empty(cols, Mp, dtype=dtype, device=x2d.device)
-    if colsum is not None:
-        ops.call("transpose_pad_sum", args=[x2d, out, rows, cols, x2d.stride(0), Mp, dtype_code(x2d), dtype_code(out), colsum])
-    else:
-        ops.call("transpose_pad", args=[x2d, out, rows, cols, x2d.stride(0), Mp, dtype_code(x2d), dtype_code(out)])
-    return out
-
-
-def _wgrad_fast(dy, x, N, Kp, prec, colsum=None):
-    """bf16 mode: dW = (dy^T) (x^T)^T with both operands transposed to reduction-contiguous form, so the weight gradient
-    runs on the direct-to-LDS GEMM kernels instead of the transposing stagers."""
-    dyT, xT = _transposed(dy, N, colsum=colsum), _transposed(x, Kp)
-    Mp = dyT.shape[1]
-    tiles = -(-N // 256) * -(-Kp // 256)
-    if tiles < 192 and Mp >= 4096:                                  # split the token reduction over the batch dimension
-        Z = max(2, min(32, -(-256 // tiles)))                       # >= one 256x256 tile per CU
-        c = (Mp // Z) // 64 * 64
-        if c >= 512:
-            nz = Mp // c
-            rem = Mp - nz * c
-            slabs = torch.empty(nz + (1 if rem else 0), N, Kp, dtype=torch.float32, device=dy.device)
-            _gemm(dyT, xT, slabs, N, Kp, c, prec, lda=Mp, ldb=Mp, ldd=Kp, batch=nz, a_zo=c, b_zo=c, d_zo=N * Kp)
-            if rem:
-                _gemm(dyT[:, nz * c:], xT[:, nz * c:], slabs[nz], N, Kp, rem, prec, lda=Mp, ldb=Mp, ldd=Kp)
-            return slabs.sum(0)
-    dW = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
-    return _gemm(dyT, xT, dW, N, Kp, Mp, prec, lda=Mp, ldb=Mp, ldd=Kp)
-
-
 N_CUS = 256                 # one 256 x 256 weight-gradient tile occupies a whole CU (128 KiB of LDS)
 
 
@@ -157,9 +122,6 @@ def _tn_splits(tiles, rows, max_splits=32):
         if cost is None or t < cost:
             best, cost = S, t
     return best
-
-
-WGRAD_TN = os.environ.get("MTT_WGRAD_TN", "1") != "0"     # host-side A/B switch: 0 = round-1 path (transposing copies + K-contiguous GEMM)
 
 
 def _wgrad_tn(dy, x, N, Kp, prec):
@@ -188,10 +150,8 @@ def _enc_wgrad(dy, x, N, Kp, prec):
     """-> (dW [N, Kp], dbias [N]) of y = x W^T + b given dy."""
     if (prec.name == "bf16" and FAST_BWD and N >= FAST_MIN_DIM and Kp >= FAST_MIN_DIM and dy.shape[0] >= FAST_MIN_ROWS
             and N % 8 == 0 and dy.stride(0) % 8 == 0):
-        if WGRAD_TN and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
+        if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
             return _wgrad_tn(dy, x, N, Kp, prec), _colsum(dy, N)
-        db = torch.zeros(N, dtype=torch.float32, device=dy.device)
-        return _wgrad_fast(dy, x, N, Kp, prec, colsum=db), db
     return _wgrad(dy, x, N, Kp, prec), _colsum(dy, N)
 
 
@@ -262,7 +222,7 @@ def attention_bwd(qkv, dao, drawlog, B, N, nH, T, prec):
     return dqkv
 
 
-FLASH_BWD = os.environ.get("MTT_FLASH_BWD", "1") != "0"
+FLASH_BWD = True        # bf16: mtt_attn_bwd (tests set it to False to exercise the materialised batched-GEMM backward in bf16)
 
 
 def attention_bwd_flash(qkv, ao, lse, dao, drawlog, B, N, nH, T, prec):
@@ -468,10 +428,10 @@ class ModulateFn(Function):
         hg = ctx.geo[7] if len(ctx.geo) > 7 else 0
         dmod = dmod.contiguous()
         dx = torch.zeros_like(xsrc)
-        dl, dc = torch.zeros_like(rawlog), torch.zeros_like(rawchan)
+        dl, dc = torch.zeros_like(rawlog), torch.empty_like(rawchan)          # drawlog: the first T columns stay zero; drawchan is written
         ops.call("modulate_bwd", x=xsrc.view(B, N, C)[:, T:], x_ld=C, x_bs=N * C, rawlog=rawlog, rawchan=rawchan, out=None,
                  B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin, out_dtype=dtype_code(dmod), hg=hg,
-                 xargs=[dmod, dx.view(B, N, C)[:, T:], dl, dc])
+                 xargs=[dmod, dx.view(B, N, C)[:, T:], dl, dc, ops.ws_for("modulate_bwd", dmod.device, B=B, T=T, C=C, h=h, w=w, nh=nwin, nw=nwin)])
         return dx, dl, dc, None, None
 
 
@@ -752,9 +712,9 @@ class CtrMixFn(Function):
         T, rows, ld = fea.shape
         dfea32 = ops.ctr_mix(dout, wmix.transpose(1, 2).contiguous(), B, C, None)
         dfea = dfea32 if fea.dtype == torch.float32 else ops.cast2d(dfea32.view(T * rows, ld), T * rows, ld, ld, fea.dtype, ldd=ld).view(T, rows, ld)
-        dw = torch.zeros_like(wmix)
+        dw = torch.empty_like(wmix)
         ops.call("ctr_dw", fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C, fea_dtype=dtype_code(fea),
-                 accumulate=0, xargs=[dout, dw])
+                 accumulate=0, xargs=[dout, dw, ops.ws_for("ctr_dw", dout.device, T=T, B=B, rows_per_b=rows // B)])
         return dfea, dw, (dout if had_acc else None), None, None
 
 

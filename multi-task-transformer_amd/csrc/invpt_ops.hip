@@ -165,8 +165,7 @@ __global__ __launch_bounds__(256) void attn_msg_kernel(const mtt_attnmsg_desc d)
 //   dw[o,h] += sum dout[b,o,..] cur[b,h,..]             dw[o,heads+h] += sum dout[b,o,..] up(prev)[b,h,..]        dbias[o] += sum dout[b,o,..]
 // One pass over the score tensors; per-thread partial sums of the (<= 36) parameter gradients are reduced through LDS and added with
 // one atomic per value per block (dw / dbias zeroed by the caller).
-__global__ __launch_bounds__(256) void attn_msg_bwd_kernel(const mtt_attnmsg_desc d, const float* dout, float* dcur, float* dup, float* dw,
-                                                           float* dbias) {
+__global__ __launch_bounds__(256) void attn_msg_bwd_kernel(const mtt_attnmsg_desc d, const float* dout, float* dcur, float* dup, float* part) {
   __shared__ float red[4][40];
   const int Qt = d.qh * d.qw, Q = d.T * Qt, sh = d.qh / 2, sw = d.qw / 2, Qp = d.T * sh * sw;
   const int H = d.heads, H2 = 2 * d.heads;
@@ -235,13 +234,15 @@ __global__ __launch_bounds__(256) void attn_msg_bwd_kernel(const mtt_attnmsg_des
   __syncthreads();
   if (threadIdx.x < 36) {
     const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (threadIdx.x < 32) {
-      const int o = threadIdx.x >> 3, h = threadIdx.x & 7;
-      if (o < H && h < H2) atomicAdd(&dw[o * H2 + h], v);
-    } else if ((int)threadIdx.x - 32 < H) {
-      atomicAdd(&dbias[threadIdx.x - 32], v);
-    }
+    part[(int64_t)blockIdx.x * 36 + threadIdx.x] = v;      // 32 weight + 4 bias partials per block; mtt_reduce_many_kernel sums the blocks in order
   }
+}
+
+// dw [H, 2H] / dbias [H] from the 36 reduced sums (slot o * 8 + h / 32 + o)
+__global__ void attn_msg_bwd_final_kernel(const float* sums, float* dw, float* dbias, int H) {
+  const int H2 = 2 * H, i = threadIdx.x;
+  if (i < 32) { const int o = i >> 3, h = i & 7; if (o < H && h < H2) dw[o * H2 + h] = sums[i]; }
+  else if (i < 36 && i - 32 < H) dbias[i - 32] = sums[i];
 }
 
 // ConvTranspose2d(k=3, s=2, p=1, output_padding=1) gather: yall [B*H*W, 9*Cop] = x @ Wall^T (tap-major columns) ->
@@ -430,12 +431,19 @@ extern "C" int mtt_attn_msg(const mtt_attnmsg_desc* d, void* stream) {
   hipLaunchKernelGGL(attn_msg_kernel, dim3(grid_for((int64_t)d->B * d->T * d->qh * d->qw * d->K)), dim3(256), 0, S_, *d);
   return (int)hipGetLastError();
 }
-extern "C" int mtt_attn_msg_bwd(const mtt_attnmsg_desc* d, const float* dout, float* dcur, float* dup, float* dw, float* dbias, void* stream) {
-  if (!d || !d->cur || !d->prev || !d->w || !dout || !dcur || !dup || !dw || !dbias || d->heads <= 0 || d->heads > 4 || (d->qh % 2) || (d->qw % 2))
-    return MTT_E_BADARG;
+static int64_t attn_msg_bwd_blocks(const mtt_attnmsg_desc* d) {
   int64_t g = ((int64_t)d->B * d->T * d->qh * d->qw * d->K + 255) / 256;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(attn_msg_bwd_kernel, dim3((unsigned)g), dim3(256), 0, S_, *d, dout, dcur, dup, dw, dbias);
+  return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
+extern "C" size_t mtt_attn_msg_bwd_ws_floats(const mtt_attnmsg_desc* d) { return d ? (size_t)(attn_msg_bwd_blocks(d) + 1) * 36 : 0; }
+extern "C" int mtt_attn_msg_bwd(const mtt_attnmsg_desc* d, const float* dout, float* dcur, float* dup, float* dw, float* dbias, float* ws, void* stream) {
+  if (!d || !d->cur || !d->prev || !d->w || !dout || !dcur || !dup || !dw || !dbias || !ws || d->heads <= 0 || d->heads > 4 || (d->qh % 2) || (d->qw % 2))
+    return MTT_E_BADARG;
+  const int64_t g = attn_msg_bwd_blocks(d);
+  float* sums = ws + g * 36;
+  hipLaunchKernelGGL(attn_msg_bwd_kernel, dim3((unsigned)g), dim3(256), 0, S_, *d, dout, dcur, dup, ws);
+  hipLaunchKernelGGL(mtt_reduce_many_kernel, dim3(36), dim3(256), 0, S_, (const float*)ws, (int)g, 36, sums, 1.0f, 0);
+  hipLaunchKernelGGL(attn_msg_bwd_final_kernel, dim3(1), dim3(64), 0, S_, (const float*)sums, dw, dbias, d->heads);
   return (int)hipGetLastError();
 }
 extern "C" int mtt_convt3x3s2_gather(const mtt_convt_desc* d, void* stream) {

@@ -27,7 +27,7 @@ MTT_DEV float block_sum256(float v) {
 
 // grid (pixel blocks, B): no per-pixel division; the class loop runs over the C coalesced rows of a pixel block (the second
 // read of the backward hits L2: a block touches 256 px x C x 4 B).
-__global__ __launch_bounds__(256) void label_stats_kernel(const mtt_loss_desc d, float* stats) {
+__global__ __launch_bounds__(256) void label_stats_kernel(const mtt_loss_desc d, float* part) {
   float cnt = 0.f, pos = 0.f;
   const int64_t b = blockIdx.y;
   const float* lab = d.label + b * d.Cl * d.HW;
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const mtt_loss_desc d,
     if (ok) { cnt += 1.f; pos += lab[hw]; }
   }
   cnt = block_sum256(cnt); pos = block_sum256(pos);
-  if (threadIdx.x == 0) { atomicAdd(&stats[0], cnt); atomicAdd(&stats[1], pos); }
+  // per-block partials (block order = blockIdx.y * gridDim.x + blockIdx.x), summed in a fixed order by mtt_reduce_many_kernel
+  if (threadIdx.x == 0) { const int64_t bi = (int64_t)blockIdx.y * gridDim.x + blockIdx.x; part[2 * bi] = cnt; part[2 * bi + 1] = pos; }
 }
 
 // softplus(-x) = -log(sigmoid(x)), stable
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const mtt_loss_desc d, const 
   }
   if (!BWD) {
     acc = block_sum256(acc);
-    if (threadIdx.x == 0) atomicAdd(d.loss, acc * inv * (d.kind == 2 ? 1.0f / factor : 1.f));
+    if (threadIdx.x == 0) d.ws[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = acc * inv * (d.kind == 2 ? 1.0f / factor : 1.f);
   }
 }
 
@@ -146,15 +147,24 @@ int loss_check(const mtt_loss_desc* d) {
 
 }  // namespace
 
+extern "C" size_t mtt_loss_ws_floats(const mtt_loss_desc* d) {
+  if (!d || d->B <= 0 || d->HW <= 0) return 0;
+  const dim3 g = loss_grid(d);
+  return (size_t)2 * g.x * g.y;
+}
 extern "C" int mtt_loss_label_stats(const mtt_loss_desc* d, float* stats, void* stream) {
-  if (!d || !d->label || !stats || d->B <= 0 || d->HW <= 0 || d->Cl <= 0) return MTT_E_BADARG;
-  hipLaunchKernelGGL(label_stats_kernel, loss_grid(d), dim3(256), 0, (hipStream_t)stream, *d, stats);
+  if (!d || !d->label || !stats || !d->ws || d->B <= 0 || d->HW <= 0 || d->Cl <= 0) return MTT_E_BADARG;
+  const dim3 g = loss_grid(d);
+  hipLaunchKernelGGL(label_stats_kernel, g, dim3(256), 0, (hipStream_t)stream, *d, d->ws);
+  hipLaunchKernelGGL(mtt_reduce_many_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)d->ws, (int)(g.x * g.y), 2, stats, 1.0f, 1);
   return (int)hipGetLastError();
 }
 extern "C" int mtt_loss_fwd(const mtt_loss_desc* d, void* stream) {
   if (int e = loss_check(d)) return e;
-  if (!d->stats || !d->loss) return MTT_E_BADARG;
-  hipLaunchKernelGGL(loss_kernel<false>, loss_grid(d), dim3(256), 0, (hipStream_t)stream, *d, (const float*)nullptr);
+  if (!d->stats || !d->loss || !d->ws) return MTT_E_BADARG;
+  const dim3 g = loss_grid(d);
+  hipLaunchKernelGGL(loss_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, *d, (const float*)nullptr);
+  hipLaunchKernelGGL(mtt_reduce_many_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)d->ws, (int)(g.x * g.y), 1, d->loss, 1.0f, 1);
   return (int)hipGetLastError();
 }
 extern "C" int mtt_loss_bwd(const mtt_loss_desc* d, const float* gout, void* stream) {

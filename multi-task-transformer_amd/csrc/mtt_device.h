@@ -207,3 +207,30 @@ MTT_DEV float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---- deterministic second stage of a cross-workgroup reduction (replaces fp32 atomics: the sums below are taken in a FIXED order, so a
+// kernel's result does not depend on the order in which its workgroups happen to finish).  First stage: workgroup s writes its partial
+// results as plane s of a caller-owned workspace, ws[s * n + i].
+//   few : one thread per output i, looping over the S planes (S small, n large)
+//   many: one workgroup per output i, S partials summed with a fixed 256-way tree (n small, S large)
+static __global__ __launch_bounds__(256) void mtt_reduce_few_kernel(const float* ws, int S, int64_t n, float* dst, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += ws[(int64_t)k * n + i];
+    dst[i] = accumulate ? dst[i] + s : s;
+  }
+}
+static __global__ __launch_bounds__(256) void mtt_reduce_many_kernel(const float* ws, int S, int n, float* dst, float scale, int accumulate) {
+  __shared__ float red[256];
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < S; k += 256) s += ws[(int64_t)k * n + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[i] = accumulate ? dst[i] + scale * red[0] : scale * red[0];
+}
+static inline unsigned mtt_reduce_few_grid(int64_t n) { const int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }

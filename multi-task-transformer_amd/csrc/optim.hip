@@ -17,7 +17,7 @@ MTT_DEV float block_sum(float v) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const mtt_adam_desc d, float* out) {
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const mtt_adam_desc d, float* part) {
   const int t = d.chunk_tensor[blockIdx.x];
   const int64_t off = d.chunk_off[blockIdx.x];
   const float* g = (const float*)d.grads[t] + off;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const mtt_adam_desc d,
     for (int i = threadIdx.x; i < n; i += 256) s += g[i] * g[i];
   }
   s = block_sum(s);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;          // per-chunk partial; summed in chunk order by mtt_reduce_many_kernel (no atomics)
 }
 
 struct AdamHyper { float step_size, inv_sqrt_bc2; };
@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const mtt_adam_desc d, c
 extern "C" int mtt_adam_chunk(void) { return CHUNK; }
 
 extern "C" int mtt_grad_sqnorm(const mtt_adam_desc* d, float* out_sq, void* stream) {
-  if (!d || !d->grads || !d->numel || !d->chunk_tensor || !d->chunk_off || !out_sq || d->n_chunks <= 0) return MTT_E_BADARG;
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(d->n_chunks), dim3(256), 0, (hipStream_t)stream, *d, out_sq);
+  if (!d || !d->grads || !d->numel || !d->chunk_tensor || !d->chunk_off || !out_sq || !d->ws || d->n_chunks <= 0) return MTT_E_BADARG;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(d->n_chunks), dim3(256), 0, (hipStream_t)stream, *d, d->ws);
+  hipLaunchKernelGGL(mtt_reduce_many_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)d->ws, d->n_chunks, 1, out_sq, 1.0f, 1);
   return (int)hipGetLastError();
 }
 

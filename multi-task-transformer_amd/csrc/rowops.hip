@@ -301,9 +301,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* img, void* c
 // ------------------------------------------------------------------------------------------------
 constexpr int CL_MAXT = 8;
 // grid (C/64 column groups, pixel splits, B*nwin); block = 8 column chunks (64 channels, 128 B per pixel) x 32 pixel lanes.
-// Pixel lanes are reduced with wave shuffles, the 4 waves through LDS; gridDim.y == 1 -> plain store, else one atomic per
-// (t, channel) per split (destination zero-initialised by the caller).
-__global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc d, int tbase) {
+// Pixel lanes are reduced with wave shuffles, the 4 waves through LDS; gridDim.y == 1 -> the result is stored, else pixel split s
+// stores its partial sums as plane s of the workspace (summed in split order by mtt_reduce_few_kernel: deterministic, no atomics).
+__global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc d, int tbase, float* part, int64_t plane_elems) {
   const int nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw, P = wh * ww;
   const int b = blockIdx.z / nwin, win = blockIdx.z % nwin;
   const int wy = win / d.nw, wx = win % d.nw;
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc
     const int col = blockIdx.x * 64 + c;
     if (col >= d.C) continue;
     const float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
-    float* dst = &d.rawchan[(((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + col];
-    if (gridDim.y == 1) *dst = v; else atomicAdd(dst, v);
+    const int64_t oi = (((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + col;
+    if (gridDim.y == 1) d.rawchan[oi] = v; else part[(int64_t)blockIdx.y * plane_elems + oi] = v;
   }
 }
 
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const void* src, float* d
 //   drawchan[b,t,win,c]    += sum_{p in win} dout[2t+1][b,p,c] * x[b,p,c]        (LDS reduce + 1 atomic)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_desc d, const void* dout, float* dx,
-                                                           float* drawlog, float* drawchan, int tbase) {
+                                                           float* drawlog, float* part, int64_t plane_elems, int tbase) {
   const int nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw, P = wh * ww, hw = d.h * d.w;
   const int hg = d.hg > 0 ? d.hg : 64;             // 64 or 32 channels per head (host-checked)
   const int nH = d.C / hg;
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += red[q][cl][j];
-        atomicAdd(&drawchan[(((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + cchunk * 8 + j], s);
+        part[(int64_t)blockIdx.y * plane_elems + (((int64_t)b * d.T + tbase + t) * nwin + win) * d.C + cchunk * 8 + j] = s;
       }
     }
     __syncthreads();
@@ -995,10 +995,8 @@ __global__ __launch_bounds__(256) void chanlogit_bwd_kernel(const mtt_chanlogit_
 // ------------------------------------------------------------------------------------------------
 // dwmix[b,t,s] += sum_{rows in b, c} dout[t][row,c] * fea[s][row,c]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ctr_dw_kernel(const mtt_ctr_desc d, const float* dout, float* dw, int rows_per_block) {
-  __shared__ float red[CTR_MAXT * CTR_MAXT];
-  for (int i = threadIdx.x; i < CTR_MAXT * CTR_MAXT; i += 256) red[i] = 0.f;
-  __syncthreads();
+__global__ __launch_bounds__(256) void ctr_dw_kernel(const mtt_ctr_desc d, const float* dout, float* part, int rows_per_block) {
+  __shared__ float red[4][CTR_MAXT * CTR_MAXT];
   const int C8 = (d.C + 7) >> 3;
   const int b = blockIdx.y;
   const int64_t rows = (int64_t)d.B * d.rows_per_b, plane = rows * d.ld;
@@ -1039,12 +1037,14 @@ __global__ __launch_bounds__(256) void ctr_dw_kernel(const mtt_ctr_desc d, const
     for (int s = 0; s < CTR_MAXT; ++s)
       if (t < d.T && s < d.T) {
         const float v = wave_sum(acc[t][s]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&red[t * CTR_MAXT + s], v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t * CTR_MAXT + s] = v;
       }
   __syncthreads();
+  // this block's partial -> plane blockIdx.x of the workspace (summed in block order by mtt_reduce_few_kernel: no atomics)
+  const int64_t n = (int64_t)d.B * d.T * d.T;
   for (int i = threadIdx.x; i < d.T * d.T; i += 256) {
-    const int t = i / d.T, s = i % d.T;
-    atomicAdd(&dw[((int64_t)b * d.T + t) * d.T + s], red[t * CTR_MAXT + s]);
+    const int t = i / d.T, s = i % d.T, j = t * CTR_MAXT + s;
+    part[(int64_t)blockIdx.x * n + ((int64_t)b * d.T + t) * d.T + s] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
   }
 }
 
@@ -1082,72 +1082,6 @@ __global__ __launch_bounds__(256) void rowscale_cast_kernel(const void* src, voi
   }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// dst[c, r] = src[r, c] (r < rows, c < cols), dst rows zero-padded up to ldd columns: turns the token-contiguous
-// operands of a weight-gradient GEMM into reduction-contiguous ones for the fast GEMM path.  64 x 64 tiles through LDS.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd,
-                                                            int sdt, int ddt) {
-  __shared__ float tile[64][65];
-  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int64_t r = r0 + ty * 16 + i, c = c0 + tx;
-    tile[ty * 16 + i][tx] = (r < rows && c < cols) ? ld_elem(src, r * lds_ + c, sdt) : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int64_t c = c0 + ty * 16 + i, r = r0 + tx;
-    if (c < cols && r < ldd) st_elem(dst, c * ldd + r, ddt, tile[tx][ty * 16 + i]);
-  }
-}
-
-// Vectorised variant for a bf16 destination: 16-byte global loads / stores on both sides, bf16 tile [64][66] in LDS.
-// Optionally accumulates the column sums of src (= row sums of dst: the bias gradient of the same weight-gradient GEMM)
-// so that no separate reduction pass over the gradient is needed.
-template <bool SRC_F32>
-__global__ __launch_bounds__(256) void transpose_pad_vec_kernel(const void* src, bf16_t* dst, int64_t rows, int64_t cols, int64_t lds_,
-                                                                int64_t ldd, float* colsum) {
-  __shared__ bf16_t tile[64][66];
-  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
-  {
-    const int r = threadIdx.x >> 2, cs = (threadIdx.x & 3) * 16;
-    const int64_t rr = r0 + r;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int64_t c = c0 + cs + h * 8;
-      float v[8];
-      if (rr < rows && c < cols) ld8(src, rr * lds_ + c, SRC_F32 ? MTT_F32 : MTT_BF16, v);
-      else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) *(unsigned*)&tile[r][cs + h * 8 + j] = pack2(v[j], v[j + 1]);
-    }
-  }
-  __syncthreads();
-  const int c = threadIdx.x >> 2, rs = (threadIdx.x & 3) * 16;
-  float sum = 0.f;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16_t a = tile[rs + h * 8 + 2 * j][c], b = tile[rs + h * 8 + 2 * j + 1][c];
-      sum += bf2f(a) + bf2f(b);
-      o[j] = (unsigned)a | ((unsigned)b << 16);
-    }
-    if (c0 + c < cols && r0 + rs + h * 8 < ldd) *(u32x4*)(dst + (c0 + c) * ldd + r0 + rs + h * 8) = o;
-  }
-  if (colsum) {
-    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
-    if ((threadIdx.x & 3) == 0 && c0 + c < cols) atomicAdd(&colsum[c0 + c], sum);
-  }
-}
 
 int grid_for(int64_t work_items) {
   int64_t g = (work_items + 255) / 256;
@@ -1223,14 +1157,46 @@ extern "C" int mtt_patchify16(const float* img, void* cols, int B, int H, int W,
   return LAUNCH_OK();
 }
 
-extern "C" int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream) {
-  if (!d || !d->q || !d->xn || !d->rawchan) return MTT_E_BADARG;
-  if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
+static int chanlogit_splits(const mtt_chanlogit_desc* d) {
   const int P = (d->h / d->nh) * (d->w / d->nw);
   const int base = ((d->C + 63) / 64) * d->B * d->nh * d->nw;
   int splits = (1024 + base - 1) / base; if (splits > P / 32) splits = P / 32; if (splits < 1) splits = 1; if (splits > 64) splits = 64;
+  return splits;
+}
+static int modulate_bwd_splits(const mtt_modulate_desc* d) {
+  const int P = (d->h / d->nh) * (d->w / d->nw);
+  int splits = P / 64; if (splits < 1) splits = 1; if (splits > 32) splits = 32;
+  return splits;
+}
+static int ctr_dw_blocks(const mtt_ctr_desc* d, int* rpb_out) {
+  int nb = (int)((d->rows_per_b + 127) / 128); if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  const int rpb = (int)((d->rows_per_b + nb - 1) / nb);
+  if (rpb_out) *rpb_out = rpb;
+  return (int)((d->rows_per_b + rpb - 1) / rpb);
+}
+// floats of caller-owned workspace the reductions of an entry point need (0: none) — see mtt_hip.h
+extern "C" size_t mtt_chan_logits_ws_floats(const mtt_chanlogit_desc* d) {
+  if (!d || d->nh <= 0 || d->nw <= 0) return 0;
+  const int s = chanlogit_splits(d);
+  return s > 1 ? (size_t)s * d->B * d->T * d->nh * d->nw * d->C : 0;
+}
+extern "C" size_t mtt_modulate_bwd_ws_floats(const mtt_modulate_desc* d) {
+  if (!d || d->nh <= 0 || d->nw <= 0) return 0;
+  return (size_t)modulate_bwd_splits(d) * d->B * d->T * d->nh * d->nw * d->C;
+}
+extern "C" size_t mtt_ctr_dw_ws_floats(const mtt_ctr_desc* d) {
+  if (!d || d->T <= 0) return 0;
+  return (size_t)ctr_dw_blocks(d, nullptr) * d->B * d->T * d->T;
+}
+extern "C" int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream) {
+  if (!d || !d->q || !d->xn || !d->rawchan) return MTT_E_BADARG;
+  if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
+  const int splits = chanlogit_splits(d);
+  if (splits > 1 && !d->ws) return MTT_E_BADARG;
+  const int64_t n = (int64_t)d->B * d->T * d->nh * d->nw * d->C;
   dim3 grid((d->C + 63) / 64, splits, d->B * d->nh * d->nw);
-  for (int tb = 0; tb < d->T; tb += CL_MAXT) hipLaunchKernelGGL(chanlogit_kernel, grid, dim3(256), 0, S_, *d, tb);
+  for (int tb = 0; tb < d->T; tb += CL_MAXT) hipLaunchKernelGGL(chanlogit_kernel, grid, dim3(256), 0, S_, *d, tb, d->ws, n);
+  if (splits > 1) hipLaunchKernelGGL(mtt_reduce_few_kernel, dim3(mtt_reduce_few_grid(n)), dim3(256), 0, S_, (const float*)d->ws, splits, n, d->rawchan, 0);
   return LAUNCH_OK();
 }
 
@@ -1357,16 +1323,17 @@ extern "C" int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t c
   return LAUNCH_OK();
 }
 
-extern "C" int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, void* stream) {
-  if (!d || !d->x || !d->rawlog || !d->rawchan || !dout || !dx || !drawlog || !drawchan || (d->C % 32)) return MTT_E_BADARG;
+extern "C" int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, float* drawlog, float* drawchan, float* ws, void* stream) {
+  if (!d || !d->x || !d->rawlog || !d->rawchan || !dout || !dx || !drawlog || !drawchan || !ws || (d->C % 32)) return MTT_E_BADARG;
   if (d->hg != 0 && d->hg != 64 && d->hg != 32) return MTT_E_UNSUPPORTED;      /* the head reduction of drawlog: 8 or 4 lanes */
   if (d->C % (d->hg > 0 ? d->hg : 64)) return MTT_E_BADARG;
   if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw)) return MTT_E_BADARG;
-  const int P = (d->h / d->nh) * (d->w / d->nw);
-  int splits = P / 64; if (splits < 1) splits = 1; if (splits > 32) splits = 32;
+  const int splits = modulate_bwd_splits(d);
+  const int64_t n = (int64_t)d->B * d->T * d->nh * d->nw * d->C;
   dim3 grid((d->C / 8 + 31) / 32, splits, d->B * d->nh * d->nw);
   for (int tb = 0; tb < d->T; tb += CL_MAXT)
-    hipLaunchKernelGGL(modulate_bwd_kernel, grid, dim3(256), 0, S_, *d, dout, dx, drawlog, drawchan, tb);
+    hipLaunchKernelGGL(modulate_bwd_kernel, grid, dim3(256), 0, S_, *d, dout, dx, drawlog, ws, n, tb);
+  hipLaunchKernelGGL(mtt_reduce_few_kernel, dim3(mtt_reduce_few_grid(n)), dim3(256), 0, S_, (const float*)ws, splits, n, drawchan, 0);
   return LAUNCH_OK();
 }
 
@@ -1379,12 +1346,13 @@ extern "C" int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* dra
   return LAUNCH_OK();
 }
 
-extern "C" int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dw, void* stream) {
-  if (!d || !d->fea || !dout || !dw || d->T <= 0 || d->T > CTR_MAXT || (d->ld % 8)) return MTT_E_BADARG;
-  int nb = (int)((d->rows_per_b + 127) / 128); if (nb > 256) nb = 256; if (nb < 1) nb = 1;
-  const int rpb = (int)((d->rows_per_b + nb - 1) / nb);
-  nb = (int)((d->rows_per_b + rpb - 1) / rpb);
-  hipLaunchKernelGGL(ctr_dw_kernel, dim3(nb, d->B), dim3(256), 0, S_, *d, dout, dw, rpb);
+extern "C" int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dw, float* ws, void* stream) {
+  if (!d || !d->fea || !dout || !dw || !ws || d->T <= 0 || d->T > CTR_MAXT || (d->ld % 8)) return MTT_E_BADARG;
+  int rpb = 0;
+  const int nb = ctr_dw_blocks(d, &rpb);
+  const int64_t n = (int64_t)d->B * d->T * d->T;
+  hipLaunchKernelGGL(ctr_dw_kernel, dim3(nb, d->B), dim3(256), 0, S_, *d, dout, ws, rpb);
+  hipLaunchKernelGGL(mtt_reduce_few_kernel, dim3(mtt_reduce_few_grid(n)), dim3(256), 0, S_, (const float*)ws, nb, n, dw, 0);
   return LAUNCH_OK();
 }
 
@@ -1401,25 +1369,3 @@ extern "C" int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32
   return LAUNCH_OK();
 }
 
-extern "C" int mtt_transpose_pad_sum(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, int src_dtype,
-                                     int dst_dtype, float* colsum, void* stream);
-extern "C" int mtt_transpose_pad(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, int src_dtype,
-                                 int dst_dtype, void* stream) {
-  return mtt_transpose_pad_sum(src, dst, rows, cols, lds_, ldd, src_dtype, dst_dtype, nullptr, stream);
-}
-
-extern "C" int mtt_transpose_pad_sum(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd, int src_dtype,
-                                     int dst_dtype, float* colsum, void* stream) {
-  if (!src || !dst || rows <= 0 || cols <= 0 || ldd < rows) return MTT_E_BADARG;
-  dim3 grid((unsigned)((ldd + 63) / 64), (unsigned)((cols + 63) / 64));
-  const bool vec = dst_dtype == MTT_BF16 && (cols % 8) == 0 && (lds_ % 8) == 0 && (ldd % 8) == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
-  if (!vec) {
-    if (colsum) return MTT_E_UNSUPPORTED;
-    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, S_, src, dst, rows, cols, lds_, ldd, src_dtype, dst_dtype);
-  } else if (src_dtype == MTT_F32) {
-    hipLaunchKernelGGL(transpose_pad_vec_kernel<true>, grid, dim3(256), 0, S_, src, (bf16_t*)dst, rows, cols, lds_, ldd, colsum);
-  } else {
-    hipLaunchKernelGGL(transpose_pad_vec_kernel<false>, grid, dim3(256), 0, S_, src, (bf16_t*)dst, rows, cols, lds_, ldd, colsum);
-  }
-  return LAUNCH_OK();
-}

@@ -261,10 +261,11 @@ class FuseAttnFn(Function):
         if S.shape[-1] > K:                                            # padded key columns carry no gradient
             dcur[..., K:] = 0
             dup[..., K:] = 0
-        dw = torch.zeros(heads, 2 * heads, dtype=torch.float32, device=S.device)
-        db = torch.zeros(heads, dtype=torch.float32, device=S.device)
+        dw = torch.empty(heads, 2 * heads, dtype=torch.float32, device=S.device)
+        db = torch.empty(heads, dtype=torch.float32, device=S.device)
         ops.call("attn_msg_bwd", cur=S, prev=prev, out=None, w=w2, bias=None, B=B, heads=heads, T=T, qh=qh, qw=qw, K=K,
-                 ldk=S.shape[-1], ldkp=prev.shape[-1], xargs=[dout, dcur, dup, dw, db])
+                 ldk=S.shape[-1], ldkp=prev.shape[-1],
+                 xargs=[dout, dcur, dup, dw, db, ops.ws_for("attn_msg_bwd", S.device, B=B, heads=heads, T=T, qh=qh, qw=qw, K=K)])
         Kp = prev.shape[-1]
         dprev = torch.zeros_like(prev)
         ops.call("bilinear_bwd", **{"in": dup}, out=dprev, B=B * heads * T, C=min(Kp, S.shape[-1]), Hin=qh // 2, Win=qw // 2, Hout=qh, Wout=qw,

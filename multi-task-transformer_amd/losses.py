@@ -134,7 +134,7 @@ class _TaskLossFn(torch.autograd.Function):
         stats = torch.zeros(2, dtype=torch.float32, device=pred.device)
         loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
         kw = dict(pred=pred, label=label, dpred=None, loss=loss, stats=stats, B=B, HW=HW, C=C, Cl=Cl, kind=kind, ignore=float(ignore),
-                  pos_weight=float(pos_weight))
+                  pos_weight=float(pos_weight), ws=ops.ws_for("loss", pred.device, B=B, HW=HW))
         ops.call("loss_label_stats", xargs=[stats], **kw)
         ops.call("loss_fwd", **kw)
         ctx.save_for_backward(pred, label, stats)

@@ -399,9 +399,9 @@ def patchify(img, prec):
 def chan_logits(cq, xn, B, T, N, C, grid, nwin_hw):
     """cq [B*T, ldq] (token_trans output), xn [B*N, C] (norm1 output) -> rawchan fp32 [B, T, nwin, C]."""
     nh, nw = nwin_hw
-    rawchan = torch.zeros(B, T, nh * nw, C, dtype=torch.float32, device=xn.device)
+    rawchan = torch.empty(B, T, nh * nw, C, dtype=torch.float32, device=xn.device)
     call("chan_logits", q=cq, xn=xn, rawchan=rawchan, B=B, T=T, N=N, C=C, h=grid[0], w=grid[1], nh=nh, nw=nw,
-         dtype=dtype_code(xn), ldq=cq.shape[-1])
+         dtype=dtype_code(xn), ldq=cq.shape[-1], ws=ws_for("chan_logits", xn.device, B=B, T=T, C=C, h=grid[0], w=grid[1], nh=nh, nw=nw))
     return rawchan
 
 
@@ -458,6 +458,12 @@ def workspace(nfloats, device):
         buf = torch.empty(max(int(nfloats), 1 << 18), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def ws_for(entry, device, **fields):
+    """the caller-owned reduction workspace of entry point `entry` (mtt_<entry>_ws_floats(desc) floats; the kernels that used fp32 atomics
+    until round 3 now write per-workgroup partials there and sum them in a fixed order: deterministic training steps)."""
+    return workspace(_lib.ws_floats(entry, **fields), device)
 
 
 def ln_bwd_ws(rows, C, device):

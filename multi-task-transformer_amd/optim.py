@@ -204,8 +204,9 @@ class FusedClipAdam(torch.optim.Optimizer):
             self._captured = [(key[0], key[1], plist) for _, plist, _, _, _, _, key in work]
         total_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         base = dict(max_norm=0.0, step_size=0.0, beta1=0.0, beta2=0.0, eps=0.0, weight_decay=0.0, inv_sqrt_bc2=0.0)
+        ws = ops.workspace(max(w[2]["n_chunks"] for w in work), dev)      # per-chunk partial sums (deterministic clip norm)
         for group, plist, tab, grads, gp, t, key in work:
-            ops.call("grad_sqnorm", grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
+            ops.call("grad_sqnorm", ws=ws, grads=gp, params=tab["params"], exp_avg=tab["exp_avg"], exp_avg_sq=tab["exp_avg_sq"], numel=tab["numel"],
                      chunk_tensor=tab["chunk_tensor"], chunk_off=tab["chunk_off"], n_chunks=tab["n_chunks"], xargs=[total_sq], **base)
         for group, plist, tab, grads, gp, t, key in work:
             if not capturing:                                     # a capture records the launch; nothing is executed, no step is taken

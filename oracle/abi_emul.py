@@ -306,7 +306,7 @@ def chan_logits(**kw):
     xw = xn.reshape(B, nh, wh, nw, ww, Cn)
     r = torch.einsum("btiajk,biajkc->btijc", qw, xw).reshape(-1)      # [B,T,nwin,C]
     idx = torch.arange(B * T * nh * nw * Cn)
-    _wr(kw["rawchan"], idx, _rd(kw["rawchan"], idx) + r)              # kernel accumulates (atomics)
+    _wr(kw["rawchan"], idx, r)                                        # written (ABI 6: deterministic partials, no atomics)
 
 
 def modulate(**kw):
@@ -492,7 +492,7 @@ def add_rows(args):
 
 
 def modulate_bwd(**kw):
-    dout, dx, drawlog, drawchan = kw["xargs"]
+    dout, dx, drawlog, drawchan = kw["xargs"][:4]                     # [4] = workspace
     B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
     hg = kw.get("hg") or 64
     hw, nH, nwin = h * w, Cn // hg, nh * nw
@@ -515,7 +515,7 @@ def modulate_bwd(**kw):
     li = torch.arange(B * nH * T)[:, None] * N + torch.arange(T, N)[None, :]
     _wr(drawlog, li, dl.view(B * nH * T, N)[:, T:])
     ci = torch.arange(B * T * nwin * Cn)
-    _wr(drawchan, ci, _rd(drawchan, ci) + dc.reshape(-1))
+    _wr(drawchan, ci, dc.reshape(-1))                                 # written
 
 
 def chan_logits_bwd(**kw):
@@ -535,7 +535,7 @@ def chan_logits_bwd(**kw):
 
 
 def ctr_dw(**kw):
-    dout, dw = kw["xargs"]
+    dout, dw = kw["xargs"][:2]                                        # [2] = workspace
     T, B, rpb, ld, Cn = kw["T"], kw["B"], kw["rows_per_b"], kw["ld"], kw["C"]
     rows = B * rpb
     C8 = (Cn + 7) // 8 * 8
@@ -543,7 +543,7 @@ def ctr_dw(**kw):
     fea = _rd(kw["fea"], idx).view(T, B, rpb, C8)
     g = _rd(dout, idx).view(T, B, rpb, C8)
     wi = torch.arange(B * T * T)
-    _wr(dw, wi, _rd(dw, wi) + torch.einsum("tbrc,sbrc->bts", g, fea).reshape(-1))
+    _wr(dw, wi, torch.einsum("tbrc,sbrc->bts", g, fea).reshape(-1))   # written
 
 
 def rowscale_cast(args):
@@ -612,8 +612,8 @@ def attn_msg(**kw):
 
 
 def attn_msg_bwd(**kw):
-    """xargs = [dout, dcur, dup, dw (accumulated), dbias (accumulated)]"""
-    dout, dcur, dup, dw, dbias = kw["xargs"]
+    """xargs = [dout, dcur, dup, dw (written), dbias (written), workspace]"""
+    dout, dcur, dup, dw, dbias = kw["xargs"][:5]
     B, heads, T, qh, qw, K, ldk, ldkp = (kw[k] for k in ("B", "heads", "T", "qh", "qw", "K", "ldk", "ldkp"))
     Q, sh, sw = T * qh * qw, qh // 2, qw // 2
     Qp = T * sh * sw
@@ -629,9 +629,9 @@ def attn_msg_bwd(**kw):
     _wr(dcur, ci, torch.einsum("oh,boqk->bhqk", w[:, :heads], g).reshape(B * heads * Q, K))
     _wr(dup, ci, torch.einsum("oh,boqk->bhqk", w[:, heads:], g).reshape(B * heads * Q, K))
     wi = torch.arange(heads * 2 * heads)
-    _wr(dw, wi, _rd(dw, wi) + torch.einsum("boqk,bhqk->oh", g, torch.cat([cur, up], 1)).reshape(-1))
+    _wr(dw, wi, torch.einsum("boqk,bhqk->oh", g, torch.cat([cur, up], 1)).reshape(-1))
     bi = torch.arange(heads)
-    _wr(dbias, bi, _rd(dbias, bi) + g.sum((0, 2, 3)))
+    _wr(dbias, bi, g.sum((0, 2, 3)))
 
 
 def convt3x3s2_gather(**kw):
@@ -649,27 +649,6 @@ def convt3x3s2_gather(**kw):
                     if 0 <= ox < 2 * W:
                         out[:, oy, ox] += ya[:, iy, ix, ky, kx]
     _wr(kw["out"], torch.arange(out.numel()), out.reshape(-1))
-
-
-def transpose_pad(args):
-    src, dst, rows, cols, lds, ldd, sdt, ddt = args[:8]
-    r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
-    v = _rd(src, r * lds + c)                                   # [rows, cols]
-    full = torch.zeros(cols, ldd, dtype=torch.float64)
-    full[:, :rows] = v.t()
-    _wr(dst, torch.arange(cols)[:, None] * ldd + torch.arange(ldd)[None, :], full)
-
-
-
-def transpose_pad_sum(args):
-    transpose_pad(args[:8])
-    src, dst, rows, cols, lds, ldd, sdt, ddt, colsum = args[:9]
-    if colsum is not None:
-        r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
-        v = _rd(src, r * lds + c)
-        if ddt == 1:                                             # sums are taken over the bf16-rounded values that are written
-            v = v.float().to(torch.bfloat16).double()
-        _wr(colsum, torch.arange(cols), _rd(colsum, torch.arange(cols)) + v.sum(0))
 
 
 def _raw_f32(addr, n):
@@ -1005,8 +984,7 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=wina
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
               loss_fwd=loss_fwd, loss_bwd=loss_bwd)
-_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast, transpose_pad=transpose_pad,
-            transpose_pad_sum=transpose_pad_sum)
+_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast)
 
 
 def call(name, **kw):

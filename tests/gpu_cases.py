@@ -460,13 +460,19 @@ def row_cases():
             B, T, C = 2, 5, 128
             N = T + h * w
             ldq = (h * w + 7) // 8 * 8
-            kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.zeros(B, T, nh * nh, C),
-                      B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, dtype=dt, ldq=ldq)
+            kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.full((B, T, nh * nh, C), 9.0),
+                      B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, dtype=dt, ldq=ldq, ws=scratch(64 * B * T * nh * nh * C))
             cases.append((f"chanlogit_{dt}_win{nh}", "chan_logits", kw, TOL_ROW))
             XT = rnd(g, B, N, C)
             kw = dict(x=XT[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // 64, T, N), rawchan=rnd(g, B, T, nh * nh, C),
                       out=torch.zeros(2 * T, B * h * w, C, dtype=DT[dt]), B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt)
             cases.append((f"modulate_{dt}_win{nh}", "modulate", kw, TOL_ROW))
+        # several pixel splits per window (partials through the workspace, summed in split order): 16 x 16 patches
+        B, T, C, h, w = 1, 3, 128, 16, 16
+        N = T + h * w
+        kw = dict(q=rnd(g, B * T, h * w, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.full((B, T, 1, C), 9.0),
+                  B=B, T=T, N=N, C=C, h=h, w=w, nh=1, nw=1, dtype=dt, ldq=h * w, ws=scratch(64 * B * T * C))
+        cases.append((f"chanlogit_{dt}_splits", "chan_logits", kw, TOL_ROW))
     # backward-only kernels
     for dt in (F32, BF16):
         for (h, w, nh) in ((4, 6, 1), (4, 6, 2)):
@@ -477,7 +483,8 @@ def row_cases():
             dXT = rnd(g, B, N, C)
             kw = dict(x=XT[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // 64, T, N), rawchan=rnd(g, B, T, nh * nh, C),
                       out=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt,
-                      xargs=[rnd(g, 2 * T, B * h * w, C, dtype=DT[dt]), dXT[:, T:], torch.zeros(B, C // 64, T, N), torch.zeros(B, T, nh * nh, C)])
+                      xargs=[rnd(g, 2 * T, B * h * w, C, dtype=DT[dt]), dXT[:, T:], torch.zeros(B, C // 64, T, N), torch.full((B, T, nh * nh, C), 9.0),
+                             scratch(32 * B * T * nh * nh * C)])
             cases.append((f"modulate_bwd_{dt}_win{nh}", "modulate_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
             kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=None,
                       B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, dtype=dt, ldq=ldq,
@@ -486,15 +493,8 @@ def row_cases():
         T, B, rpb, ld, C = 6, 2, 300, 56, 52
         fea = rnd(g, T, B * rpb, ld, dtype=DT[dt]); fea[..., C:] = 0
         kw = dict(fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rpb, ld=ld, C=C, fea_dtype=dt, accumulate=0,
-                  xargs=[rnd(g, T, B * rpb, ld), torch.zeros(B, T, T)])
+                  xargs=[rnd(g, T, B * rpb, ld), torch.full((B, T, T), 9.0), scratch(4096 * B * T * T)])      # dw is WRITTEN (stale 9.0 must vanish)
         cases.append((f"ctr_dw_{dt}", "ctr_dw", kw, dict(f32=2e-5, bf16=5e-3)))
-        cases.append((f"transpose_pad_{dt}", "transpose_pad",
-                      dict(args=[rnd(g, 203, 80, dtype=DT[dt]), torch.full((72, 256), 5.0, dtype=torch.bfloat16), 203, 72, 80, 256, dt, BF16]), TOL_ROW))
-        cases.append((f"transpose_pad_sum_{dt}", "transpose_pad_sum",
-                      dict(args=[rnd(g, 203, 80, dtype=DT[dt]), torch.full((72, 256), 5.0, dtype=torch.bfloat16), 203, 72, 80, 256, dt, BF16,
-                                 rnd(g, 72)]), dict(f32=2e-5, bf16=5e-3)))
-        cases.append((f"transpose_pad_vec_{dt}", "transpose_pad",
-                      dict(args=[rnd(g, 130, 136, dtype=DT[dt]), torch.full((136, 192), 5.0, dtype=torch.bfloat16), 130, 136, 136, 192, dt, BF16]), TOL_ROW))
         cases.append((f"rowscale_cast_vec_{dt}", "rowscale_cast",
                       dict(args=[rnd(g, 2 * 13, 24), torch.zeros(26, 32, dtype=DT[dt]), 26, 24, 24, 32, F32, dt,
                                  torch.tensor([[0.5, 2.0], [0.0, 1.5]]), 13, 3]), TOL_ROW))
@@ -617,7 +617,8 @@ def invpt_cases():
         Kp = (K + 7) // 8 * 8
         kw = dict(cur=rnd(g, B, heads, Q, Kp), prev=rnd(g, B, heads, Q // 4, Kp), out=None, w=rnd(g, heads, 2 * heads), bias=None,
                   B=B, heads=heads, T=T, qh=qh, qw=qw, K=K, ldk=Kp, ldkp=Kp,
-                  xargs=[rnd(g, B, heads, Q, Kp), torch.zeros(B, heads, Q, Kp), torch.zeros(B, heads, Q, Kp), torch.zeros(heads, 2 * heads), torch.zeros(heads)])
+                  xargs=[rnd(g, B, heads, Q, Kp), torch.zeros(B, heads, Q, Kp), torch.zeros(B, heads, Q, Kp), torch.full((heads, 2 * heads), 9.0),
+                         torch.full((heads,), 9.0), scratch(2049 * 36)])
         cases.append((f"attn_msg_bwd_K{K}", "attn_msg_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
     return cases
 

@@ -51,6 +51,59 @@ def test_invpt_x3f_runs_and_matches_forward():
     assert med < 2e-1, (worst, med)
 
 
+def _two_steps_bitwise(cfg, prec, B, kind):
+    """Two training iterations (forward, fused criterion, backward, clip + Adam) from the SAME state on the same batch: every gradient
+    and every updated parameter must be bitwise equal — no fp32 atomics anywhere on the path (ABI 6: every cross-workgroup reduction
+    sums caller-owned partials in a fixed order)."""
+    import conftest
+    import mtt_amd
+    from oracle import weights
+    model = conftest.build_product_model(cfg, prec, "cuda")
+    contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+    sd = {k: v.cuda() for k, v in weights.synth_state_dict(contract, 0).items()}
+    p = model.backbone.p if kind == "TP" else model.p
+    crit = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES).cuda()
+    H, W = cfg["img_size"]
+    x = weights.synth_images(B, cfg["img_size"], 2).cuda()
+    gt = mtt_amd.losses.synthetic_targets(p, B, H, W, "cuda", seed=1)
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-6, max_norm=1.0)
+        loss = crit(model(x), gt)["total"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+        norm = opt.step()
+        torch.cuda.synchronize()
+        runs.append((float(loss.detach()), grads, {k: v.detach().clone() for k, v in model.named_parameters()}, norm.clone()))
+    (l0, g0, p0, n0), (l1, g1, p1, n1) = runs
+    assert l0 == l1
+    assert bool(torch.equal(n0, n1))
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])] + [k for k in p0 if not torch.equal(p0[k], p1[k])]
+    assert not bad, (len(bad), bad[:6])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16", "x3", "x3f"])
+def test_training_step_is_bitwise_reproducible_taskprompter(prec):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import configs
+    _two_steps_bitwise(configs.taskprompter("mini_ctr"), prec, 2, "TP")
+    if prec != "x3":
+        _two_steps_bitwise(configs.taskprompter("ns6"), prec, 2, "TP")          # the benchmarked shape (split reductions, many workgroups)
+
+
+@pytest.mark.gpu
+def test_training_step_is_bitwise_reproducible_invpt():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import configs
+    _two_steps_bitwise(configs.invpt("mini8"), "bf16", 2, "IP")
+
+
 @pytest.mark.gpu
 def test_gradients_with_droppath_masks():
     if not torch.cuda.is_available():
