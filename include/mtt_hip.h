@@ -431,6 +431,11 @@ typedef struct {
   const float* kvbias;           /* fp32 [2*ce] added to the rows of kvT (the bias of the Linear that produced them), or NULL */
 } mtt_chanattn_desc;
 int mtt_chanattn_fwd(const mtt_chanattn_desc* d, void* stream);
+/* backward (d as in the forward with d->rawchan = the forward's logits, d->kvbias NULL): drawchan fp32 [B, T, nwin, C] (NULL = none) and
+ * dcx fp32 [B, T, ce] -> dq fp32 [B, T, ce] and dkvT fp32 [B, 2*ce, ldg] (rows: d kT, then d vT), both WRITTEN; ws: mtt_chanattn_bwd_ws_floats(d)
+ * floats.  Fixed summation orders, no atomics. */
+size_t mtt_chanattn_bwd_ws_floats(const mtt_chanattn_desc* d);
+int mtt_chanattn_bwd(const mtt_chanattn_desc* d, const float* drawchan, const float* dcx, float* dq, float* dkvT, int64_t ldg, float* ws, void* stream);
 
 /* Small-channel 3x3 stride-2 pad-1 convolution on fp32 maps (PatchMerging.spa_attn_ds, taskprompter_swin.py:437,463):
  *   x[b][ci][y*W + x] at x + b*x_bs + ci*x_cs + x_off;  w fp32 [Co, Ci, 3, 3];  y[b][co][...] at y + b*y_bs + co*y_cs + y_off  (H, W even) */
@@ -439,6 +444,9 @@ typedef struct {
   int32_t B, Ci, Co, H, W; int64_t x_bs, x_cs, x_off, y_bs, y_cs, y_off;
 } mtt_conv3s2_desc;
 int mtt_conv3s2_nchw(const mtt_conv3s2_desc* d, void* stream);
+/* backward: dy laid out as y -> dx laid out as x (written for every (b, ci, pixel); may be NULL), dw fp32 [Co, Ci, 3, 3] and db fp32 [Co]
+ * (written; dw NULL skips both; db may be NULL) */
+int mtt_conv3s2_nchw_bwd(const mtt_conv3s2_desc* d, const float* dy, float* dx, float* dw, float* db, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * Bird's-eye-view rotated boxes [x1, y1, x2, y2, ry] of the 3-D detection branch (TaskPrompter/detection_toolbox/iou3d: iou3d_kernel.cu

@@ -208,6 +208,8 @@ DESC_EXTRA = {
     "ctr_dw": (CtrDesc, [ptr, ptr, ptr]),
     "attn_bwd": (AttnDesc, [ptr, ptr, ptr, ptr]),
     "winattn_bwd": (WinAttnDesc, [ptr, ptr, ptr, ptr]),
+    "chanattn_bwd": (ChanAttnDesc, [ptr, ptr, ptr, ptr, i64, ptr]),
+    "conv3s2_nchw_bwd": (Conv3s2Desc, [ptr, ptr, ptr, ptr]),
     "grad_sqnorm": (AdamDesc, [ptr]),
     "adam_step": (AdamDesc, [ptr]),
     "loss_label_stats": (LossDesc, [ptr]),
@@ -218,7 +220,8 @@ DESC_EXTRA = {
 }
 
 # workspace-size queries mtt_<entry>_ws_floats(const desc*) of the entry points whose cross-workgroup reductions go through caller-owned partials
-WS_QUERIES = {"chan_logits": ChanLogitDesc, "modulate_bwd": ModulateDesc, "ctr_dw": CtrDesc, "attn_msg_bwd": AttnMsgDesc, "loss": LossDesc}
+WS_QUERIES = {"chan_logits": ChanLogitDesc, "modulate_bwd": ModulateDesc, "ctr_dw": CtrDesc, "attn_msg_bwd": AttnMsgDesc, "loss": LossDesc,
+              "chanattn_bwd": ChanAttnDesc}
 EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats", "mtt_nms_ws_bytes"] + ["mtt_%s_ws_floats" % n for n in WS_QUERIES] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None

@@ -470,6 +470,164 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const mtt_conv3s2_desc d) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the channel attention (autograd of taskprompter_swin.py:399-409), three small kernels over the forward's layouts:
+//   A  per (b, t, window): P = softmax_c(scale * rawchan), dP[c] = sum_{e in win} dcx[e] * vT[e, c],
+//      dS[c] = scale * P[c] * (dP[c] - sum_c' P dP) + drawchan[c]       -> workspace planes dS, P  [B*T*nwin, C]
+//   B  dq[b, t, e]   = sum_c dS[c] * kT[e, c]                           (one wave per window element)
+//   C  dkT[b, e, c]  = sum_t q[b, t, e] * dS[b, t, win(e), c];   dvT[b, e, c] = sum_t dcx[b, t, e] * P[b, t, win(e), c]
+// Fixed summation orders throughout (no atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chanattn_bwd_a_kernel(const mtt_chanattn_desc d, const float* drawchan, const float* dcx, float* ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* pr = (float*)smem_raw;                    // [C] probabilities
+  __shared__ float red[8];
+  __shared__ float gs[1024];
+  __shared__ int es[1024];
+  const ChanWin w = chan_win(d, blockIdx.x);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t grp = ((int64_t)w.b * d.T + w.t) * (d.nh * d.nw) + w.win;
+  const float* raw = d.rawchan + grp * d.C;
+  for (int e = tid; e < w.P; e += 256) {
+    const int el = chan_elem(w, e);
+    es[e] = el;
+    gs[e] = dcx[((int64_t)w.b * d.T + w.t) * d.ce + el];
+  }
+  float mx = -INFINITY;
+  for (int c = tid; c < d.C; c += 256) { const float v = raw[c] * d.scale; pr[c] = v; mx = fmaxf(mx, v); }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float l = 0.f;
+  for (int c = tid; c < d.C; c += 256) { const float pv = expf(pr[c] - mx); pr[c] = pv; l += pv; }
+  l = wave_sum(l);
+  if (lane == 0) red[4 + wave] = l;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+  const int64_t kvb = (int64_t)w.b * 2 * d.ce * d.ldk;
+  float* dS = ws + grp * d.C;
+  float* Pw = ws + (int64_t)d.B * d.T * d.nh * d.nw * d.C + grp * d.C;
+  float dot = 0.f;
+  for (int c = tid; c < d.C; c += 256) {
+    float dp = 0.f;
+    for (int e = 0; e < w.P; ++e) dp = fmaf(gs[e], ld_elem(d.kvT, kvb + (int64_t)(d.ce + es[e]) * d.ldk + c, d.kv_dtype), dp);
+    const float pv = pr[c] * inv;
+    Pw[c] = pv;
+    dS[c] = dp;                                     // dP for now
+    dot += pv * dp;
+  }
+  __syncthreads();
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int c = tid; c < d.C; c += 256) dS[c] = d.scale * Pw[c] * (dS[c] - dot) + (drawchan ? drawchan[grp * d.C + c] : 0.f);
+}
+__global__ __launch_bounds__(256) void chanattn_bwd_q_kernel(const mtt_chanattn_desc d, const float* ws, float* dq) {
+  const ChanWin w = chan_win(d, blockIdx.y);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t grp = ((int64_t)w.b * d.T + w.t) * (d.nh * d.nw) + w.win;
+  const float* dS = ws + grp * d.C;
+  const int64_t kvb = (int64_t)w.b * 2 * d.ce * d.ldk;
+  for (int k = 0; k < 8; ++k) {
+    const int e = blockIdx.x * 32 + wave * 8 + k;
+    if (e >= w.P) break;
+    const int el = chan_elem(w, e);
+    float a = 0.f;
+    for (int c = lane; c < d.C; c += 64) a = fmaf(dS[c], ld_elem(d.kvT, kvb + (int64_t)el * d.ldk + c, d.kv_dtype), a);
+    a = wave_sum(a);
+    if (lane == 0) dq[((int64_t)w.b * d.T + w.t) * d.ce + el] = a;
+  }
+}
+__global__ __launch_bounds__(256) void chanattn_bwd_kv_kernel(const mtt_chanattn_desc d, const float* dcx, const float* ws, float* dkvT, int64_t ldg) {
+  const int nwin = d.nh * d.nw;
+  const int r = (int)(sqrtf((float)d.ce) + 0.5f), wh = r / d.nh, ww = r / d.nw;
+  const float* Pw = ws + (int64_t)d.B * d.T * nwin * d.C;
+  const int64_t total = (int64_t)d.B * d.ce * d.C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % d.C);
+    const int el = (int)((i / d.C) % d.ce);
+    const int b = (int)(i / ((int64_t)d.C * d.ce));
+    const int win = ((el / r) / wh) * d.nw + (el % r) / ww;
+    float gk = 0.f, gv = 0.f;
+    for (int t = 0; t < d.T; ++t) {
+      const int64_t grp = ((int64_t)b * d.T + t) * nwin + win;
+      gk = fmaf(d.q[((int64_t)b * d.T + t) * d.ce + el], ws[grp * d.C + c], gk);
+      gv = fmaf(dcx[((int64_t)b * d.T + t) * d.ce + el], Pw[grp * d.C + c], gv);
+    }
+    dkvT[((int64_t)b * 2 * d.ce + el) * ldg + c] = gk;
+    dkvT[((int64_t)b * 2 * d.ce + d.ce + el) * ldg + c] = gv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of conv3s2_kernel (autograd of PatchMerging.spa_attn_ds, taskprompter_swin.py:437,463): input gradient by gathering
+// (a thread per input element), weight gradient with one workgroup per (co, ci) pair reducing the 9 taps over all output pixels
+// through LDS in a fixed order, bias gradient with one workgroup per output channel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3s2_bwd_dx_kernel(const mtt_conv3s2_desc d, const float* dy, float* dx) {
+  const int Ho = d.H / 2, Wo = d.W / 2;
+  const int64_t total = (int64_t)d.B * d.Ci * d.H * d.W;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int xx = (int)(t % d.W), yy = (int)((t / d.W) % d.H), ci = (int)((t / ((int64_t)d.W * d.H)) % d.Ci);
+    const int64_t b = t / ((int64_t)d.W * d.H * d.Ci);
+    float a = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = yy + 1 - ky;
+      if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = xx + 1 - kx;
+        if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+        const float* gp = dy + b * d.y_bs + d.y_off + (int64_t)(ty >> 1) * Wo + (tx >> 1);
+        for (int co = 0; co < d.Co; ++co) a = fmaf(gp[(int64_t)co * d.y_cs], d.w[((int64_t)co * d.Ci + ci) * 9 + ky * 3 + kx], a);
+      }
+    }
+    dx[b * d.x_bs + (int64_t)ci * d.x_cs + d.x_off + (int64_t)yy * d.W + xx] = a;
+  }
+}
+__global__ __launch_bounds__(256) void conv3s2_bwd_dw_kernel(const mtt_conv3s2_desc d, const float* dy, float* dw, float* db) {
+  __shared__ float red[256];
+  const int Ho = d.H / 2, Wo = d.W / 2;
+  const int co = blockIdx.x / d.Ci, ci = blockIdx.x % d.Ci;
+  const int64_t npix = (int64_t)d.B * Ho * Wo;
+  float acc[9], sb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+  for (int64_t i = threadIdx.x; i < npix; i += 256) {
+    const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+    const int64_t b = i / ((int64_t)Wo * Ho);
+    const float g = dy[b * d.y_bs + (int64_t)co * d.y_cs + d.y_off + (int64_t)yo * Wo + xo];
+    sb += g;
+    const float* xp = d.x + b * d.x_bs + (int64_t)ci * d.x_cs + d.x_off;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = 2 * yo - 1 + ky;
+      if (yy < 0 || yy >= d.H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = 2 * xo - 1 + kx;
+        if (xx < 0 || xx >= d.W) continue;
+        acc[ky * 3 + kx] = fmaf(g, xp[(int64_t)yy * d.W + xx], acc[ky * 3 + kx]);
+      }
+    }
+  }
+  for (int k = 0; k < 10; ++k) {                  // 9 taps + (ci == 0: the bias gradient of channel co), fixed-order LDS tree
+    if (k == 9 && (ci != 0 || !db)) break;
+    red[threadIdx.x] = k < 9 ? acc[k] : sb;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (k < 9) dw[((int64_t)co * d.Ci + ci) * 9 + k] = red[0]; else db[co] = red[0]; }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Bilinear resize of fp32 planes (align_corners = False): the img_ds_ratio input resize (taskprompter_swin.py:666-667).
 // ------------------------------------------------------------------------------------------------
@@ -561,6 +719,30 @@ extern "C" int mtt_chanattn_fwd(const mtt_chanattn_desc* d, void* stream) {
   const int groups = d->B * d->T * d->nh * d->nw, P = (r / d->nh) * (r / d->nw);
   hipLaunchKernelGGL(chanattn_logits_kernel, dim3((unsigned)((d->C + 255) / 256), (unsigned)groups), dim3(256), 0, S_, *d);
   hipLaunchKernelGGL(chanattn_mix_kernel, dim3((unsigned)((P + 31) / 32), (unsigned)groups), dim3(256), d->C * 4, S_, *d);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t mtt_chanattn_bwd_ws_floats(const mtt_chanattn_desc* d) {
+  return d ? (size_t)2 * d->B * d->T * d->nh * d->nw * d->C : 0;
+}
+extern "C" int mtt_chanattn_bwd(const mtt_chanattn_desc* d, const float* drawchan, const float* dcx, float* dq, float* dkvT, int64_t ldg, float* ws,
+                                void* stream) {
+  if (!d || !d->q || !d->kvT || !d->rawchan || !dcx || !dq || !dkvT || !ws || d->B <= 0 || d->T <= 0 || d->C <= 0 || d->ce <= 0 || d->nh <= 0 || d->nw <= 0)
+    return MTT_E_BADARG;
+  if (d->kvbias) return MTT_E_UNSUPPORTED;        /* the training path folds the biases into kvT */
+  const int r = (int)(sqrt((double)d->ce) + 0.5);
+  if (r * r != d->ce || (r % d->nh) || (r % d->nw) || (r / d->nh) * (r / d->nw) > 1024 || d->C > 12288 || ldg < d->C) return MTT_E_BADARG;
+  const int groups = d->B * d->T * d->nh * d->nw, P = (r / d->nh) * (r / d->nw);
+  hipLaunchKernelGGL(chanattn_bwd_a_kernel, dim3((unsigned)groups), dim3(256), d->C * 4, S_, *d, drawchan, dcx, ws);
+  hipLaunchKernelGGL(chanattn_bwd_q_kernel, dim3((unsigned)((P + 31) / 32), (unsigned)groups), dim3(256), 0, S_, *d, (const float*)ws, dq);
+  hipLaunchKernelGGL(chanattn_bwd_kv_kernel, dim3(grid_for((int64_t)d->B * d->ce * d->C)), dim3(256), 0, S_, *d, dcx, (const float*)ws, dkvT, ldg);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mtt_conv3s2_nchw_bwd(const mtt_conv3s2_desc* d, const float* dy, float* dx, float* dw, float* db, void* stream) {
+  if (!d || !d->x || !d->w || !dy || d->B <= 0 || d->Ci <= 0 || d->Co <= 0 || d->H <= 0 || d->W <= 0 || (d->H % 2) || (d->W % 2)) return MTT_E_BADARG;
+  if (dx) hipLaunchKernelGGL(conv3s2_bwd_dx_kernel, dim3(grid_for((int64_t)d->B * d->Ci * d->H * d->W)), dim3(256), 0, S_, *d, dy, dx);
+  if (dw) hipLaunchKernelGGL(conv3s2_bwd_dw_kernel, dim3((unsigned)(d->Co * d->Ci)), dim3(256), 0, S_, *d, dy, dw, db);
   return (int)hipGetLastError();
 }
 

@@ -128,26 +128,22 @@ class ChanAttnFn(Function):
         cx = torch.empty(B * T, ce, dtype=torch.float32, device=q.device)
         ops.call("chanattn_fwd", q=q, kvT=kvT, rawchan=rawchan, cx=cx, B=B, T=T, C=C, ce=ce, nh=nwin, nw=nwin, kv_dtype=0, ldk=Cp,
                  scale=ce ** -0.5, kvbias=None)
-        ctx.save_for_backward(q, kv)
+        ctx.save_for_backward(q, kvT, rawchan)
         ctx.geo = geo
         return rawchan, cx
 
     @staticmethod
     def backward(ctx, drawchan, dcx):
-        q, kv = ctx.saved_tensors
+        q, kvT, rawchan = ctx.saved_tensors
         B, T, C, ce, nwin = ctx.geo
-        r = math.isqrt(ce)
-        wh = ww = r // nwin
-        with torch.enable_grad():
-            q_ = q.detach().view(B, T, ce).requires_grad_(True)
-            kv_ = kv.detach().requires_grad_(True)
-            k, v = kv_[:, :, :ce], kv_[:, :, ce:]
-            qs, ks, vs = _chan_split(q_, B, nwin, nwin, wh, ww), _chan_split(k, B, nwin, nwin, wh, ww), _chan_split(v, B, nwin, nwin, wh, ww)
-            raw = qs @ ks.transpose(-1, -2)                                            # [B, nwin2, T, C]
-            cx = torch.softmax(raw * ce ** -0.5, -1) @ vs                              # [B, nwin2, T, P]
-            cx = cx.view(B, nwin, nwin, T, wh, ww).permute(0, 3, 1, 4, 2, 5).reshape(B * T, ce)
-            gq, gkv = torch.autograd.grad([raw.permute(0, 2, 1, 3), cx], [q_, kv_], [drawchan, dcx])
-        return gq.reshape(B * T, ce), gkv, None
+        Cp = kvT.shape[-1]
+        dq = torch.empty(B * T, ce, dtype=torch.float32, device=q.device)
+        dkvT = torch.empty(B, 2 * ce, Cp, dtype=torch.float32, device=q.device)
+        kw = dict(B=B, T=T, C=C, ce=ce, nh=nwin, nw=nwin)
+        ops.call("chanattn_bwd", q=q, kvT=kvT, rawchan=rawchan, cx=None, kv_dtype=0, ldk=Cp, scale=ce ** -0.5, kvbias=None,
+                 xargs=[drawchan.contiguous() if drawchan is not None else None, dcx.contiguous(), dq, dkvT, Cp,
+                        ops.ws_for("chanattn_bwd", q.device, **kw)], **kw)
+        return dq, dkvT[:, :, :C].transpose(1, 2), None
 
 
 class Conv3s2Fn(Function):
@@ -168,14 +164,12 @@ class Conv3s2Fn(Function):
     def backward(ctx, draw2):
         rawlog, weight, bias = ctx.saved_tensors
         B, nH, T, H, W = ctx.geo
-        with torch.enable_grad():
-            x = rawlog.detach()[..., T:].reshape(B, nH * T, H, W).requires_grad_(True)
-            w_, b_ = weight.detach().requires_grad_(True), bias.detach().requires_grad_(True)
-            y = torch.nn.functional.conv2d(x, w_, b_, stride=2, padding=1)
-            g = draw2[..., T:].reshape(B, nH * T, H // 2, W // 2)
-            gx, gw, gb = torch.autograd.grad(y, [x, w_, b_], g)
-        dl = torch.zeros_like(rawlog)
-        dl[..., T:] = gx.reshape(B, nH, T, H * W)
+        N, N2 = T + H * W, T + (H // 2) * (W // 2)
+        draw2 = draw2.contiguous()
+        dl = torch.zeros_like(rawlog)                       # the first T columns (prompt <-> prompt logits) take no gradient here
+        gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+        ops.call("conv3s2_nchw_bwd", x=rawlog, w=weight.detach().contiguous(), bias=None, y=None, B=B, Ci=nH * T, Co=nH * T, H=H, W=W,
+                 x_bs=nH * T * N, x_cs=N, x_off=T, y_bs=nH * T * N2, y_cs=N2, y_off=T, xargs=[draw2, dl, gw, gb])
         return dl, gw, gb, None
 
 

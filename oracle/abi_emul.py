@@ -960,6 +960,58 @@ def conv3s2_nchw(**kw):
     _wr(kw["y"], (b * g("y_bs") + co * g("y_cs") + g("y_off") + po).reshape(-1), y.reshape(-1))
 
 
+def chanattn_bwd(**kw):
+    """xargs = [drawchan or None, dcx, dq (written), dkvT (written, pitch ldg), ldg, workspace]: autograd of the emulated forward."""
+    drawchan, dcx, dq, dkvT, ldg = kw["xargs"][:5]
+    B, T, Cn, ce, nh, nw = (kw[k] for k in ("B", "T", "C", "ce", "nh", "nw"))
+    ldk = kw["ldk"]
+    q = _rd(kw["q"], torch.arange(B * T * ce)).view(B, T, ce).requires_grad_(True)
+    rows = torch.arange(B * 2 * ce)[:, None] * ldk + torch.arange(Cn)[None, :]
+    kv = _rd(kw["kvT"], rows).view(B, 2, ce, Cn).requires_grad_(True)
+    kT, vT = kv[:, 0], kv[:, 1]
+    r = math.isqrt(ce)
+    wh, ww = r // nh, r // nw
+
+    def split(t):
+        return t.view(B, t.shape[1], nh, wh, nw, ww).permute(0, 2, 4, 1, 3, 5).reshape(B, nh * nw, t.shape[1], wh * ww)
+    q_, k_, v_ = split(q), split(kT.transpose(1, 2)), split(vT.transpose(1, 2))
+    raw = q_ @ k_.transpose(-1, -2)
+    cx = torch.softmax(raw * kw["scale"], -1) @ v_
+    cx = cx.view(B, nh, nw, T, wh, ww).permute(0, 3, 1, 4, 2, 5).reshape(B, T, ce)
+    outs, grads = [cx], [_rd(dcx, torch.arange(B * T * ce)).view(B, T, ce)]
+    if drawchan is not None:
+        outs.append(raw.permute(0, 2, 1, 3))
+        grads.append(_rd(drawchan, torch.arange(B * T * nh * nw * Cn)).view(B, T, nh * nw, Cn))
+    gq, gkv = torch.autograd.grad(outs, [q, kv], grads)
+    _wr(dq, torch.arange(B * T * ce), gq.reshape(-1))
+    _wr(dkvT, (torch.arange(B * 2 * ce)[:, None] * ldg + torch.arange(Cn)[None, :]).reshape(-1), gkv.reshape(-1))
+
+
+def conv3s2_nchw_bwd(**kw):
+    """xargs = [dy (laid out as y), dx (as x; or None), dw [Co, Ci, 3, 3] or None, db [Co] or None]"""
+    dy, dx, dw, db = kw["xargs"][:4]
+    B, Ci, Co, H, W = (kw[k] for k in ("B", "Ci", "Co", "H", "W"))
+    g = lambda k: kw.get(k) or 0
+    b = torch.arange(B)[:, None, None]
+    c = torch.arange(Ci)[None, :, None]
+    pxl = torch.arange(H * W)[None, None, :]
+    xi = b * g("x_bs") + c * g("x_cs") + g("x_off") + pxl
+    x = _rd(kw["x"], xi).view(B, Ci, H, W).requires_grad_(True)
+    w = _rd(kw["w"], torch.arange(Co * Ci * 9)).view(Co, Ci, 3, 3).requires_grad_(True)
+    bias = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w, bias, stride=2, padding=1)
+    co = torch.arange(Co)[None, :, None]
+    po = torch.arange((H // 2) * (W // 2))[None, None, :]
+    gy = _rd(dy, b * g("y_bs") + co * g("y_cs") + g("y_off") + po).view(B, Co, H // 2, W // 2)
+    gx, gw, gb = torch.autograd.grad(y, [x, w, bias], gy)
+    if dx is not None:
+        _wr(dx, xi.reshape(-1), gx.reshape(-1))
+    if dw is not None:
+        _wr(dw, torch.arange(Co * Ci * 9), gw.reshape(-1))
+        if db is not None:
+            _wr(db, torch.arange(Co), gb)
+
+
 def boxes_overlap_bev(args):
     from . import iou3d_oracle
     a, na, b, nb, out, iou = args[:6]
@@ -983,12 +1035,12 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=wina
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg, attn_msg_bwd=attn_msg_bwd,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
-              loss_fwd=loss_fwd, loss_bwd=loss_bwd)
+              loss_fwd=loss_fwd, loss_bwd=loss_bwd, chanattn_bwd=chanattn_bwd, conv3s2_nchw_bwd=conv3s2_nchw_bwd)
 _POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast)
 
 
 def call(name, **kw):
-    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd", "upconv4_gather", "winattn_bwd") else torch.no_grad():
+    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd", "upconv4_gather", "winattn_bwd", "chanattn_bwd", "conv3s2_nchw_bwd") else torch.no_grad():
         if name in _POS:
             return _POS[name](kw["args"])
         return _TABLE[name](**kw)

@@ -45,6 +45,15 @@ def main():
                 keep = np.zeros(n, np.int64)
                 k = lib.ref_nms(n, fp(bx), ctypes.c_float(thr), rot, fp(keep))
                 out[f"nms_{tag}_t{thr}_r{rot}"] = keep[:k].copy()
+    # 4 096 boxes at the density of tools/iou3d_bench.py: only the seed and the kept index sets are stored (the boxes regenerate from the
+    # seed with `boxes`), rotated and axis-aligned, threshold 0.3
+    n, seed = 4096, 7
+    bx = boxes(np.random.default_rng(seed), n, 0.9 * n ** 0.5)
+    for rot in (1, 0):
+        keep = np.zeros(n, np.int64)
+        k = lib.ref_nms(n, fp(bx), ctypes.c_float(0.3), rot, fp(keep))
+        out[f"nms_4096_t0.3_r{rot}"] = keep[:k].astype(np.int32)
+    out["nms_4096_seed"] = np.array([seed, n], np.int64)
     np.savez_compressed(os.path.join(HERE, "iou3d.npz"), **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -723,6 +723,19 @@ def swin_cases():
         kw = dict(x=rnd(g, B, Ci, N), w=rnd(g, Ci, Ci, 3, 3, scale=0.3), bias=rnd(g, Ci), y=torch.full((B, Ci, N2), 7.0), B=B, Ci=Ci, Co=Ci, H=H, W=W,
                   x_bs=Ci * N, x_cs=N, x_off=T, y_bs=Ci * N2, y_cs=N2, y_off=T)
         cases.append((f"conv3s2_{B}x{Ci}x{H}x{W}", "conv3s2_nchw", kw, TOL_ROW))
+        # its backward: input / weight / bias gradients (dx covers the map columns only: the first T columns of every row stay as they were)
+        kb = dict(x=kw["x"], w=kw["w"], bias=None, y=None, B=B, Ci=Ci, Co=Ci, H=H, W=W, x_bs=Ci * N, x_cs=N, x_off=T, y_bs=Ci * N2, y_cs=N2, y_off=T,
+                  xargs=[rnd(g, B, Ci, N2), torch.full((B, Ci, N), 7.0), torch.full((Ci, Ci, 3, 3), 7.0), torch.full((Ci,), 7.0)])
+        cases.append((f"conv3s2_bwd_{B}x{Ci}x{H}x{W}", "conv3s2_nchw_bwd", kb, dict(f32=2e-5, bf16=5e-3)))
+    # channel attention backward (q / kT / vT gradients from the logit and the mixed-value gradients), forward logits from the emulator
+    for (B, T, C, ce, nwin, with_raw) in ((2, 2, 64, 16, 1, True), (1, 3, 136, 64, 2, True), (2, 2, 256, 256, 1, False), (1, 2, 1024, 256, 2, True)):
+        Cp = (C + 7) // 8 * 8
+        fk = dict(q=rnd(g, B, T, ce, scale=0.3), kvT=rnd(g, B, 2 * ce, Cp, scale=0.5), rawchan=torch.zeros(B, T, nwin * nwin, C), cx=torch.zeros(B, T, ce),
+                  B=B, T=T, C=C, ce=ce, nh=nwin, nw=nwin, kv_dtype=F32, ldk=Cp, scale=ce ** -0.5, kvbias=None)
+        abi_emul.call("chanattn_fwd", **fk)
+        kb = dict(fk, cx=None, xargs=[rnd(g, B, T, nwin * nwin, C, scale=0.3) if with_raw else None, rnd(g, B, T, ce), torch.full((B, T, ce), 7.0),
+                                      torch.full((B, 2 * ce, Cp + 8), 7.0), Cp + 8, scratch(2 * B * T * nwin * nwin * C)])
+        cases.append((f"chanattn_bwd_B{B}T{T}C{C}ce{ce}w{nwin}", "chanattn_bwd", kb, dict(f32=3e-5, bf16=5e-3)))
     # modulation with 32-channel heads (last Swin stage)
     B, T, h, w, C, hg = 2, 2, 4, 6, 64, 32
     N = T + h * w

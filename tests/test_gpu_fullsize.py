@@ -131,6 +131,55 @@ def test_ns6_training_step_bf16_matches_oracle_autograd():
         torch.cuda.empty_cache()
 
 
+@pytest.mark.gpu
+def test_cfg4_invpt_training_step_matches_oracle_autograd():
+    """BASELINE's 8-GPU config (InvPT ViT-L, 6 tasks, 512x512) at FULL size: train-mode forward (batch-statistic BatchNorm, intermediate
+    supervision outputs) + the hand-written backward of the ViT encoder and the InvPT decoder vs the oracle's autograd (B = 1).
+    x3: fp32-class; bf16 / x3f: bf16-class gradients (x3f: from the x3 forward).  Parameters the reference leaves without a gradient
+    (find_unused_parameters = True) must get none here either."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    from oracle import invpt_oracle as ipo
+    from tests.golden.make_golden import loss_of
+    cfg, sd, x, _ = pu.oracle_eval("cfg4_6", 1)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    t0 = time.time()
+    ref_out = ipo.forward(dict(sd, **params), cfg, x, training=True)
+    loss_of(ref_out).backward()
+    pu.report("oracle_time", config="cfg4_6 train fwd+bwd", batch=1, seconds=round(time.time() - t0, 1))
+    dead_ref = sorted(k for k, v in params.items() if v.grad is None)
+    for prec, ftol, mtol in (("x3", 1e-3, 5e-3), ("x3f", 1e-3, 2e-1), ("bf16", 4e-2, 2e-1)):
+        model = conftest.build_product_model(cfg, prec, "cuda")
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        out = model(x.cuda())
+        cpu = {k: v.cpu() for k, v in out.items() if k != "inter_preds"}
+        cpu["inter_preds"] = {k: v.cpu() for k, v in out["inter_preds"].items()}
+        loss_of(cpu).backward()
+        fwd = {t: pu.rel(cpu[t].detach(), ref_out[t].detach()) for t in cpu if t != "inter_preds"}
+        fwd.update({"inter/" + t: pu.rel(cpu["inter_preds"][t].detach(), v.detach()) for t, v in ref_out["inter_preds"].items()})
+        rels, dead = [], []
+        for k, prm in model.named_parameters():
+            if params[k].grad is None:
+                dead.append(k)
+                assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+                continue
+            assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+            n = float(params[k].grad.norm())
+            if n > 1e-6:
+                rels.append((float((prm.grad.cpu() - params[k].grad).norm()) / n, k))
+        rels.sort(reverse=True)
+        med = rels[len(rels) // 2][0]
+        pu.report("train_parity", config="cfg4_6", batch=1, prec=prec, fwd_worst=max(fwd.values()), grad_median=med, grad_worst=rels[0][0],
+                  grad_worst_param=rels[0][1], grad_p90=rels[len(rels) // 10][0], dead_parameters=len(dead))
+        assert sorted(dead) == dead_ref
+        assert max(fwd.values()) < ftol, fwd
+        assert med < mtol, (med, rels[:3])
+        del model, out
+        torch.cuda.empty_cache()
+
+
 def _attn_inputs(B, N, nH, seed, spike=None):
     g = torch.Generator().manual_seed(seed)
     C = nH * 64

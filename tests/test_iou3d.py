@@ -96,6 +96,23 @@ def test_hip_nms_matches_reference_golden(tag):
 
 
 @pytest.mark.gpu
+def test_hip_nms_4096_boxes_matches_reference_golden():
+    """4 096 boxes (64 x 64 tiles of the suppression matrix, the device-side greedy pass over 64 mask words per row): kept sets equal to
+    the reference's device functions compiled for the host (tests/golden/make_iou3d_golden.py; boxes regenerate from the stored seed)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mtt_amd
+    from tests.golden.make_iou3d_golden import boxes
+    seed, n = (int(v) for v in GOLD["nms_4096_seed"])
+    bx = torch.from_numpy(boxes(np.random.default_rng(seed), n, 0.9 * n ** 0.5)).cuda()
+    scores = torch.linspace(1.0, 0.0, n).cuda()
+    for rot, fn in ((1, mtt_amd.iou3d.nms_gpu), (0, mtt_amd.iou3d.nms_normal_gpu)):
+        got = fn(bx, scores, 0.3).cpu().numpy()
+        want = GOLD[f"nms_4096_t0.3_r{rot}"]
+        assert np.array_equal(got, want.astype(got.dtype)), (rot, len(got), len(want))
+
+
+@pytest.mark.gpu
 def test_hip_properties_at_scale():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
