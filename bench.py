@@ -550,6 +550,37 @@ def main():
         except Exception as e:  # noqa: BLE001
             parity_mode = dict(mode="x3f", error=repr(e)[:300])
 
+    torch_base = None
+    if rank == 0 and world == 1 and not a.no_torch_baseline:
+        torch.cuda.empty_cache()
+        torch_base = torch_rocm_baseline(a.config)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(a.config, a.cpu_sample_batch, a.cpu_threads, ref_in=ref_paths[0] if outs else None, ref_out=ref_paths[1])
+        except Exception as e:  # noqa: BLE001
+            cpu = dict(value=None, unit="images/s", cores=a.cpu_threads, kind="port", host_cores=os.cpu_count(), sample=f"failed: {e!r}")
+    if rank == 0 and outs:
+        ref_txt = ("the CPU oracle's eval forward (fp32, %d host threads) on this model's weights and 2 of the bench images; per-head relative "
+                   "L2 error, north_star's tolerance = 1e-3" % a.cpu_threads)
+        try:
+            ref = torch.load(ref_paths[1], map_location="cpu")
+            for mode, o in outs.items():
+                errs = {t: float((o[t].double() - ref[t].double()).norm() / ref[t].double().norm()) for t in p.TASKS.NAMES}
+                rec = dict(worst_head_rel_err=max(errs.values()), per_head=errs, reference=ref_txt, meets_1e_3=max(errs.values()) <= 1e-3)
+                if mode == a.prec and want_parity:
+                    parity = dict(mode=a.prec, **rec)
+                if mode == "x3f" and parity_mode is not None:
+                    parity_mode.update(rec)
+        except Exception as e:  # noqa: BLE001  (no oracle reference: cpu_baseline skipped or failed)
+            if want_parity:
+                parity = dict(mode=a.prec, error="no oracle reference: " + repr(e)[:200])
+            if parity_mode is not None:
+                parity_mode["error"] = "no oracle reference: " + repr(e)[:200]
+        import shutil
+        shutil.rmtree(os.path.dirname(ref_paths[0]), ignore_errors=True)
+
     if rank == 0:
         train_tflops = 3 * gflop_fwd * value / 1e3
         # model FLOPs follow the REFERENCE's operation order.  ConvHeads run "taps first" (3x3 conv commuted with the x4

@@ -269,6 +269,10 @@ int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, in
  * reduction through the caller-owned workspace ws (>= mtt_colsum_ws_floats(rows, cols) floats, contents unspecified afterwards). */
 size_t mtt_colsum_ws_floats(int64_t rows, int32_t cols);
 int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, float* ws, void* stream);
+/* Z maps in one launch pair: map z starts src_zs elements after map z - 1, its sums dst_zs floats after those of z - 1;
+ * ws >= Z * mtt_colsum_ws_floats(rows, cols) floats. */
+int mtt_colsum_batched(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, int32_t Z, int64_t src_zs,
+                       int64_t dst_zs, float* ws, void* stream);
 int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype,
                  float alpha, void* stream);
 

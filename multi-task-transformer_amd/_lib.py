@@ -195,6 +195,7 @@ POSITIONAL = {
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
     "split_cast": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr, ptr],
+    "colsum_batched": [ptr, ptr, i64, i32, i64, C.c_int, i32, i64, i64, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
 }

@@ -507,10 +507,14 @@ class BLinearFn(Function):
         else:
             dW = _wgrad_batched(dy, x, N, Kp, M, prec, Z, lda, x.shape[-1], M * lda, xz)
         dys = dy.view(-1, M, lda)
-        dws, dbs = [], []
+        # bias gradients of all Z layers in one launch pair (catpair: one per half, the half's columns start s * Np into every row)
+        if layout == 'catpair':
+            h0, h1 = (ops.colsum_batched(dys, N, Z // 2, M * lda, col_off=sft * Np) for sft in (0, 1))
+            dball = torch.stack([h0, h1], 1).reshape(Z, N)
+        else:
+            dball = ops.colsum_batched(dys, N, Z, M * lda)
+        dws, dbs = [], list(dball.unbind(0))
         for z in range(Z):
-            view = dys[z // 2][:, (z % 2) * Np:] if layout == 'catpair' else dys[z]
-            dbs.append(_colsum(view, N))
             if kmap is None:
                 dws.append(dW[z][:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
             else:
@@ -568,7 +572,7 @@ class Conv3x3Fn(Function):
                   a_zo=rows * Cop, a_zi=c * Cop, b_zo=rows * Cip, b_zi=c * Cip, d_zo=S * Co * 9 * Cip, d_zi=Co * 9 * Cip, conv=conv)
             dW = slabs.sum(1)
         dws = [dW[z].view(Co, 3, 3, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous() for z in range(Z)]
-        dbs = [_colsum(dy[z], Co) if has_bias else None for z in range(Z)]
+        dbs = list(ops.colsum_batched(dy, Co, Z, dy.stride(0)).unbind(0)) if has_bias else [None] * Z
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 
@@ -609,7 +613,7 @@ class UpConv3x3Fn(Function):
         dW9 = _wgrad_batched(dz, xa, N9, Kp, M, prec, Z, N9, Kp, M * N9, M * Kp)              # [Z, N9, Kp] fp32
         Cop = N9 // 9
         dws = [dW9[z].view(3, 3, Cop, Kp)[:, :, :Co, :Ci].permute(2, 3, 0, 1).contiguous() for z in range(Z)]
-        dbs = [_colsum(dy[z], Co) for z in range(Z)]
+        dbs = list(ops.colsum_batched(dy, Co, Z, dy.stride(0)).unbind(0))
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 

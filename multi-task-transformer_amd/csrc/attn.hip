@@ -271,6 +271,7 @@ int launch_attn(const AttnP& p, hipStream_t s) {
 }  // namespace
 
 int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s);     // attn_fast.hip
+int mtt_attn_fwd_x3_split(const mtt_attn_desc* dd, hipStream_t s); // attn_fast.hip
 
 extern "C" int mtt_attn_fwd(const mtt_attn_desc* dd, void* stream) {
   if (!dd || !dd->qkv || !dd->out) return MTT_E_BADARG;
@@ -281,6 +282,8 @@ extern "C" int mtt_attn_fwd(const mtt_attn_desc* dd, void* stream) {
   if (dd->variant != MTT_ATTN_PLAIN && dd->prec == MTT_PREC_BF16 && dd->dtype == MTT_BF16 && !((uintptr_t)dd->out & 15))
     return mtt_attn_fwd_fast(dd, (hipStream_t)stream);
   AttnP p; p.d = *dd;
+  if (dd->prec == MTT_PREC_X3 && dd->dtype == MTT_SPLIT && dd->variant != MTT_ATTN_PLAIN && !((uintptr_t)dd->out & 15) && !((uintptr_t)dd->out_lo & 15))
+    return mtt_attn_fwd_x3_split(dd, (hipStream_t)stream);
   if (dd->prec == MTT_PREC_X3) return dd->dtype == MTT_SPLIT ? launch_attn<true, 2>(p, (hipStream_t)stream) : launch_attn<true, 1>(p, (hipStream_t)stream);
   return dd->dtype == MTT_F32 ? launch_attn<false, 1>(p, (hipStream_t)stream) : launch_attn<false, 0>(p, (hipStream_t)stream);
 }

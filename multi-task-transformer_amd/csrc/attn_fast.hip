@@ -405,7 +405,300 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fast_kernel(const AttnP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// attn_fwd_x3_kernel: the same swapped-product flash kernel in fp32-class arithmetic on MTT_SPLIT planes (x = hi + lo bf16; the forward
+// of the x3f training mode and of x3f inference).  qkv arrives as two planes, every product is three MFMAs
+//   S^T = Kh Qh^T + Kh Ql^T + Kl Qh^T,      O^T += Vh^T Ph^T + Vh^T Pl^T + Vl^T Ph^T      (P = Ph + Pl split in registers)
+// and the output leaves as two planes again (the A operand of the LDS-DMA proj GEMM).  Staging as VER 2: the K / V tiles of BOTH planes
+// go HBM -> LDS by LDS-DMA (4 x 8 KiB per stage, 2 stages = 64 KiB, 2 workgroups per CU); K fragments by ds_read_b128, V^T fragments
+// by ds_read_b64_tr_b16.  The hi and the lo plane of an operand take turns in the SAME fragment registers (pass 1: Kh against Qh and Ql,
+// pass 2: Kl against Qh; likewise V), so the kernel stays under 256 VGPRs.  Softmax statistics, raw prompt-row logits and the
+// log-sum-exp (for the bf16 flash backward of the x3f mode) are fp32 exactly as in the bf16 kernel.
+// Inline-asm transpose reads follow the rule of tools/check_tr_hazards.py: all reads of a group are issued unconditionally, the waits
+// name every destination, no control flow in between.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int STAGE = 4 * KTILE;                  // K hi, K lo, V hi, V lo
+  const mtt_attn_desc& d = p.d;
+  const int nqb = (d.N + 127) / 128;
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = wi % nqb, bh = wi / nqb;
+  const int h = bh % d.nH, b = bh / d.nH;
+  const int N = d.N, C = d.nH * HD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t tok0 = (int64_t)b * N;
+  const bf16_t* qh_ = (const bf16_t*)d.qkv;
+  const bf16_t* ql_ = (const bf16_t*)d.qkv_lo;
+  const int q0 = qb * 128 + wave * 32;
+  const bool active = q0 < N;
+
+  u32x4 qfh[2][2], qfl[2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int qrow = q0 + sub * 16 + li;
+    const bool ok = qrow < N;
+    const int64_t qi = (tok0 + (ok ? qrow : 0)) * 3 * C + h * HD + lg * 8;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+      qfh[sub][kh] = ok ? *(const u32x4*)(qh_ + qi + kh * 32) : z;
+      qfl[sub][kh] = ok ? *(const u32x4*)(ql_ + qi + kh * 32) : z;
+    }
+  }
+
+  // LDS-DMA: wave w moves key rows [16 w, 16 w + 16) of the K and of the V tile of both planes as two 1-KiB pieces each
+  int dma_off[4], dma_row[2];
+  uint64_t zpage = (uint64_t)(uintptr_t)g_attn_zero_page;
+  asm volatile("" : "+s"(zpage));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wave * 16 + i * 8 + (lane >> 3), pc = lane & 7;
+    dma_row[i] = r;
+    dma_off[i] = r * 3 * C + C + ((pc ^ (r >> 1)) & 7) * 8;
+    dma_off[2 + i] = r * 3 * C + 2 * C + (((((pc >> 1) ^ (r >> 1)) & 3) << 1) | (pc & 1)) * 8;
+  }
+  auto dma_issue = [&](unsigned char* st, int kv0) {
+    const int64_t boff = (tok0 + kv0) * 3 * C + h * HD;
+    const bool full = kv0 + KV <= N;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const bf16_t* base = (pl ? ql_ : qh_) + boff;
+#pragma unroll
+      for (int kv = 0; kv < 2; ++kv) {
+        unsigned char* dst = st + (kv * 2 + pl) * KTILE + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bool ok = full || kv0 + dma_row[i] < N;
+          attn_glds16((const bf16_t*)(uintptr_t)(ok ? (uint64_t)(uintptr_t)(base + dma_off[kv * 2 + i]) : zpage), dst + i * 1024);
+        }
+      }
+    }
+  };
+  const int vrow = 4 * lg + (li >> 2);
+  const int vf_ = (vrow >> 1) & 3;
+  unsigned vaddr[4];                                 // V hi plane, stage 0; lo plane = + KTILE
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vaddr[dt] = (unsigned)(uintptr_t)smem + (unsigned)(2 * KTILE + vrow * 128 + (li & 3) * 8 + ((dt ^ vf_) & 3) * 32);
+  const unsigned char* kaddr[2];                     // K hi plane, stage 0; lo plane = + KTILE
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) kaddr[kh] = smem + li * 128 + (((kh * 4 + lg) ^ (li >> 1)) & 7) * 16;
+
+  f32x4 o[2][4];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[sub][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
+  const float sc2 = d.scale * LOG2E;
+  const bool write_raw = d.rawlog != nullptr && d.T > 0 && qb == 0 && wave == 0 && li < d.T;
+
+  const int nkv = (N + KV - 1) / KV;
+  dma_issue(smem, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto tile = [&](auto stage_tag, int j) {
+    constexpr int ST = decltype(stage_tag)::value;
+    const bool more = j + 1 < nkv;
+    if (more) dma_issue(smem + (1 - ST) * STAGE, (j + 1) * KV);
+    const int kv0 = j * KV;
+    if (active) {
+      // ---- S^T = Kh Qh^T + Kh Ql^T + Kl Qh^T ----------------------------------------------------------------------------
+      f32x4 s[2][4];
+      {
+        u32x4 kf[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) kf[kt][kh] = *(const u32x4*)(kaddr[kh] + ST * STAGE + kt * 2048);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          s[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          s[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) {
+            s[0][kt] = mfma16(kf[kt][kh], qfl[0][kh], s[0][kt]);
+            s[1][kt] = mfma16(kf[kt][kh], qfl[1][kh], s[1][kt]);
+            s[0][kt] = mfma16(kf[kt][kh], qfh[0][kh], s[0][kt]);
+            s[1][kt] = mfma16(kf[kt][kh], qfh[1][kh], s[1][kt]);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) kf[kt][kh] = *(const u32x4*)(kaddr[kh] + ST * STAGE + KTILE + kt * 2048);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) {
+            s[0][kt] = mfma16(kf[kt][kh], qfh[0][kh], s[0][kt]);
+            s[1][kt] = mfma16(kf[kt][kh], qfh[1][kh], s[1][kt]);
+          }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (write_raw) {
+        float* rl = d.rawlog + (((int64_t)b * d.nH + h) * d.T + li) * N;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + kt * 16 + lg * 4 + r;
+            if (key < N) rl[key] = s[0][kt][r];
+          }
+      }
+      if (kv0 + KV > N) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if ((kv0 + kt * 16 + lg * 4 + r) >= N) s[sub][kt][r] = -INFINITY;
+      }
+      u32x4 pbh[2][2], pbl[2][2];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        float mx = s[sub][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][kt][r]);
+        mx = groups_max(mx);
+        const float m_new = fmaxf(m_run[sub], mx * sc2);
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[sub]) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new);
+          l_part[sub] *= alpha;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[sub][t][r] *= alpha;
+          m_run[sub] = m_new;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sc2, -m_new));
+            s[sub][kt][r] = pv;
+            rs += pv;
+          }
+        l_part[sub] += rs;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4 ph = (u32x4){pack2(s[sub][2 * ks][0], s[sub][2 * ks][1]), pack2(s[sub][2 * ks][2], s[sub][2 * ks][3]),
+                                   pack2(s[sub][2 * ks + 1][0], s[sub][2 * ks + 1][1]), pack2(s[sub][2 * ks + 1][2], s[sub][2 * ks + 1][3])};
+          pbh[sub][ks] = ph;
+          pbl[sub][ks] = (u32x4){pack2(s[sub][2 * ks][0] - lo_of(ph.x), s[sub][2 * ks][1] - hi_of(ph.x)),
+                                 pack2(s[sub][2 * ks][2] - lo_of(ph.y), s[sub][2 * ks][3] - hi_of(ph.y)),
+                                 pack2(s[sub][2 * ks + 1][0] - lo_of(ph.z), s[sub][2 * ks + 1][1] - hi_of(ph.z)),
+                                 pack2(s[sub][2 * ks + 1][2] - lo_of(ph.w), s[sub][2 * ks + 1][3] - hi_of(ph.w))};
+        }
+      }
+      // ---- O^T += Vh^T Ph^T + Vh^T Pl^T (pass 0), + Vl^T Ph^T (pass 1): the two planes take turns in the same fragment registers ----
+      const bool half1 = kv0 + 32 < N;
+#define ATW(x) "+v"(x)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        u32x2 v0l[4], v0h[4], v1l[4], v1h[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          if (pass == 0) {
+            v0l[dt] = attn_ds_read_tr16<ST * STAGE>(vaddr[dt]);
+            v0h[dt] = attn_ds_read_tr16<ST * STAGE + 16 * 128>(vaddr[dt]);
+          } else {
+            v0l[dt] = attn_ds_read_tr16<ST * STAGE + KTILE>(vaddr[dt]);
+            v0h[dt] = attn_ds_read_tr16<ST * STAGE + KTILE + 16 * 128>(vaddr[dt]);
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          if (pass == 0) {
+            v1l[dt] = attn_ds_read_tr16<ST * STAGE + 32 * 128>(vaddr[dt]);
+            v1h[dt] = attn_ds_read_tr16<ST * STAGE + 48 * 128>(vaddr[dt]);
+          } else {
+            v1l[dt] = attn_ds_read_tr16<ST * STAGE + KTILE + 32 * 128>(vaddr[dt]);
+            v1h[dt] = attn_ds_read_tr16<ST * STAGE + KTILE + 48 * 128>(vaddr[dt]);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : ATW(v0l[0]), ATW(v0l[1]), ATW(v0l[2]), ATW(v0l[3]), ATW(v0h[0]), ATW(v0h[1]), ATW(v0h[2]), ATW(v0h[3]),
+                       ATW(v1l[0]), ATW(v1l[1]), ATW(v1l[2]), ATW(v1l[3]), ATW(v1h[0]), ATW(v1h[1]), ATW(v1h[2]), ATW(v1h[3]) :: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const u32x4 vf = (u32x4){v0l[dt][0], v0l[dt][1], v0h[dt][0], v0h[dt][1]};
+          if (pass == 0) {
+            o[0][dt] = mfma16(vf, pbl[0][0], o[0][dt]);
+            o[1][dt] = mfma16(vf, pbl[1][0], o[1][dt]);
+          }
+          o[0][dt] = mfma16(vf, pbh[0][0], o[0][dt]);
+          o[1][dt] = mfma16(vf, pbh[1][0], o[1][dt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : ATW(v1l[0]), ATW(v1l[1]), ATW(v1l[2]), ATW(v1l[3]), ATW(v1h[0]), ATW(v1h[1]), ATW(v1h[2]), ATW(v1h[3]) :: "memory");
+        if (half1) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const u32x4 vf = (u32x4){v1l[dt][0], v1l[dt][1], v1h[dt][0], v1h[dt][1]};
+            if (pass == 0) {
+              o[0][dt] = mfma16(vf, pbl[0][1], o[0][dt]);
+              o[1][dt] = mfma16(vf, pbl[1][1], o[1][dt]);
+            }
+            o[0][dt] = mfma16(vf, pbh[0][1], o[0][dt]);
+            o[1][dt] = mfma16(vf, pbh[1][1], o[1][dt]);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+#undef ATW
+    }
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  for (int j = 0; j < nkv; j += 2) {
+    tile(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < nkv) tile(std::integral_constant<int, 1>{}, j + 1);
+  }
+
+  // ---- epilogue: o[sub][dt][r] = O[q = li][d = 16 dt + 4 lg + r], written as hi / lo planes ----------------------------------
+  bf16_t* outh = (bf16_t*)d.out;
+  bf16_t* outl = (bf16_t*)d.out_lo;
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const float l = groups_sum(l_part[sub]);
+    const int qrow = q0 + sub * 16 + li;
+    if (qrow >= N) continue;
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const float v0 = o[sub][dt][0] * inv, v1 = o[sub][dt][1] * inv, v2 = o[sub][dt][2] * inv, v3 = o[sub][dt][3] * inv;
+      const u32x2 hi = (u32x2){pack2(v0, v1), pack2(v2, v3)};
+      const int64_t oi = (tok0 + qrow) * C + h * HD + dt * 16 + lg * 4;
+      *(u32x2*)(outh + oi) = hi;
+      *(u32x2*)(outl + oi) = (u32x2){pack2(v0 - lo_of(hi.x), v1 - hi_of(hi.x)), pack2(v2 - lo_of(hi.y), v3 - hi_of(hi.y))};
+    }
+    if (d.lse && lg == 0) d.lse[((int64_t)b * d.nH + h) * N + qrow] = (m_run[sub] + log2f(l)) * 0.6931471805599453f;
+  }
+}
+
 }  // namespace
+
+// called by mtt_attn_fwd (attn.hip) for MTT_SPLIT storage + MTT_PREC_X3
+int mtt_attn_fwd_x3_split(const mtt_attn_desc* dd, hipStream_t s) {
+  constexpr int smem = 2 * 4 * KTILE;
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)attn_fwd_x3_kernel, smem, done)) return e;
+  AttnP p; p.d = *dd;
+  dim3 grid((unsigned)(((dd->N + 127) / 128) * dd->nH * dd->B));
+  hipLaunchKernelGGL(attn_fwd_x3_kernel, grid, dim3(256), smem, s, p);
+  return (int)hipGetLastError();
+}
 
 // called by mtt_attn_fwd (attn.hip) for bf16 storage + MTT_PREC_BF16
 int mtt_attn_fwd_fast(const mtt_attn_desc* dd, hipStream_t s) {

@@ -575,9 +575,12 @@ MTT_DEV float act_bwd(float u, int act) { return act == MTT_ACT_GELU ? gelu_grad
 // Column sums (bias gradients), deterministic: no atomics, fixed summation order.  Stage 1, grid (row blocks, chunks of 2048 columns):
 // every lane sums its rows of one 8-column group with four independent loads in flight, the row lanes of the block are combined
 // through LDS in lane order, one partial row per block goes to ws [nblk][pad8(cols)].  Stage 2 sums the partials in block order.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* src, float* ws, int64_t rows, int cols, int64_t ld, int dtype,
-                                                             int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* src_, float* ws, int64_t rows, int cols, int64_t ld, int dtype,
+                                                             int rows_per_block, int64_t src_zs) {
   __shared__ float lsm[2048];
+  // blockIdx.z = map z of a batch: source z starts src_zs elements after source z - 1, its partials after those of z - 1
+  const void* src = (const unsigned char*)src_ + (int64_t)blockIdx.z * src_zs * (dtype == MTT_F32 ? 4 : 2);
+  ws += (int64_t)blockIdx.z * gridDim.x * (((int64_t)cols + 7) / 8 * 8);
   const int c0 = blockIdx.y * 2048;
   const int ncol = cols - c0 < 2048 ? cols - c0 : 2048;
   const int C8 = (ncol + 7) >> 3, Cp = C8 * 8;
@@ -618,8 +621,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* src, fl
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* ws, float* dst, int cols, int nblk) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* ws, float* dst, int cols, int nblk, int64_t dst_zs) {
   __shared__ float sh[8][32];
+  ws += (int64_t)blockIdx.z * nblk * (((int64_t)cols + 7) / 8 * 8);
+  dst += (int64_t)blockIdx.z * dst_zs;
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int64_t colsP = ((int64_t)cols + 7) / 8 * 8;
@@ -994,6 +999,60 @@ __global__ __launch_bounds__(256) void chanlogit_bwd_kernel(const mtt_chanlogit_
 
 // ------------------------------------------------------------------------------------------------
 // dwmix[b,t,s] += sum_{rows in b, c} dout[t][row,c] * fea[s][row,c]
+// Token-grouped form (T <= 8, window width % 4 == 0): a wave takes FOUR consecutive pixels of one window row, so the T gradient rows
+// drawchan[b, t, win, :] it multiplies with — 4 KiB each, served by L2 — are loaded once per group instead of once per pixel (the
+// one-pixel form above moved 24 KiB of L2 traffic per pixel for 10 KiB of HBM traffic and ran at 1.0-1.6 TB/s).
+__global__ __launch_bounds__(256) void chanlogit_bwd_tok4_kernel(const mtt_chanlogit_desc d, const float* drawchan, void* dq, int dq_dtype,
+                                                                 float* dxn) {
+  constexpr int TOK = 4;
+  const int lane = threadIdx.x & 63;
+  const int hw = d.h * d.w, nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw;
+  const int64_t gid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gid >= (int64_t)d.B * hw / TOK) return;
+  const int b = (int)(gid / (hw / TOK)), p0 = (int)(gid % (hw / TOK)) * TOK;
+  const int y = p0 / d.w, x = p0 % d.w;
+  const int win = (y / wh) * d.nw + (x / ww);
+  const int64_t xrow = ((int64_t)b * d.N + d.T + p0) * d.C;
+  const int C8 = d.C >> 3;
+  float qv[CL_MAXT][TOK], sq[CL_MAXT][TOK];
+#pragma unroll
+  for (int t = 0; t < CL_MAXT; ++t)
+#pragma unroll
+    for (int k = 0; k < TOK; ++k) {
+      sq[t][k] = 0.f;
+      qv[t][k] = t < d.T ? ld_elem(d.q, ((int64_t)b * d.T + t) * d.ldq + p0 + k, d.dtype) : 0.f;
+    }
+#pragma unroll 1
+  for (int c8 = lane; c8 < C8; c8 += 64) {
+    float xv[TOK][8], da[TOK][8];
+#pragma unroll
+    for (int k = 0; k < TOK; ++k) {
+      ld8(d.xn, xrow + (int64_t)k * d.C + c8 * 8, d.dtype, xv[k]);
+      ld8(dxn, xrow + (int64_t)k * d.C + c8 * 8, MTT_F32, da[k]);
+    }
+#pragma unroll
+    for (int t = 0; t < CL_MAXT; ++t)
+      if (t < d.T) {
+        float g[8];
+        ld8(drawchan, (((int64_t)b * d.T + t) * nwin + win) * d.C + c8 * 8, MTT_F32, g);
+#pragma unroll
+        for (int k = 0; k < TOK; ++k)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { sq[t][k] += g[j] * xv[k][j]; da[k][j] += g[j] * qv[t][k]; }
+      }
+#pragma unroll
+    for (int k = 0; k < TOK; ++k) st8(dxn, xrow + (int64_t)k * d.C + c8 * 8, MTT_F32, da[k]);
+  }
+#pragma unroll
+  for (int t = 0; t < CL_MAXT; ++t)
+    if (t < d.T) {
+#pragma unroll
+      for (int k = 0; k < TOK; ++k) {
+        const float v = wave_sum(sq[t][k]);
+        if (lane == 0) st_elem(dq, ((int64_t)b * d.T + t) * d.ldq + p0 + k, dq_dtype, v);
+      }
+    }
+}
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ctr_dw_kernel(const mtt_ctr_desc d, const float* dout, float* part, int rows_per_block) {
   __shared__ float red[4][CTR_MAXT * CTR_MAXT];
@@ -1264,7 +1323,7 @@ extern "C" int mtt_bn_stats(const mtt_bn_desc* d, float* ws, void* stream) {
 static void colsum_cfg(int64_t rows, int32_t cols, int& nblk, int& rpb, int& nchunk) {
   nchunk = (cols + 2047) / 2048;
   int64_t nb = (rows + 63) / 64;
-  const int64_t cap = 1536 / nchunk > 1 ? 1536 / nchunk : 1;
+  const int64_t cap = 768 / nchunk > 1 ? 768 / nchunk : 1;      // 768 row blocks saturate HBM; more only lengthen the second stage
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   rpb = (int)((rows + nb - 1) / nb);
@@ -1276,10 +1335,14 @@ extern "C" size_t mtt_colsum_ws_floats(int64_t rows, int32_t cols) {
   return (size_t)nblk * (size_t)((cols + 7) / 8 * 8);
 }
 extern "C" int mtt_colsum(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, float* ws, void* stream) {
-  if (!src || !dst || !ws || rows <= 0 || cols <= 0 || (ld % 8) || ld < (cols + 7) / 8 * 8) return MTT_E_BADARG;
+  return mtt_colsum_batched(src, dst, rows, cols, ld, src_dtype, 1, 0, 0, ws, stream);
+}
+extern "C" int mtt_colsum_batched(const void* src, float* dst, int64_t rows, int32_t cols, int64_t ld, int src_dtype, int32_t Z, int64_t src_zs,
+                                  int64_t dst_zs, float* ws, void* stream) {
+  if (!src || !dst || !ws || rows <= 0 || cols <= 0 || Z <= 0 || Z > 65535 || (ld % 8) || ld < (cols + 7) / 8 * 8 || (src_zs % 8)) return MTT_E_BADARG;
   int nblk, rpb, nchunk; colsum_cfg(rows, cols, nblk, rpb, nchunk);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, nchunk), dim3(256), 0, S_, src, ws, rows, cols, ld, src_dtype, rpb);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, S_, (const float*)ws, dst, cols, nblk);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, nchunk, Z), dim3(256), 0, S_, src, ws, rows, cols, ld, src_dtype, rpb, src_zs);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32, 1, Z), dim3(256), 0, S_, (const float*)ws, dst, cols, nblk, dst_zs);
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, float* ws, void* stream) {
@@ -1342,7 +1405,10 @@ extern "C" int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* dra
   if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
   if (d->T > 2 * CL_MAXT) return MTT_E_UNSUPPORTED;
   const int64_t toks = (int64_t)d->B * d->h * d->w;
-  hipLaunchKernelGGL(chanlogit_bwd_kernel, dim3((unsigned)((toks + 3) / 4)), dim3(256), 0, S_, *d, drawchan, dq, dq_dtype, dxn);
+  if (d->T <= CL_MAXT && ((d->w / d->nw) % 4) == 0 && (d->w % 4) == 0)
+    hipLaunchKernelGGL(chanlogit_bwd_tok4_kernel, dim3((unsigned)((toks / 4 + 3) / 4)), dim3(256), 0, S_, *d, drawchan, dq, dq_dtype, dxn);
+  else
+    hipLaunchKernelGGL(chanlogit_bwd_kernel, dim3((unsigned)((toks + 3) / 4)), dim3(256), 0, S_, *d, drawchan, dq, dq_dtype, dxn);
   return LAUNCH_OK();
 }
 

@@ -478,6 +478,17 @@ def colsum(x2d, cols):
     return out
 
 
+def colsum_batched(x3d, cols, Z, src_zs, col_off=0):
+    """fp32 [Z, cols] column sums of Z maps [rows, ld] of one tensor (map z starts col_off + z * src_zs elements into x3d's storage view
+    `x3d.reshape(-1)`): the bias gradients of a task-batched layer in ONE launch pair."""
+    rows, ld = x3d.shape[-2], x3d.stride(-2)
+    out = torch.empty(Z, cols, dtype=torch.float32, device=x3d.device)
+    ws = workspace(Z * _lib.load().mtt_colsum_ws_floats(rows, cols), x3d.device)
+    src = x3d.reshape(-1)[col_off:] if col_off else x3d
+    call("colsum_batched", args=[src, out, rows, cols, ld, dtype_code(x3d), Z, src_zs, cols, ws])
+    return out
+
+
 def _bn_ws(rows, C, Z, device):
     return workspace(_lib.load().mtt_bn_reduce_ws_floats(rows, C, Z), device)
 

@@ -484,6 +484,13 @@ def colsum(args):
     _wr(dst, ci, _rd(src, r * ld + c).sum(0))
 
 
+def colsum_batched(args):
+    src, dst, rows, cols, ld, dt, Z, src_zs, dst_zs = args[:9]
+    for z in range(Z):
+        r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
+        _wr(dst, z * dst_zs + torch.arange(cols), _rd(src, z * src_zs + r * ld + c).sum(0))
+
+
 def add_rows(args):
     src, dst, rows, cols, lds, ldd, sdt, alpha = args[:8]
     r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
@@ -1036,7 +1043,7 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=wina
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
               loss_fwd=loss_fwd, loss_bwd=loss_bwd, chanattn_bwd=chanattn_bwd, conv3s2_nchw_bwd=conv3s2_nchw_bwd)
-_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, add_rows=add_rows, rowscale_cast=rowscale_cast)
+_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, colsum_batched=colsum_batched, add_rows=add_rows, rowscale_cast=rowscale_cast)
 
 
 def call(name, **kw):

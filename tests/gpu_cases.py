@@ -389,6 +389,9 @@ def attn_cases():
                   out_lo=torch.zeros(B * N, C, dtype=torch.bfloat16), rawlog=torch.zeros(B, nH, max(T, 1), N) if T else None,
                   lse=torch.zeros(B, nH, N), B=B, N=N, nH=nH, T=T, dtype=SPLIT, prec=1, scale=0.125)
         cases.append((f"attn_B{B}N{N}T{T}_split", "attn_fwd", kw, dict(f32=3e-5, bf16=6e-3, split=3e-5, split_pairs=[("out", "out_lo")])))
+        kp = dict(kw, out=torch.zeros(B * N, C, dtype=torch.bfloat16), out_lo=torch.zeros(B * N, C, dtype=torch.bfloat16),
+                  rawlog=torch.zeros(B, nH, max(T, 1), N) if T else None, lse=torch.zeros(B, nH, N), variant=1)      # the register-staged x3 kernel on planes
+        cases.append((f"attn_B{B}N{N}T{T}_split_plain", "attn_fwd", kp, dict(f32=3e-5, bf16=6e-3, split=3e-5, split_pairs=[("out", "out_lo")])))
     # softmax spike (forces large running-max jumps across tiles)
     B, N, nH, T = 1, 200, 1, 2
     q = rnd(g, B * N, 3 * 64)
@@ -473,9 +476,9 @@ def row_cases():
         kw = dict(q=rnd(g, B * T, h * w, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.full((B, T, 1, C), 9.0),
                   B=B, T=T, N=N, C=C, h=h, w=w, nh=1, nw=1, dtype=dt, ldq=h * w, ws=scratch(64 * B * T * C))
         cases.append((f"chanlogit_{dt}_splits", "chan_logits", kw, TOL_ROW))
-    # backward-only kernels
+    # backward-only kernels ((8, 8, *): window widths that are multiples of 4 take the token-grouped chan_logits_bwd kernel)
     for dt in (F32, BF16):
-        for (h, w, nh) in ((4, 6, 1), (4, 6, 2)):
+        for (h, w, nh) in ((4, 6, 1), (4, 6, 2), (8, 8, 1), (8, 8, 2)):
             B, T, C = 2, 5, 128
             N = T + h * w
             ldq = (h * w + 7) // 8 * 8
@@ -485,11 +488,11 @@ def row_cases():
                       out=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt,
                       xargs=[rnd(g, 2 * T, B * h * w, C, dtype=DT[dt]), dXT[:, T:], torch.zeros(B, C // 64, T, N), torch.full((B, T, nh * nh, C), 9.0),
                              scratch(32 * B * T * nh * nh * C)])
-            cases.append((f"modulate_bwd_{dt}_win{nh}", "modulate_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
+            cases.append((f"modulate_bwd_{dt}_{h}x{w}_win{nh}", "modulate_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
             kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=None,
                       B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, dtype=dt, ldq=ldq,
                       xargs=[rnd(g, B, T, nh * nh, C), torch.zeros(B * T, ldq, dtype=DT[dt]), dt, rnd(g, B * N, C)])
-            cases.append((f"chanlogit_bwd_{dt}_win{nh}", "chan_logits_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
+            cases.append((f"chanlogit_bwd_{dt}_{h}x{w}_win{nh}", "chan_logits_bwd", kw, dict(f32=2e-5, bf16=5e-3)))
         T, B, rpb, ld, C = 6, 2, 300, 56, 52
         fea = rnd(g, T, B * rpb, ld, dtype=DT[dt]); fea[..., C:] = 0
         kw = dict(fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rpb, ld=ld, C=C, fea_dtype=dt, accumulate=0,
@@ -567,6 +570,13 @@ def row_cases():
         for (r_, c_, ld_) in ((5000, 4104, 4112), (1031, 350, 352), (70, 1024, 1024)):     # two column chunks + ragged tail / row lanes / few rows
             cases.append((f"colsum_{dt}_{r_}x{c_}", "colsum",
                           dict(args=[rnd(g, r_, ld_, dtype=DT[dt]), torch.full((c_,), 3.0), r_, c_, ld_, dt, scratch(1536 * ld_)]), TOL_ROW))
+        # Z maps per launch pair (task-batched bias gradients): plain stack, and the second half of a 'catpair' row (column offset)
+        Zb, r_, c_, ld_ = 5, 700, 300, 2 * 304
+        src = rnd(g, Zb, r_, ld_, dtype=DT[dt])
+        cases.append((f"colsum_batched_{dt}", "colsum_batched",
+                      dict(args=[src, torch.full((Zb, c_), 3.0), r_, c_, ld_, dt, Zb, r_ * ld_, c_, scratch(Zb * 1536 * ld_)]), TOL_ROW))
+        cases.append((f"colsum_batched_half_{dt}", "colsum_batched",
+                      dict(args=[src.reshape(-1)[304:], torch.full((Zb, c_), 3.0), r_, c_, ld_, dt, Zb, r_ * ld_, c_, scratch(Zb * 1536 * ld_)]), TOL_ROW))
         cases.append((f"add_rows_{dt}", "add_rows", dict(args=[rnd(g, 30, 24, dtype=DT[dt]), rnd(g, 30, 32), 30, 20, 24, 32, dt, 0.5]), TOL_ROW))
     return cases
 

