@@ -105,15 +105,14 @@ class GemmTimer:
     dominant variant, with its algorithmic FLOPs."""
 
     def __init__(self, lib, variant_of):
-        self.lib, self.orig, self.rec, self.variant_of, self.persistent = lib, lib.call, [], variant_of, 0
+        self.lib, self.orig, self.rec, self.variant_of = lib, lib.call, [], variant_of
 
     def __enter__(self):
         def hooked(name, **kw):
             if name == "gemm" and getattr(self.lib, "GEMM_VARIANT", None) is not None and not kw.get("variant"):
                 kw["variant"] = self.lib.GEMM_VARIANT
             v = self.variant_of(**kw) if name == "gemm" else -1
-            if v in (3, 7):                                            # the dominant kernel: 256 x 256 LDS-DMA MFMA GEMM (7 = persistent form)
-                self.persistent += int(v == 7)
+            if v == 3:                                                 # the dominant kernel: 256 x 256 LDS-DMA MFMA GEMM (bf16)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self.orig(name, **kw)
@@ -467,17 +466,12 @@ def main():
             step()
             flops, ms, n = gt_.result()
         tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        pers = gt_.persistent * 2 > n
-        traffic, tsrc = _pmc_traffic("gemm_pdma_kernel" if pers else "gemm_dma_kernel<256")
+        traffic, tsrc = _pmc_traffic("gemm_dma_kernel<1>")
         roof = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc, algorithmic_bytes_per_launch=int(gt_.algorithmic_bytes / max(n, 1)),
-                    kernel=("gemm_pdma_kernel<KIND> (persistent workgroups, K loop continuous across 256x256x64 tiles, bf16 MFMA 16x16x32, LDS-DMA "
-                            "staging, staggered read / MFMA phases, per-wave epilogue) + gemm_dma_kernel<256> for the ineligible calls"
-                            if pers else
-                            "gemm_dma_kernel<256, false, 7> (256x256x64 tile, bf16 MFMA 16x16x32, LDS-DMA staging with wave-uniform base + 32-bit lane "
-                            "offset addressing, staggered read / MFMA phases, specialised interior-tile epilogue; <256, false, 0> = the same kernel with "
-                            "general addressing for calls with a K tail)") + ": every encoder Linear forward and input gradient of the step",
-                    persistent_launches=gt_.persistent,
+                    kernel="gemm_dma_kernel<1> (256x256x64 tile, bf16 MFMA 16x16x32, LDS-DMA staging with wave-uniform base + 32-bit lane offset "
+                           "addressing, staggered read / MFMA phases, specialised interior-tile epilogue; <0> = the same kernel with general "
+                           "addressing for calls with a K tail): every encoder Linear forward and input gradient of the step",
                     launches=n, kernel_ms_per_step=round(ms, 3), algorithmic_tflop_per_step=round(flops / 1e12, 2))
 
     # the reference's own per-GPU batch (trBatch: 2, yml:8), same step, same process

@@ -5,7 +5,7 @@ both in KiB.  Run ON THE GPU BOX after the two passes:
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f -o f -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-ref-batch
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w -o w -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-ref-batch
-    python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w gemm_dma_kernel<256 > gpurun_out/pmc_traffic.json
+    python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w 'gemm_dma_kernel<1>' > gpurun_out/pmc_traffic.json
 
 Output: one JSON object {kernel, launches, fetch_kib_raw, write_kib, hbm_bytes_per_launch, source} — committed as
 profiles/pmc_traffic.json, which bench.py reports as roofline.traffic.
