@@ -250,6 +250,7 @@ def _torch_baseline_worker(cfg_name, mode):
                 opt.step()
                 return loss
             step()
+            step()                                   # two untimed steps: MIOpen / hipBLASLt pick their kernels on first use
             T.cuda.synchronize()
             n = 3 if batch <= 8 else 2
             t0 = time.perf_counter()
