@@ -12,6 +12,9 @@
 
 namespace {
 
+#ifndef MTT_GROUP_M
+#define MTT_GROUP_M 4        // tile rows swept together by the grouped tile order (tools/gemm_bench.py measures other values on library builds)
+#endif
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per bf16 plane
 
@@ -1135,7 +1138,7 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   p.divPsW = make_div(d.ps_W > 0 ? d.ps_W : 1); p.divPsH = make_div(d.ps_H > 0 ? d.ps_H : 1);
   p.divPsCo = make_div(d.ps_Co > 0 ? d.ps_Co : 1);
   p.tiles_m = (d.M + BM - 1) / BM; p.tiles_n = (d.N + BN - 1) / BN;
-  p.group_m = 4;
+  p.group_m = MTT_GROUP_M;
   hipStream_t s = (hipStream_t)stream;
   const int v = gemm_variant_for(d);
   if (v < 0) return v;
