@@ -73,3 +73,22 @@ for name, M, N, K, act in SHAPES:
         line += f"  |  split x3: {2.0 * M * N * K / m2 / 1e9:6.0f} TF/s effective = {6.0 * M * N * K / m2 / 1e9:6.0f} MFMA TF/s ({m2 * 1e3:7.1f} us)"
     print(line, flush=True)
 print(f"sum of the step's five shapes: {tot * 1e3:.1f} us", flush=True)
+
+# correctness screen of the loaded build: the LDS-DMA kernel against the register-staged general kernel (ragged M, K = 1024 and 4096),
+# 20 launches each bitwise equal to the first (race screen)
+for (M, N, K) in ((M63, 1024, 1024), (5000, 768, 4096)):
+    x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
+    w = (torch.rand(1, N, K, device="cuda") * 2 - 1).bfloat16()
+    b = torch.randn(1, N, device="cuda")
+    ref = torch.empty(1, M, N, device="cuda")
+    ops.call("gemm", A=x, B=w, D=ref, M=M, N=N, K=K, a_op=0, b_op=0, a_dtype=1, b_dtype=1, d_dtype=0, prec=0, lda=K, ldb=K, ldd=N, batch=1,
+             batch_inner=1, alpha=1.0, colshift=b, n_store=N, variant=1)
+    first, bad = None, 0
+    for i in range(20):
+        out = torch.full((1, M, N), 7.0, device="cuda")
+        ops.call("gemm", A=x, B=w, D=out, M=M, N=N, K=K, a_op=0, b_op=0, a_dtype=1, b_dtype=1, d_dtype=0, prec=0, lda=K, ldb=K, ldd=N, batch=1,
+                 batch_inner=1, alpha=1.0, colshift=b, n_store=N, variant=3)
+        first = out if first is None else first
+        bad += int(not torch.equal(out, first))
+    err = float((first - ref).norm() / ref.norm())
+    print(f"check M={M} N={N} K={K}: rel diff vs general kernel {err:.2e}, {bad} of 20 launches differ from the first", flush=True)
