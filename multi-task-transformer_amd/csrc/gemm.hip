@@ -12,9 +12,6 @@
 
 namespace {
 
-#ifndef MTT_DMA_SCHED
-#define MTT_DMA_SCHED 0      // 1: LDS-DMA issues interleaved with the C-phase MFMAs (library-build experiment, tools/gemm_bench.py)
-#endif
 #ifndef MTT_GROUP_M
 #define MTT_GROUP_M 4        // tile rows swept together by the grouped tile order (tools/gemm_bench.py measures other values on library builds)
 #endif
@@ -759,24 +756,6 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
     }
   };
 
-  // one of this wave's 8 pieces of K step s (0-3: A, 4-7: B), FASTADDR only: the MFMA-interleaved schedule (MTT_DMA_SCHED = 1)
-  auto issue_piece = [&](int stage, int s, int i) {
-    if constexpr (FASTADDR) {
-      int t = s;
-      const unsigned char* Ak = (const unsigned char*)Abase;
-      const unsigned char* Bk = (const unsigned char*)Bbase;
-      if constexpr (X3CAT) {
-        t = (s * 21846) >> 16;
-        const int j = s - 3 * t;
-        if (j == 1) Ak = (const unsigned char*)AbaseL;
-        if (j == 2) Bk = (const unsigned char*)BbaseL;
-      }
-      if (i < 4) glds16((const bf16_t*)(Ak + (size_t)t * (BK * 2) + aoff32[i]), smem + stage * STAGE + wave * 4096 + i * 1024);
-      else glds16((const bf16_t*)(Bk + (size_t)t * (BK * 2) + boff32[i - 4]), smem + stage * STAGE + TILE_A + wave * 4096 + (i - 4) * 1024);
-    }
-  };
-  constexpr bool ILV = FASTADDR && (MTT_DMA_SCHED == 1);      // LDS-DMA issues interleaved with the MFMAs of the C phases (experiment)
-
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -787,75 +766,44 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // tile 0 is in LDS
-  if (ILV && late && nk > 1) {                     // what C1(-1) of the late half would have issued: tile 1
-#pragma unroll
-    for (int i = 0; i < 8; ++i) issue_piece(1, 1, i);
-  }
   if (late) __builtin_amdgcn_s_barrier();          // stagger: waves 4-7 start one slot later
   __builtin_amdgcn_sched_barrier(0);
 
-  // the loop body is instantiated once per half, as in round 2 (one straight-line schedule per half for the register allocator)
-  // MTT_DMA_SCHED = 1 (ILV): no LDS-DMA in the R phases.  Slot = 4 kt + phase (+ 1 for the late half); tile kt+1 must have landed by the
-  // barrier closing slot 4 kt + 3, and stage (kt+1)&1 may be overwritten from slot 4 kt on (its last readers ran in slot 4 kt - 1):
-  //   early half: the 8 pieces of tile kt+1 between the MFMAs of C0(kt) [slot 4kt+1], vmcnt(0) at the end of C1(kt) [slot 4kt+3]
-  //   late  half: the 8 pieces of tile kt+2 between the MFMAs of C1(kt) [slot 4kt+4 = 4(kt+1)] — stage kt&1, last read in R1(kt)
-  //               [slots 4kt+2 / 4kt+3] —, vmcnt(0) at the end of R1(kt+1) [slot 4(kt+1)+3]
+  // the loop body is instantiated once per half, as in round 2 (one straight-line schedule per half for the register allocator).
+  // (Round 3 also measured the LDS-DMA issues moved out of R0 and interleaved with the MFMAs of the C phases — early half: tile kt+1 in
+  // C0(kt), late half: tile kt+2 in C1(kt) — bitwise equal and race-clean, but within +-1 % on every step shape:
+  // profiles/r03_gemm_bench_f_dma_sched.log.  Where the pieces are issued is not what bounds the K loop.)
   auto main_loop = [&](auto late_tag) {
-  constexpr bool LATE = decltype(late_tag)::value;
-  // one K step; CARRY (ILV only): this step's C phase issues a tile — a compile-time property, so that the MFMA / LDS-DMA interleave
-  // carries no branches (the last one or two steps of a tile are a second instantiation)
-  auto kstep = [&](int kt, auto carry_tag) {
-    constexpr bool CARRY = decltype(carry_tag)::value;
+  (void)late_tag;
+  for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* Ah = smem + (kt & 1) * STAGE;
     const unsigned char* Bh = Ah + TILE_A;
-    auto half = [&](auto kh_tag) {
-      constexpr int kh = decltype(kh_tag)::value;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
       // ---- R phase: fragments of this 32-deep half (+ this wave's share of the next tile's LDS-DMA) ----
-      if (!ILV && kh == 0 && kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+      if (kh == 0 && kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
       u32x4 fa[MT], fb[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
 #pragma unroll
       for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * (MT * 16) + t * 16 + li, kh * 4 + lg));
-      if (kh == 1 && (!ILV || LATE)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile (own part) landed
+      if (kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile (own part) landed
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---- C phase ----
       __builtin_amdgcn_s_setprio(1);
-      if constexpr (ILV) {
-        // which tile this phase carries: early C0: tile kt+1; late C1: tile kt+2
-        const int tnext = LATE ? kt + 2 : kt + 1;
-        constexpr bool carry = CARRY && (LATE ? kh == 1 : kh == 0);
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
+      for (int a = 0; a < MT; ++a)
 #pragma unroll
-          for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
-          if constexpr (carry) issue_piece(tnext & 1, tnext, a);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!LATE && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // early half: tile kt+1 landed
-      } else {
-#pragma unroll
-        for (int a = 0; a < MT; ++a)
-#pragma unroll
-          for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
-      }
+        for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-    };
-    half(std::integral_constant<int, 0>{});
-    half(std::integral_constant<int, 1>{});
-  };
-  int kt = 0;
-  if constexpr (ILV) {
-    const int n_carry = nk - (LATE ? 2 : 1);       // steps whose C phase issues a tile
-    for (; kt < n_carry; ++kt) kstep(kt, std::true_type{});
+    }
   }
-  for (; kt < nk; ++kt) kstep(kt, std::false_type{});
   };
   if (late) main_loop(std::true_type{}); else main_loop(std::false_type{});
   if (!late) __builtin_amdgcn_s_barrier();         // waves 0-3 wait one slot for the late half
