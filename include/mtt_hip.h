@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 6
+#define MTT_ABI_VERSION 7
 
 /* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
  * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
@@ -114,7 +114,13 @@ typedef struct {
   int32_t ps_H, ps_W, ps_Co;
   int32_t variant;               /* MTT_GEMM_* (0 = AUTO) */
   const void* A_lo; const void* B_lo; void* D_lo;   /* lo planes of MTT_SPLIT operands / output (same layout, strides and batch offsets as the hi plane) */
+  float* colsum_out; float* colsum_ws;   /* optional: colsum_out[n] = sum_m D[m,n] of the values AS STORED (bf16 D: the rounded values), n < N
+                                            — the bias gradient when D is the gradient of a Linear's output (the fc2 input gradient with its
+                                            GELU' epilogue IS fc1's output gradient), taken in the epilogue instead of re-reading D.  Per
+                                            row-block partials go to colsum_ws (>= mtt_gemm_colsum_ws_floats(d) floats) and are summed in
+                                            block order (deterministic).  batch == 1, MTT_STORE_ROWS only. */
 } mtt_gemm_desc;
+size_t mtt_gemm_colsum_ws_floats(const mtt_gemm_desc* d);
 
 int mtt_abi_version(void);
 /* sizeof(descriptor): 0 gemm, 1 attn, 2 softmax, 3 ln, 4 chanlogit, 5 modulate, 6 ctr, 7 resize, 8 bn, 9 conv_geom, (15 adam, 16 loss, 17 upconv, 18 gather, 19 winattn, 20 chanattn, 21 conv3s2)
@@ -259,12 +265,40 @@ int mtt_bn_bwd_apply(const mtt_bn_desc* d, void* stream);
 /* fp32 [rows, cols] (pitch lds) -> MTT_SPLIT planes hi / lo [rows, ldd] (bf16; columns cols..ldd-1 zero): hi = bf16(x), lo = bf16(x - hi) */
 int mtt_split_cast(const float* src, void* hi, void* lo, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, void* stream);
 
+/* Multi-segment strided copy / cast: ONE launch re-packs every weight of a model (the reference re-reads nn.Parameter tensors directly;
+ * the packs are this implementation's operand layouts: [N, pad8(K)] casts, tap-major conv matrices, padded concatenations, hi/lo planes)
+ * and scatters packed weight gradients back to parameter layout.  Segment g copies the logical box [n0][n1][n2] (n2 innermost):
+ *     dst[i0*d0 + i1*d1 + i2*d2] = cast(src[i0*s0 + i1*s1 + i2*s2])
+ * `table` is a DEVICE array of n_seg rows of MTT_SEG_WORDS int64 words:
+ *     0 src address, 1 dst address, 2 dst_lo address (MTT_SPLIT destinations: hi -> dst, lo -> dst_lo; else 0), 3 total = n0*n1*n2,
+ *     4 n1, 5 n2, 6..8 s0 s1 s2, 9..11 d0 d1 d2 (elements), 12 src dtype, 13 dst dtype, 14 vec (1: n2, s0, s1, d0, d1 multiples of 4,
+ *     s2 = d2 = 1 and both addresses 16-byte aligned -> four elements per lane), 15 transpose (1: s1 = 1 and d2 = 1 — the source is
+ *     contiguous along i1, the destination along i2; copied in 64 x 64 tiles of (i1, i2) through LDS; word 3 is then
+ *     n0 * ceil(n1/64) * ceil(n2/64) * 4096 and chunk offsets count tile slots of 4096).
+ * src_base / dst_base (bytes) are added to every src / dst(+dst_lo) address: 0 for tables of absolute addresses (persistent packs),
+ * the buffers' addresses for tables of offsets (gradient scatter out of a fresh buffer).  Work is cut into chunks of
+ * mtt_segcopy_chunk() logical elements: chunk c covers [chunk_off[c], chunk_off[c] + chunk) of segment chunk_seg[c].
+ * Destination elements outside the boxes (padding) are not touched: the caller zeroes the buffers once. */
+#define MTT_SEG_WORDS 16
+typedef struct {
+  const int64_t* table; const int32_t* chunk_seg; const int64_t* chunk_off; int32_t n_chunks;
+  int64_t src_base, dst_base;
+} mtt_segcopy_desc;
+int mtt_segcopy_chunk(void);
+int mtt_segcopy(const mtt_segcopy_desc* d, void* stream);
+
 /* Small utilities: dtype cast / strided 2-D copy, column sums (bias gradients), axpy-style accumulate. */
 int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
                int src_dtype, int dst_dtype, int zero_pad_cols, void* stream);
 /* dst[r,:] = rowscale[(r/mb)*2 + ((r%mb) >= n_prompt)] * src[r,:] with dtype cast (DropPath scale of a branch gradient) */
 int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
                       const float* rowscale, int32_t mb, int32_t n_prompt, void* stream);
+/* the same + colsum_out[c] = sum_r dst[r, c] of the values as stored (c < cols): when src is the gradient of a Linear's output (the
+ * residual-stream gradient entering proj / fc2), the cast that prepares it for the bf16 GEMMs also yields that layer's bias gradient.
+ * cols, lds, ldd multiples of 8; ws: mtt_rowscale_cast_colsum_ws_floats(rows, cols) floats of per-row-block partials (fixed-order sum). */
+size_t mtt_rowscale_cast_colsum_ws_floats(int64_t rows, int32_t cols);
+int mtt_rowscale_cast_colsum(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
+                             const float* rowscale, int32_t mb, int32_t n_prompt, float* colsum_out, float* ws, void* stream);
 /* dst[c] = sum_r src[r, c] for c < cols (bias gradients; ld >= pad8(cols), columns up to pad8(cols) are read).  Deterministic two-stage
  * reduction through the caller-owned workspace ws (>= mtt_colsum_ws_floats(rows, cols) floats, contents unspecified afterwards). */
 size_t mtt_colsum_ws_floats(int64_t rows, int32_t cols);

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -55,6 +55,7 @@ class GemmDesc(C.Structure):
         ("ps_H", i32), ("ps_W", i32), ("ps_Co", i32),
         ("variant", i32),
         ("A_lo", ptr), ("B_lo", ptr), ("D_lo", ptr),
+        ("colsum_out", ptr), ("colsum_ws", ptr),
     ]
 
 
@@ -171,6 +172,10 @@ class Conv3s2Desc(C.Structure):
                 ("x_bs", i64), ("x_cs", i64), ("x_off", i64), ("y_bs", i64), ("y_cs", i64), ("y_off", i64)]
 
 
+class SegcopyDesc(C.Structure):
+    _fields_ = [("table", ptr), ("chunk_seg", ptr), ("chunk_off", ptr), ("n_chunks", i32), ("src_base", i64), ("dst_base", i64)]
+
+
 # entry point -> (descriptor struct, size index in mtt_desc_size) ; None = positional-argument entry
 DESCS = {
     "loss_fwd": LossDesc,
@@ -182,10 +187,11 @@ DESCS = {
     "convt3x3s2_gather": ConvtDesc,
     "upconv4_expand": UpconvDesc, "upconv4_gather": UpconvDesc,
     "gather_rows": GatherDesc, "winattn_fwd": WinAttnDesc, "chanattn_fwd": ChanAttnDesc, "conv3s2_nchw": Conv3s2Desc,
+    "segcopy": SegcopyDesc,
 }
 _SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom,
                DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc, LossDesc, UpconvDesc,
-               GatherDesc, WinAttnDesc, ChanAttnDesc, Conv3s2Desc]
+               GatherDesc, WinAttnDesc, ChanAttnDesc, Conv3s2Desc, SegcopyDesc]
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "patchify": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int, ptr],
@@ -198,6 +204,7 @@ POSITIONAL = {
     "colsum_batched": [ptr, ptr, i64, i32, i64, C.c_int, i32, i64, i64, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],
     "rowscale_cast": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr],
+    "rowscale_cast_colsum": [ptr, ptr, i64, i32, i64, i64, C.c_int, C.c_int, ptr, i32, i32, ptr, ptr, ptr],
 }
 
 # descriptor + extra positional arguments: mtt_<name>(const desc*, extras..., stream)
@@ -221,9 +228,9 @@ DESC_EXTRA = {
 }
 
 # workspace-size queries mtt_<entry>_ws_floats(const desc*) of the entry points whose cross-workgroup reductions go through caller-owned partials
-WS_QUERIES = {"chan_logits": ChanLogitDesc, "modulate_bwd": ModulateDesc, "ctr_dw": CtrDesc, "attn_msg_bwd": AttnMsgDesc, "loss": LossDesc,
+WS_QUERIES = {"gemm_colsum": GemmDesc, "chan_logits": ChanLogitDesc, "modulate_bwd": ModulateDesc, "ctr_dw": CtrDesc, "attn_msg_bwd": AttnMsgDesc, "loss": LossDesc,
               "chanattn_bwd": ChanAttnDesc}
-EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats", "mtt_nms_ws_bytes"] + ["mtt_%s_ws_floats" % n for n in WS_QUERIES] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
+EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_segcopy_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_rowscale_cast_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats", "mtt_nms_ws_bytes"] + ["mtt_%s_ws_floats" % n for n in WS_QUERIES] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None
 

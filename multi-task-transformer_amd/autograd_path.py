@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import bn as bn_mod
-from . import ops
+from . import _lib, ops
 from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code  # noqa: F401
 
 pad8 = ops.pad8
@@ -42,6 +42,22 @@ def _scaled(g, rowscale, mb, n_prompt, prec):
     ops.call("rowscale_cast", args=[g, out, g.shape[0], g.shape[1], g.stride(0), out.stride(0), dtype_code(g), dtype_code(out),
                                     rowscale, mb, n_prompt])
     return out
+
+
+def _scaled_colsum(g, rowscale, mb, n_prompt, prec):
+    """-> (_scaled(g, ...), column sums of the result as stored): g is the gradient of a Linear's output (proj / fc2 write the residual
+    stream), so the cast that prepares it for the bf16 GEMMs yields that layer's bias gradient in the same pass (mtt_rowscale_cast_colsum).
+    Falls back to a separate column sum when no cast is needed."""
+    cols = g.shape[1]
+    if (rowscale is None and (g.dtype == prec.adt or not FAST_BWD)) or cols % 8 or g.stride(0) % 8:
+        out = _scaled(g, rowscale, mb, n_prompt, prec)
+        return out, _colsum(out, cols)
+    out = torch.empty(g.shape, dtype=prec.adt, device=g.device)
+    cs = torch.empty(cols, dtype=torch.float32, device=g.device)
+    ws = ops.workspace(_lib.load().mtt_rowscale_cast_colsum_ws_floats(g.shape[0], cols), g.device)
+    ops.call("rowscale_cast_colsum", args=[g, out, g.shape[0], cols, g.stride(0), out.stride(0), dtype_code(g), dtype_code(out),
+                                           rowscale, mb, n_prompt, cs, ws])
+    return out, cs
 
 
 def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
@@ -146,21 +162,27 @@ def _wgrad_tn(dy, x, N, Kp, prec):
     return _gemm(dy, x, dW, N, Kp, rows, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp)
 
 
-def _enc_wgrad(dy, x, N, Kp, prec):
-    """-> (dW [N, Kp], dbias [N]) of y = x W^T + b given dy."""
+def _enc_wgrad(dy, x, N, Kp, prec, bias=True):
+    """-> (dW [N, Kp], dbias [N]) of y = x W^T + b given dy (bias=False: the caller already has dbias, e.g. from a GEMM epilogue)."""
+    db = _colsum(dy, N) if bias else None
     if (prec.name == "bf16" and FAST_BWD and N >= FAST_MIN_DIM and Kp >= FAST_MIN_DIM and dy.shape[0] >= FAST_MIN_ROWS
             and N % 8 == 0 and dy.stride(0) % 8 == 0):
         if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
-            return _wgrad_tn(dy, x, N, Kp, prec), _colsum(dy, N)
-    return _wgrad(dy, x, N, Kp, prec), _colsum(dy, N)
+            return _wgrad_tn(dy, x, N, Kp, prec), db
+    return _wgrad(dy, x, N, Kp, prec), db
 
 
-def _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, **epi):
+def _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, colsum=False, **epi):
     """dx = dy @ W.  bf16 mode: uses a cached transposed pack W^T [N_in, K_out] so that both operands are
-    reduction-contiguous (fast GEMM path); otherwise the transposing B stager."""
+    reduction-contiguous (fast GEMM path); otherwise the transposing B stager.  colsum=True -> (dx, column sums of dx as stored): with the
+    GELU' epilogue dx IS the gradient of the previous Linear's output, so its column sums are that layer's bias gradient — taken in the
+    GEMM epilogue (mtt_gemm_desc.colsum_out) instead of re-reading the [tokens, hidden] gradient."""
+    if colsum:
+        cs = torch.empty(N_in, dtype=torch.float32, device=dy.device)
+        epi = dict(epi, colsum_out=cs, colsum_ws=ops.ws_for("gemm_colsum", dy.device, M=M, N=N_in))
+        return _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, **epi), cs
     if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and K_out % 64 == 0 and N_in >= FAST_MIN_DIM:
-        wT = ops._cached((tag, 'wT', id(weight)), [weight],
-                         lambda: weight.detach().reshape(weight.shape[0], -1).t().contiguous().to(torch.bfloat16))
+        wT = ops.pack_linear_T(weight, torch.bfloat16, tag)
         dx = torch.empty(M, N_in, dtype=out_dtype, device=dy.device)
         return _gemm(dy, wT, dx, M, N_in, K_out, prec, lda=dy.stride(0), ldb=wT.stride(0), ldd=N_in, n_store=N_in, **epi)
     return _dgrad(dy, wpack2d, M, N_in, K_out, prec, out_dtype, **epi)
@@ -304,8 +326,8 @@ class AttnHalfFn(Function):
         xn_c = xn32 if xn32 is not None else xn                    # the rows the channel attention read (fp32 in the x3f mode)
         dXT2 = dXT2.contiguous()
         # ---- spatial attention ---------------------------------------------------------------------------------
-        g = _scaled(dXT2, rowscale, N, T, prec)
-        dWproj, dbproj = _enc_wgrad(g, ao, C, C, prec)
+        g, dbproj = _scaled_colsum(dXT2, rowscale, N, T, prec)
+        dWproj, _ = _enc_wgrad(g, ao, C, C, prec, bias=False)
         dao = _enc_dgrad(g, Wproj_, wp[0], M, C, C, prec, prec.adt, 'proj')
         dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
         if lse is not None:
@@ -368,11 +390,12 @@ class MlpHalfFn(Function):
         prec, M = ctx.prec.bwd, B * N
         C, Hd = xn2.shape[1], z.shape[1]
         dXT3 = dXT3.contiguous()
-        g = _scaled(dXT3, rowscale, N, T, prec)
+        g, db2 = _scaled_colsum(dXT3, rowscale, N, T, prec)
         W1_, W2_ = ctx.params
-        dW2, db2 = _enc_wgrad(g, hmid, C, Hd, prec)
-        dz = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z), ldaux=Hd)
-        dW1, db1 = _enc_wgrad(dz, xn2, Hd, C, prec)
+        dW2, _ = _enc_wgrad(g, hmid, C, Hd, prec, bias=False)
+        dz, db1 = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', colsum=True, act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z),
+                             ldaux=Hd)
+        dW1, _ = _enc_wgrad(dz, xn2, Hd, C, prec, bias=False)
         dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
         dXT2, dg2, dbn2 = _ln_bwd_join(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps)
         return dXT2, dg2, dbn2, None, dW1, db1, dW2, db2, None, None, None, None
@@ -449,17 +472,7 @@ class BLinearFn(Function):
         if kmap is None:
             wpack = ops.pack_linear(list(ws), prec, tag)
         else:
-            Kp, segs = kmap
-
-            def build():
-                with torch.no_grad():
-                    buf = torch.zeros(Z, N, Kp, dtype=torch.float32, device=ws[0].device)
-                    for i, wt in enumerate(ws):
-                        w2 = wt.detach().reshape(N, -1)
-                        for (d0, s0, ln) in segs:
-                            buf[i, :, d0:d0 + ln] = w2[:, s0:s0 + ln]
-                    return buf.to(prec.adt)
-            wpack = ops._cached((tag, prec.name, 'kmap', tuple(id(q) for q in ws)), list(ws), build)
+            wpack = ops.pack_kmap(list(ws), N, kmap[0], kmap[1], prec, tag)
         bias = ops.stack_vec(list(bs), (tag, 'b'))
         M, Np = x.shape[-2], pad8(N)
         if layout == 'catpair':
@@ -513,15 +526,14 @@ class BLinearFn(Function):
             dball = torch.stack([h0, h1], 1).reshape(Z, N)
         else:
             dball = ops.colsum_batched(dys, N, Z, M * lda)
-        dws, dbs = [], list(dball.unbind(0))
-        for z in range(Z):
-            if kmap is None:
-                dws.append(dW[z][:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
-            else:
-                g = torch.zeros(N, math.prod(wshapes[z][1:]), dtype=torch.float32, device=x.device)
-                for (d0, s0, ln) in kmap[1]:
-                    g[:, s0:s0 + ln] = dW[z][:, d0:d0 + ln]
-                dws.append(g.reshape(wshapes[z]))
+        dbs = list(dball.unbind(0))
+        K = math.prod(wshapes[0][1:])
+        cols = [(0, 0, K)] if kmap is None else kmap[1]
+        dW = dW.contiguous()
+        dws = ops.unpack_grads(dW, ('blinear', N, Kp, tuple(cols)), wshapes,
+                               lambda src, flat, offs: [ops.segment(src, z * N * Kp + d0, flat, offs[z] + s0, (1, N, ln), (0, Kp, 1), (0, K, 1))
+                                                        for z in range(Z) for (d0, s0, ln) in cols],
+                               partial=sum(c[2] for c in cols) != K)      # a column range of a shared weight (InvPT mix projections)
         if x.dim() == 3 and x.shape[0] == 1 and Z > 1:
             dx = dx.sum(0, keepdim=True)
         elif x.dim() == 2:
@@ -571,7 +583,9 @@ class Conv3x3Fn(Function):
             _gemm(dy, x, slabs, Co, 9 * Cip, c, prec, a_op=OP_R, b_op=OP_CONV_R, lda=Cop, ldb=Cip, ldd=9 * Cip, batch=Z * S, batch_inner=S,
                   a_zo=rows * Cop, a_zi=c * Cop, b_zo=rows * Cip, b_zi=c * Cip, d_zo=S * Co * 9 * Cip, d_zi=Co * 9 * Cip, conv=conv)
             dW = slabs.sum(1)
-        dws = [dW[z].view(Co, 3, 3, Cip)[..., :Ci].permute(0, 3, 1, 2).contiguous() for z in range(Z)]
+        dws = ops.unpack_grads(dW, 'conv3', [(Co, Ci, 3, 3)] * Z,       # dW[z][co, tap*Cip + ci] -> W[co, ci, tap]
+                               lambda src, flat, offs: [ops.segment(src, z * Co * 9 * Cip, flat, offs[z], (Co, 9, Ci), (9 * Cip, Cip, 1), (Ci * 9, 1, 9))
+                                                        for z in range(Z)])
         dbs = list(ops.colsum_batched(dy, Co, Z, dy.stride(0)).unbind(0)) if has_bias else [None] * Z
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
@@ -612,7 +626,9 @@ class UpConv3x3Fn(Function):
                   n_store=Kp)
         dW9 = _wgrad_batched(dz, xa, N9, Kp, M, prec, Z, N9, Kp, M * N9, M * Kp)              # [Z, N9, Kp] fp32
         Cop = N9 // 9
-        dws = [dW9[z].view(3, 3, Cop, Kp)[:, :, :Co, :Ci].permute(2, 3, 0, 1).contiguous() for z in range(Z)]
+        dws = ops.unpack_grads(dW9, 'upconv9', [(Co, Ci, 3, 3)] * Z,    # dW9[z][tap*Cop + co, ci] -> W[co, ci, tap]
+                               lambda src, flat, offs: [ops.segment(src, z * N9 * Kp, flat, offs[z], (9, Co, Ci), (Cop * Kp, Kp, 1), (1, Ci * 9, 9))
+                                                        for z in range(Z)])
         dbs = list(ops.colsum_batched(dy, Co, Z, dy.stride(0)).unbind(0))
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 

@@ -54,12 +54,17 @@ def train_stats(x, C, bns):
         if tracked:
             torch._foreach_add_([bn.num_batches_tracked for bn in tracked], 1)
             var_u = m2 * unbias
+            groups = {}                                    # momentum -> (running buffers, batch statistics): one foreach pair per group
             for z, bn in enumerate(bns):
                 if bn not in tracked:
                     continue
                 m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)   # None: cumulative average
-                bn.running_mean.mul_(1 - m).add_(mean[z], alpha=m)
-                bn.running_var.mul_(1 - m).add_(var_u[z], alpha=m)
+                run, new = groups.setdefault(m, ([], []))
+                run += [bn.running_mean, bn.running_var]
+                new += [mean[z], var_u[z]]
+            for m, (run, new) in groups.items():           # running = (1 - m) * running + m * batch  (nn.BatchNorm2d)
+                torch._foreach_mul_(run, 1 - m)
+                torch._foreach_add_(run, new, alpha=m)
     return mean.contiguous(), rstd.contiguous(), scale
 
 

@@ -232,10 +232,36 @@ MTT_DEV u32x4 split_lo(const float (&v)[8], u32x4 hi) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column sums of the stored tile (mtt_gemm_desc.colsum_out): every thread of the epilogue owns one 8-column chunk of the tile
+// (tid = row_slot * CHUNKS + chunk) and has summed its rows into cacc[8]; this adds the row slots of the workgroup in a fixed order
+// (lanes of a wave by xor-shuffles, waves in index order through LDS) and writes the tile's partial row of the workspace.
+template <int NTHREADS, int TBN>
+MTT_DEV void epilogue_colsum_flush(float (&cacc)[8], float* red, float* part, int ncols) {
+  constexpr int CHUNKS = TBN / 8, W = NTHREADS / 64;
+  static_assert(CHUNKS <= 64 && 64 % CHUNKS == 0, "tile width");
+#pragma unroll
+  for (int o = CHUNKS; o < 64; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cacc[j] += __shfl_xor(cacc[j], o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < CHUNKS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave * TBN + lane * 8 + j] = cacc[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < TBN; c += NTHREADS) {
+    float t = red[c];
+#pragma unroll
+    for (int w = 1; w < W; ++w) t += red[w * TBN + c];
+    if (c < ncols) part[c] = t;
+  }
+}
+MTT_DEV float stored_value(float v, int d_dtype) { return d_dtype == MTT_BF16 ? bf2f(f2bf(v)) : v; }
+
 // Shared epilogue.  Block tile TBN columns wide, WAVES_M x WAVES_N waves, each wave MT x NTL tiles of 16 x 16:
 //   acc[a][b][r] = D[(wm*MT + a)*16 + lg*4 + r][(wn*NTL + b)*16 + li]
 // ---------------------------------------------------------------------------------------------
-template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL, bool CS = true>
 MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -265,6 +291,13 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
     sh[j] = (d.colshift && nv) ? d.colshift[zcol + n] : 0.0f;
   }
   const bool full_chunk = ncol0 + 8 <= d.N && d.store_mode == MTT_STORE_ROWS;
+  // colsum_out: this thread's column sums over its rows of the tile, kept in its own 8 LDS slots behind the staging area (this
+  // general path is at the register limit in some instantiations; the specialised path below keeps them in registers)
+#define csl (ep + 64 * EP_LD + (threadIdx.x << 3))
+  if (CS && d.colsum_out) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csl[j] = 0.f;
+  }
 
 #pragma unroll 1
   for (int half = 0; half < NSLAB; ++half) {          // 64-row slabs of the block tile
@@ -336,6 +369,10 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
             const float4 r1 = *(const float4*)(d.resid + roff + 4);
             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
           }
+          if (CS && d.colsum_out) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csl[j] += stored_value(v[j], d.d_dtype);
+          }
           if (d.d_dtype == MTT_F32) {
             *(float4*)((float*)d.D + doff) = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)((float*)d.D + doff + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -361,6 +398,7 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
               else if (d.act == MTT_ACT_RELU_BWD) w = ld_elem(d.aux_in, auxoff + j, d.aux_dtype) > 0.0f ? w : 0.0f;
               w *= rs;
               if (d.resid) w += d.resid[roff + j];
+              if (CS && d.colsum_out) csl[j] += stored_value(w, d.d_dtype);
             }
             if (d.store_mode == MTT_STORE_PIXSHUF2) {
               if (n >= d.N) continue;
@@ -385,6 +423,14 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
     }
     __syncthreads();
   }
+  if (CS && d.colsum_out) {
+    constexpr int TBM = WAVES_M * MT * 16;
+    float cacc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cacc[j] = csl[j];
+    epilogue_colsum_flush<NTHREADS, TBN>(cacc, ep, d.colsum_ws + (int64_t)(m0 / TBM) * ((d.N + 7) / 8 * 8) + n0, d.N - n0);
+  }
+#undef csl
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,10 +469,11 @@ __host__ __device__ inline int epilogue_kind_of(const mtt_gemm_desc& d) {
 }
 MTT_DEV int fast_epilogue_kind(const mtt_gemm_desc& d, int m0, int n0, int tbm, int tbn) {
   if (m0 + tbm > d.M || n0 + tbn > d.N) return -1;                                   // interior tiles only
-  return epilogue_kind_of(d);
+  const int k = epilogue_kind_of(d);
+  return (d.colsum_out && k != 0 && k != 4) ? -1 : k;                                // column sums: specialised for the bf16 gradient kinds
 }
 
-template <int KIND, int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+template <int KIND, int TBN, int WAVES_M, int WAVES_N, int MT, int NTL, bool CS = true>
 MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -447,6 +494,8 @@ MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned 
   const int64_t zAux = (int64_t)zo * d.aux_zo + (int64_t)zi * d.aux_zi + ncol0;
   const int64_t zR = (int64_t)zo * d.r_zo + (int64_t)zi * d.r_zi + ncol0;
   const float* const epr = ep + rl0 * EP_LD + c8 * 8;
+  constexpr bool CSUM = CS && (KIND == 0 || KIND == 4);        // bf16 gradients: the kinds whose column sums are a bias gradient
+  float cacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
   for (int half = 0; half < NSLAB; ++half) {
@@ -509,24 +558,32 @@ MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned 
         const u32x4 hi = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
         *(u32x4*)((bf16_t*)d.D + (zD + m * d.ldd)) = hi;
         if (KIND == 5 || KIND == 6) *(u32x4*)((bf16_t*)d.D_lo + (zD + m * d.ldd)) = split_lo(v, hi);
+        if (CSUM && d.colsum_out) {                              // sums of the ROUNDED values (what a later read of D would see)
+          cacc[0] += lo_of(hi.x); cacc[1] += hi_of(hi.x); cacc[2] += lo_of(hi.y); cacc[3] += hi_of(hi.y);
+          cacc[4] += lo_of(hi.z); cacc[5] += hi_of(hi.z); cacc[6] += lo_of(hi.w); cacc[7] += hi_of(hi.w);
+        }
       }
     }
     __syncthreads();
   }
+  if (CSUM && d.colsum_out) {
+    constexpr int TBM = WAVES_M * MT * 16;
+    epilogue_colsum_flush<NTHREADS, TBN>(cacc, ep, d.colsum_ws + (int64_t)(m0 / TBM) * ((d.N + 7) / 8 * 8) + n0, TBN);
+  }
 }
 
 // epilogue dispatch (workgroup-uniform): specialised path for interior tiles of the hot call sites, general path otherwise
-template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL>
+template <int TBN, int WAVES_M, int WAVES_N, int MT, int NTL, bool CS = true>
 MTT_DEV void gemm_epilogue_auto(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char* smem, int m0, int n0, int zo, int zi) {
   const int kind = p.d.variant == MTT_GEMM_GENERAL_EPILOGUE ? -1 : fast_epilogue_kind(p.d, m0, n0, WAVES_M * MT * 16, TBN);
-  if (kind == 0) gemm_epilogue_fast<0, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
-  else if (kind == 1) gemm_epilogue_fast<1, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
-  else if (kind == 2) gemm_epilogue_fast<2, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
-  else if (kind == 3) gemm_epilogue_fast<3, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
-  else if (kind == 4) gemm_epilogue_fast<4, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
-  else if (kind == 5) gemm_epilogue_fast<5, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
-  else if (kind == 6) gemm_epilogue_fast<6, TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
-  else gemm_epilogue<TBN, WAVES_M, WAVES_N, MT, NTL>(p, acc, smem, m0, n0, zo, zi);
+  if (kind == 0) gemm_epilogue_fast<0, TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 1) gemm_epilogue_fast<1, TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 2) gemm_epilogue_fast<2, TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 3) gemm_epilogue_fast<3, TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 4) gemm_epilogue_fast<4, TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 5) gemm_epilogue_fast<5, TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
+  else if (kind == 6) gemm_epilogue_fast<6, TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
+  else gemm_epilogue<TBN, WAVES_M, WAVES_N, MT, NTL, CS>(p, acc, smem, m0, n0, zo, zi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     __syncthreads();
   }
 
-  gemm_epilogue_auto<BN, 2, 2, 4, 4>(p, acc, smem, m0, n0, zo, zi);
+  gemm_epilogue_auto<BN, 2, 2, 4, 4, MODE != 3>(p, acc, smem, m0, n0, zo, zi);   // MODE 3 is at 256 VGPRs: no column-sum option there
 }
 
 
@@ -1058,6 +1115,7 @@ extern "C" size_t mtt_desc_size(int which) {
     case 19: return sizeof(mtt_winattn_desc);
     case 20: return sizeof(mtt_chanattn_desc);
     case 21: return sizeof(mtt_conv3s2_desc);
+    case 22: return sizeof(mtt_segcopy_desc);
     default: return 0;
   }
 }
@@ -1111,6 +1169,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
 }
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }
 
+static int gemm_launch(GemmP& p, hipStream_t s, int v);
 extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (!dd || !dd->A || !dd->B || !dd->D) return MTT_E_BADARG;
   GemmP p; p.d = *dd;
@@ -1147,6 +1206,26 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if (v < 0) return v;
   if (d.d_dtype == MTT_SPLIT && !d.D_lo) return MTT_E_BADARG;
   if (d.d_dtype == MTT_SPLIT && d.store_mode != MTT_STORE_ROWS) return MTT_E_UNSUPPORTED;
+  if (d.colsum_out) {                                   // bias gradient from the epilogue: per-row-block partials + a fixed-order second stage
+    if (!d.colsum_ws) return MTT_E_BADARG;
+    if (d.batch != 1 || d.store_mode != MTT_STORE_ROWS || v == 6) return MTT_E_UNSUPPORTED;
+    const int rc = gemm_launch(p, s, v);
+    if (rc) return rc;
+    const int tbm = (v == 3 || v == 8) ? 256 : BM;
+    hipLaunchKernelGGL(mtt_colsum_final_kernel, dim3((d.N + 31) / 32, 1, 1), dim3(256), 0, s, (const float*)d.colsum_ws, d.colsum_out, d.N,
+                       (d.M + tbm - 1) / tbm, (int64_t)0);
+    return (int)hipGetLastError();
+  }
+  return gemm_launch(p, s, v);
+}
+
+extern "C" size_t mtt_gemm_colsum_ws_floats(const mtt_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0) return 0;
+  return (size_t)((d->M + BM - 1) / BM) * (size_t)((d->N + 7) / 8 * 8);     // the smallest row block of any kernel variant
+}
+
+static int gemm_launch(GemmP& p, hipStream_t s, int v) {
+  mtt_gemm_desc& d = p.d;
   if (v == 8) return launch_dma<2>(p, s);
   if (v == 3) return dma_fastaddr_ok(d) ? launch_dma<1>(p, s) : launch_dma<0>(p, s);
   if (v == 6) return d.b_op == MTT_OP_CONV_R ? launch_tn<true>(p, s) : launch_tn<false>(p, s);
@@ -1158,7 +1237,7 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     mode = 2;
   } else if (d.a_dtype == MTT_BF16 && d.b_dtype == MTT_BF16) mode = 0;
   else if (d.a_dtype == MTT_F32 && d.b_dtype == MTT_BF16) mode = 1;
-  else if (d.a_dtype == MTT_F32 && d.b_dtype == MTT_F32) mode = 3;
+  else if (d.a_dtype == MTT_F32 && d.b_dtype == MTT_F32) { mode = 3; if (d.colsum_out) return MTT_E_UNSUPPORTED; }
   else if (d.a_dtype == MTT_BF16 && d.b_dtype == MTT_F32) mode = 4;
   else return MTT_E_UNSUPPORTED;
 #define MTT_CASE(AO, BO) \

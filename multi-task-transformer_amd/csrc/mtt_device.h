@@ -233,4 +233,23 @@ static __global__ __launch_bounds__(256) void mtt_reduce_many_kernel(const float
   }
   if (threadIdx.x == 0) dst[i] = accumulate ? dst[i] + scale * red[0] : scale * red[0];
 }
+// column sums, second stage: ws [nblk][pad8(cols)] per-row-block partials -> dst[cols]; 32 columns per workgroup, 8 row groups summed in order
+static __global__ __launch_bounds__(256) void mtt_colsum_final_kernel(const float* ws, float* dst, int cols, int nblk, int64_t dst_zs) {
+  __shared__ float sh[8][32];
+  ws += (int64_t)blockIdx.z * nblk * (((int64_t)cols + 7) / 8 * 8);
+  dst += (int64_t)blockIdx.z * dst_zs;
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int64_t colsP = ((int64_t)cols + 7) / 8 * 8;
+  float t = 0.f;
+  if (c < cols)
+    for (int b = pl; b < nblk; b += 8) t += ws[(int64_t)b * colsP + c];
+  sh[pl][cl] = t;
+  __syncthreads();
+  if (pl == 0 && c < cols) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) t += sh[l][cl];
+    dst[c] = t;
+  }
+}
 static inline unsigned mtt_reduce_few_grid(int64_t n) { const int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }

@@ -621,25 +621,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* src_, f
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* ws, float* dst, int cols, int nblk, int64_t dst_zs) {
-  __shared__ float sh[8][32];
-  ws += (int64_t)blockIdx.z * nblk * (((int64_t)cols + 7) / 8 * 8);
-  dst += (int64_t)blockIdx.z * dst_zs;
-  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  const int64_t colsP = ((int64_t)cols + 7) / 8 * 8;
-  float t = 0.f;
-  if (c < cols)
-    for (int b = pl; b < nblk; b += 8) t += ws[(int64_t)b * colsP + c];
-  sh[pl][cl] = t;
-  __syncthreads();
-  if (pl == 0 && c < cols) {
-#pragma unroll
-    for (int l = 1; l < 8; ++l) t += sh[l][cl];
-    dst[c] = t;
-  }
-}
-
 // BatchNorm reductions, deterministic (no atomics) and centred.  Grid (row blocks, Z maps).  Each block reduces its rows to one
 // partial per channel in `ws` [Z][nblk][2][Cp]; bn_final_kernel merges the partials in block order.
 //   MODE 0 (statistics): the block accumulates sums of (x - shift) and (x - shift)^2 with shift = the block's first row (a value
@@ -835,6 +816,69 @@ __global__ __launch_bounds__(256) void cast2d_kernel(const void* src, void* dst,
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int64_t r = t / wcols, c = t % wcols;
     st_elem(dst, r * ldd + c, ddt, c < cols ? ld_elem(src, r * lds_ + c, sdt) : 0.f);
+  }
+}
+
+// multi-segment strided copy / cast (mtt_segcopy): one workgroup = one chunk of SEG_CHUNK logical elements of one segment
+constexpr int SEG_CHUNK = 16384;
+MTT_DEV void seg_store(int ddt, void* dst, void* dst_lo, int64_t o, float v) {
+  if (ddt == MTT_F32) ((float*)dst)[o] = v;
+  else {
+    const bf16_t h = f2bf(v);
+    ((bf16_t*)dst)[o] = h;
+    if (ddt == MTT_SPLIT) ((bf16_t*)dst_lo)[o] = f2bf(v - bf2f(h));
+  }
+}
+__global__ __launch_bounds__(256) void segcopy_kernel(const mtt_segcopy_desc d) {
+  const int64_t* g = d.table + (int64_t)d.chunk_seg[blockIdx.x] * MTT_SEG_WORDS;
+  const char* src = (const char*)(g[0] + d.src_base);
+  char* dst = (char*)(g[1] + d.dst_base);
+  char* dst_lo = g[2] ? (char*)(g[2] + d.dst_base) : nullptr;
+  const int64_t total = g[3], n1 = g[4], n2 = g[5];
+  const int64_t s0 = g[6], s1 = g[7], s2 = g[8], d0 = g[9], d1 = g[10], d2 = g[11];
+  const int sdt = (int)g[12], ddt = (int)g[13];
+  const int64_t e0 = d.chunk_off[blockIdx.x];
+  const int64_t e1 = e0 + SEG_CHUNK < total ? e0 + SEG_CHUNK : total;
+  if (g[15]) {                                        // transposing segment: 64 x 64 tiles of (i1, i2) through LDS; s1 == 1, d2 == 1
+    __shared__ float tile[64][65];
+    const int64_t t1 = (n1 + 63) >> 6, t2 = (n2 + 63) >> 6;
+    const int64_t tile0 = e0 >> 12, tile1 = tile0 + SEG_CHUNK / 4096 < total >> 12 ? tile0 + SEG_CHUNK / 4096 : total >> 12;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int64_t t = tile0; t < tile1; ++t) {
+      const int64_t j2 = t % t2, r = t / t2, j1 = r % t1, i0 = r / t1;
+      __syncthreads();
+      for (int k = ly; k < 64; k += 4) {                 // row k of the tile = i2, lanes along i1 (contiguous in the source)
+        const int64_t i1 = j1 * 64 + lx, i2 = j2 * 64 + k;
+        if (i1 < n1 && i2 < n2) tile[k][lx] = ld_elem(src, i0 * s0 + i1 + i2 * s2, sdt);
+      }
+      __syncthreads();
+      for (int k = ly; k < 64; k += 4) {                 // lanes along i2 (contiguous in the destination)
+        const int64_t i1 = j1 * 64 + k, i2 = j2 * 64 + lx;
+        if (i1 < n1 && i2 < n2) seg_store(ddt, dst, dst_lo, i0 * d0 + i1 * d1 + i2, tile[lx][k]);
+      }
+    }
+    return;
+  }
+  if (g[14]) {                                        // four consecutive elements of a row per lane
+    for (int64_t e = e0 + threadIdx.x * 4; e < e1; e += 256 * 4) {
+      const int64_t i2 = e % n2, r = e / n2, i1 = r % n1, i0 = r / n1;
+      const int64_t so = i0 * s0 + i1 * s1 + i2, o = i0 * d0 + i1 * d1 + i2;
+      float v[4];
+      if (sdt == MTT_F32) { const float4 q = *(const float4*)((const float*)src + so); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+      else { const uint2 q = *(const uint2*)((const bf16_t*)src + so); v[0] = lo_of(q.x); v[1] = hi_of(q.x); v[2] = lo_of(q.y); v[3] = hi_of(q.y); }
+      if (ddt == MTT_F32) *(float4*)((float*)dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+      else {
+        const uint2 h = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        *(uint2*)((bf16_t*)dst + o) = h;
+        if (ddt == MTT_SPLIT)
+          *(uint2*)((bf16_t*)dst_lo + o) = make_uint2(pack2(v[0] - lo_of(h.x), v[1] - hi_of(h.x)), pack2(v[2] - lo_of(h.y), v[3] - hi_of(h.y)));
+      }
+    }
+    return;
+  }
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int64_t i2 = e % n2, r = e / n2, i1 = r % n1, i0 = r / n1;
+    seg_store(ddt, dst, dst_lo, i0 * d0 + i1 * d1 + i2 * d2, ld_elem(src, i0 * s0 + i1 * s1 + i2 * s2, sdt));
   }
 }
 
@@ -1142,6 +1186,44 @@ __global__ __launch_bounds__(256) void rowscale_cast_vec_kernel(const void* src,
   }
 }
 
+// rowscale cast + column sums of the values as stored (mtt_rowscale_cast_colsum): grid (row blocks, 256-column panels); a thread owns one
+// 8-column chunk of the panel and every 8th row of the block, the 8 row groups are added in index order through LDS and the block's
+// partial row goes to ws [nblk][pad8(cols)] (second stage: mtt_colsum_final_kernel).  No atomics: the bias gradient is deterministic.
+__global__ __launch_bounds__(256) void rowscale_cast_colsum_kernel(const void* src, void* dst, int rows, int C8, int64_t lds_, int64_t ldd, int sdt,
+                                                                   int ddt, const float* rowscale, int mb, int n_prompt, float* part, int rpb) {
+  __shared__ float red[8][256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c8 = blockIdx.y * 32 + tx;
+  const int r0 = blockIdx.x * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c8 < C8) {
+    for (int r = r0 + ty; r < r1; r += 8) {
+      float rs = 1.0f;
+      if (rowscale) {
+        const unsigned q = mb > 0 ? (unsigned)r / (unsigned)mb : 0u, rem = mb > 0 ? (unsigned)r - q * (unsigned)mb : (unsigned)r;
+        rs = rowscale[q * 2 + (rem >= (unsigned)n_prompt ? 1 : 0)];
+      }
+      float v[8];
+      ld8(src, (int64_t)r * lds_ + c8 * 8, sdt, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= rs;
+      st8(dst, (int64_t)r * ldd + c8 * 8, ddt, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += ddt == MTT_BF16 ? bf2f(f2bf(v[j])) : v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx * 8 + j] = acc[j];
+  __syncthreads();
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col < C8 * 8) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g][threadIdx.x];
+    part[(int64_t)blockIdx.x * (C8 * 8) + col] = t;
+  }
+}
+
 // dst[r, :] = rowscale(r) * src[r, :]  (dtype cast; DropPath scale of the branch gradient)
 __global__ __launch_bounds__(256) void rowscale_cast_kernel(const void* src, void* dst, int64_t rows, int cols, int64_t lds_, int64_t ldd,
                                                             int sdt, int ddt, const float* rowscale, int mb, int n_prompt) {
@@ -1358,7 +1440,7 @@ extern "C" int mtt_colsum_batched(const void* src, float* dst, int64_t rows, int
   if (!src || !dst || !ws || rows <= 0 || cols <= 0 || Z <= 0 || Z > 65535 || (ld % 8) || ld < (cols + 7) / 8 * 8 || (src_zs % 8)) return MTT_E_BADARG;
   int nblk, rpb, nchunk; colsum_cfg(rows, cols, nblk, rpb, nchunk);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, nchunk, Z), dim3(256), 0, S_, src, ws, rows, cols, ld, src_dtype, rpb, src_zs);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32, 1, Z), dim3(256), 0, S_, (const float*)ws, dst, cols, nblk, dst_zs);
+  hipLaunchKernelGGL(mtt_colsum_final_kernel, dim3((cols + 31) / 32, 1, Z), dim3(256), 0, S_, (const float*)ws, dst, cols, nblk, dst_zs);
   return LAUNCH_OK();
 }
 extern "C" int mtt_bn_bwd_reduce(const mtt_bn_desc* d, float* ws, void* stream) {
@@ -1388,6 +1470,13 @@ extern "C" int mtt_split_cast(const float* src, void* hi, void* lo, int64_t rows
   hipLaunchKernelGGL(split_cast_kernel, dim3(grid_for(rows * (ldd / 8))), dim3(256), 0, S_, src, (bf16_t*)hi, (bf16_t*)lo, rows, cols, lds_, ldd);
   return LAUNCH_OK();
 }
+extern "C" int mtt_segcopy_chunk(void) { return SEG_CHUNK; }
+extern "C" int mtt_segcopy(const mtt_segcopy_desc* d, void* stream) {
+  if (!d || !d->table || !d->chunk_seg || !d->chunk_off || d->n_chunks <= 0) return MTT_E_BADARG;
+  hipLaunchKernelGGL(segcopy_kernel, dim3(d->n_chunks), dim3(256), 0, S_, *d);
+  return LAUNCH_OK();
+}
+
 extern "C" int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds_, int64_t ldd,
                           int src_dtype, int dst_dtype, int zero_pad_cols, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;
@@ -1438,6 +1527,31 @@ extern "C" int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dw, f
   return LAUNCH_OK();
 }
 
+static void rscs_cfg(int64_t rows, int32_t cols, int& nblk, int& rpb) {
+  const int panels = (cols + 255) / 256;
+  int64_t nb = (rows + 63) / 64;
+  const int64_t cap = 1024 / panels > 1 ? 1024 / panels : 1;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  rpb = (int)((rows + nb - 1) / nb);
+  nblk = (int)((rows + rpb - 1) / rpb);
+}
+extern "C" size_t mtt_rowscale_cast_colsum_ws_floats(int64_t rows, int32_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  int nblk, rpb; rscs_cfg(rows, cols, nblk, rpb);
+  return (size_t)nblk * (size_t)((cols + 7) / 8 * 8);
+}
+extern "C" int mtt_rowscale_cast_colsum(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds_, int64_t ldd, int src_dtype,
+                                        int dst_dtype, const float* rowscale, int32_t mb, int32_t n_prompt, float* colsum_out, float* ws,
+                                        void* stream) {
+  if (!src || !dst || !colsum_out || !ws || rows <= 0 || cols <= 0 || rows >= (1ll << 31)) return MTT_E_BADARG;
+  if ((cols % 8) || (lds_ % 8) || (ldd % 8) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MTT_E_ALIGN;
+  int nblk, rpb; rscs_cfg(rows, cols, nblk, rpb);
+  hipLaunchKernelGGL(rowscale_cast_colsum_kernel, dim3(nblk, (cols + 255) / 256), dim3(256), 0, S_, src, dst, (int)rows, cols / 8, lds_, ldd,
+                     src_dtype, dst_dtype, rowscale, mb, n_prompt, ws, rpb);
+  hipLaunchKernelGGL(mtt_colsum_final_kernel, dim3((cols + 31) / 32, 1, 1), dim3(256), 0, S_, (const float*)ws, colsum_out, cols, nblk, (int64_t)0);
+  return LAUNCH_OK();
+}
 extern "C" int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds_, int64_t ldd, int src_dtype,
                                  int dst_dtype, const float* rowscale, int32_t mb, int32_t n_prompt, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;

@@ -129,10 +129,6 @@ def _cached(key, params, build):
     return val
 
 
-def clear_pack_cache():
-    _pack_cache.clear()
-
-
 def cast2d(src, rows, cols, lds, dst_dtype, ldd=None, zero_pad=True):
     ldd = ldd or pad8(cols)
     dst = torch.empty(rows, ldd, dtype=dst_dtype, device=src.device)
@@ -141,76 +137,261 @@ def cast2d(src, rows, cols, lds, dst_dtype, ldd=None, zero_pad=True):
 
 
 def pack_matrix(w2d, prec):
-    """[N, K] fp32 -> [N, pad8(K)] in the activation dtype (zero padded)."""
+    """[N, K] fp32 -> [N, pad8(K)] in the activation dtype (zero padded); the lazily cached one-off packs (InvPT, deconv heads)."""
     N, K = w2d.shape
     if prec.adt == torch.float32 and K % 8 == 0 and w2d.is_contiguous():
         return w2d
     return cast2d(w2d.contiguous(), N, K, K, prec.adt)
 
 
+# ---------------------------------------------------------------------------------------------
+# persistent packs, refreshed by ONE mtt_segcopy launch per parameter update
+# ---------------------------------------------------------------------------------------------
+_ITEM = {torch.float32: 4, torch.bfloat16: 2}
+
+
+def segment(src, src_off, dst, dst_off, n, s, d, dst_lo=None):
+    """One mtt_segcopy segment: the box n = (n0, n1, n2) read from `src` (tensor, element offset src_off, element strides s) and written to
+    `dst` (element offset dst_off, strides d; `dst_lo` = the lo plane of a Split destination).  Strides of singleton dimensions are ignored."""
+    n = tuple(int(v) for v in n)
+    s = tuple(int(v) if k > 1 else 0 for v, k in zip(s, n))
+    d = tuple(int(v) if k > 1 else 0 for v, k in zip(d, n))
+    sa = src.data_ptr() + src_off * _ITEM[src.dtype]
+    da = dst.data_ptr() + dst_off * 2 if dst.dtype == torch.bfloat16 else dst.data_ptr() + dst_off * 4
+    la = dst_lo.data_ptr() + dst_off * 2 if dst_lo is not None else 0
+    ddt = SPLIT if dst_lo is not None else _lib.dtype_code(dst)
+    vec = int(n[2] % 4 == 0 and (s[2] == 1 or n[2] == 1) and (d[2] == 1 or n[2] == 1) and n[2] > 1 and all(v % 4 == 0 for v in s[:2] + d[:2])
+              and sa % 16 == 0 and da % 16 == 0 and la % 16 == 0)
+    if n[1] >= 16 and n[2] >= 16 and s[1] == 1 and d[2] == 1 and s[2] != 1:      # a transposition: tiled through LDS by the kernel
+        tiles = n[0] * ((n[1] + 63) // 64) * ((n[2] + 63) // 64)
+        return [sa, da, la, tiles * 4096, n[1], n[2], s[0], 1, s[2], d[0], d[1], 1, _lib.dtype_code(src), ddt, 0, 1]
+    return [sa, da, la, n[0] * n[1] * n[2], n[1], n[2], s[0], s[1], s[2], d[0], d[1], d[2], _lib.dtype_code(src), ddt, vec, 0]
+
+
+class SegProgram:
+    """Device tables of an mtt_segcopy launch over a list of `segment(...)` rows (absolute addresses: the tensors must outlive it)."""
+
+    def __init__(self, rows, device):
+        import numpy as np
+        chunk = int(_lib.load().mtt_segcopy_chunk())
+        rows = [r for r in rows if r[3] > 0]
+        seg, off = [], []
+        for i, r in enumerate(rows):
+            for o in range(0, r[3], chunk):
+                seg.append(i)
+                off.append(o)
+        self.n_chunks = len(seg)
+        self.nbytes = sum(r[3] for r in rows)
+        if self.n_chunks:
+            self.table = torch.from_numpy(np.asarray(rows, dtype=np.int64).reshape(-1, 16)).to(device)
+            self.chunk_seg = torch.from_numpy(np.asarray(seg, dtype=np.int32)).to(device)
+            self.chunk_off = torch.from_numpy(np.asarray(off, dtype=np.int64)).to(device)
+
+    def run(self, src_base=0, dst_base=0):
+        if self.n_chunks:
+            call("segcopy", table=self.table, chunk_seg=self.chunk_seg, chunk_off=self.chunk_off, n_chunks=self.n_chunks,
+                 src_base=src_base, dst_base=dst_base)
+
+
+class _Pack:
+    __slots__ = ("value", "params", "ver", "rows")
+
+
+_packs = {}                  # key -> _Pack: persistent operand layouts of parameters
+_packs_prog = None           # SegProgram over the rows of every pack (rebuilt when the set changes)
+_packs_dirty = True
+pack_refreshes = 0           # number of whole-registry refresh launches (tests / launch accounting)
+
+
+def _capturing(device):
+    return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
+def _refresh_packs(device):
+    """Parameters moved on (optimizer step): re-copy EVERY registered pack with one launch.  Entries whose parameters died or were
+    re-allocated are dropped (and rebuilt lazily by their next lookup)."""
+    global _packs_prog, _packs_dirty, pack_refreshes
+    live = []
+    for k in list(_packs):
+        e = _packs[k]
+        ps = [r() for r in e.params]
+        if any(p is None for p in ps) or tuple(p.data_ptr() for p in ps) != tuple(v[0] for v in e.ver[1]) or ps[0].device != device:
+            if any(p is None for p in ps) or ps[0].device == device:
+                del _packs[k]
+                _packs_dirty = True
+            continue
+        live.append((e, ps))
+    if _packs_dirty:
+        if _capturing(device):
+            raise RuntimeError("the set of weight packs changed under stream capture (run a warm-up step before capturing)")
+        _packs_prog = SegProgram([r for e, _ in live for r in e.rows], device)
+        _packs_dirty = False
+    _packs_prog.run()
+    pack_refreshes += 1
+    for e, ps in live:
+        e.ver = _pver(ps)
+
+
+def _pver(params):
+    return (_param_epoch, tuple((p.data_ptr(), p._version) for p in params))
+
+
+def seg_pack(key, params, alloc, rows_of):
+    """Persistent pack `key` of the parameters `params`: `alloc()` -> zero-initialised destination (tensor or Split), `rows_of(value)` ->
+    its segcopy rows.  Served from the registry while the parameters are unchanged; after a parameter update the FIRST stale lookup
+    refreshes every registered pack in one launch (mtt_segcopy), so a training step re-packs all weights with one kernel instead of one
+    cast / copy per weight.  Padding (outside the boxes) is written once, by `alloc`."""
+    global _packs_dirty
+    ver = _pver(params)
+    e = _packs.get(key)
+    if e is not None and len(e.params) == len(params) and all(r() is p for r, p in zip(e.params, params)) \
+            and tuple(v[0] for v in e.ver[1]) == tuple(v[0] for v in ver[1]):
+        if e.ver != ver:
+            _refresh_packs(params[0].device)
+            e = _packs.get(key)
+        if e is not None and e.ver == ver:
+            return e.value
+    if _capturing(params[0].device):
+        raise RuntimeError("a weight pack would be built under stream capture (run a warm-up step before capturing)")
+    with torch.no_grad():
+        e = _Pack()
+        e.value = alloc()
+        e.rows = rows_of(e.value)
+        e.params = [weakref.ref(p) for p in params]
+        e.ver = ver
+        SegProgram(e.rows, params[0].device).run()
+    _packs[key] = e
+    _packs_dirty = True
+    return e.value
+
+
+_unpack_progs = {}
+
+
+def unpack_grads(src, key, shapes, rows_of, partial=False):
+    """Packed fp32 weight gradients `src` -> one contiguous fp32 gradient per parameter shape in `shapes` (views of ONE flat buffer),
+    written by ONE mtt_segcopy launch: the inverse of the pack layouts above (column padding dropped, tap-major -> [Co, Ci, 3, 3], padded
+    concatenations split).  `rows_of(src, flat, offsets)` -> segcopy rows built with `segment(src, ..., flat, offsets[z] + ...)`; they are
+    stored relative to the two buffers, so the cached program serves every later step's fresh buffers.  Unless `partial`, every
+    destination element must be covered by a segment (the flat buffer is then not zeroed)."""
+    import math
+    sizes = [math.prod(sh) for sh in shapes]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + (n + 3) // 4 * 4)                      # 16-byte aligned starts (vector path)
+    flat = (torch.zeros if partial else torch.empty)(offs[-1], dtype=torch.float32, device=src.device)
+    k = (key, tuple(src.shape), tuple(src.stride()), tuple(tuple(sh) for sh in shapes), src.device)
+    prog = _unpack_progs.get(k)
+    if prog is None:
+        if _capturing(src.device):
+            raise RuntimeError("a gradient-scatter table would be built under stream capture (run a warm-up step before capturing)")
+        rows = rows_of(src, flat, offs)
+        assert src.data_ptr() % 16 == 0 and flat.data_ptr() % 16 == 0
+        for r in rows:
+            r[0] -= src.data_ptr()
+            r[1] -= flat.data_ptr()
+        assert partial or sum(r[3] for r in rows) == sum(sizes), "gradient scatter must cover every parameter element exactly once"
+        prog = _unpack_progs[k] = SegProgram(rows, src.device)
+    assert src.data_ptr() % 16 == 0
+    prog.run(src_base=src.data_ptr(), dst_base=flat.data_ptr())
+    return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
+def clear_pack_cache():
+    global _packs_dirty, _packs_prog
+    _pack_cache.clear()
+    _packs.clear()
+    _unpack_progs.clear()
+    _packs_prog = None
+    _packs_dirty = True
+
+
+def _w2d(w):
+    return w.shape[0], w.numel() // w.shape[0]
+
+
 def pack_linear(weights, prec, tag):
-    """List of Z parameters [N, K] (or 1x1 conv [N, K, 1, 1]) -> one [Z, N, Kp] buffer."""
-    def build():
-        with torch.no_grad():
-            mats = [pack_matrix(w.detach().reshape(w.shape[0], -1), prec) for w in weights]
-            return torch.stack(mats, 0) if len(mats) > 1 else mats[0][None]
-    return _cached((tag, prec.name, tuple(id(w) for w in weights)), weights, build)
+    """List of Z parameters [N, K] (or 1x1 conv [N, K, 1, 1]) -> one [Z, N, Kp] buffer in the activation dtype (zero padded)."""
+    N, K = _w2d(weights[0])
+    Kp, Z = pad8(K), len(weights)
+    if prec.adt == torch.float32 and Z == 1 and K % 8 == 0 and weights[0].is_contiguous():
+        return weights[0].detach().reshape(1, N, K)               # fp32 storage: the parameter itself is the operand
+    assert all(w.is_contiguous() and _w2d(w) == (N, K) for w in weights)
+    return seg_pack((tag, prec.name, tuple(id(w) for w in weights)), list(weights),
+                    lambda: torch.zeros(Z, N, Kp, dtype=prec.adt, device=weights[0].device),
+                    lambda buf: [segment(w, 0, buf, z * N * Kp, (1, N, K), (0, K, 1), (0, Kp, 1)) for z, w in enumerate(weights)])
+
+
+def pack_linear_T(weight, dtype, tag):
+    """Parameter [N, K] -> its transpose [K, N] in `dtype`: the reduction-contiguous operand of the input-gradient GEMM dx = dy @ W."""
+    N, K = _w2d(weight)
+    assert weight.is_contiguous()
+    return seg_pack((tag, 'wT', dtype, id(weight)), [weight], lambda: torch.zeros(K, N, dtype=dtype, device=weight.device),
+                    lambda buf: [segment(weight, 0, buf, 0, (1, N, K), (0, K, 1), (0, 1, N))] if min(N, K) < 16 else
+                                [segment(weight, 0, buf, 0, (1, K, N), (0, 1, K), (0, N, 1))])
 
 
 def pack_linear_split(weights, tag):
     """List of Z parameters [N, K] -> Split [Z, N, pad8(K)]: pre-split weight planes for the LDS-DMA x3 GEMM (x3f mode)."""
-    def build():
-        with torch.no_grad():
-            mats = [w.detach().reshape(w.shape[0], -1).float() for w in weights]
-            N, K = mats[0].shape
-            buf = torch.zeros(2, len(mats), N, pad8(K), dtype=torch.bfloat16, device=mats[0].device)
-            for z, m in enumerate(mats):
-                hi = m.to(torch.bfloat16)
-                buf[0, z, :, :K] = hi
-                buf[1, z, :, :K] = (m - hi.float()).to(torch.bfloat16)
-            return Split(buf[0], buf[1])
-    return _cached((tag, 'split', tuple(id(w) for w in weights)), weights, build)
+    N, K = _w2d(weights[0])
+    Kp, Z = pad8(K), len(weights)
+    assert all(w.is_contiguous() and _w2d(w) == (N, K) for w in weights)
+    dev = weights[0].device
+    return seg_pack((tag, 'split', tuple(id(w) for w in weights)), list(weights),
+                    lambda: Split(torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev)),
+                    lambda sp: [segment(w, 0, sp.hi, z * N * Kp, (1, N, K), (0, K, 1), (0, Kp, 1), dst_lo=sp.lo) for z, w in enumerate(weights)])
 
 
 def pack_conv3(weights, prec, tag, transpose=False):
     """List of Z conv weights [Co, Ci, 3, 3] -> [Z, Co, 9*Cip] with k = tap*Cip + ci (taps row-major).
     transpose=True packs the dgrad operand [Z, Ci, 9*Cop] with k = tap*Cop + co."""
-    def build():
-        with torch.no_grad():
-            out = []
-            for w in weights:
-                w = w.detach()
-                w = w.permute(1, 2, 3, 0) if transpose else w.permute(0, 2, 3, 1)     # [R, 3, 3, Cin]
-                R, _, _, Cin = w.shape
-                Cp = pad8(Cin)
-                buf = torch.zeros(R, 9, Cp, dtype=torch.float32, device=w.device)
-                buf[:, :, :Cin] = w.reshape(R, 9, Cin)
-                out.append(pack_matrix(buf.reshape(R, 9 * Cp), prec))
-            return torch.stack(out, 0)
-    return _cached((tag, prec.name, transpose, tuple(id(w) for w in weights)), weights, build)
+    Co, Ci = weights[0].shape[:2]
+    R, Cin = (Ci, Co) if transpose else (Co, Ci)
+    Cp, Z = pad8(Cin), len(weights)
+    assert all(w.is_contiguous() and tuple(w.shape) == (Co, Ci, 3, 3) for w in weights)
+    # logical box (r, tap, c): source W[co, ci, tap] has strides (Ci*9, 9, 1) over (co, ci, tap)
+    s = (9, 1, Ci * 9) if transpose else (Ci * 9, 1, 9)
+    return seg_pack((tag, prec.name, transpose, tuple(id(w) for w in weights)), list(weights),
+                    lambda: torch.zeros(Z, R, 9 * Cp, dtype=prec.adt, device=weights[0].device),
+                    lambda buf: [segment(w, 0, buf, z * R * 9 * Cp, (R, 9, Cin), s, (9 * Cp, Cp, 1)) for z, w in enumerate(weights)])
 
 
 def pack_upconv9(weights, prec, tag):
     """List of Z conv weights [Co, Ci, 3, 3] -> [Z, 9*pad8(Co), pad8(Ci)]: row (ky*3+kx)*pad8(Co) + co holds W[co, :, ky, kx] — the nine
     tap matrices of the "taps first" form of upsample x4 + 3x3 conv (mtt_upconv_desc) stacked as ONE linear layer; rows of the channel
     padding are zero, so its output planes carry zero padding channels."""
-    def build():
-        with torch.no_grad():
-            out = []
-            for w in weights:
-                Co, Ci = w.shape[:2]
-                buf = torch.zeros(9, pad8(Co), Ci, dtype=torch.float32, device=w.device)
-                buf[:, :Co] = w.detach().permute(2, 3, 0, 1).reshape(9, Co, Ci)
-                out.append(pack_matrix(buf.reshape(9 * pad8(Co), Ci), prec))
-            return torch.stack(out, 0)
-    return _cached((tag, prec.name, 'up9', tuple(id(w) for w in weights)), weights, build)
+    Co, Ci = weights[0].shape[:2]
+    Cop, Kp, Z = pad8(Co), pad8(Ci), len(weights)
+    assert all(w.is_contiguous() and tuple(w.shape) == (Co, Ci, 3, 3) for w in weights)
+    return seg_pack((tag, prec.name, 'up9', tuple(id(w) for w in weights)), list(weights),
+                    lambda: torch.zeros(Z, 9 * Cop, Kp, dtype=prec.adt, device=weights[0].device),
+                    lambda buf: [segment(w, 0, buf, z * 9 * Cop * Kp, (9, Co, Ci), (1, Ci * 9, 9), (Cop * Kp, Kp, 1)) for z, w in enumerate(weights)])
+
+
+def pack_kmap(weights, N, Kp, kmap, prec, tag):
+    """List of Z parameters [N, K...] -> [Z, N, Kp] with the column ranges (dst0, src0, len) of `kmap` copied (inputs that are padded
+    concatenations: taskprompter.py:471 torch.cat([spa, chan], 1) feeding fea_fuse[0])."""
+    Z = len(weights)
+    K = weights[0].numel() // N
+    assert all(w.is_contiguous() and w.numel() == N * K for w in weights)
+    return seg_pack((tag, prec.name, 'kmap', tuple(id(w) for w in weights)), list(weights),
+                    lambda: torch.zeros(Z, N, Kp, dtype=prec.adt, device=weights[0].device),
+                    lambda buf: [segment(w, s0, buf, z * N * Kp + d0, (1, N, ln), (0, K, 1), (0, Kp, 1))
+                                 for z, w in enumerate(weights) for (d0, s0, ln) in kmap])
 
 
 def stack_vec(vs, tag):
-    def build():
-        with torch.no_grad():
-            return torch.stack([v.detach().float().reshape(-1) for v in vs], 0).contiguous()
-    return _cached((tag, tuple(id(v) for v in vs)), vs, build)
+    """List of Z fp32 vectors (biases) -> [Z, n] fp32."""
+    n, Z = vs[0].numel(), len(vs)
+    if any(v.dtype != torch.float32 or not v.is_contiguous() or v.numel() != n for v in vs):
+        def build():
+            with torch.no_grad():
+                return torch.stack([v.detach().float().reshape(-1) for v in vs], 0).contiguous()
+        return _cached((tag, tuple(id(v) for v in vs)), vs, build)
+    return seg_pack((tag, 'vec', tuple(id(v) for v in vs)), list(vs),
+                    lambda: torch.zeros(Z, n, dtype=torch.float32, device=vs[0].device),
+                    lambda buf: [segment(v, 0, buf, z * n, (1, 1, n), (0, 0, 1), (0, 0, 1)) for z, v in enumerate(vs)])
+
 
 
 # ---------------------------------------------------------------------------------------------

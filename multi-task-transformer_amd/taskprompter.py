@@ -332,16 +332,8 @@ class TaskPrompter(nn.Module):
         Wdec = ops.pack_linear(dec_w, prec, ('dec', il))
         bdec = ops.stack_vec(dec_b, ('decb', il))
         f0 = [self.fea_fuse[il][t][0].weight for t in names]
-
-        def build_f0():
-            with torch.no_grad():
-                buf = torch.zeros(len(names), F, 2 * tarp, dtype=torch.float32, device=f0[0].device)
-                for i, wt in enumerate(f0):
-                    w2 = wt.detach().reshape(F, 2 * tar)
-                    buf[i, :, :tar] = w2[:, :tar]
-                    buf[i, :, tarp:tarp + tar] = w2[:, tar:]
-                return buf.to(pf.adt)
-        W0 = ops._cached(('f0', il, pf.name, tuple(id(q) for q in f0)), f0, build_f0)
+        # fea_fuse[0] reads torch.cat([spa, chan], 1) (:471): its K = 2*tar columns land at 0 and pad8(tar) of the padded concatenation
+        W0 = ops.pack_kmap(f0, F, 2 * tarp, [(0, 0, tar), (tarp, tar, tar)], pf, ('f0', il))
         b0 = ops.stack_vec([self.fea_fuse[il][t][0].bias for t in names], ('f0b', il))
         Wc = ops.pack_conv3([self.fea_fuse[il][t][1].weight for t in names], pf, ('f1', il))
         bc = ops.stack_vec([self.fea_fuse[il][t][1].bias for t in names], ('f1b', il))

@@ -164,6 +164,10 @@ def gemm(**kw):
             _wr(D, didx, v)
             if d_split:
                 _wr(kw["D_lo"], didx, v - _bf16_round(v))
+            if kw.get("colsum_out") is not None:         # column sums of the values AS STORED (bf16 D: rounded); batch == 1 only
+                assert batch == 1 and kw.get("colsum_ws") is not None
+                stored = _bf16_round(v) if D.dtype == torch.bfloat16 and not d_split else v
+                _wr(kw["colsum_out"], ncol, stored.sum(0))
             n_store = g("n_store")
             if n_store and n_store > N:
                 pad = torch.arange(N, n_store)
@@ -563,7 +567,15 @@ def rowscale_cast(args):
         rem = (rr % mb) if mb > 0 else rr
         v = v * _rd(rowscale, q * 2 + (rem >= n_prompt).long())[:, None]
     _wr(dst, r * ldd + c, v)
+    return v
 
+
+def rowscale_cast_colsum(args):
+    """mtt_rowscale_cast_colsum: the cast + column sums of the values as stored in dst."""
+    v = rowscale_cast(args[:11])
+    dst, out = args[1], args[11]
+    stored = _bf16_round(v) if dst.dtype == torch.bfloat16 else v
+    _wr(out, torch.arange(args[3]), stored.sum(0))
 
 
 def dwconv3x3s2(**kw):
@@ -663,6 +675,46 @@ def _raw_f32(addr, n):
     import ctypes
     import numpy as np
     return np.ctypeslib.as_array((ctypes.c_float * int(n)).from_address(int(addr)))
+
+
+def _raw(addr, count, code):
+    """typed numpy view of host memory at a raw address (code: F32 -> float32, else uint16 = bf16 bit patterns)."""
+    import ctypes
+    import numpy as np
+    ct = ctypes.c_float if code == F32 else ctypes.c_uint16
+    return np.ctypeslib.as_array((ct * int(count)).from_address(int(addr)))
+
+
+def segcopy(**kw):
+    """mtt_segcopy (include/mtt_hip.h): multi-segment strided copy / cast driven by the device tables; padding is not touched."""
+    import numpy as np
+    table = kw["table"].tolist()
+    used = sorted(set(kw["chunk_seg"].tolist()))
+    assert used == list(range(len(table))), "every segment must be covered by the chunk table"
+    assert kw["n_chunks"] == kw["chunk_seg"].numel() == kw["chunk_off"].numel()
+    for g in table:
+        sa, da, la, total, n1, n2, s0, s1, s2, d0, d1, d2, sdt, ddt, vec, _ = g
+        if g[15]:                                     # transposing segment: `total` counts 64 x 64 tile slots; same element mapping
+            assert s1 == 1 and d2 == 1 and not vec
+            n0 = total // (4096 * ((n1 + 63) // 64) * ((n2 + 63) // 64))
+        else:
+            n0 = total // (n1 * n2)
+        i0, i1, i2 = np.meshgrid(np.arange(n0), np.arange(n1), np.arange(n2), indexing="ij")
+        so = (i0 * s0 + i1 * s1 + i2 * s2).ravel()
+        do = (i0 * d0 + i1 * d1 + i2 * d2).ravel()
+        if vec:
+            assert n2 % 4 == 0 and s0 % 4 == 0 and s1 % 4 == 0 and d0 % 4 == 0 and d1 % 4 == 0 and (sa + kw["src_base"]) % 16 == 0 \
+                and (da + kw["dst_base"]) % 16 == 0, "vec segment violates its alignment contract"
+        src = _raw(sa + kw["src_base"], so.max() + 1, sdt)[so]
+        v = torch.from_numpy(src.astype(np.float32)) if sdt == F32 else (torch.from_numpy(src.astype(np.int32)) << 16).view(torch.float32)
+        if ddt == F32:
+            _raw(da + kw["dst_base"], do.max() + 1, F32)[do] = v.numpy()
+        else:
+            hi = v.to(torch.bfloat16)
+            _raw(da + kw["dst_base"], do.max() + 1, BF16)[do] = hi.view(torch.int16).numpy().view(np.uint16)
+            if ddt == SPLIT:
+                lo = (v - hi.float()).to(torch.bfloat16)
+                _raw(la + kw["dst_base"], do.max() + 1, BF16)[do] = lo.view(torch.int16).numpy().view(np.uint16)
 
 
 def _adam_tables(kw):
@@ -1042,8 +1094,8 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=wina
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg, attn_msg_bwd=attn_msg_bwd,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
-              loss_fwd=loss_fwd, loss_bwd=loss_bwd, chanattn_bwd=chanattn_bwd, conv3s2_nchw_bwd=conv3s2_nchw_bwd)
-_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, colsum_batched=colsum_batched, add_rows=add_rows, rowscale_cast=rowscale_cast)
+              loss_fwd=loss_fwd, loss_bwd=loss_bwd, chanattn_bwd=chanattn_bwd, conv3s2_nchw_bwd=conv3s2_nchw_bwd, segcopy=segcopy)
+_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, colsum_batched=colsum_batched, add_rows=add_rows, rowscale_cast=rowscale_cast, rowscale_cast_colsum=rowscale_cast_colsum)
 
 
 def call(name, **kw):

@@ -551,3 +551,11 @@ def test_swin_window_tables_are_consistent():
         xs = torch.roll(xp, (-shift, -shift), (1, 2)) if shift else xp
         win = xs.view(1, Hp // ws, ws, Wp // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
         assert torch.equal(torch.where(pix >= 0, pix + 1, torch.zeros_like(pix)).float(), win)
+
+
+def test_persistent_packs_match_torch_relayouts_on_emulator(emulated):
+    """ops.seg_pack / mtt_segcopy (emulated): every pack layout bit-exact against a plain torch re-layout; one refresh per parameter update."""
+    import pack_check
+    pack_check.check_packs("cpu")
+    pack_check.check_refresh("cpu")
+    pack_check.check_unpack("cpu")
