@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-ref-batch", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg (the oracle's torch ops on the GPU)")
+    ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency leg (profiling runs: every launch then belongs to a training step)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the tolerance-compliant sub-record (parity_mode)")
     ap.add_argument("--torch-baseline-worker", default=None, help="(internal) subprocess leg of torch_rocm_baseline: 'fp32' or 'bf16'")
     ap.add_argument("--no-fuse-upsample", action="store_true",
@@ -93,7 +94,7 @@ def parse():
     ap.add_argument("--measure-no-repack", action="store_true",
                     help="MEASUREMENT ONLY (invalid training: the forward keeps using the step-0 weight packs): what the per-step re-packing costs")
     ap.add_argument("--gemm-variant", type=int, default=None,
-                    help="A/B: mtt_gemm_desc.variant for every GEMM left at AUTO (12 = policy + persistent kernel, 14 = policy without it)")
+                    help="A/B: mtt_gemm_desc.variant for every GEMM left at AUTO (1 = general kernel, 3 = LDS-DMA kernel, 11 = general epilogue everywhere)")
     ap.add_argument("--graphed-worker", action="store_true", help="(internal) the subprocess leg of ref_batch.graphed")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
@@ -447,17 +448,19 @@ def main():
     host = host_share(step)
 
     # forward-only latency (the metric's second half), same process
-    model.eval()
-    with torch.no_grad():
-        for _ in range(2):
-            model(x)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            model(x)
-        torch.cuda.synchronize()
-    fwd_ms_img = (time.perf_counter() - t1) / 3 / batch * 1e3
-    model.train()
+    fwd_ms_img = float("nan")
+    if not a.no_fwd:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                model(x)
+            torch.cuda.synchronize()
+        fwd_ms_img = (time.perf_counter() - t1) / 3 / batch * 1e3
+        model.train()
 
     roof = None
     if not a.no_roofline and rank != 0:
@@ -593,9 +596,10 @@ def main():
                                 optimizer="clip_grad_norm 10 + Adam (mtt_grad_sqnorm / mtt_adam_step)", loss=final_loss,
                                 grad_comm=a.grad_comm if ddp_mode else None, bucket_mb=a.bucket_mb if ddp_mode else None,
                                 rccl_ranks=world if ddp_mode else None),
-                    fwd_ms_per_img=round(fwd_ms_img, 3), peak_hbm_gb=round(peak_gb, 1), host=host,
+                    fwd_ms_per_img=None if a.no_fwd else round(fwd_ms_img, 3), peak_hbm_gb=round(peak_gb, 1), host=host,
                     model_tflops=dict(train=round(train_tflops, 1), frac_of_bf16_peak=round(train_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
-                                      fwd=round(gflop_fwd / fwd_ms_img, 1), fwd_frac_of_bf16_peak=round(gflop_fwd / fwd_ms_img / MFMA_BF16_PEAK_TFLOPS, 4),
+                                      fwd=None if a.no_fwd else round(gflop_fwd / fwd_ms_img, 1),
+                                      fwd_frac_of_bf16_peak=None if a.no_fwd else round(gflop_fwd / fwd_ms_img / MFMA_BF16_PEAK_TFLOPS, 4),
                                       gflop_fwd_per_img=gflop_fwd, gflop_fwd_executed_per_img=round(gflop_exec, 1),
                                       convention="FLOPs of the reference's operation order; 'executed' subtracts what the taps-first "
                                                  "ConvHead (upsample x4 + 3x3 conv commuted) does not compute"),

@@ -34,6 +34,7 @@ class GraphedTrainStep:
                 self._iteration()
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad(set_to_none=True)                 # gradients are re-created inside the graph's memory pool
+        ops.finalize_packs(x.device)                          # the recorded forward's weight refresh is then one bare launch
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._iteration()
@@ -61,5 +62,6 @@ class GraphedTrainStep:
 
 
 def clear():
-    """Drop cached packs that live in a released graph's memory pool (call after deleting a GraphedTrainStep)."""
+    """Drop the cached packs / gradient-scatter tables (call after deleting a GraphedTrainStep: lazily cached one-off packs built under
+    its capture live in the released graph's memory pool)."""
     ops.clear_pack_cache()

@@ -198,8 +198,8 @@ class _Pack:
 
 
 _packs = {}                  # key -> _Pack: persistent operand layouts of parameters
-_packs_prog = None           # SegProgram over the rows of every pack (rebuilt when the set changes)
-_packs_dirty = True
+_packs_gen = 0               # bumped whenever the set of packs changes
+_packs_prog = {}             # device -> (generation, SegProgram over the rows of every pack on that device)
 pack_refreshes = 0           # number of whole-registry refresh launches (tests / launch accounting)
 
 
@@ -207,26 +207,42 @@ def _capturing(device):
     return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
 
 
-def _refresh_packs(device):
-    """Parameters moved on (optimizer step): re-copy EVERY registered pack with one launch.  Entries whose parameters died or were
-    re-allocated are dropped (and rebuilt lazily by their next lookup)."""
-    global _packs_prog, _packs_dirty, pack_refreshes
+def _live_packs(device):
+    """[(pack, parameters)] of the registered packs on `device`; entries whose parameters died or were re-allocated are dropped (their
+    next lookup rebuilds them)."""
+    global _packs_gen
     live = []
     for k in list(_packs):
         e = _packs[k]
         ps = [r() for r in e.params]
-        if any(p is None for p in ps) or tuple(p.data_ptr() for p in ps) != tuple(v[0] for v in e.ver[1]) or ps[0].device != device:
-            if any(p is None for p in ps) or ps[0].device == device:
-                del _packs[k]
-                _packs_dirty = True
-            continue
-        live.append((e, ps))
-    if _packs_dirty:
+        if any(p is None for p in ps) or tuple(p.data_ptr() for p in ps) != tuple(v[0] for v in e.ver[1]):
+            del _packs[k]
+            _packs_gen += 1
+        elif ps[0].device == device:
+            live.append((e, ps))
+    return live
+
+
+def _packs_program(device, live):
+    hit = _packs_prog.get(device)
+    if hit is None or hit[0] != _packs_gen:
         if _capturing(device):
             raise RuntimeError("the set of weight packs changed under stream capture (run a warm-up step before capturing)")
-        _packs_prog = SegProgram([r for e, _ in live for r in e.rows], device)
-        _packs_dirty = False
-    _packs_prog.run()
+        hit = _packs_prog[device] = (_packs_gen, SegProgram([r for e, _ in live for r in e.rows], device))
+    return hit[1]
+
+
+def finalize_packs(device):
+    """Build the whole-registry refresh program now (host -> device table copy) so that the next refresh is a bare kernel launch:
+    called before a stream capture whose recorded forward must contain that launch (graphs.GraphedTrainStep)."""
+    _packs_program(device, _live_packs(device))
+
+
+def _refresh_packs(device):
+    """Parameters moved on (optimizer step): re-copy EVERY registered pack of this device with one launch."""
+    global pack_refreshes
+    live = _live_packs(device)
+    _packs_program(device, live).run()
     pack_refreshes += 1
     for e, ps in live:
         e.ver = _pver(ps)
@@ -241,7 +257,7 @@ def seg_pack(key, params, alloc, rows_of):
     its segcopy rows.  Served from the registry while the parameters are unchanged; after a parameter update the FIRST stale lookup
     refreshes every registered pack in one launch (mtt_segcopy), so a training step re-packs all weights with one kernel instead of one
     cast / copy per weight.  Padding (outside the boxes) is written once, by `alloc`."""
-    global _packs_dirty
+    global _packs_gen
     ver = _pver(params)
     e = _packs.get(key)
     if e is not None and len(e.params) == len(params) and all(r() is p for r, p in zip(e.params, params)) \
@@ -261,7 +277,7 @@ def seg_pack(key, params, alloc, rows_of):
         e.ver = ver
         SegProgram(e.rows, params[0].device).run()
     _packs[key] = e
-    _packs_dirty = True
+    _packs_gen += 1
     return e.value
 
 
@@ -298,12 +314,12 @@ def unpack_grads(src, key, shapes, rows_of, partial=False):
 
 
 def clear_pack_cache():
-    global _packs_dirty, _packs_prog
+    global _packs_gen
     _pack_cache.clear()
     _packs.clear()
     _unpack_progs.clear()
-    _packs_prog = None
-    _packs_dirty = True
+    _packs_prog.clear()
+    _packs_gen += 1
 
 
 def _w2d(w):
