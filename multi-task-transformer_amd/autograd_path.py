@@ -97,10 +97,29 @@ def _n_splits(tiles, units, max_splits=16):
 def _wgrad_batched(dy, x, N, Kp, M, prec, Z, lda, ldb, a_zo, b_zo, a0=0, b0=0):
     """dW[z] = dy[z]^T x[z] for z < Z (row-contiguous operands, element offsets a0 + z*a_zo / b0 + z*b_zo): one launch over
     (task, reduction slice) with fp32 slabs summed afterwards when the tile count alone cannot fill the chip."""
-    tiles = Z * (-(-N // 128)) * (-(-Kp // 128))
-    S = _n_splits(tiles, M // SPLIT_ROW_UNIT)
     A = dy.reshape(-1)[a0:] if a0 else dy
     B = x.reshape(-1)[b0:] if b0 else x
+    p256 = (-(-N // 256)) * (-(-Kp // 256))
+    if (prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and M >= SPLITK_MIN_ROWS
+            and min(N, Kp) >= FAST_MIN_DIM and 100 * N * Kp >= 45 * p256 * 65536 and lda % 8 == 0 and ldb % 8 == 0):
+        # token-major LDS-DMA kernel (the policy of mtt_gemm picks it for these launches): 256 x 256 tiles, slices chosen to fill the
+        # 256 CUs in whole rounds.  N = 300 / 350 outputs waste 41-53 % of a tile pair and it still wins: 432 vs 697 us (fea_decode),
+        # 313 vs 424 (fea_fuse[0]), 232 vs 286 (fea_fuse[4]) at B = 63 (profiles/r03_dec_wgrad_bench_h.log)
+        S = _tn_splits(Z * p256, M)
+        c = (M // S) // 64 * 64
+        if c >= 512:
+            nz = M // c
+            rem = M - nz * c
+            slabs = torch.empty(Z, nz + (1 if rem else 0), N, Kp, dtype=torch.float32, device=dy.device)
+            SS = slabs.shape[1]
+            _gemm(A, B, slabs, N, Kp, c, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp, batch=Z * nz, batch_inner=nz,
+                  a_zo=a_zo, a_zi=c * lda, b_zo=b_zo, b_zi=c * ldb, d_zo=SS * N * Kp, d_zi=N * Kp)
+            if rem:
+                _gemm(dy.reshape(-1)[a0 + nz * c * lda:], x.reshape(-1)[b0 + nz * c * ldb:], slabs[:, nz], N, Kp, rem, prec, a_op=OP_R,
+                      b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp, batch=Z, a_zo=a_zo, b_zo=b_zo, d_zo=SS * N * Kp)
+            return slabs.sum(1)
+    tiles = Z * (-(-N // 128)) * (-(-Kp // 128))
+    S = _n_splits(tiles, M // SPLIT_ROW_UNIT)
     if S == 1:
         dW = torch.empty(Z, N, Kp, dtype=torch.float32, device=dy.device)
         _gemm(A, B, dW, N, Kp, M, prec, a_op=OP_R, b_op=OP_R, lda=lda, ldb=ldb, ldd=Kp, batch=Z, a_zo=a_zo, b_zo=b_zo, d_zo=N * Kp)

@@ -767,9 +767,14 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
       if (BWD) { s0[j] = ok ? d.dsum[pz + c] * invn : 0.f; s1[j] = ok ? d.dsumxh[pz + c] * invn : 0.f; }
     }
     const bool tail = c8 * 8 + 8 > d.C;
-    auto one = [&](int64_t r, const float (&x)[8], const float (&g)[8]) {
-      float o[8];
+    // one row of 8 channels per lane and iteration.  (Four rows per iteration — their loads in flight together — measured SLOWER: 104 instead
+    // of 56 VGPRs halves the waves in flight, 1 557 vs 1 157 us on the head maps: profiles/r03_train_ns6_b63_g.txt vs _d.txt.)
+    for (int64_t r = r0 + rl; r < r1; r += lanes) {
+      float x[8], o[8];
+      ld8(xz, r * d.ld + c8 * 8, d.dtype, x);
       if (BWD) {
+        float g[8];
+        ld8(dyz, r * d.ld + c8 * 8, d.dtype, g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = (x[j] - mu[j]) * rs[j];
@@ -785,25 +790,6 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
         for (int j = 0; j < 8; ++j) if (c8 * 8 + j >= d.C) o[j] = 0.f;
       }
       st8(oz, r * d.ld + c8 * 8, d.dtype, o);
-    };
-    // four rows per iteration: their loads are in flight together (one 16-byte load per iteration left the kernel latency-bound at
-    // ~2 TB/s on the 4 GB head maps: the erf polynomial of GELU is ~160 VALU instructions per load)
-    int64_t r = r0 + rl;
-    for (; r + 3 * lanes < r1; r += 4 * lanes) {
-      float x[4][8], g[4][8];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        ld8(xz, (r + u * lanes) * d.ld + c8 * 8, d.dtype, x[u]);
-        if (BWD) ld8(dyz, (r + u * lanes) * d.ld + c8 * 8, d.dtype, g[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) one(r + u * lanes, x[u], g[u]);
-    }
-    for (; r < r1; r += lanes) {
-      float x[8], g[8];
-      ld8(xz, r * d.ld + c8 * 8, d.dtype, x);
-      if (BWD) ld8(dyz, r * d.ld + c8 * 8, d.dtype, g);
-      one(r, x, g);
     }
   }
 }
