@@ -57,6 +57,7 @@ enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
 enum { MTT_GEMM_AUTO = 0,
        MTT_GEMM_GENERAL = 1           /* the register-staged 128 x 128 kernel (any layout / dtype / precision) */,
        MTT_GEMM_DMA256 = 3            /* the 256 x 256 LDS-DMA kernel (or, for two MTT_OP_R operands, the token-major weight-gradient kernel) on any shape it supports */,
+       MTT_GEMM_DMA128 = 4            /* the 128 x 128 LDS-DMA kernel (K-contiguous bf16 operands; narrow or mid-size outputs) */,
        MTT_GEMM_GENERAL_EPILOGUE = 11 /* policy kernel, but always the general (run-time configured) epilogue: A/B of the specialised one */ };
 enum { MTT_ATTN_AUTO = 0, MTT_ATTN_PLAIN = 1,
        MTT_ATTN_FAST_V0 = 2 /* A/B: the first flash kernels (run-time LDS stage, predicated register staging) */,

@@ -880,6 +880,122 @@ int launch_dma(const GemmP& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_dma128_kernel<FASTADDR>: 128 x 128 x 64 tile, 4 waves (2 x 2, each 64 x 64 = 4 x 4 MFMA tiles, 64 fp32 accumulators per lane),
+// operands streamed by LDS-DMA into 2 stages of 32 KiB — TWO workgroups per CU, so a SIMD alternates between a wave of each: while
+// one waits for its K tile the other issues MFMAs.  For the K-contiguous bf16 GEMMs whose N is too narrow for the 256-wide tile
+// (decoder 1x1 convs with 300 / 350 output channels, head predictions): the register-staged general kernel runs them latency-bound
+// (~25 % MFMA issue at K = 1024: global -> VGPR -> LDS with one K step of lookahead), and a 256-wide tile pair wastes 41 / 32 % of its
+// columns.  One K step: issue the LDS-DMA of tile kt + 1, read the fragments of tile kt, 32 MFMAs, wait for the DMA, barrier.
+//   RAW  tile kt + 1 is read after the barrier that follows every wave's vmcnt(0).
+//   WAR  stage (kt + 1) & 1 held tile kt - 1, whose last fragment reads completed (lgkmcnt(0)) before the barrier closing step kt - 1.
+// ---------------------------------------------------------------------------------------------
+template <bool FASTADDR>
+__global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MT = 4, NT = 4, TILE = 128 * BK * 2, STAGE = 2 * TILE;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + 127) / 128, tiles_m = (p.d.M + 127) / 128;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, 2 * p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  const bf16_t* Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
+  const bf16_t* Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int K = p.d.K;
+  uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
+  asm volatile("" : "+s"(zpage));
+
+  // wave w streams rows [32 w, 32 w + 32) of both tiles as 4 pieces of 8 rows x 128 B; lane -> (row, swizzled 16-byte chunk)
+  int64_t aoff[4], boff[4];
+  int ack[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ lds_swz(row);
+    ack[i] = c * 8;
+    int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;      // ragged edge: re-read the last valid row (results unused)
+    aoff[i] = row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + ack[i];
+    int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
+    boff[i] = (int64_t)rb * p.d.ldb + ack[i];
+  }
+  uint32_t aoff32[4], boff32[4];
+  if constexpr (FASTADDR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { aoff32[i] = (uint32_t)aoff[i] * 2u; boff32[i] = (uint32_t)boff[i] * 2u; }
+  }
+  auto issue = [&](int stage, int s) {
+    unsigned char* sA = smem + stage * STAGE + wave * 4096;
+    unsigned char* sB = sA + TILE;
+    if constexpr (FASTADDR) {
+      const unsigned char* Ak = (const unsigned char*)Abase + (size_t)s * (BK * 2);
+      const unsigned char* Bk = (const unsigned char*)Bbase + (size_t)s * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Ak + aoff32[i]), sA + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Bk + boff32[i]), sB + i * 1024);
+    } else {
+      const int k0 = s * BK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint64_t src = (uint64_t)(uintptr_t)(Abase + (aoff[i] + k0));
+        glds16((const bf16_t*)(uintptr_t)(k0 + ack[i] < K ? src : zpage), sA + i * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint64_t src = (uint64_t)(uintptr_t)(Bbase + (boff[i] + k0));
+        glds16((const bf16_t*)(uintptr_t)(k0 + ack[i] < K ? src : zpage), sB + i * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* Ah = smem + (kt & 1) * STAGE;
+    const unsigned char* Bh = Ah + TILE;
+    if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      u32x4 fa[MT], fb[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * 64 + t * 16 + li, kh * 4 + lg));
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own share of tile kt + 1 landed; own reads of tile kt done
+    __builtin_amdgcn_s_barrier();
+  }
+  gemm_epilogue_auto<128, 2, 2, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+}
+
+template <bool FASTADDR>
+int launch_dma128(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = 2 * 2 * 128 * BK * 2;               // 64 KiB: two workgroups per CU
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_dma128_kernel<FASTADDR>, smem, done)) return e;
+  const int tm = (p.d.M + 127) / 128, tn = (p.d.N + 127) / 128;
+  dim3 grid(tm * tn, 1, p.d.batch);
+  hipLaunchKernelGGL((gemm_dma128_kernel<FASTADDR>), grid, dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_tn_kernel<CONVB>: D[m, n] = sum_k A[k, m] * B[k, n] with BOTH operands "row = reduction index" (MTT_OP_R: element (r, k) at
 // base + k * ld + r) — the weight-gradient form dW = dy^T x on the token-major activations as they sit in HBM, no transposing copies
 // (round 1 transposed both operands into reduction-contiguous buffers first: 26 ms of a 450 ms step) and, with CONVB, the 3x3 conv
@@ -1123,6 +1239,7 @@ extern "C" size_t mtt_desc_size(int which) {
 // Kernel choice, a pure function of the descriptor.  Return codes (also what mtt_gemm_variant reports):
 //   0 register-staged 128 x 128 (general: any operand layout / dtype / precision)
 //   3 LDS-DMA 256 x 256 phased / staggered (gemm_dma_kernel)
+//   4 LDS-DMA 128 x 128, two workgroups per CU (gemm_dma128_kernel)
 //   6 token-major weight-gradient kernel (gemm_tn_kernel): LDS-DMA + ds_read_b64_tr_b16 fragments
 //   8 gemm_dma_kernel<2>: MTT_SPLIT operands, fp32-class product as one K-concatenated bf16 GEMM
 //  <0 MTT_E_* (no kernel takes this descriptor)
@@ -1158,6 +1275,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   const bool dma = d.a_op == MTT_OP_K && d.b_op == MTT_OP_K && (d.K % 8) == 0;
   if (!dma || d.variant == MTT_GEMM_GENERAL) return 0;
   if (d.variant == MTT_GEMM_DMA256) return 3;
+  if (d.variant == MTT_GEMM_DMA128) return 4;
   // AUTO.  Measured on MI355X (profiles/r02_gemm_bench_b*.log, r02_conv_bench_b.log, B = 63 shapes): the 256 x 256 DMA tile wins for
   // wide outputs (qkv / proj / fc1 / fc2: 830-1170 vs 610-740 TFLOP/s on the register-staged 128 x 128 kernel); narrow decoder shapes
   // (N = 300 / 350: 22 % of a 256-wide tile pair is padding) and few-tile problems stay on the general kernel.
@@ -1166,6 +1284,10 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   const int batch = d.batch < 1 ? 1 : d.batch;
   const int64_t blocks = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * batch;
   if (wide && d.M >= 512 && d.N >= 512 && blocks >= 96) return 3;
+  // 4: the 128 x 128 LDS-DMA kernel (two workgroups per CU) for what is left: narrow outputs (decoder 1x1s with 300 / 350 channels, head
+  // predictions) and mid-size problems — whenever there is enough work to fill the chip's 512 workgroup slots
+  const int64_t blocks128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * batch;
+  if (d.M >= 512 && d.K >= 128 && blocks128 >= 256) return 4;
   return 0;
 }
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }
@@ -1212,7 +1334,7 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     if (d.batch != 1 || d.store_mode != MTT_STORE_ROWS || v == 6) return MTT_E_UNSUPPORTED;
     const int rc = gemm_launch(p, s, v);
     if (rc) return rc;
-    const int tbm = (v == 3 || v == 8) ? 256 : BM;
+    const int tbm = (v == 3 || v == 8) ? 256 : BM;           // (the 128 x 128 LDS-DMA kernel has the general kernel's row block)
     hipLaunchKernelGGL(mtt_colsum_final_kernel, dim3((d.N + 31) / 32, 1, 1), dim3(256), 0, s, (const float*)d.colsum_ws, d.colsum_out, d.N,
                        (d.M + tbm - 1) / tbm, (int64_t)0);
     return (int)hipGetLastError();
@@ -1229,6 +1351,7 @@ static int gemm_launch(GemmP& p, hipStream_t s, int v) {
   mtt_gemm_desc& d = p.d;
   if (v == 8) return launch_dma<2>(p, s);
   if (v == 3) return dma_fastaddr_ok(d) ? launch_dma<1>(p, s) : launch_dma<0>(p, s);
+  if (v == 4) return dma_fastaddr_ok(d) ? launch_dma128<true>(p, s) : launch_dma128<false>(p, s);
   if (v == 6) return d.b_op == MTT_OP_CONV_R ? launch_tn<true>(p, s) : launch_tn<false>(p, s);
   // general kernel.  MODE: 0 bf16 x bf16; 1 A f32 (rounded while staged) x bf16; 2 x3 (both f32, split while staged);
   // 3 f32 x f32, 4 bf16 x f32, rounded while staged (bf16 arithmetic on fp32-stored tensors: the backward of the x3-forward training mode)

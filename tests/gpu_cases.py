@@ -159,12 +159,31 @@ def gemm_cases():
     for (M, N, K) in ((300, 260, 200), (70, 700, 64), (513, 350, 1096), (256, 128, 8), (1000, 300, 72)):
         kw = base(M, N, K, BF16, BF16, BF16, 0, variant=3, colshift=rnd(g, N), act=1)
         cases.append((f"gemm_dma_forced_{M}x{N}x{K}", "gemm", kw, TOL_BF))
+    # 1d'. the 128 x 128 LDS-DMA kernel (variant = 4; two workgroups per CU): K tails / fast addressing, ragged edges, one and many K tiles,
+    #      task batches with an inner pair (the decoder's catpair output), A row groups + fp32 residual epilogue
+    for (M, N, K) in ((300, 260, 200), (70, 700, 64), (513, 350, 1096), (256, 128, 8), (1000, 300, 72), (640, 300, 1024), (300, 350, 608)):
+        kw = base(M, N, K, BF16, BF16, BF16, 0, variant=4, colshift=rnd(g, N), act=1)
+        cases.append((f"gemm_dma128_{M}x{N}x{K}", "gemm", kw, TOL_BF))
+    Z, M, N, K = 6, 300, 44, 128
+    kw = dict(A=rnd(g, Z, M, K, dtype=torch.bfloat16), B=rnd(g, Z, N, K, dtype=torch.bfloat16), D=torch.zeros(Z // 2, M, 96, dtype=torch.bfloat16),
+              M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=96, batch=Z, batch_inner=2,
+              a_zo=2 * M * K, a_zi=M * K, b_zo=2 * N * K, b_zi=N * K, d_zo=M * 96, d_zi=48, alpha=1.0, n_store=48, variant=4,
+              colshift=rnd(g, Z, N), col_zo=2 * N, col_zi=N)
+    cases.append(("gemm_dma128_batched_pair", "gemm", kw, TOL_BF))
+    Bn, Mb, K, N = 6, 117, 192, 300
+    XA = rnd(g, Bn, Mb + 3, K, dtype=torch.bfloat16)
+    XT = rnd(g, Bn, Mb + 3, 304)
+    kw = dict(A=XA[:, 3:], B=rnd(g, N, K, dtype=torch.bfloat16), D=XT[:, 3:], M=Bn * Mb, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16,
+              d_dtype=F32, prec=0, lda=K, ldb=K, ldd=304, a_mb=Mb, a_bs=(Mb + 3) * K, d_mb=Mb, d_bs=(Mb + 3) * 304, batch=1, batch_inner=1,
+              alpha=1.0, colshift=rnd(g, N), resid=XT[:, 3:], ldr=304, r_mb=Mb, r_bs=(Mb + 3) * 304,
+              rowscale=torch.rand(Bn, 2, generator=g), n_prompt=5, n_store=304, variant=4)
+    cases.append(("gemm_dma128_rowgroups_resid", "gemm", kw, TOL_BF))
     # many K tiles / both parities of the tile count (fast addressing: K % 64 == 0) and K tails (general addressing)
     for (M, N, K, v) in ((300, 520, 200, 3), (513, 600, 1096, 3), (520, 700, 1152, 3), (300, 512, 1088, 3), (256, 256, 64, 3), (256, 256, 128, 3)):
         cases.append((f"gemm_dma_sched{v}_{M}x{N}x{K}", "gemm", base(M, N, K, BF16, BF16, BF16, 0, variant=v, colshift=rnd(g, N)), TOL_BF))
     # 1e. specialised interior-tile epilogues (KIND 0..4 of gemm_epilogue_fast) on the DMA kernel (variant 3) and the general kernel
     #     (variant 1), next to edge tiles that take the general epilogue in the same launch; variant 11 = general epilogue everywhere
-    for v in (3, 1, 11):
+    for v in (3, 4, 1, 11):
         M, N, K = 600, 520, 136
         A16 = rnd(g, M, K, dtype=torch.bfloat16)
         B16 = rnd(g, N, K, dtype=torch.bfloat16)
@@ -486,6 +505,13 @@ def row_cases():
         kw = dict(q=rnd(g, B * T, h * w, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.full((B, T, 1, C), 9.0),
                   B=B, T=T, N=N, C=C, h=h, w=w, nh=1, nw=1, dtype=dt, ldq=h * w, ws=scratch(64 * B * T * C))
         cases.append((f"chanlogit_{dt}_splits", "chan_logits", kw, TOL_ROW))
+        # windows whose width is a multiple of 8: the eight-pixels-per-lane kernel (windowed, non-square, padded query pitch, 7 tasks)
+        for (B, T, h, w, nh, nw) in ((2, 6, 16, 16, 2, 2), (1, 7, 8, 24, 1, 3), (2, 6, 32, 32, 1, 1)):
+            N = T + h * w
+            ldq = h * w + 8
+            kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.full((B, T, nh * nw, C), 9.0),
+                      B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nw, dtype=dt, ldq=ldq, ws=scratch(64 * B * T * nh * nw * C))
+            cases.append((f"chanlogit_px8_{dt}_{h}x{w}_win{nh}x{nw}", "chan_logits", kw, TOL_ROW))
     # backward-only kernels ((8, 8, *): window widths that are multiples of 4 take the token-grouped chan_logits_bwd kernel)
     for dt in (F32, BF16):
         for (h, w, nh) in ((4, 6, 1), (4, 6, 2), (8, 8, 1), (8, 8, 2)):

@@ -16,6 +16,7 @@ from mtt_amd import ops  # noqa: E402
 ap = importlib.import_module("multi-task-transformer_amd.autograd_path")
 prec = ops.Prec("bf16")
 M = 63 * 1024
+M_OF = {"head linear_pred (128 x 128 map, 21 classes)": 63 * 128 * 128}
 
 
 def timed(fn, rounds=5):
@@ -34,7 +35,9 @@ def timed(fn, rounds=5):
 
 # (name, Z, N, K) : D[z] [M, pad8(N)] = A[z] [M, pad8(K)] @ W[z] [N, pad8(K)]^T + bias
 for name, Z, N, K in (("fea_decode fwd (12 = 6 tasks x spa/chan)", 12, 300, 1024), ("fea_fuse[0] fwd", 6, 350, 608), ("fea_fuse[4] fwd", 6, 350, 350),
-                      ("fea_decode dgrad", 12, 1024, 300), ("fea_fuse[0] dgrad", 6, 608, 350), ("fea_fuse[4] dgrad", 6, 350, 350)):
+                      ("fea_decode dgrad", 12, 1024, 300), ("fea_fuse[0] dgrad", 6, 608, 350), ("fea_fuse[4] dgrad", 6, 350, 350),
+                      ("head linear_pred (128 x 128 map, 21 classes)", 1, 21, 350), ("encoder qkv (for reference)", 1, 3072, 1024)):
+    M = M_OF.get(name, 63 * 1024)
     Np, Kp = ops.pad8(N), ops.pad8(K)
     A = (torch.rand(Z, M, Kp, device="cuda") - 0.5).bfloat16()
     A[..., K:] = 0
@@ -44,7 +47,7 @@ for name, Z, N, K in (("fea_decode fwd (12 = 6 tasks x spa/chan)", 12, 300, 1024
     D = torch.empty(Z, M, Np, dtype=torch.bfloat16, device="cuda")
     fl = 2.0 * Z * M * N * K
     ref = None
-    for variant, label in ((1, "register-staged 128 x 128"), (3, "LDS-DMA 256 x 256")):
+    for variant, label in ((1, "register-staged 128 x 128"), (3, "LDS-DMA 256 x 256"), (4, "LDS-DMA 128 x 128, 2 WG/CU")):
         def go():
             ap._gemm(A, W, D, M, N, Kp, prec, lda=Kp, ldb=Kp, ldd=Np, batch=Z, a_zo=M * Kp, b_zo=N * Kp, d_zo=M * Np, colshift=bias, col_zo=N,
                      n_store=Np, variant=variant)
