@@ -880,24 +880,26 @@ int launch_dma(const GemmP& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm_dma128_kernel<FASTADDR>: 128 x 128 x 64 tile, 4 waves (2 x 2, each 64 x 64 = 4 x 4 MFMA tiles, 64 fp32 accumulators per lane),
+// gemm_dma128_kernel<FASTADDR, NT>: 128 x (32 NT) x 64 tile, 4 waves (2 x 2, each 64 rows x 16 NT columns).  NT = 4: 128 x 128, 64 fp32 accumulators per lane,
 // operands streamed by LDS-DMA into 2 stages of 32 KiB — TWO workgroups per CU, so a SIMD alternates between a wave of each: while
-// one waits for its K tile the other issues MFMAs.  For the K-contiguous bf16 GEMMs whose N is too narrow for the 256-wide tile
+// one waits for its K tile the other issues MFMAs; NT = 1 / 2: 32 / 64-column tiles for outputs of a few channels (head predictions:
+// HBM-bound on reading A once, 40 KiB of LDS, four workgroups per CU).  For the K-contiguous bf16 GEMMs whose N is too narrow for the 256-wide tile
 // (decoder 1x1 convs with 300 / 350 output channels, head predictions): the register-staged general kernel runs them latency-bound
 // (~25 % MFMA issue at K = 1024: global -> VGPR -> LDS with one K step of lookahead), and a 256-wide tile pair wastes 41 / 32 % of its
 // columns.  One K step: issue the LDS-DMA of tile kt + 1, read the fragments of tile kt, 32 MFMAs, wait for the DMA, barrier.
 //   RAW  tile kt + 1 is read after the barrier that follows every wave's vmcnt(0).
 //   WAR  stage (kt + 1) & 1 held tile kt - 1, whose last fragment reads completed (lgkmcnt(0)) before the barrier closing step kt - 1.
 // ---------------------------------------------------------------------------------------------
-template <bool FASTADDR>
+template <bool FASTADDR, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int MT = 4, NT = 4, TILE = 128 * BK * 2, STAGE = 2 * TILE;
+  constexpr int MT = 4, TBN = 32 * NT, TILE_A = 128 * BK * 2, TILE_B = TBN * BK * 2, STAGE = TILE_A + TILE_B;
+  constexpr int BP = TBN >= 128 ? 4 : (TBN / 8 < 4 ? TBN / 8 : 4);     // B pieces (8 rows each) per streaming wave; waves past the tile stream none
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles_n = (p.d.N + 127) / 128, tiles_m = (p.d.M + 127) / 128;
+  const int tiles_n = (p.d.N + TBN - 1) / TBN, tiles_m = (p.d.M + 127) / 128;
   int tile_m, tile_n;
   grouped_tile(wg, tiles_m, tiles_n, 2 * p.group_m, tile_m, tile_n);
-  const int m0 = tile_m * 128, n0 = tile_n * 128;
+  const int m0 = tile_m * 128, n0 = tile_n * TBN;
   const int z = blockIdx.z;
   const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
   const bf16_t* Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
@@ -929,14 +931,17 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmP p) {
   }
   auto issue = [&](int stage, int s) {
     unsigned char* sA = smem + stage * STAGE + wave * 4096;
-    unsigned char* sB = sA + TILE;
+    unsigned char* sB = smem + stage * STAGE + TILE_A + wave * 4096;
+    const bool bw = wave * 32 < TBN;                             // this wave streams B rows [32 w, 32 w + 32) if the tile has them
     if constexpr (FASTADDR) {
       const unsigned char* Ak = (const unsigned char*)Abase + (size_t)s * (BK * 2);
       const unsigned char* Bk = (const unsigned char*)Bbase + (size_t)s * (BK * 2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Ak + aoff32[i]), sA + i * 1024);
+      if (bw) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Bk + boff32[i]), sB + i * 1024);
+        for (int i = 0; i < BP; ++i) glds16((const bf16_t*)(Bk + boff32[i]), sB + i * 1024);
+      }
     } else {
       const int k0 = s * BK;
 #pragma unroll
@@ -944,10 +949,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmP p) {
         const uint64_t src = (uint64_t)(uintptr_t)(Abase + (aoff[i] + k0));
         glds16((const bf16_t*)(uintptr_t)(k0 + ack[i] < K ? src : zpage), sA + i * 1024);
       }
+      if (bw) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint64_t src = (uint64_t)(uintptr_t)(Bbase + (boff[i] + k0));
-        glds16((const bf16_t*)(uintptr_t)(k0 + ack[i] < K ? src : zpage), sB + i * 1024);
+        for (int i = 0; i < BP; ++i) {
+          const uint64_t src = (uint64_t)(uintptr_t)(Bbase + (boff[i] + k0));
+          glds16((const bf16_t*)(uintptr_t)(k0 + ack[i] < K ? src : zpage), sB + i * 1024);
+        }
       }
     }
   };
@@ -964,13 +971,13 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmP p) {
   __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* Ah = smem + (kt & 1) * STAGE;
-    const unsigned char* Bh = Ah + TILE;
+    const unsigned char* Bh = Ah + TILE_A;
     if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       u32x4 fa[MT], fb[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * 64 + t * 16 + li, kh * 4 + lg));
+      for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(Bh + lds_off(wn * (NT * 16) + t * 16 + li, kh * 4 + lg));
 #pragma unroll
       for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(Ah + lds_off(wm * 64 + t * 16 + li, kh * 4 + lg));
 #pragma unroll
@@ -981,19 +988,22 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmP p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own share of tile kt + 1 landed; own reads of tile kt done
     __builtin_amdgcn_s_barrier();
   }
-  gemm_epilogue_auto<128, 2, 2, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  gemm_epilogue_auto<TBN, 2, 2, MT, NT>(p, acc, smem, m0, n0, zo, zi);
 }
 
-template <bool FASTADDR>
+template <bool FASTADDR, int NT>
 int launch_dma128(const GemmP& p, hipStream_t stream) {
-  constexpr int smem = 2 * 2 * 128 * BK * 2;               // 64 KiB: two workgroups per CU
+  constexpr int TBN = 32 * NT;
+  constexpr int stage = (128 + TBN) * BK * 2, ep = 64 * (TBN + 4) * 4 + 256 * 8 * 4;   // K-loop stages / epilogue staging + column-sum slots
+  constexpr int smem = 2 * stage > ep ? 2 * stage : ep;     // 64 KiB at TBN = 128 (two workgroups per CU), 40 KiB at TBN = 32 (four)
   static std::atomic<unsigned long long> done{0};
-  if (int e = mtt_ensure_dyn_lds((const void*)gemm_dma128_kernel<FASTADDR>, smem, done)) return e;
-  const int tm = (p.d.M + 127) / 128, tn = (p.d.N + 127) / 128;
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_dma128_kernel<FASTADDR, NT>, smem, done)) return e;
+  const int tm = (p.d.M + 127) / 128, tn = (p.d.N + TBN - 1) / TBN;
   dim3 grid(tm * tn, 1, p.d.batch);
-  hipLaunchKernelGGL((gemm_dma128_kernel<FASTADDR>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((gemm_dma128_kernel<FASTADDR, NT>), grid, dim3(256), smem, stream, p);
   return (int)hipGetLastError();
 }
+static int dma128_nt(const mtt_gemm_desc& d) { return d.N <= 32 ? 1 : (d.N <= 64 ? 2 : 4); }   // column tile 32 / 64 / 128
 
 // ---------------------------------------------------------------------------------------------
 // gemm_tn_kernel<CONVB>: D[m, n] = sum_k A[k, m] * B[k, n] with BOTH operands "row = reduction index" (MTT_OP_R: element (r, k) at
@@ -1286,7 +1296,8 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   if (wide && d.M >= 512 && d.N >= 512 && blocks >= 96) return 3;
   // 4: the 128 x 128 LDS-DMA kernel (two workgroups per CU) for what is left: narrow outputs (decoder 1x1s with 300 / 350 channels, head
   // predictions) and mid-size problems — whenever there is enough work to fill the chip's 512 workgroup slots
-  const int64_t blocks128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * batch;
+  const int tbn = 32 * dma128_nt(d);                      // narrow outputs (head predictions: 1 - 21 classes) get a 32 / 64-column tile
+  const int64_t blocks128 = (int64_t)((d.M + 127) / 128) * ((d.N + tbn - 1) / tbn) * batch;
   if (d.M >= 512 && d.K >= 128 && blocks128 >= 256) return 4;
   return 0;
 }
@@ -1351,7 +1362,14 @@ static int gemm_launch(GemmP& p, hipStream_t s, int v) {
   mtt_gemm_desc& d = p.d;
   if (v == 8) return launch_dma<2>(p, s);
   if (v == 3) return dma_fastaddr_ok(d) ? launch_dma<1>(p, s) : launch_dma<0>(p, s);
-  if (v == 4) return dma_fastaddr_ok(d) ? launch_dma128<true>(p, s) : launch_dma128<false>(p, s);
+  if (v == 4) {
+    const bool fa = dma_fastaddr_ok(d);
+    switch (dma128_nt(d)) {
+      case 1: return fa ? launch_dma128<true, 1>(p, s) : launch_dma128<false, 1>(p, s);
+      case 2: return fa ? launch_dma128<true, 2>(p, s) : launch_dma128<false, 2>(p, s);
+      default: return fa ? launch_dma128<true, 4>(p, s) : launch_dma128<false, 4>(p, s);
+    }
+  }
   if (v == 6) return d.b_op == MTT_OP_CONV_R ? launch_tn<true>(p, s) : launch_tn<false>(p, s);
   // general kernel.  MODE: 0 bf16 x bf16; 1 A f32 (rounded while staged) x bf16; 2 x3 (both f32, split while staged);
   // 3 f32 x f32, 4 bf16 x f32, rounded while staged (bf16 arithmetic on fp32-stored tensors: the backward of the x3-forward training mode)

@@ -164,6 +164,10 @@ def gemm_cases():
     for (M, N, K) in ((300, 260, 200), (70, 700, 64), (513, 350, 1096), (256, 128, 8), (1000, 300, 72), (640, 300, 1024), (300, 350, 608)):
         kw = base(M, N, K, BF16, BF16, BF16, 0, variant=4, colshift=rnd(g, N), act=1)
         cases.append((f"gemm_dma128_{M}x{N}x{K}", "gemm", kw, TOL_BF))
+    # narrow outputs: 32- and 64-column tiles (N = 1, 21, 40, 64), fp32 and bf16 stores, K tail
+    for (M, N, K, ddt) in ((700, 21, 352, F32), (300, 1, 64, F32), (513, 40, 200, BF16), (260, 64, 128, BF16), (1000, 7, 72, BF16)):
+        kw = base(M, N, K, BF16, BF16, ddt, 0, variant=4, colshift=rnd(g, N))
+        cases.append((f"gemm_dma128_narrow_{M}x{N}x{K}", "gemm", kw, TOL_BF))
     Z, M, N, K = 6, 300, 44, 128
     kw = dict(A=rnd(g, Z, M, K, dtype=torch.bfloat16), B=rnd(g, Z, N, K, dtype=torch.bfloat16), D=torch.zeros(Z // 2, M, 96, dtype=torch.bfloat16),
               M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=96, batch=Z, batch_inner=2,
