@@ -13,6 +13,7 @@ import torch  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--variant", type=int, default=None, help="force mtt_gemm_desc.variant (3 = 256 x 256 LDS-DMA, 4 = 128 x 128 LDS-DMA, 1 = register-staged)")
 ap.add_argument("--split", action="store_true", help="also the x3 product on MTT_SPLIT planes (gemm_dma_kernel<2>)")
 a = ap.parse_args()
 import mtt_amd  # noqa: E402
@@ -21,6 +22,7 @@ if a.lib:
 from mtt_amd import ops  # noqa: E402
 
 prec = ops.Prec("bf16")
+ops.GEMM_VARIANT = a.variant
 M63 = 63 * 1030
 SHAPES = [("qkv", M63, 3072, 1024, 0), ("proj+resid", M63, 1024, 1024, 2), ("fc1+gelu", M63, 4096, 1024, 1),
           ("fc2+resid", M63, 1024, 4096, 2), ("fc2 dgrad*gelu'", M63, 4096, 1024, 3), ("big", 8192, 8192, 8192, 0)]
@@ -87,7 +89,7 @@ for (M, N, K) in ((M63, 1024, 1024), (5000, 768, 4096)):
     for i in range(20):
         out = torch.full((1, M, N), 7.0, device="cuda")
         ops.call("gemm", A=x, B=w, D=out, M=M, N=N, K=K, a_op=0, b_op=0, a_dtype=1, b_dtype=1, d_dtype=0, prec=0, lda=K, ldb=K, ldd=N, batch=1,
-                 batch_inner=1, alpha=1.0, colshift=b, n_store=N, variant=3)
+                 batch_inner=1, alpha=1.0, colshift=b, n_store=N, variant=a.variant or 3)
         first = out if first is None else first
         bad += int(not torch.equal(out, first))
     err = float((first - ref).norm() / ref.norm())
