@@ -590,6 +590,19 @@ class Conv3x3Fn(Function):
         conv = dict(H=H, W=W, C=Ci, Cp=Cip, dil=dil, flip=0)
         tiles = Z * (-(-Co // 128)) * (-(-9 * Cip // 128))
         S = _n_splits(tiles, B)                                          # slices = whole images (the gather decomposes pixel -> (y, x))
+        p256 = Z * (-(-Co // 256)) * (-(-9 * Cip // 256))
+        if (prec.name == "bf16" and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and p256 >= 64
+                and 100 * Co * 9 * Cip >= 45 * (-(-Co // 256)) * (-(-9 * Cip // 256)) * 65536):
+            # the token-major kernel takes this launch (256 x 256 tiles, one per CU): slice the pixels so that the workgroups fill whole
+            # rounds of the 256 CUs — InvPT's 576-channel convs at 128 x 128: 378 tiles = 1.48 rounds, two slices = 2.95
+            best = None
+            for cand in range(1, min(B, 8) + 1):
+                if B % cand:
+                    continue
+                cost = -(-p256 * cand // N_CUS) / cand + 0.02 * (cand - 1)        # rounds per slice + the slab it writes and re-reads
+                if best is None or cost < best[0] - 1e-9:
+                    best = (cost, cand)
+            S = best[1]
         while B % S:
             S -= 1
         if S == 1:
