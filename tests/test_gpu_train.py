@@ -53,7 +53,7 @@ def test_invpt_x3f_runs_and_matches_forward():
 
 def _two_steps_bitwise(cfg, prec, B, kind):
     """Two training iterations (forward, fused criterion, backward, clip + Adam) from the SAME state on the same batch: every gradient
-    and every updated parameter must be bitwise equal — no fp32 atomics anywhere on the path (ABI 6: every cross-workgroup reduction
+    and every updated parameter must be bitwise equal — no fp32 atomics anywhere on the path (since ABI 6: every cross-workgroup reduction
     sums caller-owned partials in a fixed order)."""
     import conftest
     import mtt_amd
