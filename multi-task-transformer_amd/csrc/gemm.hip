@@ -889,6 +889,10 @@ int launch_dma(const GemmP& p, hipStream_t stream) {
 // columns.  One K step: issue the LDS-DMA of tile kt + 1, read the fragments of tile kt, 32 MFMAs, wait for the DMA, barrier.
 //   RAW  tile kt + 1 is read after the barrier that follows every wave's vmcnt(0).
 //   WAR  stage (kt + 1) & 1 held tile kt - 1, whose last fragment reads completed (lgkmcnt(0)) before the barrier closing step kt - 1.
+// (Also measured in round 3, then removed: a 256 x 128 x 32 form of this loop — the MAIN kernel's 128 x 64 wave tile, three 24-KiB stages with
+// counted vmcnt, two workgroups per CU so that one's prologue / epilogue runs under the other's K loop.  Bitwise equal and race-clean, but
+// 1 050 vs 1 411 TFLOP/s at 8192^3 and 745 vs 873 on the qkv shape: one barrier per 32 MFMAs costs more than the overlap returns —
+// profiles/r03_gemm_bench_o_v5.log.)
 // ---------------------------------------------------------------------------------------------
 template <bool FASTADDR, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmP p) {
