@@ -558,6 +558,50 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const mtt_resize
   }
 }
 
+// Integer scale S (2 or 4: the x4 / x2 resize of the head predictions to the image size, taskprompter_wrapper.py:36): one lane = one INPUT
+// column j of output row oy and 4 channels -> its S output columns S j .. S j + S - 1 of each channel.  The three source columns j - 1, j,
+// j + 1 (clamped) are loaded once for all S outputs (6 loads of 4 channels per 4 S outputs instead of 4 scalar loads per output) and each
+// channel's outputs leave as one 16 / 8-byte store.  Weights are the exact constants of src_index for an integer scale.
+template <int S>
+__global__ __launch_bounds__(256) void bilinear_fwd_nchw_int_kernel(const mtt_resize_desc d) {
+  const int oy = blockIdx.y, b = blockIdx.z;
+  int y0, y1; float wy;
+  src_index(oy, d.Hin, d.Hout, y0, y1, wy);
+  const int64_t ib = (int64_t)b * d.Hin * d.Win;
+  const unsigned C4 = (unsigned)((d.C + 3) >> 2), total = (unsigned)d.Win * C4;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+    const int c4 = (int)(t / (unsigned)d.Win), j = (int)(t - (unsigned)c4 * (unsigned)d.Win);   // lanes run along the row: coalesced stores
+    const int xm = j > 0 ? j - 1 : 0, xp = j < d.Win - 1 ? j + 1 : j;
+    float r0[3][4], r1[3][4];
+    const int xs[3] = {xm, j, xp};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c4 * 4 + q;
+        r0[k][q] = c < d.C ? ld_elem(d.in, (ib + (int64_t)y0 * d.Win + xs[k]) * d.ld_in + c, d.in_dtype) : 0.f;
+        r1[k][q] = c < d.C ? ld_elem(d.in, (ib + (int64_t)y1 * d.Win + xs[k]) * d.ld_in + c, d.in_dtype) : 0.f;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c4 * 4 + q;
+      if (c >= d.C) break;
+      float o[S];
+#pragma unroll
+      for (int r = 0; r < S; ++r) {
+        const int k0 = r < S / 2 ? 0 : 1;                                     // source pair (j - 1, j) or (j, j + 1)
+        const float wx = r < S / 2 ? (r + 0.5f) / S + 0.5f : (r + 0.5f) / S - 0.5f;
+        const float top = r0[k0][q] * (1.f - wx) + r0[k0 + 1][q] * wx;
+        const float bot = r1[k0][q] * (1.f - wx) + r1[k0 + 1][q] * wx;
+        o[r] = top * (1.f - wy) + bot * wy;
+      }
+      float* out = (float*)d.out + (((int64_t)b * d.C + c) * d.Hout + oy) * d.Wout + S * j;
+      if (S == 4) *(float4*)out = make_float4(o[0], o[1], o[2], o[3]);
+      else *(float2*)out = make_float2(o[0], o[1]);
+    }
+  }
+}
+
 // backward as a GATHER (deterministic, no atomics): `in` = dout (NHWC of Hout x Wout, or NCHW fp32 when out_nchw),
 // `out` = din fp32 NHWC, accumulated (+=).  An input pixel i receives from the output pixels o whose source interval
 // touches i: o in (  (i - 0.5)/s - 0.5 ,  (i + 1.5)/s - 0.5 ),  s = in/out  (plus the clamped borders).
@@ -576,6 +620,63 @@ MTT_DEV float tap_weight(int o, int i, int in, int out) {
   if (i0 == i) w += 1.f - w1;
   if (i1 == i) w += w1;
   return w;
+}
+
+// Integer scale S, NCHW gradient planes: input pixel i gathers the 2 S outputs S i - S/2 .. S i + 3 S/2 - 1 of each axis with the tent
+// weights (t + 1/2) / S and their mirror (constants, no per-tap weight evaluation); a border pixel also holds the share of its replicated
+// neighbour (align_corners = False clamps the source index) and outputs beyond the map do not exist.  One lane = (channel, input column).
+template <int S>
+MTT_DEV void int_scale_weights(int i, int in, float (&w)[2 * S]) {
+#pragma unroll
+  for (int t = 0; t < 2 * S; ++t) w[t] = t < S ? (t + 0.5f) / S : 2.f - (t + 0.5f) / S;
+  if (i == 0) {
+#pragma unroll
+    for (int t = 0; t < S; ++t) w[t] = t < S / 2 ? 0.f : 1.f;
+  }
+  if (i == in - 1) {
+#pragma unroll
+    for (int t = S; t < 2 * S; ++t) w[t] = t < S + S / 2 ? 1.f : 0.f;
+  }
+}
+template <int S>
+__global__ __launch_bounds__(256) void bilinear_bwd_nchw_int_kernel(const mtt_resize_desc d) {
+  float* din = (float*)d.out;
+  const int iy = blockIdx.y, b = blockIdx.z;
+  float wy[2 * S];
+  int_scale_weights<S>(iy, d.Hin, wy);
+  const unsigned total = (unsigned)d.C * (unsigned)d.Win;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+    const unsigned c = t / (unsigned)d.Win, ix = t - c * (unsigned)d.Win;
+    float wx[2 * S];
+    int_scale_weights<S>((int)ix, d.Win, wx);
+    const float* g = (const float*)d.in + ((int64_t)b * d.C + c) * d.Hout * d.Wout;
+    const int ox0 = S * (int)ix - S / 2, oy0 = S * iy - S / 2;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2 * S; ++u) {
+      const int oy = oy0 + u;
+      if (oy < 0 || oy >= d.Hout) continue;                      // their weights are zero (border rows)
+      const float* row = g + (int64_t)oy * d.Wout;
+      float rowacc = 0.f;
+      if (S == 4) {
+#pragma unroll
+        for (int v = 0; v < 2 * S; v += 2) {                     // S = 4: ox0 = 4 ix - 2 is even -> the pairs are 8-byte aligned and never straddle the edge
+          const int ox = ox0 + v;
+          float2 q = make_float2(0.f, 0.f);
+          if (ox >= 0 && ox + 1 < d.Wout) q = *(const float2*)(row + ox);
+          rowacc += wx[v] * q.x + wx[v + 1] * q.y;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 2 * S; ++v) {
+          const int ox = ox0 + v;
+          if (ox >= 0 && ox < d.Wout) rowacc += wx[v] * row[ox];
+        }
+      }
+      acc += wy[u] * rowacc;
+    }
+    din[(((int64_t)b * d.Hin + iy) * d.Win + ix) * d.ld_in + c] += acc;
+  }
 }
 
 // grid (column blocks, input row, batch)
@@ -1427,7 +1528,11 @@ extern "C" int mtt_bilinear_fwd(const mtt_resize_desc* d, void* stream) {
   if (!d || !d->in || !d->out || d->B <= 0 || d->C <= 0) return MTT_E_BADARG;
   if (d->Hout > 65535 || d->B > 65535) return MTT_E_UNSUPPORTED;
   if (d->out_nchw) {
-    hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3((unsigned)((d->Wout + 255) / 256), d->Hout, d->B), dim3(256), 0, S_, *d);
+    const int sc = d->Hin > 1 && d->Win > 1 && d->Hout % d->Hin == 0 && d->Hout / d->Hin == d->Wout / d->Win && d->Wout % d->Win == 0 ? d->Hout / d->Hin : 0;
+    const unsigned gx = (unsigned)(((int64_t)d->Win * ((d->C + 3) / 4) + 255) / 256);
+    if (sc == 4 && !((uintptr_t)d->out & 15)) hipLaunchKernelGGL(bilinear_fwd_nchw_int_kernel<4>, dim3(gx, d->Hout, d->B), dim3(256), 0, S_, *d);
+    else if (sc == 2 && !((uintptr_t)d->out & 7)) hipLaunchKernelGGL(bilinear_fwd_nchw_int_kernel<2>, dim3(gx, d->Hout, d->B), dim3(256), 0, S_, *d);
+    else hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3((unsigned)((d->Wout + 255) / 256), d->Hout, d->B), dim3(256), 0, S_, *d);
   } else {
     if ((d->ld_in % 8) || (d->ld_out % 8)) return MTT_E_ALIGN;
     const int64_t cols = (int64_t)d->Wout * ((d->C + 7) / 8);
@@ -1440,7 +1545,12 @@ extern "C" int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream) {
   if (d->Hin > 65535 || d->B > 65535) return MTT_E_UNSUPPORTED;
   const int64_t cols = d->out_nchw ? (int64_t)d->Win * d->C : (int64_t)d->Win * ((d->C + 7) / 8);
   if (!d->out_nchw && (d->ld_in % 8)) return MTT_E_ALIGN;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((cols + 255) / 256), d->Hin, d->B), dim3(256), 0, S_, *d);
+  const int sc = d->out_nchw && d->Hin > 1 && d->Win > 1 && d->Hout % d->Hin == 0 && d->Wout % d->Win == 0 && d->Hout / d->Hin == d->Wout / d->Win &&
+                 !((uintptr_t)d->in & 7) ? d->Hout / d->Hin : 0;
+  const dim3 grid((unsigned)((cols + 255) / 256), d->Hin, d->B);
+  if (sc == 4) hipLaunchKernelGGL(bilinear_bwd_nchw_int_kernel<4>, grid, dim3(256), 0, S_, *d);
+  else if (sc == 2) hipLaunchKernelGGL(bilinear_bwd_nchw_int_kernel<2>, grid, dim3(256), 0, S_, *d);
+  else hipLaunchKernelGGL(bilinear_bwd_kernel, grid, dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }
 

@@ -575,6 +575,15 @@ def row_cases():
         kw = {"in": rnd(g, 2, 5, 16, 24), "out": torch.zeros(2 * 4 * 6, 8), "B": 2, "C": 5, "Hin": 4, "Win": 6, "Hout": 16, "Wout": 24,
               "ld_in": 8, "ld_out": 0, "in_dtype": F32, "out_dtype": F32, "out_nchw": 1, "accumulate": 1}
         cases.append((f"bilinear_bwd_nchw_{dt}", "bilinear_bwd", kw, TOL_ROW))
+        # integer scales 4 / 2 of the NCHW forms (the head predictions -> image size): specialised kernels; C not a multiple of 4, 2-pixel maps
+        for (Hi, Wi, sc, C) in ((8, 12, 4, 21), (6, 10, 2, 7), (2, 2, 4, 1), (16, 8, 4, 3)):
+            ld = (C + 7) // 8 * 8
+            kw = {"in": rnd(g, 2 * Hi * Wi, ld, dtype=DT[dt]), "out": torch.zeros(2, C, sc * Hi, sc * Wi), "B": 2, "C": C, "Hin": Hi, "Win": Wi,
+                  "Hout": sc * Hi, "Wout": sc * Wi, "ld_in": ld, "ld_out": 0, "in_dtype": dt, "out_dtype": F32, "out_nchw": 1, "accumulate": 0}
+            cases.append((f"bilinear_nchw_x{sc}_{dt}_{Hi}x{Wi}_c{C}", "bilinear_fwd", kw, TOL_ROW))
+            kw = {"in": rnd(g, 2, C, sc * Hi, sc * Wi), "out": rnd(g, 2 * Hi * Wi, ld), "B": 2, "C": C, "Hin": Hi, "Win": Wi, "Hout": sc * Hi,
+                  "Wout": sc * Wi, "ld_in": ld, "ld_out": 0, "in_dtype": F32, "out_dtype": F32, "out_nchw": 1, "accumulate": 1}
+            cases.append((f"bilinear_bwd_nchw_x{sc}_{dt}_{Hi}x{Wi}_c{C}", "bilinear_bwd", kw, TOL_ROW))
     for dt in (F32, BF16):
         rows, C, ld = 300, 52, 56
         x = rnd(g, rows, ld, dtype=DT[dt]); x[:, C:] = 0
