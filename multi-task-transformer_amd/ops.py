@@ -326,13 +326,22 @@ def _w2d(w):
     return w.shape[0], w.numel() // w.shape[0]
 
 
+def _check_sources(weights, ok):
+    """Pack sources are read by address (mtt_segcopy): they must be contiguous fp32 tensors of one shape."""
+    for w in weights:
+        if not (w.is_contiguous() and w.dtype == torch.float32 and ok(w)):
+            raise ValueError(f"weight pack: parameter of shape {tuple(w.shape)}, strides {tuple(w.stride())}, {w.dtype} is not a contiguous fp32 "
+                             "tensor of the layer's shape (channels_last / sliced / half-precision parameters are not supported: call "
+                             ".contiguous().float() on the module's parameters)")
+
+
 def pack_linear(weights, prec, tag):
     """List of Z parameters [N, K] (or 1x1 conv [N, K, 1, 1]) -> one [Z, N, Kp] buffer in the activation dtype (zero padded)."""
     N, K = _w2d(weights[0])
     Kp, Z = pad8(K), len(weights)
     if prec.adt == torch.float32 and Z == 1 and K % 8 == 0 and weights[0].is_contiguous():
         return weights[0].detach().reshape(1, N, K)               # fp32 storage: the parameter itself is the operand
-    assert all(w.is_contiguous() and _w2d(w) == (N, K) for w in weights)
+    _check_sources(weights, lambda w: _w2d(w) == (N, K))
     return seg_pack((tag, prec.name, tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, N, Kp, dtype=prec.adt, device=weights[0].device),
                     lambda buf: [segment(w, 0, buf, z * N * Kp, (1, N, K), (0, K, 1), (0, Kp, 1)) for z, w in enumerate(weights)])
@@ -341,7 +350,7 @@ def pack_linear(weights, prec, tag):
 def pack_linear_T(weight, dtype, tag):
     """Parameter [N, K] -> its transpose [K, N] in `dtype`: the reduction-contiguous operand of the input-gradient GEMM dx = dy @ W."""
     N, K = _w2d(weight)
-    assert weight.is_contiguous()
+    _check_sources([weight], lambda w: True)
     return seg_pack((tag, 'wT', dtype, id(weight)), [weight], lambda: torch.zeros(K, N, dtype=dtype, device=weight.device),
                     lambda buf: [segment(weight, 0, buf, 0, (1, N, K), (0, K, 1), (0, 1, N))] if min(N, K) < 16 else
                                 [segment(weight, 0, buf, 0, (1, K, N), (0, 1, K), (0, N, 1))])
@@ -351,7 +360,7 @@ def pack_linear_split(weights, tag):
     """List of Z parameters [N, K] -> Split [Z, N, pad8(K)]: pre-split weight planes for the LDS-DMA x3 GEMM (x3f mode)."""
     N, K = _w2d(weights[0])
     Kp, Z = pad8(K), len(weights)
-    assert all(w.is_contiguous() and _w2d(w) == (N, K) for w in weights)
+    _check_sources(weights, lambda w: _w2d(w) == (N, K))
     dev = weights[0].device
     return seg_pack((tag, 'split', tuple(id(w) for w in weights)), list(weights),
                     lambda: Split(torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev)),
@@ -364,7 +373,7 @@ def pack_conv3(weights, prec, tag, transpose=False):
     Co, Ci = weights[0].shape[:2]
     R, Cin = (Ci, Co) if transpose else (Co, Ci)
     Cp, Z = pad8(Cin), len(weights)
-    assert all(w.is_contiguous() and tuple(w.shape) == (Co, Ci, 3, 3) for w in weights)
+    _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3))
     # logical box (r, tap, c): source W[co, ci, tap] has strides (Ci*9, 9, 1) over (co, ci, tap)
     s = (9, 1, Ci * 9) if transpose else (Ci * 9, 1, 9)
     return seg_pack((tag, prec.name, transpose, tuple(id(w) for w in weights)), list(weights),
@@ -378,7 +387,7 @@ def pack_upconv9(weights, prec, tag):
     padding are zero, so its output planes carry zero padding channels."""
     Co, Ci = weights[0].shape[:2]
     Cop, Kp, Z = pad8(Co), pad8(Ci), len(weights)
-    assert all(w.is_contiguous() and tuple(w.shape) == (Co, Ci, 3, 3) for w in weights)
+    _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3))
     return seg_pack((tag, prec.name, 'up9', tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, 9 * Cop, Kp, dtype=prec.adt, device=weights[0].device),
                     lambda buf: [segment(w, 0, buf, z * 9 * Cop * Kp, (9, Co, Ci), (1, Ci * 9, 9), (Cop * Kp, Kp, 1)) for z, w in enumerate(weights)])
@@ -389,7 +398,7 @@ def pack_kmap(weights, N, Kp, kmap, prec, tag):
     concatenations: taskprompter.py:471 torch.cat([spa, chan], 1) feeding fea_fuse[0])."""
     Z = len(weights)
     K = weights[0].numel() // N
-    assert all(w.is_contiguous() and w.numel() == N * K for w in weights)
+    _check_sources(weights, lambda w: w.numel() == N * K)
     return seg_pack((tag, prec.name, 'kmap', tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, N, Kp, dtype=prec.adt, device=weights[0].device),
                     lambda buf: [segment(w, s0, buf, z * N * Kp + d0, (1, N, ln), (0, K, 1), (0, Kp, 1))
