@@ -65,6 +65,60 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const mtt_ln_desc d) {
   }
 }
 
+// C <= 1024: the row lives in registers (4 float4 chunks per lane) between the statistics and the store — ONE read of x instead of three —
+// gamma / beta are loaded once per wave and a wave walks rows with a grid stride (the kernel above spends a wave per row: 16 k workgroups
+// of 4 rows for one encoder LayerNorm).  Same summation order as above: bitwise the same statistics and outputs.
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const mtt_ln_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int C4 = d.C >> 2;
+  float4 ga[4], be[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c4 = lane + 64 * k;
+    ga[k] = c4 < C4 ? ((const float4*)d.gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    be[k] = c4 < C4 ? ((const float4*)d.beta)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < d.rows; row += stride) {
+    const float4* x = (const float4*)(d.x + row * d.ldx);
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = lane + 64 * k;
+      v[k] = c4 < C4 ? x[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < C4) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / d.C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (lane + 64 * k < C4) {
+        const float a = v[k].x - mean, b = v[k].y - mean, e = v[k].z - mean, f = v[k].w - mean;
+        q += (a * a + b * b) + (e * e + f * f);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / d.C + d.eps);
+    if (lane == 0) { if (d.mean) d.mean[row] = mean; if (d.rstd) d.rstd[row] = rstd; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = lane + 64 * k;
+      if (c4 >= C4) continue;
+      const float y0 = (v[k].x - mean) * rstd * ga[k].x + be[k].x, y1 = (v[k].y - mean) * rstd * ga[k].y + be[k].y;
+      const float y2 = (v[k].z - mean) * rstd * ga[k].z + be[k].z, y3 = (v[k].w - mean) * rstd * ga[k].w + be[k].w;
+      const int64_t o = row * d.ldy + (int64_t)c4 * 4;
+      if (d.y_dtype == MTT_F32) *(float4*)((float*)d.y + o) = make_float4(y0, y1, y2, y3);
+      else {
+        const u32x2 hi = (u32x2){pack2(y0, y1), pack2(y2, y3)};
+        *(u32x2*)((bf16_t*)d.y + o) = hi;
+        if (d.y_dtype == MTT_SPLIT)
+          *(u32x2*)((bf16_t*)d.y_lo + o) = (u32x2){pack2(y0 - lo_of(hi.x), y1 - hi_of(hi.x)), pack2(y2 - lo_of(hi.y), y3 - hi_of(hi.y))};
+      }
+      if (d.y32) *(float4*)(d.y32 + row * d.ldy32 + (int64_t)c4 * 4) = make_float4(y0, y1, y2, y3);
+    }
+  }
+}
+
 // backward, part 1 (one wave per row): dx += rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const mtt_ln_desc d) {
   const int lane = threadIdx.x & 63;
@@ -562,6 +616,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const mtt_resize
 // column j of output row oy and 4 channels -> its S output columns S j .. S j + S - 1 of each channel.  The three source columns j - 1, j,
 // j + 1 (clamped) are loaded once for all S outputs (6 loads of 4 channels per 4 S outputs instead of 4 scalar loads per output) and each
 // channel's outputs leave as one 16 / 8-byte store.  Weights are the exact constants of src_index for an integer scale.
+MTT_DEV void ld4(const void* p, int64_t idx, int dtype, float (&v)[4]) {      // idx % 4 == 0, 16 / 8-byte aligned
+  if (dtype == MTT_F32) { const float4 q = *(const float4*)((const float*)p + idx); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+  else { const uint2 q = *(const uint2*)((const bf16_t*)p + idx); v[0] = lo_of(q.x); v[1] = hi_of(q.x); v[2] = lo_of(q.y); v[3] = hi_of(q.y); }
+}
 template <int S>
 __global__ __launch_bounds__(256) void bilinear_fwd_nchw_int_kernel(const mtt_resize_desc d) {
   const int oy = blockIdx.y, b = blockIdx.z;
@@ -575,13 +633,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nchw_int_kernel(const mtt_re
     float r0[3][4], r1[3][4];
     const int xs[3] = {xm, j, xp};
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = c4 * 4 + q;
-        r0[k][q] = c < d.C ? ld_elem(d.in, (ib + (int64_t)y0 * d.Win + xs[k]) * d.ld_in + c, d.in_dtype) : 0.f;
-        r1[k][q] = c < d.C ? ld_elem(d.in, (ib + (int64_t)y1 * d.Win + xs[k]) * d.ld_in + c, d.in_dtype) : 0.f;
-      }
+    for (int k = 0; k < 3; ++k) {                    // 4 channels per load (the pitch is pad8(C) >= 4 C4: padding channels are readable zeros)
+      ld4(d.in, (ib + (int64_t)y0 * d.Win + xs[k]) * d.ld_in + c4 * 4, d.in_dtype, r0[k]);
+      ld4(d.in, (ib + (int64_t)y1 * d.Win + xs[k]) * d.ld_in + c4 * 4, d.in_dtype, r1[k]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = c4 * 4 + q;
@@ -1068,6 +1123,8 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const void* src, float* d
 //   drawlog[b,head,t,T+p]   = sum_{c in head} dout[2t][b,p,c] * x[b,p,c]         (unique owner: 8 lanes)
 //   drawchan[b,t,win,c]    += sum_{p in win} dout[2t+1][b,p,c] * x[b,p,c]        (LDS reduce + 1 atomic)
 // ------------------------------------------------------------------------------------------------
+// NT = tasks of this launch (compile time: exact accumulator count and no per-task predicates — the run-time form with CL_MAXT slots spilled)
+template <int NT>
 __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_desc d, const void* dout, float* dx,
                                                            float* drawlog, float* part, int64_t plane_elems, int tbase) {
   const int nwin = d.nh * d.nw, wh = d.h / d.nh, ww = d.w / d.nw, P = wh * ww, hw = d.h * d.w;
@@ -1078,11 +1135,11 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
   const int cl = threadIdx.x & 31, plane = threadIdx.x >> 5;
   const int cchunk = blockIdx.x * 32 + cl;
   const bool cok = cchunk * 8 < d.C;
-  const int nT = d.T - tbase < CL_MAXT ? d.T - tbase : CL_MAXT;
+  constexpr int nT = NT;
   const int64_t planeElems = (int64_t)d.B * hw * d.C;
-  float acc[CL_MAXT][8];
+  float acc[NT][8];
 #pragma unroll
-  for (int t = 0; t < CL_MAXT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
   const int per = (P + gridDim.y - 1) / gridDim.y;
@@ -1101,8 +1158,8 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
     for (int j = 0; j < 8; ++j) { xv[j] = 0.f; dxa[j] = 0.f; }
     if (pok) ld8(d.x, (int64_t)b * d.x_bs + (int64_t)pix * d.x_ld + cchunk * 8, MTT_F32, xv);
 #pragma unroll
-    for (int t = 0; t < CL_MAXT; ++t) {
-      if (t < nT) {
+    for (int t = 0; t < NT; ++t) {
+      {
         const int tk = tbase + t;
         float gs[8], gc[8], bw[8];
 #pragma unroll
@@ -1126,6 +1183,7 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
         if (lanes_per_head == 8) dl += __shfl_xor(dl, 4, 64);
         if (pok && (cl & (lanes_per_head - 1)) == 0) drawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + pix] = dl;
       }
+      if (t & 1) __builtin_amdgcn_sched_barrier(0);      // two tasks' loads in flight at a time: hoisting all NT of them costs 36 VGPRs per task
     }
     if (pok && tbase == 0) {
       float cur[8];
@@ -1144,7 +1202,8 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
     }
   }
   __shared__ float red[8][32][8];
-  for (int t = 0; t < nT; ++t) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[plane][cl][j] = acc[t][j];
     __syncthreads();
@@ -1408,7 +1467,12 @@ extern "C" int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream) {
   if ((d->C % 4) || (d->ldx % 4) || (d->ldy % 4)) return MTT_E_ALIGN;
   if (d->y_dtype == MTT_SPLIT && !d->y_lo) return MTT_E_BADARG;
   if (d->y32 && (d->ldy32 % 4)) return MTT_E_ALIGN;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
+  if (d->C <= 1024 && !(((uintptr_t)d->x | (uintptr_t)d->gamma | (uintptr_t)d->beta) & 15)) {
+    int64_t nb = (d->rows + 3) / 4; if (nb > 256 * 16) nb = 256 * 16;           // a wave walks rows with a grid stride
+    hipLaunchKernelGGL(ln_fwd_reg_kernel, dim3((unsigned)nb), dim3(256), 0, S_, *d);
+  } else {
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
+  }
   return LAUNCH_OK();
 }
 
@@ -1530,8 +1594,9 @@ extern "C" int mtt_bilinear_fwd(const mtt_resize_desc* d, void* stream) {
   if (d->out_nchw) {
     const int sc = d->Hin > 1 && d->Win > 1 && d->Hout % d->Hin == 0 && d->Hout / d->Hin == d->Wout / d->Win && d->Wout % d->Win == 0 ? d->Hout / d->Hin : 0;
     const unsigned gx = (unsigned)(((int64_t)d->Win * ((d->C + 3) / 4) + 255) / 256);
-    if (sc == 4 && !((uintptr_t)d->out & 15)) hipLaunchKernelGGL(bilinear_fwd_nchw_int_kernel<4>, dim3(gx, d->Hout, d->B), dim3(256), 0, S_, *d);
-    else if (sc == 2 && !((uintptr_t)d->out & 7)) hipLaunchKernelGGL(bilinear_fwd_nchw_int_kernel<2>, dim3(gx, d->Hout, d->B), dim3(256), 0, S_, *d);
+    const bool v4 = (d->ld_in % 4) == 0 && d->ld_in >= (d->C + 3) / 4 * 4 && !((uintptr_t)d->in & 15);
+    if (sc == 4 && v4 && !((uintptr_t)d->out & 15)) hipLaunchKernelGGL(bilinear_fwd_nchw_int_kernel<4>, dim3(gx, d->Hout, d->B), dim3(256), 0, S_, *d);
+    else if (sc == 2 && v4 && !((uintptr_t)d->out & 7)) hipLaunchKernelGGL(bilinear_fwd_nchw_int_kernel<2>, dim3(gx, d->Hout, d->B), dim3(256), 0, S_, *d);
     else hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3((unsigned)((d->Wout + 255) / 256), d->Hout, d->B), dim3(256), 0, S_, *d);
   } else {
     if ((d->ld_in % 8) || (d->ld_out % 8)) return MTT_E_ALIGN;
@@ -1663,8 +1728,12 @@ extern "C" int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, fl
   const int splits = modulate_bwd_splits(d);
   const int64_t n = (int64_t)d->B * d->T * d->nh * d->nw * d->C;
   dim3 grid((d->C / 8 + 31) / 32, splits, d->B * d->nh * d->nw);
-  for (int tb = 0; tb < d->T; tb += CL_MAXT)
-    hipLaunchKernelGGL(modulate_bwd_kernel, grid, dim3(256), 0, S_, *d, dout, dx, drawlog, ws, n, tb);
+  for (int tb = 0; tb < d->T; tb += CL_MAXT) {
+    const int nt = d->T - tb < CL_MAXT ? d->T - tb : CL_MAXT;
+#define MTT_MB(NT_) case NT_: hipLaunchKernelGGL(modulate_bwd_kernel<NT_>, grid, dim3(256), 0, S_, *d, dout, dx, drawlog, ws, n, tb); break;
+    switch (nt) { MTT_MB(1) MTT_MB(2) MTT_MB(3) MTT_MB(4) MTT_MB(5) MTT_MB(6) MTT_MB(7) MTT_MB(8) }
+#undef MTT_MB
+  }
   hipLaunchKernelGGL(mtt_reduce_few_kernel, dim3(mtt_reduce_few_grid(n)), dim3(256), 0, S_, (const float*)ws, splits, n, drawchan, 0);
   return LAUNCH_OK();
 }

@@ -457,6 +457,11 @@ def row_cases():
         kw = dict(x=rnd(g, rows, C + 4), y=torch.zeros(rows, C, dtype=DT[ydt]), gamma=rnd(g, C), beta=rnd(g, C),
                   mean=torch.zeros(rows), rstd=torch.zeros(rows), rows=rows, C=C, ldx=C + 4, ldy=C, y_dtype=ydt, eps=1e-6)
         cases.append((f"ln_fwd_{ydt}", "layernorm_fwd", kw, TOL_ROW))
+        # register-resident rows at the encoder width and a ragged one (C = 1024 / 300), more rows than one grid pass; C = 1500: the streaming kernel
+        for (rows2, C2) in ((70, 1024), (9, 300), (5, 1500)):
+            kw = dict(x=rnd(g, rows2, C2 + 4), y=torch.zeros(rows2, C2 + 8, dtype=DT[ydt]), gamma=rnd(g, C2), beta=rnd(g, C2),
+                      mean=torch.zeros(rows2), rstd=torch.zeros(rows2), rows=rows2, C=C2, ldx=C2 + 4, ldy=C2 + 8, y_dtype=ydt, eps=1e-6)
+            cases.append((f"ln_fwd_{ydt}_{rows2}x{C2}", "layernorm_fwd", kw, TOL_ROW))
         x = rnd(g, rows, C)
         mean = x.mean(-1); rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
         kw = dict(x=x, dy=rnd(g, rows, C, dtype=DT[ydt]), gamma=rnd(g, C), mean=mean, rstd=rstd, dx=rnd(g, rows, C),
