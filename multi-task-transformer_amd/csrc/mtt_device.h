@@ -242,8 +242,16 @@ static __global__ __launch_bounds__(256) void mtt_colsum_final_kernel(const floa
   const int c = blockIdx.x * 32 + cl;
   const int64_t colsP = ((int64_t)cols + 7) / 8 * 8;
   float t = 0.f;
-  if (c < cols)
-    for (int b = pl; b < nblk; b += 8) t += ws[(int64_t)b * colsP + c];
+  if (c < cols) {                                       // 4 independent accumulators: 4 loads in flight per lane, fixed order
+    float u[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = pl;
+    for (; b + 24 < nblk; b += 32) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] += ws[(int64_t)(b + 8 * k) * colsP + c];
+    }
+    for (; b < nblk; b += 8) u[0] += ws[(int64_t)b * colsP + c];
+    t = (u[0] + u[1]) + (u[2] + u[3]);
+  }
   sh[pl][cl] = t;
   __syncthreads();
   if (pl == 0 && c < cols) {
