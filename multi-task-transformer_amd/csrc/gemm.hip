@@ -1007,7 +1007,16 @@ int launch_dma128(const GemmP& p, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_dma128_kernel<FASTADDR, NT>), grid, dim3(256), smem, stream, p);
   return (int)hipGetLastError();
 }
-static int dma128_nt(const mtt_gemm_desc& d) { return d.N <= 32 ? 1 : (d.N <= 64 ? 2 : 4); }   // column tile 32 / 64 / 128
+// column tile 32 / 64 / 128: narrow outputs get a narrow tile; so do SMALL problems (the channel attention's prompt-row GEMMs: 378 x 1024 x 1024
+// is 24 tiles of 128 x 128 on 256 CUs) — they are bound by the latency of their K loop, not by MFMA issue, and narrower tiles put it on more CUs
+static int dma128_nt(const mtt_gemm_desc& d) {
+  if (d.N <= 32) return 1;
+  if (d.N <= 64) return 2;
+  const int batch = d.batch < 1 ? 1 : d.batch;
+  const int64_t tm = (d.M + 127) / 128;
+  if (tm * ((d.N + 127) / 128) * batch >= 64) return 4;
+  return tm * ((d.N + 63) / 64) * batch >= 64 ? 2 : 1;
+}
 
 // ---------------------------------------------------------------------------------------------
 // gemm_tn_kernel<CONVB>: D[m, n] = sum_k A[k, m] * B[k, n] with BOTH operands "row = reduction index" (MTT_OP_R: element (r, k) at
@@ -1303,6 +1312,8 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   const int tbn = 32 * dma128_nt(d);                      // narrow outputs (head predictions: 1 - 21 classes) get a 32 / 64-column tile
   const int64_t blocks128 = (int64_t)((d.M + 127) / 128) * ((d.N + tbn - 1) / tbn) * batch;
   if (d.M >= 512 && d.K >= 128 && blocks128 >= 256) return 4;
+  // small problems with a long reduction (few tiles, >= 8 K steps): the LDS-DMA loop has a third of the register-staged loop's K-step latency
+  if (d.M >= 128 && d.N >= 256 && d.K >= 512) return 4;
   return 0;
 }
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }

@@ -16,27 +16,30 @@ from mtt_amd import ops  # noqa: E402
 ap = importlib.import_module("multi-task-transformer_amd.autograd_path")
 prec = ops.Prec("bf16")
 M = 63 * 1024
-M_OF = {"head linear_pred (128 x 128 map, 21 classes)": 63 * 128 * 128}
+M_OF = {"head linear_pred (128 x 128 map, 21 classes)": 63 * 128 * 128, "channel attention, prompt rows (M = 378)": 63 * 6}
 
 
-def timed(fn, rounds=5):
+def timed(fn, rounds=5, inner=4):
+    fn()
     fn()
     ts = []
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / inner)
     return statistics.median(ts)
 
 
 # (name, Z, N, K) : D[z] [M, pad8(N)] = A[z] [M, pad8(K)] @ W[z] [N, pad8(K)]^T + bias
 for name, Z, N, K in (("fea_decode fwd (12 = 6 tasks x spa/chan)", 12, 300, 1024), ("fea_fuse[0] fwd", 6, 350, 608), ("fea_fuse[4] fwd", 6, 350, 350),
                       ("fea_decode dgrad", 12, 1024, 300), ("fea_fuse[0] dgrad", 6, 608, 350), ("fea_fuse[4] dgrad", 6, 350, 350),
-                      ("head linear_pred (128 x 128 map, 21 classes)", 1, 21, 350), ("encoder qkv (for reference)", 1, 3072, 1024)):
+                      ("head linear_pred (128 x 128 map, 21 classes)", 1, 21, 350), ("encoder qkv (for reference)", 1, 3072, 1024),
+                      ("channel attention, prompt rows (M = 378)", 1, 1024, 1024)):
     M = M_OF.get(name, 63 * 1024)
     Np, Kp = ops.pad8(N), ops.pad8(K)
     A = (torch.rand(Z, M, Kp, device="cuda") - 0.5).bfloat16()
