@@ -332,14 +332,14 @@ class AttnHalfFn(Function):
         ctx.save_for_backward(XT, g1, mean, rstd, xn_b, ops._hi(qkv), ops._hi(ao), ops._hi(wq), ops._hi(wp), rowscale, lse, cq, wt, wt1,
                               xn_c if chan and split else None)
         ctx.geo, ctx.prec, ctx.eps, ctx.chan = geo, prec, eps, chan
-        ctx.params = (Wqkv, Wproj)
+        ctx.params = (Wqkv, Wproj, Wtt, Wtt1)
         z = torch.zeros(0, device=XT.device)
         return XT2, (rawlog if rawlog is not None else z), (rawchan if rawchan is not None else z)
 
     @staticmethod
     def backward(ctx, dXT2, drawlog, drawchan):
         XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1, xn32 = ctx.saved_tensors
-        Wqkv_, Wproj_ = ctx.params
+        Wqkv_, Wproj_, Wtt_, Wtt1_ = ctx.params
         B, N, nH, T, h, w, nwin = ctx.geo
         prec, C, M, hw = ctx.prec.bwd, nH * 64, B * N, h * w
         xn_c = xn32 if xn32 is not None else xn                    # the rows the channel attention read (fp32 in the x3f mode)
@@ -364,7 +364,14 @@ class AttnHalfFn(Function):
                 gp = gp * rowscale[:, 0].repeat_interleave(T)[:, None]
             dWtt1 = _wgrad(gp, cq, C, hwp, prec)[:, :hw]
             dbtt1 = _colsum(gp, C)
-            dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
+            # the two input gradients of the prompt-row Linears (M = B*T rows, K = 1024): bf16 operands + transposed packs put them on the
+            # LDS-DMA kernel (a third of the register-staged kernel's K-step latency; the fp32 operand was rounded to bf16 while staged anyway)
+            fast_tt = prec.name == "bf16" and FAST_BWD and hwp == hw and hw >= FAST_MIN_DIM and C >= FAST_MIN_DIM and C % 64 == 0
+            if fast_tt:
+                gp16 = ops.cast2d(gp, B * T, C, gp.stride(0), torch.bfloat16, ldd=C)
+                dcq = _enc_dgrad(gp16, Wtt1_, wt1[0], B * T, hwp, C, prec, torch.float32, 'tt1')
+            else:
+                dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
             if drawchan is not None and drawchan.numel():
                 dq2 = torch.zeros(B * T, hwp, dtype=torch.float32, device=xn.device)
                 ops.call("chan_logits_bwd", q=cq, xn=xn_c, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
@@ -374,8 +381,14 @@ class AttnHalfFn(Function):
             dWtt = _wgrad(dcq, xnp, hw, C, prec)[:, :C]
             dbtt = _colsum(dcq, hw)
             dp = dxn.view(B, N, C)[:, :T]
-            _gemm(dcq, wt[0], dp, B * T, C, hw, prec, b_op=OP_R, lda=hwp, ldb=wt.shape[-1], ldd=C, d_mb=T, d_bs=N * C,
-                  resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
+            if fast_tt:
+                dcq16 = ops.cast2d(dcq, B * T, hw, hwp, torch.bfloat16, ldd=hwp)
+                wT = ops.pack_linear_T(Wtt_, torch.bfloat16, 'tt')                        # [C, hw]
+                _gemm(dcq16, wT, dp, B * T, C, hw, prec, lda=hwp, ldb=hw, ldd=C, d_mb=T, d_bs=N * C,
+                      resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
+            else:
+                _gemm(dcq, wt[0], dp, B * T, C, hw, prec, b_op=OP_R, lda=hwp, ldb=wt.shape[-1], ldd=C, d_mb=T, d_bs=N * C,
+                      resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
         # ---- norm1 backward accumulated into the residual gradient ------------------------------------------------
         dXT, dg1, db1 = _ln_bwd_join(dXT2, XT, dxn, g1, mean, rstd, ctx.eps)
         return (dXT, dg1, db1, None, dWqkv, dbqkv, dWproj, dbproj, dWtt, dbtt, dWtt1, dbtt1, None, None, None, None)
