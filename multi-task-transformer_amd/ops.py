@@ -252,7 +252,7 @@ def _pver(params):
     return (_param_epoch, tuple((p.data_ptr(), p._version) for p in params))
 
 
-def seg_pack(key, params, alloc, rows_of):
+def seg_pack(key, params, alloc, rows_of, check=None):
     """Persistent pack `key` of the parameters `params`: `alloc()` -> zero-initialised destination (tensor or Split), `rows_of(value)` ->
     its segcopy rows.  Served from the registry while the parameters are unchanged; after a parameter update the FIRST stale lookup
     refreshes every registered pack in one launch (mtt_segcopy), so a training step re-packs all weights with one kernel instead of one
@@ -269,6 +269,8 @@ def seg_pack(key, params, alloc, rows_of):
             return e.value
     if _capturing(params[0].device):
         raise RuntimeError("a weight pack would be built under stream capture (run a warm-up step before capturing)")
+    if check is not None:
+        check()                                     # layout / dtype of the sources: verified when the entry is (re)built, not per lookup
     with torch.no_grad():
         e = _Pack()
         e.value = alloc()
@@ -341,30 +343,30 @@ def pack_linear(weights, prec, tag):
     Kp, Z = pad8(K), len(weights)
     if prec.adt == torch.float32 and Z == 1 and K % 8 == 0 and weights[0].is_contiguous():
         return weights[0].detach().reshape(1, N, K)               # fp32 storage: the parameter itself is the operand
-    _check_sources(weights, lambda w: _w2d(w) == (N, K))
     return seg_pack((tag, prec.name, tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, N, Kp, dtype=prec.adt, device=weights[0].device),
-                    lambda buf: [segment(w, 0, buf, z * N * Kp, (1, N, K), (0, K, 1), (0, Kp, 1)) for z, w in enumerate(weights)])
+                    lambda buf: [segment(w, 0, buf, z * N * Kp, (1, N, K), (0, K, 1), (0, Kp, 1)) for z, w in enumerate(weights)],
+                    check=lambda: _check_sources(weights, lambda w: _w2d(w) == (N, K)))
 
 
 def pack_linear_T(weight, dtype, tag):
     """Parameter [N, K] -> its transpose [K, N] in `dtype`: the reduction-contiguous operand of the input-gradient GEMM dx = dy @ W."""
     N, K = _w2d(weight)
-    _check_sources([weight], lambda w: True)
     return seg_pack((tag, 'wT', dtype, id(weight)), [weight], lambda: torch.zeros(K, N, dtype=dtype, device=weight.device),
                     lambda buf: [segment(weight, 0, buf, 0, (1, N, K), (0, K, 1), (0, 1, N))] if min(N, K) < 16 else
-                                [segment(weight, 0, buf, 0, (1, K, N), (0, 1, K), (0, N, 1))])
+                                [segment(weight, 0, buf, 0, (1, K, N), (0, 1, K), (0, N, 1))],
+                    check=lambda: _check_sources([weight], lambda w: True))
 
 
 def pack_linear_split(weights, tag):
     """List of Z parameters [N, K] -> Split [Z, N, pad8(K)]: pre-split weight planes for the LDS-DMA x3 GEMM (x3f mode)."""
     N, K = _w2d(weights[0])
     Kp, Z = pad8(K), len(weights)
-    _check_sources(weights, lambda w: _w2d(w) == (N, K))
     dev = weights[0].device
     return seg_pack((tag, 'split', tuple(id(w) for w in weights)), list(weights),
                     lambda: Split(torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev)),
-                    lambda sp: [segment(w, 0, sp.hi, z * N * Kp, (1, N, K), (0, K, 1), (0, Kp, 1), dst_lo=sp.lo) for z, w in enumerate(weights)])
+                    lambda sp: [segment(w, 0, sp.hi, z * N * Kp, (1, N, K), (0, K, 1), (0, Kp, 1), dst_lo=sp.lo) for z, w in enumerate(weights)],
+                    check=lambda: _check_sources(weights, lambda w: _w2d(w) == (N, K)))
 
 
 def pack_conv3(weights, prec, tag, transpose=False):
@@ -373,12 +375,12 @@ def pack_conv3(weights, prec, tag, transpose=False):
     Co, Ci = weights[0].shape[:2]
     R, Cin = (Ci, Co) if transpose else (Co, Ci)
     Cp, Z = pad8(Cin), len(weights)
-    _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3))
     # logical box (r, tap, c): source W[co, ci, tap] has strides (Ci*9, 9, 1) over (co, ci, tap)
     s = (9, 1, Ci * 9) if transpose else (Ci * 9, 1, 9)
     return seg_pack((tag, prec.name, transpose, tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, R, 9 * Cp, dtype=prec.adt, device=weights[0].device),
-                    lambda buf: [segment(w, 0, buf, z * R * 9 * Cp, (R, 9, Cin), s, (9 * Cp, Cp, 1)) for z, w in enumerate(weights)])
+                    lambda buf: [segment(w, 0, buf, z * R * 9 * Cp, (R, 9, Cin), s, (9 * Cp, Cp, 1)) for z, w in enumerate(weights)],
+                    check=lambda: _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3)))
 
 
 def pack_upconv9(weights, prec, tag):
@@ -387,10 +389,10 @@ def pack_upconv9(weights, prec, tag):
     padding are zero, so its output planes carry zero padding channels."""
     Co, Ci = weights[0].shape[:2]
     Cop, Kp, Z = pad8(Co), pad8(Ci), len(weights)
-    _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3))
     return seg_pack((tag, prec.name, 'up9', tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, 9 * Cop, Kp, dtype=prec.adt, device=weights[0].device),
-                    lambda buf: [segment(w, 0, buf, z * 9 * Cop * Kp, (9, Co, Ci), (1, Ci * 9, 9), (Cop * Kp, Kp, 1)) for z, w in enumerate(weights)])
+                    lambda buf: [segment(w, 0, buf, z * 9 * Cop * Kp, (9, Co, Ci), (1, Ci * 9, 9), (Cop * Kp, Kp, 1)) for z, w in enumerate(weights)],
+                    check=lambda: _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3)))
 
 
 def pack_kmap(weights, N, Kp, kmap, prec, tag):
@@ -398,11 +400,11 @@ def pack_kmap(weights, N, Kp, kmap, prec, tag):
     concatenations: taskprompter.py:471 torch.cat([spa, chan], 1) feeding fea_fuse[0])."""
     Z = len(weights)
     K = weights[0].numel() // N
-    _check_sources(weights, lambda w: w.numel() == N * K)
     return seg_pack((tag, prec.name, 'kmap', tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, N, Kp, dtype=prec.adt, device=weights[0].device),
                     lambda buf: [segment(w, s0, buf, z * N * Kp + d0, (1, N, ln), (0, K, 1), (0, Kp, 1))
-                                 for z, w in enumerate(weights) for (d0, s0, ln) in kmap])
+                                 for z, w in enumerate(weights) for (d0, s0, ln) in kmap],
+                    check=lambda: _check_sources(weights, lambda w: w.numel() == N * K))
 
 
 def stack_vec(vs, tag):

@@ -2,8 +2,8 @@
 # r03 GPU session S: small long-K GEMMs on the LDS-DMA 128 kernel (narrow tiles): bench + parity + training tests + bench line
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 300 python tools/dec_gemm_bench.py > gpurun_out/r03_dec_gemm_bench_s.log 2>&1; tail -4 gpurun_out/r03_dec_gemm_bench_s.log
-timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py tests/test_gpu_model.py -m gpu -q -rf -x > gpurun_out/r03_pytest_s.log 2>&1; tail -4 gpurun_out/r03_pytest_s.log
+true
+timeout 600 python -m pytest tests/test_gpu_train.py tests/test_gpu_model.py tests/test_gpu_fullsize.py -m gpu -q -rf -x -k "not cfg4 and not cfg5 and not swin" > gpurun_out/r03_pytest_s.log 2>&1; tail -4 gpurun_out/r03_pytest_s.log
 B="--no-cpu-baseline --no-roofline --no-parity --no-parity-mode --no-ref-batch --no-torch-baseline"
 timeout 300 python bench.py --steps 6 --warmup 2 $B > gpurun_out/r03_bench_s_bf16.log 2>&1
 python - <<'PY'
