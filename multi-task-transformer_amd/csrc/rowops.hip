@@ -1543,8 +1543,8 @@ extern "C" int mtt_patchify16(const float* img, void* cols, int B, int H, int W,
 static int chanlogit_splits(const mtt_chanlogit_desc* d) {
   const int P = (d->h / d->nh) * (d->w / d->nw);
   const int base = ((d->C + 63) / 64) * d->B * d->nh * d->nw;
-  // enough workgroups for three per CU; not more: a split costs the partial planes + the second-stage launch (NS-6: 1 008 workgroups, no split)
-  int splits = (768 + base - 1) / base; if (splits > P / 32) splits = P / 32; if (splits < 1) splits = 1; if (splits > 64) splits = 64;
+  // (NS-6: 1 008 workgroups before splitting; two pixel splits measured 76 us against 85 us unsplit, profiles/r03_train_ns6_b63_l.txt / _t.txt)
+  int splits = (1024 + base - 1) / base; if (splits > P / 32) splits = P / 32; if (splits < 1) splits = 1; if (splits > 64) splits = 64;
   return splits;
 }
 static int modulate_bwd_splits(const mtt_modulate_desc* d) {
