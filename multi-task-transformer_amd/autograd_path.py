@@ -60,6 +60,16 @@ def _scaled_colsum(g, rowscale, mb, n_prompt, prec):
     return out, cs
 
 
+def _to_bwd(t, prec):
+    """x3f backward on fp32-STORED decoder tensors: a bf16 copy, so that the backward GEMMs take the token-major / LDS-DMA kernels instead of
+    the register-staged kernel's fp32 modes (which round the operand to bf16 while staging: the same arithmetic at a third of the rate).
+    No-op in the bf16 mode (already bf16) and in x3 (its backward stays fp32-class)."""
+    if prec.name != "bf16" or t.dtype != torch.float32 or not FAST_BWD:
+        return t
+    t2 = t.reshape(-1, t.shape[-1])
+    return ops.cast2d(t2, t2.shape[0], t2.shape[1], t2.stride(0), torch.bfloat16, ldd=t2.shape[1]).view(t.shape)
+
+
 def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
     """dW[N, Kp] = dy[rows, :N]^T @ x[rows, :Kp]  (both operands row-contiguous views).
 
@@ -521,7 +531,8 @@ class BLinearFn(Function):
         x, wpack = ctx.saved_tensors
         Z, N, layout, kmap, prec, wshapes = ctx.meta
         prec = prec.bwd
-        dy = dy.contiguous()
+        xdt = x.dtype
+        x, dy = _to_bwd(x, prec), _to_bwd(dy.contiguous(), prec)
         M, Np, Kp = x.shape[-2], pad8(N), wpack.shape[-1]
         if layout == 'catpair':
             az = dict(batch=Z, batch_inner=2, a_zo=M * 2 * Np, a_zi=Np)
@@ -531,13 +542,15 @@ class BLinearFn(Function):
             lda = Np
         xz = x.stride(0) if (x.dim() == 3 and x.shape[0] > 1) else 0
         bi = az['batch_inner']
-        dx = torch.empty(Z, M, Kp, dtype=x.dtype, device=x.device)
+        dx = torch.empty(Z, M, Kp, dtype=xdt, device=x.device)
         if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and M >= FAST_MIN_ROWS and Kp >= 128:
             # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T.  The reduction runs over pad8(N) columns of dy:
             # the padding columns [N, pad8(N)) meet zero rows of W^T, but 0 * NaN is NaN, so they must hold FINITE values.  Invariant of
             # this file: every producer of a task-stack gradient writes its padding channels as zeros (conv / linear dgrads through
             # n_store = pitch, bn_bwd_apply, ctr_mix, upconv4_gather, cast2d with zero_pad) — never torch.empty garbage.
             wT = _pad_last(wpack.transpose(1, 2), Np)                  # [Z, Kp, pad8(N)]: a few MB, once per backward of this node
+            if wT.dtype != torch.bfloat16:                             # x3f: the forward's pack is fp32
+                wT = wT.to(torch.bfloat16)
             _gemm(dy, wT, dx, M, Kp, Np, prec, lda=lda, ldb=Np, ldd=Kp, b_zo=wT.stride(0) * bi, b_zi=wT.stride(0) if bi > 1 else 0,
                   d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
         else:
@@ -596,10 +609,11 @@ class Conv3x3Fn(Function):
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         (B, H, W, Co, Ci, dil), prec, tag, Z, has_bias = ctx.meta
         prec = prec.bwd
-        dy = dy.contiguous()
+        xdt = x.dtype
+        x, dy = _to_bwd(x, prec), _to_bwd(dy.contiguous(), prec)
         rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
         wd = ops.pack_conv3(list(ws), prec, tag, transpose=True)                     # [Z, Ci, 9*Cop]
-        dx = ops.conv3x3(dy, wd, Ci, Co, B, H, W, prec, flip=1, dil=dil, out_dtype=x.dtype)
+        dx = ops.conv3x3(dy, wd, Ci, Co, B, H, W, prec, flip=1, dil=dil, out_dtype=xdt)
         conv = dict(H=H, W=W, C=Ci, Cp=Cip, dil=dil, flip=0)
         tiles = Z * (-(-Co // 128)) * (-(-9 * Cip // 128))
         S = _n_splits(tiles, B)                                          # slices = whole images (the gather decomposes pixel -> (y, x))
@@ -661,10 +675,11 @@ class UpConv3x3Fn(Function):
         prec = prec.bwd
         dy = dy.contiguous()
         M, Kp, N9 = xa.shape[1], xa.shape[2], w9.shape[1]
-        dz = ops.upconv4_gather(dy, Co, B, h, w)                         # [Z, M, N9]
+        dz = _to_bwd(ops.upconv4_gather(dy, Co, B, h, w), prec)          # [Z, M, N9]
+        xa = _to_bwd(xa, prec)
         dx = torch.empty(Z, M, Kp, dtype=xdtype, device=dy.device)
         if prec.name == "bf16" and FAST_BWD and M >= FAST_MIN_ROWS and Kp >= 128:
-            wT = w9.transpose(1, 2).contiguous()                         # [Z, Kp, N9]: reduction-contiguous dgrad operand
+            wT = w9.transpose(1, 2).contiguous().to(torch.bfloat16)      # [Z, Kp, N9]: reduction-contiguous dgrad operand (x3f: fp32 pack)
             _gemm(dz, wT, dx, M, Kp, N9, prec, lda=N9, ldb=N9, ldd=Kp, batch=Z, a_zo=M * N9, b_zo=Kp * N9, d_zo=M * Kp, n_store=Kp)
         else:
             _gemm(dz, w9, dx, M, Kp, N9, prec, b_op=OP_R, lda=N9, ldb=Kp, ldd=Kp, batch=Z, a_zo=M * N9, b_zo=N9 * Kp, d_zo=M * Kp,
