@@ -222,8 +222,9 @@ int mtt_modulate_bwd(const mtt_modulate_desc* d, const void* dout, float* dx, fl
 /* Cross-task reweighting, taskprompter.py:478-485: w[b,t,s] from the per-head MLP on the prompt<->prompt
  * logits, then out[t][b,p,:] = sum_s w[b,t,s] * fea[s][b,p,:] (+= into acc when accumulate=1). */
 typedef struct {
-  const void* fea; void* out; const float* wmix;   /* fea [T, rows, ld]; wmix [B,T,T] fp32; out fp32 [T, rows, ld] */
+  const void* fea; void* out; const float* wmix;   /* fea [T, rows, ld]; wmix [B,T,T] fp32; out [T, rows, ld] (fp32 unless out_dtype says bf16) */
   int32_t T, B; int64_t rows_per_b, ld; int32_t C; int32_t fea_dtype; int32_t accumulate;
+  int32_t out_dtype;             /* MTT_F32 (0, default) or MTT_BF16 (mtt_ctr_mix without accumulate only: the backward's gradient of bf16 features) */
 } mtt_ctr_desc;
 int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream);
 /* dwmix[b,t,s] = sum_{rows of b, c} dout[t][row,c] * fea[s][row,c]   (dout fp32 [T, rows, ld]; dwmix WRITTEN; ws: mtt_ctr_dw_ws_floats(d)

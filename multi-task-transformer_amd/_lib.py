@@ -92,7 +92,7 @@ class ModulateDesc(C.Structure):
 
 class CtrDesc(C.Structure):
     _fields_ = [("fea", ptr), ("out", ptr), ("wmix", ptr), ("T", i32), ("B", i32), ("rows_per_b", i64), ("ld", i64),
-                ("C", i32), ("fea_dtype", i32), ("accumulate", i32)]
+                ("C", i32), ("fea_dtype", i32), ("accumulate", i32), ("out_dtype", i32)]
 
 
 class ResizeDesc(C.Structure):

@@ -790,8 +790,7 @@ class CtrMixFn(Function):
         B, C, had_acc = ctx.meta
         dout = dout.contiguous()
         T, rows, ld = fea.shape
-        dfea32 = ops.ctr_mix(dout, wmix.transpose(1, 2).contiguous(), B, C, None)
-        dfea = dfea32 if fea.dtype == torch.float32 else ops.cast2d(dfea32.view(T * rows, ld), T * rows, ld, ld, fea.dtype, ldd=ld).view(T, rows, ld)
+        dfea = ops.ctr_mix(dout, wmix.transpose(1, 2).contiguous(), B, C, None, out_dtype=fea.dtype)   # written in the features' dtype
         dw = torch.empty_like(wmix)
         ops.call("ctr_dw", fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C, fea_dtype=dtype_code(fea),
                  accumulate=0, xargs=[dout, dw, ops.ws_for("ctr_dw", dout.device, T=T, B=B, rows_per_b=rows // B)])

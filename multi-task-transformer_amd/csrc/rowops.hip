@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void ctr_mix_kernel(const mtt_ctr_desc d) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += w * f[s][j];
         }
-      st8(d.out, oi, MTT_F32, o);
+      st8(d.out, oi, d.accumulate ? MTT_F32 : d.out_dtype, o);
     }
   }
 }
@@ -1596,6 +1596,7 @@ extern "C" int mtt_modulate(const mtt_modulate_desc* d, void* stream) {
 
 extern "C" int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream) {
   if (!d || !d->fea || !d->out || !d->wmix || d->T <= 0 || d->T > CTR_MAXT || (d->ld % 8)) return MTT_E_BADARG;
+  if (d->out_dtype != MTT_F32 && (d->out_dtype != MTT_BF16 || d->accumulate)) return MTT_E_UNSUPPORTED;
   hipLaunchKernelGGL(ctr_mix_kernel, dim3(grid_for((int64_t)d->B * d->rows_per_b * ((d->C + 7) / 8))), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }

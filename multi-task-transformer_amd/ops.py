@@ -623,12 +623,12 @@ def modulate(x, x_ld, x_bs, rawlog, rawchan, B, T, N, C, grid, nwin_hw, prec, hg
     return out
 
 
-def ctr_mix(fea, wmix, B, C, acc=None):
-    """fea [T, rows, ld]; wmix fp32 [B, T, T] -> acc (+)= mix.  Returns fp32 [T, rows, ld]."""
+def ctr_mix(fea, wmix, B, C, acc=None, out_dtype=torch.float32):
+    """fea [T, rows, ld]; wmix fp32 [B, T, T] -> acc (+)= mix.  Returns [T, rows, ld] in fp32 (or `out_dtype` bf16 when there is no `acc`)."""
     T, rows, ld = fea.shape
-    out = acc if acc is not None else torch.empty(T, rows, ld, dtype=torch.float32, device=fea.device)
+    out = acc if acc is not None else torch.empty(T, rows, ld, dtype=out_dtype, device=fea.device)
     call("ctr_mix", fea=fea, out=out, wmix=wmix, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C,
-         fea_dtype=dtype_code(fea), accumulate=1 if acc is not None else 0)
+         fea_dtype=dtype_code(fea), accumulate=1 if acc is not None else 0, out_dtype=dtype_code(out))
     return out
 
 

@@ -343,7 +343,9 @@ def ctr_mix(**kw):
     wm = _rd(kw["wmix"], torch.arange(B * T * T)).view(B, T, T)
     out = torch.einsum("bts,sbrc->tbrc", wm, fea).reshape(T, rows, C8)
     if kw.get("accumulate"):
+        assert kw.get("out_dtype", F32) == F32, "accumulating ctr_mix output is fp32"
         out = out + _rd(kw["out"], idx)
+    assert kw.get("out_dtype", F32) == (BF16 if kw["out"].dtype == torch.bfloat16 else F32)
     _wr(kw["out"], idx, out)
 
 

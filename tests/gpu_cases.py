@@ -564,6 +564,9 @@ def row_cases():
             kw = dict(fea=fea, out=rnd(g, T, B * rpb, ld), wmix=rnd(g, B, T, T), T=T, B=B, rows_per_b=rpb, ld=ld, C=C,
                       fea_dtype=dt, accumulate=accum)
             cases.append((f"ctr_mix_{dt}_acc{accum}", "ctr_mix", kw, TOL_ROW))
+        kw = dict(fea=rnd(g, T, B * rpb, ld), out=torch.full((T, B * rpb, ld), 3.0, dtype=torch.bfloat16), wmix=rnd(g, B, T, T), T=T, B=B,
+                  rows_per_b=rpb, ld=ld, C=C, fea_dtype=F32, accumulate=0, out_dtype=BF16)
+        cases.append((f"ctr_mix_bf16out_{dt}", "ctr_mix", kw, TOL_ROW))
     for dt in (F32, BF16):
         for (Hi, Wi, Ho, Wo) in ((4, 6, 16, 24), (8, 8, 4, 4), (5, 7, 11, 9)):
             B, C, ld = 2, 20, 24
