@@ -213,7 +213,7 @@ typedef struct {
   int32_t hg;                    /* channels per attention head (a multiple of 8; 0 = 64, the ViT variants; 32 in the last Swin stage) */
 } mtt_modulate_desc;
 int mtt_modulate(const mtt_modulate_desc* d, void* stream);
-/* backward: dout [2T, B*hw, C] (d->out_dtype) -> dx += (fp32, same addressing as x), drawlog[b,head,t,T+p] = (fp32 [B,nH,T,N],
+/* backward: dout [2T, B*hw, C] (d->out_dtype) -> dx = (fp32, same addressing as x; WRITTEN), drawlog[b,head,t,T+p] = (fp32 [B,nH,T,N],
  * caller zeroes the first T columns), drawchan = (fp32 [B,T,nwin,C], WRITTEN: per-split partials in ws, mtt_modulate_bwd_ws_floats(d)
  * floats, summed in split order). */
 size_t mtt_modulate_bwd_ws_floats(const mtt_modulate_desc* d);

@@ -492,7 +492,8 @@ class ModulateFn(Function):
         B, N, T, C, h, w, nwin = ctx.geo[:7]
         hg = ctx.geo[7] if len(ctx.geo) > 7 else 0
         dmod = dmod.contiguous()
-        dx = torch.zeros_like(xsrc)
+        dx = torch.empty_like(xsrc)                                           # patch rows are WRITTEN by the kernel; the T prompt rows get no gradient here
+        dx.view(B, N, C)[:, :T].zero_()
         dl, dc = torch.zeros_like(rawlog), torch.empty_like(rawchan)          # drawlog: the first T columns stay zero; drawchan is written
         ops.call("modulate_bwd", x=xsrc.view(B, N, C)[:, T:], x_ld=C, x_bs=N * C, rawlog=rawlog, rawchan=rawchan, out=None,
                  B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin, out_dtype=dtype_code(dmod), hg=hg,

@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const void* src, float* d
 // ------------------------------------------------------------------------------------------------
 // Backward of the task-feature modulation.  grid (C/8/32 column groups, pixel splits, B*nwin); block =
 // 32 column chunks x 8 pixel lanes (same shape as chanlogit_kernel).
-//   dx[b,p,c]              += sum_t dout[2t]*(1+a) + dout[2t+1]*(1+bw)
+//   dx[b,p,c]               = sum_t dout[2t]*(1+a) + dout[2t+1]*(1+bw)                          (written)
 //   drawlog[b,head,t,T+p]   = sum_{c in head} dout[2t][b,p,c] * x[b,p,c]         (unique owner: 8 lanes)
 //   drawchan[b,t,win,c]    += sum_{p in win} dout[2t+1][b,p,c] * x[b,p,c]        (LDS reduce + 1 atomic)
 // ------------------------------------------------------------------------------------------------
@@ -1196,13 +1196,8 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const mtt_modulate_de
       }
       if (t & 1) __builtin_amdgcn_sched_barrier(0);      // two tasks' loads in flight at a time: hoisting all NT of them costs 36 VGPRs per task
     }
-    if (pok && tbase == 0) {
-      float cur[8];
-      const int64_t xi = (int64_t)b * d.x_bs + (int64_t)pix * d.x_ld + cchunk * 8;
-      ld8(dx, xi, MTT_F32, cur);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cur[j] += dxa[j];
-      st8(dx, xi, MTT_F32, cur);
+    if (pok && tbase == 0) {                             // the first task group WRITES dx (nothing to pre-zero), later groups add to it
+      st8(dx, (int64_t)b * d.x_bs + (int64_t)pix * d.x_ld + cchunk * 8, MTT_F32, dxa);
     } else if (pok) {
       float cur[8];
       const int64_t xi = (int64_t)b * d.x_bs + (int64_t)pix * d.x_ld + cchunk * 8;

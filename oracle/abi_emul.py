@@ -524,7 +524,7 @@ def modulate_bwd(**kw):
         dxv += g[t, 0] * (1 + a) + g[t, 1] * (1 + rc[:, t][:, win])
         dl[:, :, t, T:] = (g[t, 0] * x).view(B, hw, nH, hg).sum(-1).transpose(1, 2)
         dc[:, t].index_add_(1, win, g[t, 1] * x)
-    _wr(dx, xi, _rd(dx, xi) + dxv)
+    _wr(dx, xi, dxv)                                                  # written (the rows outside the addressed block are the caller's)
     li = torch.arange(B * nH * T)[:, None] * N + torch.arange(T, N)[None, :]
     _wr(drawlog, li, dl.view(B * nH * T, N)[:, T:])
     ci = torch.arange(B * T * nwin * Cn)
