@@ -67,7 +67,7 @@ def _to_bwd(t, prec):
     if prec.name != "bf16" or t.dtype != torch.float32 or not FAST_BWD:
         return t
     t2 = t.reshape(-1, t.shape[-1])
-    return ops.cast2d(t2, t2.shape[0], t2.shape[1], t2.stride(0), torch.bfloat16, ldd=t2.shape[1]).view(t.shape)
+    return ops.cast_rows(t2, torch.bfloat16).view(t.shape)
 
 
 def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
@@ -378,7 +378,7 @@ class AttnHalfFn(Function):
             # LDS-DMA kernel (a third of the register-staged kernel's K-step latency; the fp32 operand was rounded to bf16 while staged anyway)
             fast_tt = prec.name == "bf16" and FAST_BWD and hwp == hw and hw >= FAST_MIN_DIM and C >= FAST_MIN_DIM and C % 64 == 0
             if fast_tt:
-                gp16 = ops.cast2d(gp, B * T, C, gp.stride(0), torch.bfloat16, ldd=C)
+                gp16 = ops.cast_rows(gp, torch.bfloat16)
                 dcq = _enc_dgrad(gp16, Wtt1_, wt1[0], B * T, hwp, C, prec, torch.float32, 'tt1')
             else:
                 dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
@@ -392,7 +392,7 @@ class AttnHalfFn(Function):
             dbtt = _colsum(dcq, hw)
             dp = dxn.view(B, N, C)[:, :T]
             if fast_tt:
-                dcq16 = ops.cast2d(dcq, B * T, hw, hwp, torch.bfloat16, ldd=hwp)
+                dcq16 = ops.cast_rows(dcq, torch.bfloat16)
                 wT = ops.pack_linear_T(Wtt_, torch.bfloat16, 'tt')                        # [C, hw]
                 _gemm(dcq16, wT, dp, B * T, C, hw, prec, lda=hwp, ldb=hw, ldd=C, d_mb=T, d_bs=N * C,
                       resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
@@ -662,8 +662,7 @@ class UpConv3x3Fn(Function):
         Z = len(wb) // 2
         ws, bs = wb[:Z], wb[Z:]
         w9 = ops.pack_upconv9(list(ws), prec, tag)
-        xa = x if x.dtype == prec.adt else ops.cast2d(x.reshape(-1, x.shape[-1]), x.shape[0] * x.shape[1], x.shape[-1], x.shape[-1],
-                                                      prec.adt, ldd=x.shape[-1]).view(x.shape)
+        xa = x if x.dtype == prec.adt else ops.cast_rows(x.reshape(-1, x.shape[-1]), prec.adt).view(x.shape)
         y = ops.upconv3x3(xa, w9, Co, B, h, w, prec, bias=ops.stack_vec(list(bs), (tag, 'b')))
         ctx.save_for_backward(xa, w9)
         ctx.meta = (geo, prec, Z, x.dtype)

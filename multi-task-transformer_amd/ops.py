@@ -136,6 +136,17 @@ def cast2d(src, rows, cols, lds, dst_dtype, ldd=None, zero_pad=True):
     return dst
 
 
+def cast_rows(src2d, dst_dtype):
+    """[rows, ld] -> a copy in `dst_dtype` with the same pitch (all ld columns, padding included): the 8-elements-per-lane cast kernel
+    (mtt_rowscale_cast without scales) when the pitch allows it — the generic cast2d kernel works element by element."""
+    rows, ld = src2d.shape
+    if ld % 8 or src2d.stride(0) % 8 or src2d.stride(1) != 1:
+        return cast2d(src2d, rows, ld, src2d.stride(0), dst_dtype, ldd=ld)
+    dst = torch.empty(rows, ld, dtype=dst_dtype, device=src2d.device)
+    call("rowscale_cast", args=[src2d, dst, rows, ld, src2d.stride(0), ld, dtype_code(src2d), dtype_code(dst), None, 0, 0])
+    return dst
+
+
 def pack_matrix(w2d, prec):
     """[N, K] fp32 -> [N, pad8(K)] in the activation dtype (zero padded); the lazily cached one-off packs (InvPT, deconv heads)."""
     N, K = w2d.shape
