@@ -213,3 +213,62 @@ def test_upconv_taps_first_is_upsample_then_conv():
                             acc[:, dy] += wy[tr + dy - 2] * s
                 dz[:, i, j] = acc
         assert (dz - dref).abs().max() < 1e-12
+
+
+def test_bias_gradients_from_the_producers():
+    """mtt_gemm_desc.colsum_out (column sums of the stored tile: the fc2 input gradient with its GELU' epilogue is fc1's output gradient)
+    and mtt_rowscale_cast_colsum (the cast of the residual gradient yields the proj / fc2 bias gradients) against autograd."""
+    g = g_(7)
+    M, C, Hd = 40, 24, 48
+    x = torch.randn(M, C, generator=g)
+    W1 = (torch.randn(Hd, C, generator=g) * 0.3).requires_grad_(True)
+    b1 = torch.randn(Hd, generator=g).requires_grad_(True)
+    W2 = (torch.randn(C, Hd, generator=g) * 0.3).requires_grad_(True)
+    b2 = torch.randn(C, generator=g).requires_grad_(True)
+    z = F.linear(x, W1, b1)
+    y = F.linear(F.gelu(z), W2, b2)
+    dy = torch.randn(M, C, generator=g)
+    y.backward(dy)
+    # fc2 input gradient * GELU'(z) with the column sums taken by the "epilogue": = db1
+    dz, db1 = torch.zeros(M, Hd), torch.full((Hd,), 9.0)
+    E.call("gemm", A=dy, B=W2.detach(), D=dz, M=M, N=Hd, K=C, a_op=0, b_op=1, prec=1, lda=C, ldb=Hd, ldd=Hd, alpha=1.0, act=3,
+           aux_in=z.detach(), aux_dtype=E_F32, ldaux=Hd, batch=1, colsum_out=db1, colsum_ws=torch.zeros(4 * Hd))
+    assert torch.allclose(db1, b1.grad, atol=1e-4)
+    assert torch.allclose(dz.t() @ x, W1.grad, atol=1e-4)
+    # the cast of dy (here with per-sample scales of 1) yields db2
+    out, db2 = torch.zeros(M, C), torch.full((C,), 9.0)
+    E.call("rowscale_cast_colsum", args=[dy, out, M, C, C, C, E_F32, E_F32, None, 0, 0, db2, torch.zeros(64 * C)])
+    assert torch.equal(out, dy) and torch.allclose(db2, b2.grad, atol=1e-5)
+    # with DropPath scales: rows of sample q are scaled by rowscale[q, row >= n_prompt]
+    rs = torch.tensor([[0.5, 2.0], [0.0, 1.5]])
+    E.call("rowscale_cast_colsum", args=[dy, out, M, C, C, C, E_F32, E_F32, rs, 20, 3, db2, torch.zeros(64 * C)])
+    scale = torch.cat([rs[q, (torch.arange(20) >= 3).long()] for q in range(2)])
+    assert torch.allclose(out, dy * scale[:, None]) and torch.allclose(db2, (dy * scale[:, None]).sum(0), atol=1e-5)
+
+
+def test_segcopy_and_ctr_mix_bf16_output():
+    """mtt_segcopy against plain strided copies (vector, scalar, transposing and split segments through raw addresses), and the
+    non-accumulating cross-task mix written in bf16."""
+    import numpy as np
+    g = g_(8)
+    src = torch.randn(6, 20, generator=g)
+    dst = torch.full((6, 24), 7.0, dtype=torch.bfloat16)
+    hi, lo = torch.zeros(6, 24, dtype=torch.bfloat16), torch.zeros(6, 24, dtype=torch.bfloat16)
+    tr = torch.full((20, 6), 7.0)
+    rows = [[src.data_ptr(), dst.data_ptr(), 0, 120, 6, 20, 0, 20, 1, 0, 24, 1, 0, 1, 1, 0],             # fp32 -> bf16 with padding, "vector"
+            [src.data_ptr(), hi.data_ptr(), lo.data_ptr(), 120, 6, 20, 0, 20, 1, 0, 24, 1, 0, 2, 0, 0],   # fp32 -> hi / lo planes
+            [src.data_ptr(), tr.data_ptr(), 0, 4096, 20, 6, 0, 1, 20, 0, 6, 1, 0, 0, 0, 1]]               # transposing: box (1, 20, 6), 1 tile slot
+    table = torch.from_numpy(np.asarray(rows, dtype=np.int64))
+    E.call("segcopy", table=table, chunk_seg=torch.tensor([0, 1, 2], dtype=torch.int32), chunk_off=torch.zeros(3, dtype=torch.int64), n_chunks=3,
+           src_base=0, dst_base=0)
+    assert torch.equal(dst[:, :20], src.to(torch.bfloat16)) and float((dst[:, 20:].float() - 7.0).abs().max()) == 0.0     # padding untouched
+    assert torch.equal(hi[:, :20], src.to(torch.bfloat16)) and torch.allclose(hi[:, :20].float() + lo[:, :20].float(), src, atol=1e-4)
+    assert torch.equal(tr, src.t().contiguous())
+    T, B, rpb, ld, C = 3, 2, 5, 16, 12
+    fea = torch.randn(T, B * rpb, ld, generator=g)
+    fea[..., C:] = 0
+    wm = torch.randn(B, T, T, generator=g)
+    out = torch.full((T, B * rpb, ld), 3.0, dtype=torch.bfloat16)
+    E.call("ctr_mix", fea=fea, out=out, wmix=wm, T=T, B=B, rows_per_b=rpb, ld=ld, C=C, fea_dtype=E_F32, accumulate=0, out_dtype=1)
+    ref = torch.einsum("bts,sbrc->tbrc", wm, fea.view(T, B, rpb, ld)).reshape(T, B * rpb, ld)
+    assert torch.allclose(out.float(), ref, atol=2e-2, rtol=1e-2)
