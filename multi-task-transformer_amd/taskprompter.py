@@ -491,8 +491,7 @@ def run_heads(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False)
         bns = [hd.mt_proj[1] for hd in heads]
         if lowres:
             if fea.dtype != prec.adt:
-                fea = ops.cast2d(fea.reshape(-1, fea.shape[-1]), fea.shape[0] * fea.shape[1], fea.shape[-1], fea.shape[-1], prec.adt,
-                                 ldd=fea.shape[-1]).view(fea.shape)
+                fea = ops.cast_rows(fea.reshape(-1, fea.shape[-1]), prec.adt).view(fea.shape)
             W9 = ops.pack_upconv9(conv_w, prec, 'hc9')
 
             def conv(**epi):
