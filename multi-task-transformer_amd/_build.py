@@ -42,5 +42,23 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines, source="gemm.hip"):
+    """A/B builds for tools/*_bench.py --lib: the library with ONE source recompiled under extra -D flags (e.g. -DMTT_RING_S=5), written to
+    build/variants/libmtt_<name>.so (build/ is git-ignored and still ships to the GPU box)."""
+    build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    vdir = os.path.join(ROOT, "build", "variants")
+    os.makedirs(vdir, exist_ok=True)
+    obj = os.path.join(vdir, f"{source.replace('.hip', '')}_{name}.o")
+    lib = os.path.join(vdir, f"libmtt_{name}.so")
+    subprocess.run([hipcc] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, source), "-o", obj], check=True)
+    objs = [obj if s == source else os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib], check=True)
+    return lib
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python _build.py --variant NAME -DFOO=1 ...
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

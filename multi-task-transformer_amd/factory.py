@@ -3,9 +3,12 @@ InvPT/utils/common_config.py:12-51): `get_model(p)` returns the drop-in nn.Modul
 config object `p`.  `p` may be the reference's EasyDict or the `AttrDict` below — the models only use
 attribute access, item access and `keys()`.
 
-Extra (non-reference) key: `p.mtt_prec` in {'bf16', 'x3'} selects the arithmetic mode (default 'bf16').
+Extra (non-reference) key: `p.mtt_prec` in {'x3f', 'bf16', 'x3'} selects the arithmetic mode.  Default `ops.DEFAULT_PREC` = 'x3f': the mode whose
+forward matches the reference's fp32 forward within north_star's 1e-3 per task head (bf16 does not: 1.5e-2).
 """
 import torch
+
+from .ops import DEFAULT_PREC
 
 
 class AttrDict(dict):
@@ -35,11 +38,11 @@ TASK_ORDER = ["semseg", "depth", "human_parts", "sal", "normals", "edge"]   # Ta
 
 
 def make_p(tasks, img_size, model="TaskPrompter", backbone="TaskPrompter_vitL", head="conv", embed_dim=300,
-           final_embed_dim=350, prompt_len=1, chan_nheads=1, use_ctr=True, num_output=None, prec="bf16", **extra):
+           final_embed_dim=350, prompt_len=1, chan_nheads=1, use_ctr=True, num_output=None, prec=None, **extra):
     """Reference-style config for synthetic runs (what create_config would produce from a YAML)."""
     nout = dict(PASCAL_NUM_OUTPUT, **(num_output or {}))
     p = AttrDict(model=model, backbone=backbone, head=head, embed_dim=embed_dim, final_embed_dim=final_embed_dim,
-                 prompt_len=prompt_len, chan_nheads=chan_nheads, use_ctr=use_ctr, mtt_prec=prec)
+                 prompt_len=prompt_len, chan_nheads=chan_nheads, use_ctr=use_ctr, mtt_prec=prec or DEFAULT_PREC)
     p.TASKS = AttrDict(NAMES=list(tasks), NUM_OUTPUT=AttrDict({t: nout[t] for t in tasks}))
     p.TRAIN = AttrDict(SCALE=tuple(img_size))
     for k, v in extra.items():
@@ -94,7 +97,7 @@ def get_head(p, backbone_channels, task):
 def get_invpt_backbone(p):
     """InvPT/utils/common_config.py:12-25."""
     from . import invpt
-    prec = p.get('mtt_prec', 'bf16')
+    prec = p.get('mtt_prec', DEFAULT_PREC)
     if p['backbone'] == 'vitL':
         backbone = invpt.vit_large_patch16_384(pretrained=False, drop_path_rate=p.get('drop_path_rate', 0.15), img_size=p.TRAIN.SCALE, prec=prec)
         C = 1024

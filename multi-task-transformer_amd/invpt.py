@@ -58,7 +58,7 @@ class VisionTransformer(nn.Module):
     def __init__(self, select_list, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False, drop_rate=0.,
                  attn_drop_rate=0., drop_path_rate=0., embed_layer=None, norm_layer=None, act_layer=None, weight_init='',
-                 prec='bf16'):
+                 prec=ops.DEFAULT_PREC):
         super().__init__()
         assert patch_size == 16 and embed_dim // num_heads == 64 and not distilled
         self.num_features = self.embed_dim = embed_dim

@@ -21,6 +21,9 @@ def pad8(n):
     return (n + 7) // 8 * 8
 
 
+DEFAULT_PREC = "x3f"        # arithmetic mode of a model whose config does not name one (`p.mtt_prec`): the tolerance-compliant mode
+
+
 class Prec:
     """Arithmetic mode: name in {'bf16', 'x3', 'x3f'}.
 

@@ -41,7 +41,7 @@ def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
 
 
 def _prec_of(p):
-    return ops.Prec(p.get('mtt_prec', 'bf16') if hasattr(p, 'get') else getattr(p, 'mtt_prec', 'bf16'))
+    return ops.Prec(p.get('mtt_prec', ops.DEFAULT_PREC) if hasattr(p, 'get') else getattr(p, 'mtt_prec', ops.DEFAULT_PREC))
 
 
 PREC_GROUPS = ('enc', 'attn', 'side', 'fuse', 'heads')
@@ -442,7 +442,7 @@ class _HeadBase(nn.Module):
     prec = None
 
     def forward(self, x):
-        prec = self.prec or ops.Prec('bf16')
+        prec = self.prec or ops.Prec(ops.DEFAULT_PREC)
         B, _, H, W = x.shape
         rows = _to_rows(x, prec)
         kind = 'conv' if isinstance(self, ConvHead) else 'deconv'

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variant", type=int, default=None, help="force mtt_gemm_desc.variant (3 = 256 x 256 LDS-DMA, 4 = 128 x 128 LDS-DMA, 1 = register-staged)")
+ap.add_argument("--no-check", action="store_true", help="skip the correctness / race screens (A/B timing of variant builds)")
 ap.add_argument("--split", action="store_true", help="also the x3 product on MTT_SPLIT planes (gemm_dma_kernel<2>)")
 a = ap.parse_args()
 import mtt_amd  # noqa: E402
@@ -76,9 +77,12 @@ for name, M, N, K, act in SHAPES:
     print(line, flush=True)
 print(f"sum of the step's five shapes: {tot * 1e3:.1f} us", flush=True)
 
-# correctness screen of the loaded build: the LDS-DMA kernel against the register-staged general kernel (ragged M, K = 1024 and 4096),
-# 20 launches each bitwise equal to the first (race screen)
-for (M, N, K) in ((M63, 1024, 1024), (5000, 768, 4096)):
+if a.no_check:
+    sys.exit(0)
+
+# correctness screen of the loaded build: the LDS-DMA kernel against the register-staged general kernel (ragged M; K from the shortest legal
+# reduction — 64 = two 32-deep ring steps, shorter than the ring — to 4096), 20 launches each bitwise equal to the first (race screen)
+for (M, N, K) in ((M63, 1024, 1024), (5000, 768, 4096), (777, 512, 64), (3000, 1280, 128), (2049, 512, 192), (1500, 768, 320)):
     x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
     w = (torch.rand(1, N, K, device="cuda") * 2 - 1).bfloat16()
     b = torch.randn(1, N, device="cuda")
@@ -94,3 +98,20 @@ for (M, N, K) in ((M63, 1024, 1024), (5000, 768, 4096)):
         bad += int(not torch.equal(out, first))
     err = float((first - ref).norm() / ref.norm())
     print(f"check M={M} N={N} K={K}: rel diff vs general kernel {err:.2e}, {bad} of 20 launches differ from the first", flush=True)
+
+# the split-plane (x3) kernel against an fp64 product of the SAME split operands (hi + lo), same K sweep + race screen
+x3 = ops.Prec("x3f")
+for (M, N, K) in ((M63, 1024, 1024), (5000, 768, 4096), (777, 512, 64), (3000, 1280, 128), (2049, 512, 192)):
+    xs = ops.split_cast((torch.rand(M, K, device="cuda") * 2 - 1))
+    wp = torch.nn.Parameter(torch.rand(N, K, device="cuda") * 2 - 1)
+    ws = ops.pack_linear_split([wp], ("chk", M, N, K))
+    b = torch.randn(1, N, device="cuda")
+    ref = (xs.hi.double() + xs.lo.double()) @ (ws.hi[0].double() + ws.lo[0].double()).t() + b.double()
+    first, bad = None, 0
+    for i in range(10):
+        o32 = torch.full((1, M, N), 7.0, device="cuda")
+        ops.linear(xs, ws, N, x3, bias=b, out=o32)
+        first = o32 if first is None else first
+        bad += int(not torch.equal(o32, first))
+    err = float((first[0].double() - ref).norm() / ref.norm())
+    print(f"check split x3 M={M} N={N} K={K}: rel diff vs fp64 product of the planes {err:.2e}, {bad} of 10 launches differ from the first", flush=True)
