@@ -18,6 +18,9 @@ namespace {
 #ifndef MTT_RING
 #define MTT_RING 1           // 1: the ring kernels (gemm_ring_kernel / gemm_ring3_kernel) take the LDS-DMA calls with fast addressing; 0: round 3's gemm_dma_kernel<1 / 2>
 #endif
+#ifndef MTT_PAIR
+#define MTT_PAIR 0           // 1: gemm_pair_kernel (256 x 128 tile, two workgroups per CU) takes the bf16 LDS-DMA calls with fast addressing
+#endif
 #ifndef MTT_RING_S
 #define MTT_RING_S 4         // ring slots of 32 KiB (4 or 5)
 #endif
@@ -34,7 +37,28 @@ struct GemmP {
   FastDiv divPsW, divPsH, divPsCo;   // pixel-shuffle store
   int tiles_m, tiles_n;
   int group_m;
+#ifdef MTT_GEMM_TRACE
+  unsigned long long* trace;       // experiment builds only (tools/gemm_trace.py): 8 words per workgroup
+#endif
 };
+
+#ifdef MTT_GEMM_TRACE
+// experiment builds only: per-workgroup timestamps of the LDS-DMA kernels (thread 0): word 0 s_memrealtime at entry, 1..4 s_memtime at
+// entry / after the prologue / after the K loop / after the epilogue, 5 s_memrealtime at exit, 6 HW_ID | XCC_ID << 32, 7 tile index
+MTT_DEV unsigned long long trace_hwid() {
+  unsigned a, b;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(a));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(b));
+  return (unsigned long long)a | ((unsigned long long)b << 32);
+}
+#define MTT_TRACE(slot) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MTT_TRACE_RT(slot) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MTT_TRACE_ID(tile) do { if (p.trace && threadIdx.x == 0) { p.trace[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + 6] = trace_hwid(); p.trace[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + 7] = (tile); } } while (0)
+#else
+#define MTT_TRACE(slot) do {} while (0)
+#define MTT_TRACE_RT(slot) do {} while (0)
+#define MTT_TRACE_ID(tile) do {} while (0)
+#endif
 
 MTT_DEV int64_t row_off(uint32_t m, int mb, int64_t bs, int64_t ld, FastDiv f) {
   if (mb <= 0) return (int64_t)m * ld;
@@ -746,6 +770,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   constexpr int WAVES_N = 4, WAVES_M = 2, MT = 8, NT = 4;
   constexpr int TILE_A = BM2 * BK * 2, TILE_B = 256 * BK * 2, STAGE = TILE_A + TILE_B;
   constexpr bool FASTADDR = ADDR >= 1, X3CAT = ADDR == 2;
+  MTT_TRACE_RT(0); MTT_TRACE(1);
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + BM2 - 1) / BM2;
   int tile_m, tile_n;
@@ -832,6 +857,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                    // tile 0 is in LDS
+  MTT_TRACE(2);
   if (late) __builtin_amdgcn_s_barrier();          // stagger: waves 4-7 start one slot later
   __builtin_amdgcn_sched_barrier(0);
 
@@ -874,7 +900,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GemmP p) {
   if (late) main_loop(std::true_type{}); else main_loop(std::false_type{});
   if (!late) __builtin_amdgcn_s_barrier();         // waves 0-3 wait one slot for the late half
   __syncthreads();                                 // everyone is past its last LDS read: the epilogue may reuse the stages
+  MTT_TRACE(3);
   gemm_epilogue_auto<256, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  MTT_TRACE(4); MTT_TRACE_RT(5); MTT_TRACE_ID(tile_m * tiles_n + tile_n);
 }
 
 template <int ADDR>
@@ -1189,6 +1217,164 @@ int launch_ring3(const GemmP& p, hipStream_t stream) {
   const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + 255) / 256;
   dim3 grid(tm * tn, 1, p.d.batch);
   hipLaunchKernelGGL(gemm_ring3_kernel, grid, dim3(512), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_pair_kernel (round 4): 256 x 128 x 32 tile, FOUR waves (2 x 2, the main kernel's 128 x 64 wave tile, 128 accumulators per lane), three
+// ring slots of 24 KiB -> TWO workgroups per CU with independent timelines, so that one's prologue / epilogue (7 - 26 us of a 36 - 50 us
+// tile on the K = 1024 step shapes: VALU- or HBM-bound, tools/gemm_trace.py) runs under the other's K loop.  Round 3's form of this idea
+// alternated fragment reads and MFMAs inside each wave (a wave is alone on its SIMD within its workgroup) and lost 25 % in the loop; here
+// every wave is SOFTWARE-PIPELINED: A fragments are read two rows ahead of the MFMAs that use them (ring of 4), the next step's B fragments
+// and first A rows during rows 4 - 7 of the current step, so the wave's MFMA chain only breaks at the one workgroup barrier per step — which
+// sits in the MIDDLE of a step (after row 3), where it (RAW) publishes sub-tile j + 1 behind every wave's vmcnt(0) and (WAR) frees the slot
+// of sub-tile j - 1 for the LDS-DMA of sub-tile j + 2, issued right after it.
+// ---------------------------------------------------------------------------------------------
+#ifndef MTT_PAIR_DIST
+#define MTT_PAIR_DIST 3          // A fragment rows read ahead of their MFMAs (ring of 4 rows)
+#endif
+__global__ __launch_bounds__(256, 2) void gemm_pair_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WAVES_N = 2, WAVES_M = 2, MT = 8, NT = 4, S = 3, DIST = MTT_PAIR_DIST;
+  constexpr int PART_A = 256 * 64, PART_B = 128 * 64, SLOT = PART_A + PART_B;
+  MTT_TRACE_RT(0); MTT_TRACE(1);
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + 127) / 128, tiles_m = (p.d.M + BM2 - 1) / BM2;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * BM2, n0 = tile_n * 128;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  const unsigned char* Abase = (const unsigned char*)((const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi));
+  const unsigned char* Bbase = (const unsigned char*)((const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi));
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nk = p.d.K >> 5;
+
+  // LDS-DMA pieces (16 rows x 64 B): this wave streams A pieces 4 w .. 4 w + 3 and B pieces 2 w, 2 w + 1
+  uint32_t aoff32[4], boff32[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ring_swz(row);
+    int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;
+    aoff32[i] = (uint32_t)(row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + c * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ring_swz(row);
+    int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
+    boff32[i] = (uint32_t)((int64_t)rb * p.d.ldb + c * 8) * 2u;
+  }
+  auto issue = [&](int j, int slot) {
+    unsigned char* dA = smem + slot * SLOT + wave * 4096;
+    unsigned char* dB = smem + slot * SLOT + PART_A + wave * 2048;
+    const unsigned char* Ak = Abase + (size_t)j * 64;
+    const unsigned char* Bk = Bbase + (size_t)j * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16((const bf16_t*)(Ak + aoff32[i]), dA + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16((const bf16_t*)(Bk + boff32[i]), dB + i * 1024);
+  };
+  const int fsw = ((lg ^ ring_swz(li)) << 4) + li * 64;
+  const int fragA = wm * (MT * 16) * 64 + fsw, fragB = PART_A + wn * (NT * 16) * 64 + fsw;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  MTT_TRACE(2);
+  u32x4 fa[4], fb[NT], fbn[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(smem + fragB + t * 1024);
+#pragma unroll
+  for (int t = 0; t < DIST; ++t) fa[t] = *(const u32x4*)(smem + fragA + t * 1024);
+
+  // one 32-deep step.  TAIL 0: steady state; 1: the step before the last (nothing left to issue); 2: the last step (no next fragments)
+  auto step = [&](auto tail_tag, int j, int slot) {
+    constexpr int TAIL = decltype(tail_tag)::value;
+    const int slot1 = slot == S - 1 ? 0 : slot + 1, slot2 = slot1 == S - 1 ? 0 : slot1 + 1;
+    const unsigned char* sb = smem + slot * SLOT;
+    const unsigned char* sn = smem + slot1 * SLOT;
+    // ---- rows 0 .. 3 ----
+#pragma unroll
+    for (int a = 0; a < MT / 2; ++a) {
+      fa[(a + DIST) & 3] = *(const u32x4*)(sb + fragA + (a + DIST) * 1024);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a & 3], fb[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < MT / 2; ++a) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one fragment read ...
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);      // ... then a row of MFMAs
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // mid-step: sub-tile j + 1 complete in LDS for every wave; every wave past the reads of step j - 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- rows 4 .. 7, the LDS-DMA of sub-tile j + 2 between them, the next step's first fragments ----
+    const unsigned char* Ak = Abase + (size_t)(j + 2) * 64;
+    const unsigned char* Bk = Bbase + (size_t)(j + 2) * 64;
+    unsigned char* dA = smem + slot2 * SLOT + wave * 4096;
+    unsigned char* dB = smem + slot2 * SLOT + PART_A + wave * 2048;
+#pragma unroll
+    for (int a = MT / 2; a < MT; ++a) {
+      if (TAIL == 0) {
+        if (a == 4) { glds16((const bf16_t*)(Ak + aoff32[0]), dA); glds16((const bf16_t*)(Ak + aoff32[1]), dA + 1024); }
+        if (a == 5) { glds16((const bf16_t*)(Ak + aoff32[2]), dA + 2048); glds16((const bf16_t*)(Ak + aoff32[3]), dA + 3072); }
+        if (a == 6) { glds16((const bf16_t*)(Bk + boff32[0]), dB); glds16((const bf16_t*)(Bk + boff32[1]), dB + 1024); }
+      }
+      if (a + DIST < MT) fa[(a + DIST) & 3] = *(const u32x4*)(sb + fragA + (a + DIST) * 1024);
+      else if (TAIL < 2) fa[(a + DIST) & 3] = *(const u32x4*)(sn + fragA + (a + DIST - MT) * 1024);
+      if (TAIL < 2) fbn[a - MT / 2] = *(const u32x4*)(sn + fragB + (a - MT / 2) * 1024);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a & 3], fb[b], acc[a][b]);
+    }
+    static_assert(DIST == 3 && MT == 8, "the schedule below is written for three rows of read-ahead");
+    // row 4: A row 7 of this step (+ B fragment 0 of the next); rows 5 - 7: A rows 0 - 2 and B fragments 1 - 3 of the next step
+#define MTT_PAIR_ROW(NVM, NDS) do { if (NVM) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); \
+                                    if ((NDS) == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); \
+                                    if ((NDS) == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+                                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0); } while (0)
+    MTT_PAIR_ROW(TAIL == 0, TAIL < 2 ? 2 : 1);
+    MTT_PAIR_ROW(TAIL == 0, TAIL < 2 ? 2 : 0);
+    MTT_PAIR_ROW(TAIL == 0, TAIL < 2 ? 2 : 0);
+    MTT_PAIR_ROW(false, TAIL < 2 ? 2 : 0);
+#undef MTT_PAIR_ROW
+    __builtin_amdgcn_sched_barrier(0);
+    if (TAIL < 2) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fb[t] = fbn[t];
+    }
+  };
+  int slot = 0;                                     // ring slot of sub-tile j
+  int j = 0;
+  for (; j < nk - 2; ++j) { step(std::integral_constant<int, 0>{}, j, slot); slot = slot == S - 1 ? 0 : slot + 1; }
+  step(std::integral_constant<int, 1>{}, j, slot); slot = slot == S - 1 ? 0 : slot + 1; ++j;
+  step(std::integral_constant<int, 2>{}, j, slot);
+  __syncthreads();                                 // everyone is past its last LDS read: the epilogue may reuse the ring
+  MTT_TRACE(3);
+  gemm_epilogue_auto<128, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  MTT_TRACE(4); MTT_TRACE_RT(5); MTT_TRACE_ID(tile_m * tiles_n + tile_n);
+}
+
+int launch_pair(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = 3 * (256 * 64 + 128 * 64);
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_pair_kernel, smem, done)) return e;
+  const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + 127) / 128;
+  dim3 grid(tm * tn, 1, p.d.batch);
+  hipLaunchKernelGGL(gemm_pair_kernel, grid, dim3(256), smem, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -1629,6 +1815,10 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   if (d.M >= 128 && d.N >= 256 && d.K >= 512) return 4;
   return 0;
 }
+#ifdef MTT_GEMM_TRACE
+static unsigned long long* g_trace_host = nullptr;
+extern "C" void mtt_debug_set_trace(void* buf) { g_trace_host = (unsigned long long*)buf; }
+#endif
 extern "C" int mtt_gemm_variant(const mtt_gemm_desc* d) { return d ? gemm_variant_for(*d) : MTT_E_BADARG; }
 
 static int gemm_launch(GemmP& p, hipStream_t s, int v);
@@ -1663,6 +1853,9 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   p.divPsCo = make_div(d.ps_Co > 0 ? d.ps_Co : 1);
   p.tiles_m = (d.M + BM - 1) / BM; p.tiles_n = (d.N + BN - 1) / BN;
   p.group_m = MTT_GROUP_M;
+#ifdef MTT_GEMM_TRACE
+  p.trace = g_trace_host;
+#endif
   hipStream_t s = (hipStream_t)stream;
   const int v = gemm_variant_for(d);
   if (v < 0) return v;
@@ -1688,6 +1881,9 @@ extern "C" size_t mtt_gemm_colsum_ws_floats(const mtt_gemm_desc* d) {
 
 static int gemm_launch(GemmP& p, hipStream_t s, int v) {
   mtt_gemm_desc& d = p.d;
+#if MTT_PAIR
+  if (v == 3 && dma_fastaddr_ok(d)) return launch_pair(p, s);
+#endif
 #if MTT_RING
   if (v == 8) return launch_ring3(p, s);
   if (v == 3) return dma_fastaddr_ok(d) ? launch_ring<MTT_RING_S, MTT_RING_NR>(p, s) : launch_dma<0>(p, s);
