@@ -150,11 +150,13 @@ class GemmTimer:
 
 
 KERNELS = {
-    3: ("gemm_ring_kernel", "gemm_ring_kernel<S, NR> (256x256 tile, 8 waves x (8x4) v_mfma_f32_16x16x32_bf16, operands streamed HBM -> LDS by "
-        "global_load_lds_dwordx4 into a ring of 32-deep K slots with counted vmcnt, staggered read / MFMA phases, specialised interior-tile "
-        "epilogue; calls with a K tail take gemm_dma_kernel<0>): every encoder Linear forward (bf16 mode) and input gradient of the step"),
-    8: ("gemm_ring3_kernel", "gemm_ring3_kernel (the same tile on MTT_SPLIT operands: hi / lo bf16 planes of both operands staged once per 32-deep K step, "
-        "three MFMA products Ah Bh + Ah Bl + Al Bh per step, fp32 accumulate): every encoder Linear of the fp32-class forward"),
+    3: ("gemm_dma_kernel<1>", "gemm_dma_kernel<1> (256x256x64 tile, 8 waves x (8x4) v_mfma_f32_16x16x32_bf16, operands streamed HBM -> LDS by "
+        "global_load_lds_dwordx4 with wave-uniform base + 32-bit lane offset addressing, staggered read / MFMA phases, specialised "
+        "interior-tile epilogue; <0> = the same kernel with general addressing for calls with a K tail): every encoder Linear forward "
+        "(bf16 mode) and input gradient of the step"),
+    8: ("gemm_ring3_kernel", "gemm_ring3_kernel (the same tile on MTT_SPLIT operands: hi / lo bf16 planes of both operands staged once per 32-deep K step "
+        "into a part-recycled LDS ring with counted vmcnt, three MFMA products Ah Bh + Ah Bl + Al Bh per step, fp32 accumulate): every "
+        "encoder Linear of the fp32-class forward"),
 }
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 7
+#define MTT_ABI_VERSION 8
 
 /* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
  * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
@@ -206,11 +206,13 @@ int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* drawchan, void
 
 /* Task-feature modulation, taskprompter.py:436-467: from x fp32 [B, hw, C] (row pitch/batch stride given)
  *   out[2t  ][b,p,c] = x[b,p,c] * (1 + rawlog[b, c/hg, t, T+p])          (rawlog fp32 [B, C/hg, T, N])
- *   out[2t+1][b,p,c] = x[b,p,c] * (1 + rawchan[b, t, win(p), c])            out dtype act, [2T, B*hw, C] */
+ *   out[2t+1][b,p,c] = x[b,p,c] * (1 + rawchan[b, t, win(p), c])            out dtype act (or MTT_SPLIT: two bf16 planes), [2T, B*hw, C] */
 typedef struct {
   const float* x; int64_t x_ld, x_bs; const float* rawlog; const float* rawchan; void* out;
   int32_t B, T, N, C, h, w, nh, nw; int32_t out_dtype;
   int32_t hg;                    /* channels per attention head (a multiple of 8; 0 = 64, the ViT variants; 32 in the last Swin stage) */
+  void* out_lo;                  /* ABI 8: out_dtype == MTT_SPLIT writes hi = bf16(v) at out and lo = bf16(v - hi) here (same layout): the
+                                    fea_decode GEMMs of the fp32-class forward then stream pre-split planes (gemm_ring3_kernel) */
 } mtt_modulate_desc;
 int mtt_modulate(const mtt_modulate_desc* d, void* stream);
 /* backward: dout [2T, B*hw, C] (d->out_dtype) -> dx = (fp32, same addressing as x; WRITTEN), drawlog[b,head,t,T+p] = (fp32 [B,nH,T,N],

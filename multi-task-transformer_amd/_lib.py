@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -87,7 +87,7 @@ class ChanLogitDesc(C.Structure):
 class ModulateDesc(C.Structure):
     _fields_ = [("x", ptr), ("x_ld", i64), ("x_bs", i64), ("rawlog", ptr), ("rawchan", ptr), ("out", ptr),
                 ("B", i32), ("T", i32), ("N", i32), ("C", i32), ("h", i32), ("w", i32), ("nh", i32), ("nw", i32),
-                ("out_dtype", i32), ("hg", i32)]
+                ("out_dtype", i32), ("hg", i32), ("out_lo", ptr)]
 
 
 class CtrDesc(C.Structure):

@@ -478,16 +478,21 @@ class ModulateFn(Function):
     """cal_task_feature's (1 + logit) modulation for all tasks (taskprompter.py:436-467)."""
 
     @staticmethod
-    def forward(ctx, xsrc, rawlog, rawchan, geo, prec):
+    def forward(ctx, xsrc, rawlog, rawchan, geo, prec, split=False):
+        """split=True (x3f): the modulated copies as hi / lo bf16 planes (returned as two tensors; lo carries no gradient) for the
+        split-plane fea_decode GEMM — the hi plane is also the bf16 operand of its weight gradient, so no cast pass in the backward."""
         B, N, T, C, h, w, nwin = geo[:7]
         hg = geo[7] if len(geo) > 7 else 0               # channels per attention head (0 = 64; the Swin stages pass theirs)
-        mod = ops.modulate(xsrc.view(B, N, C)[:, T:], C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec, hg=hg)
+        mod = ops.modulate(xsrc.view(B, N, C)[:, T:], C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec, hg=hg, split=split)
         ctx.save_for_backward(xsrc, rawlog, rawchan)
         ctx.geo = geo
+        if split:
+            ctx.mark_non_differentiable(mod.lo)
+            return mod.hi, mod.lo
         return mod
 
     @staticmethod
-    def backward(ctx, dmod):
+    def backward(ctx, dmod, *_):
         xsrc, rawlog, rawchan = ctx.saved_tensors
         B, N, T, C, h, w, nwin = ctx.geo[:7]
         hg = ctx.geo[7] if len(ctx.geo) > 7 else 0
@@ -498,7 +503,7 @@ class ModulateFn(Function):
         ops.call("modulate_bwd", x=xsrc.view(B, N, C)[:, T:], x_ld=C, x_bs=N * C, rawlog=rawlog, rawchan=rawchan, out=None,
                  B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin, out_dtype=dtype_code(dmod), hg=hg,
                  xargs=[dmod, dx.view(B, N, C)[:, T:], dl, dc, ops.ws_for("modulate_bwd", dmod.device, B=B, T=T, C=C, h=h, w=w, nh=nwin, nw=nwin)])
-        return dx, dl, dc, None, None
+        return dx, dl, dc, None, None, None
 
 
 # =================================================================================================
@@ -509,26 +514,35 @@ class BLinearFn(Function):
     column remap used when the input is such a padded concatenation."""
 
     @staticmethod
-    def forward(ctx, x, N, layout, kmap, out_dtype, prec, tag, *wb):
+    def forward(ctx, x, N, layout, kmap, out_dtype, prec, tag, xlo, *wb):
+        """xlo: None, or the lo plane of a split input (x is then its hi plane): the product runs on the split-plane LDS-DMA kernel with
+        pre-split weight planes.  out_dtype "split": the output as (hi, lo) planes — two tensors, lo without gradient."""
         Z = len(wb) // 2
         ws, bs = wb[:Z], wb[Z:]
-        if kmap is None:
+        xin = ops.Split(x, xlo) if xlo is not None else x
+        if xlo is not None:
+            wpack = ops.pack_linear_split(list(ws), tag) if kmap is None else ops.pack_kmap_split(list(ws), N, kmap[0], kmap[1], tag)
+        elif kmap is None:
             wpack = ops.pack_linear(list(ws), prec, tag)
         else:
             wpack = ops.pack_kmap(list(ws), N, kmap[0], kmap[1], prec, tag)
         bias = ops.stack_vec(list(bs), (tag, 'b'))
         M, Np = x.shape[-2], pad8(N)
         if layout == 'catpair':
-            out = torch.empty(Z // 2, M, 2 * Np, dtype=out_dtype or prec.adt, device=x.device)
-            ops.linear(x, wpack, N, prec, bias=bias, out=out, batch_inner=2, d_z=(M * 2 * Np, Np), ldd=2 * Np, n_store=Np)
+            shape = (Z // 2, M, 2 * Np)
+            out = ops.Split.empty(shape, x.device) if out_dtype == "split" else torch.empty(shape, dtype=out_dtype or prec.adt, device=x.device)
+            ops.linear(xin, wpack, N, prec, bias=bias, out=out, batch_inner=2, d_z=(M * 2 * Np, Np), ldd=2 * Np, n_store=Np)
         else:
-            out = ops.linear(x, wpack, N, prec, bias=bias, out_dtype=out_dtype)
-        ctx.save_for_backward(x, wpack)
+            out = ops.linear(xin, wpack, N, prec, bias=bias, out_dtype=out_dtype)
+        ctx.save_for_backward(x, ops._hi(wpack))          # split: the hi planes ARE the bf16 operands of the (bf16) backward
         ctx.meta = (Z, N, layout, kmap, prec, [tuple(w.shape) for w in ws])
+        if isinstance(out, ops.Split):
+            ctx.mark_non_differentiable(out.lo)
+            return out.hi, out.lo
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, wpack = ctx.saved_tensors
         Z, N, layout, kmap, prec, wshapes = ctx.meta
         prec = prec.bwd
@@ -584,7 +598,7 @@ class BLinearFn(Function):
             dx = dx.sum(0, keepdim=True)
         elif x.dim() == 2:
             dx = dx.sum(0)
-        return (dx, None, None, None, None, None, None) + tuple(dws) + tuple(dbs)
+        return (dx, None, None, None, None, None, None, None) + tuple(dws) + tuple(dbs)
 
 
 class Conv3x3Fn(Function):
@@ -882,18 +896,22 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
     tar, F = p.embed_dim, p.final_embed_dim
     tarp = pad8(tar)
     nwin = int(math.isqrt(model.chan_nheads))
-    mod = ModulateFn.apply(xsrc, rawlog, rawchan, (B, N, T, C, h, w, nwin), prec)
+    sp = model._decoder_split()          # x3f: modulate and the fea_decode epilogue write hi / lo planes, both GEMMs on the split-plane kernel
+    mod = ModulateFn.apply(xsrc, rawlog, rawchan, (B, N, T, C, h, w, nwin), prec, sp)
+    mod, mod_lo = mod if sp else (mod, None)
     dec_w, dec_b = [], []
     for t in names:
         dec_w += [model.fea_decode_spa[il][t][0].weight, model.fea_decode_chan[il][t][0].weight]
         dec_b += [model.fea_decode_spa[il][t][0].bias, model.fea_decode_chan[il][t][0].bias]
-    cat = BLinearFn.apply(mod, tar, 'catpair', None, None, prec, ('dec', il), *dec_w, *dec_b)
+    cat = BLinearFn.apply(mod, tar, 'catpair', None, "split" if sp else None, prec, ('dec', il), mod_lo, *dec_w, *dec_b)
+    cat, cat_lo = cat if sp else (cat, None)
+    del mod, mod_lo
     ff = [model.fea_fuse[il][t] for t in names]
     kmap = (2 * tarp, [(0, 0, tar), (tarp, tar, tar)])
-    y0 = BLinearFn.apply(cat, F, 'plain', kmap, None, prec, ('f0', il), *[m[0].weight for m in ff], *[m[0].bias for m in ff])
+    y0 = BLinearFn.apply(cat, F, 'plain', kmap, torch.float32 if sp else None, prec, ('f0', il), cat_lo, *[m[0].weight for m in ff], *[m[0].bias for m in ff])
     y1 = Conv3x3Fn.apply(y0, (B, h, w, F, F), prec, ('f1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
     y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)
-    fea = BLinearFn.apply(y1, F, 'plain', None, None, prec, ('f4', il), *[m[4].weight for m in ff], *[m[4].bias for m in ff])
+    fea = BLinearFn.apply(y1, F, 'plain', None, None, prec, ('f4', il), None, *[m[4].weight for m in ff], *[m[4].bias for m in ff])
     wmix = model._ctr_weights(rawlog, il, B, T)
     return CtrMixFn.apply(fea, wmix, acc, B, F)
 
@@ -958,6 +976,6 @@ def heads_forward(kind, heads, fea, B, h4, w4, target, prec, training, lowres=Fa
         y = Conv3x3Fn.apply(y, (B, 2 * h4, 2 * w4, F2, F2), prec, 'hd3', hd.mt_proj[3].weight, hd.mt_proj[3].bias)
         y = bn_act_single(y[0], hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, training)[None]
         n_out = hd.linear_pred.weight.shape[0]
-        pred = BLinearFn.apply(y, n_out, 'plain', None, torch.float32, prec, 'hp', hd.linear_pred.weight, hd.linear_pred.bias)
+        pred = BLinearFn.apply(y, n_out, 'plain', None, torch.float32, prec, 'hp', None, hd.linear_pred.weight, hd.linear_pred.bias)
         outs.append(BilinearFn.apply(pred, (B, n_out, 2 * h4, 2 * w4, tgt[0], tgt[1]), torch.float32, True))
     return outs

@@ -27,6 +27,18 @@ MTT_DEV void st8(void* p, int64_t idx, int dtype, const float (&v)[8]) {
   }
 }
 
+// 8 values as MTT_F32 / MTT_BF16, or as MTT_SPLIT planes: hi = bf16(v) at p, lo = bf16(v - hi) at p_lo
+MTT_DEV void st8s(void* p, void* p_lo, int64_t idx, int dtype, const float (&v)[8]) {
+  if (dtype == MTT_SPLIT) {
+    const u32x4 hi = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    *(u32x4*)((bf16_t*)p + idx) = hi;
+    *(u32x4*)((bf16_t*)p_lo + idx) = (u32x4){pack2(v[0] - lo_of(hi.x), v[1] - hi_of(hi.x)), pack2(v[2] - lo_of(hi.y), v[3] - hi_of(hi.y)),
+                                             pack2(v[4] - lo_of(hi.z), v[5] - hi_of(hi.z)), pack2(v[6] - lo_of(hi.w), v[7] - hi_of(hi.w))};
+  } else {
+    st8(p, idx, dtype, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, 4 rows per block.
 // ------------------------------------------------------------------------------------------------
@@ -511,12 +523,12 @@ __global__ __launch_bounds__(256) void modulate_kernel(const mtt_modulate_desc d
       const float a = d.rawlog[(((int64_t)b * nH + head) * d.T + tk) * d.N + d.T + p];
 #pragma unroll
       for (int j = 0; j < 8; ++j) ov[j] = xv[j] * (1.0f + a);
-      st8(d.out, (int64_t)(2 * tk) * plane + tok * d.C + c8 * 8, d.out_dtype, ov);
+      st8s(d.out, d.out_lo, (int64_t)(2 * tk) * plane + tok * d.C + c8 * 8, d.out_dtype, ov);
       float bw[8];
       ld8(d.rawchan, (((int64_t)b * d.T + tk) * nwin + win) * d.C + c8 * 8, MTT_F32, bw);
 #pragma unroll
       for (int j = 0; j < 8; ++j) ov[j] = xv[j] * (1.0f + bw[j]);
-      st8(d.out, (int64_t)(2 * tk + 1) * plane + tok * d.C + c8 * 8, d.out_dtype, ov);
+      st8s(d.out, d.out_lo, (int64_t)(2 * tk + 1) * plane + tok * d.C + c8 * 8, d.out_dtype, ov);
     }
   }
 }
@@ -1585,6 +1597,7 @@ extern "C" int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream) {
 
 extern "C" int mtt_modulate(const mtt_modulate_desc* d, void* stream) {
   if (!d || !d->x || !d->rawlog || !d->rawchan || !d->out || d->hg < 0 || (d->hg % 8) || (d->C % (d->hg > 0 ? d->hg : 64))) return MTT_E_BADARG;
+  if (d->out_dtype == MTT_SPLIT && !d->out_lo) return MTT_E_BADARG;
   hipLaunchKernelGGL(modulate_kernel, dim3(grid_for((int64_t)d->B * d->h * d->w * (d->C / 8))), dim3(256), 0, S_, *d);
   return LAUNCH_OK();
 }

@@ -105,21 +105,23 @@ class VisionTransformer(nn.Module):
                    bias=self.patch_embed.proj.bias.detach()[None], out=XT.view(B, N, C)[:, 1:], d_rows=(hw, N * C, C),
                    resid=self.pos_embed.detach()[0, 1:], r_rows=(hw, 0, C), M=B * hw)
         taps = []
+        # x3f: the four big Linears of a block on the split-plane LDS-DMA kernel (operands written as hi / lo planes by LayerNorm, the
+        # qkv / fc1 epilogues and the attention kernel), as TaskPrompter._block_split; the K = C reductions must be whole 32-deep steps
+        split = prec.split and C % 32 == 0
+        pack = (lambda ws, tg: ops.pack_linear_split(ws, tg)) if split else (lambda ws, tg: ops.pack_linear(ws, prec, tg))
+        sp = dict(out_dtype="split") if split else {}
         for i, blk in enumerate(self.blocks):
             tag = ('vblk', i)
-            xn, _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec)
-            qkv = ops.linear(xn, ops.pack_linear([blk.attn.qkv.weight], prec, tag + ('qkv',)), 3 * C, prec,
-                             bias=blk.attn.qkv.bias.detach()[None])[0]
+            xn, _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec, **sp)
+            qkv = ops.linear(xn, pack([blk.attn.qkv.weight], tag + ('qkv',)), 3 * C, prec, bias=blk.attn.qkv.bias.detach()[None], **sp)[0]
             ao, _, _ = ops.attention(qkv, B, N, nH, 0, prec)
             XT2 = torch.empty_like(XT)
-            ops.linear(ao, ops.pack_linear([blk.attn.proj.weight], prec, tag + ('proj',)), C, prec,
-                       bias=blk.attn.proj.bias.detach()[None], out=XT2, resid=XT)
-            xn2, _, _ = ops.layernorm(XT2, blk.norm2.weight.detach(), blk.norm2.bias.detach(), blk.norm2.eps, prec)
-            hmid = ops.linear(xn2, ops.pack_linear([blk.mlp.fc1.weight], prec, tag + ('fc1',)), 4 * C, prec,
-                              bias=blk.mlp.fc1.bias.detach()[None], act=ACT_GELU)[0]
+            ops.linear(ao, pack([blk.attn.proj.weight], tag + ('proj',)), C, prec, bias=blk.attn.proj.bias.detach()[None], out=XT2, resid=XT)
+            xn2, _, _ = ops.layernorm(XT2, blk.norm2.weight.detach(), blk.norm2.bias.detach(), blk.norm2.eps, prec, **sp)
+            hmid = ops.linear(xn2, pack([blk.mlp.fc1.weight], tag + ('fc1',)), 4 * C, prec, bias=blk.mlp.fc1.bias.detach()[None],
+                              act=ACT_GELU, **sp)[0]
             XT = torch.empty_like(XT)
-            ops.linear(hmid, ops.pack_linear([blk.mlp.fc2.weight], prec, tag + ('fc2',)), C, prec,
-                       bias=blk.mlp.fc2.bias.detach()[None], out=XT, resid=XT2)
+            ops.linear(hmid, pack([blk.mlp.fc2.weight], tag + ('fc2',)), C, prec, bias=blk.mlp.fc2.bias.detach()[None], out=XT, resid=XT2)
             if (i + 1) in self.select_list:
                 taps.append(XT.view(B, N, C)[:, 1:].to(prec.adt).reshape(B * hw, C))
         xf, _, _ = ops.layernorm(XT, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps, prec)

@@ -324,7 +324,7 @@ def _block(dec, blk, si, Xf, B, T, D, gh, gw, prev_score):
     kvmap = AvgPoolFn.apply(xn, (B, gh, gw, kk))
 
     def proj(src, lin, n, name):
-        y = BLinearFn.apply(src.reshape(1, -1, D), D, 'plain', None, None, prec, tag + (name,), lin.weight, lin.bias)
+        y = BLinearFn.apply(src.reshape(1, -1, D), D, 'plain', None, None, prec, tag + (name,), None, lin.weight, lin.bias)
         return _to_batch_major(y, T, B, n)
     q, k, v = proj(qmap, at.proj_q, nq, 'q'), proj(kvmap, at.proj_k, nk, 'k'), proj(kvmap, at.proj_v, nk, 'v')
     S = ScoresFn.apply(q.contiguous(), k.contiguous(), heads, float(D) ** -0.5, prec)             # scale = full dim (invpt.py:92)
@@ -338,7 +338,7 @@ def _block(dec, blk, si, Xf, B, T, D, gh, gw, prev_score):
     P = SoftmaxFn.apply(S, K, prec)
     o = PVFn.apply(P, v.contiguous(), prec)                                                     # [B, T*nq, D]
     o_tm = o.view(B, T, nq, D).permute(1, 0, 2, 3).reshape(1, T * B * nq, D)
-    om = BLinearFn.apply(o_tm, D, 'plain', None, None, prec, tag + ('po',), at.proj.weight, at.proj.bias).view(T, B * nq, D)
+    om = BLinearFn.apply(o_tm, D, 'plain', None, None, prec, tag + ('po',), None, at.proj.weight, at.proj.bias).view(T, B * nq, D)
     X2 = Xf + BilinearFn.apply(om, (B, D, qh, qw, gh, gw), torch.float32, False)
     X3 = MlpHalfFn.apply(X2.view(T * rows, D), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
                          blk.mlp.fc2.weight, blk.mlp.fc2.bias, None, (1, T * rows, 0), prec, tag)
@@ -373,11 +373,11 @@ def decoder_forward(dec, taps, B):
     for i, t in enumerate(names):
         n_out = p.TASKS.NUM_OUTPUT[t]
         ih = dec.intermediate_head[t]
-        inter[t] = BLinearFn.apply(y[i][None], n_out, 'plain', None, torch.float32, prec, ('ih', t), ih.weight, ih.bias)
+        inter[t] = BLinearFn.apply(y[i][None], n_out, 'plain', None, torch.float32, prec, ('ih', t), None, ih.weight, ih.bias)
         mp = dec.invpt.mix_proj[t][0]                                                      # 1x1 on cat([feature, inter_pred])
-        part = BLinearFn.apply(y[i][None], E, 'plain', (Ed, [(0, 0, Ed)]), torch.float32, prec, ('mixa', t), mp.weight, mp.bias)
+        part = BLinearFn.apply(y[i][None], E, 'plain', (Ed, [(0, 0, Ed)]), torch.float32, prec, ('mixa', t), None, mp.weight, mp.bias)
         zero_b = ops._cached(('mixzb', t, id(mp.bias)), [], lambda: torch.zeros(E, dtype=torch.float32, device=mp.bias.device))
-        second = BLinearFn.apply(inter[t].to(prec.adt), E, 'plain', (pad8(n_out), [(0, Ed, n_out)]), torch.float32, prec, ('mixb', t),
+        second = BLinearFn.apply(inter[t].to(prec.adt), E, 'plain', (pad8(n_out), [(0, Ed, n_out)]), torch.float32, prec, ('mixb', t), None,
                                  mp.weight, zero_b)
         xs.append(part[0] + second[0])
     Xf = torch.stack(xs, 0)                                                                # fp32 [T, rows0, E]
@@ -408,7 +408,7 @@ def decoder_forward(dec, taps, B):
         yn = LayerNormFn.apply(cat, nm.weight, nm.bias, nm.eps, prec, None).view(rows, T, D).permute(1, 0, 2).contiguous()
         if i > 0:
             rc = dec.invpt.redu_chan[i]
-            yn = BLinearFn.apply(yn, E, 'plain', None, None, prec, ('rc', i), *[m.weight for m in rc], *[m.bias for m in rc])
+            yn = BLinearFn.apply(yn, E, 'plain', None, None, prec, ('rc', i), None, *[m.weight for m in rc], *[m.bias for m in rc])
         r = BilinearFn.apply(yn, (B, E, gh, gw, th, tw), torch.float32, False)
         acc = r if acc is None else acc + r
     mps = [dec.invpt.mt_proj[t] for t in names]

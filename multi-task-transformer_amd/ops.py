@@ -421,6 +421,18 @@ def pack_kmap(weights, N, Kp, kmap, prec, tag):
                     check=lambda: _check_sources(weights, lambda w: w.numel() == N * K))
 
 
+def pack_kmap_split(weights, N, Kp, kmap, tag):
+    """pack_kmap as pre-split planes (Split [Z, N, Kp]) for the split-plane GEMM."""
+    Z = len(weights)
+    K = weights[0].numel() // N
+    dev = weights[0].device
+    return seg_pack((tag, 'split', 'kmap', tuple(id(w) for w in weights)), list(weights),
+                    lambda: Split(torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev)),
+                    lambda sp: [segment(w, s0, sp.hi, z * N * Kp + d0, (1, N, ln), (0, K, 1), (0, Kp, 1), dst_lo=sp.lo)
+                                for z, w in enumerate(weights) for (d0, s0, ln) in kmap],
+                    check=lambda: _check_sources(weights, lambda w: w.numel() == N * K))
+
+
 def stack_vec(vs, tag):
     """List of Z fp32 vectors (biases) -> [Z, n] fp32."""
     n, Z = vs[0].numel(), len(vs)
@@ -627,14 +639,20 @@ def chan_logits(cq, xn, B, T, N, C, grid, nwin_hw):
     return rawchan
 
 
-def modulate(x, x_ld, x_bs, rawlog, rawchan, B, T, N, C, grid, nwin_hw, prec, hg=0):
+def modulate(x, x_ld, x_bs, rawlog, rawchan, B, T, N, C, grid, nwin_hw, prec, hg=0, split=False):
     """x: fp32 base view of the patch rows ([B, hw, C] with row pitch x_ld, batch stride x_bs).
-    -> [2T, B*hw, C] activation dtype (spatially- then channel-modulated copy per task)."""
+    -> [2T, B*hw, C] activation dtype (spatially- then channel-modulated copy per task); split=True: a Split (hi / lo bf16 planes
+    written by the kernel) for the fea_decode GEMMs of the fp32-class forward on the split-plane LDS-DMA kernel."""
     hw = grid[0] * grid[1]
-    out = torch.empty(2 * T, B * hw, C, dtype=prec.adt, device=x.device)
-    call("modulate", x=x, x_ld=x_ld, x_bs=x_bs, rawlog=rawlog, rawchan=rawchan, out=out, B=B, T=T, N=N, C=C,
-         h=grid[0], w=grid[1], nh=nwin_hw[0], nw=nwin_hw[1], out_dtype=dtype_code(out), hg=hg)
+    out = Split.empty((2 * T, B * hw, C), x.device) if split else torch.empty(2 * T, B * hw, C, dtype=prec.adt, device=x.device)
+    call("modulate", x=x, x_ld=x_ld, x_bs=x_bs, rawlog=rawlog, rawchan=rawchan, out=_hi(out), out_lo=out.lo if split else None,
+         B=B, T=T, N=N, C=C, h=grid[0], w=grid[1], nh=nwin_hw[0], nw=nwin_hw[1], out_dtype=dtype_code(out), hg=hg)
     return out
+
+
+def split_gemm_ok(K):
+    """mtt_gemm takes MTT_SPLIT operands on ONE kernel (gemm_ring3_kernel): whole 32-deep K steps, at least two."""
+    return K % 32 == 0 and K >= 64
 
 
 def ctr_mix(fea, wmix, B, C, acc=None, out_dtype=torch.float32):

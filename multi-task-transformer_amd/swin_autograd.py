@@ -186,7 +186,7 @@ def _lin(model, x, layer, tag, out_dtype=None):
         bias = _zero_bias[key]
     if x.shape[-1] % 8:                                   # reduction length not a multiple of 8 (chan_kv on a 6 x 9 map): zero columns
         x = torch.nn.functional.pad(x, (0, 8 - x.shape[-1] % 8))
-    y = BLinearFn.apply(x, layer.weight.shape[0], 'plain', None, out_dtype, model.prec, tag, layer.weight, bias)
+    y = BLinearFn.apply(x, layer.weight.shape[0], 'plain', None, out_dtype, model.prec, tag, None, layer.weight, bias)
     return y[0][:, :layer.weight.shape[0]]
 
 
@@ -358,10 +358,10 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, res, C, hg):
     for t in names:
         dec_w += [model.fea_decode_spa[il][t][0].weight, model.fea_decode_chan[il][t][0].weight]
         dec_b += [model.fea_decode_spa[il][t][0].bias, model.fea_decode_chan[il][t][0].bias]
-    cat = BLinearFn.apply(mod, tar, 'catpair', None, None, prec, ('swtdec', il), *dec_w, *dec_b)
+    cat = BLinearFn.apply(mod, tar, 'catpair', None, None, prec, ('swtdec', il), None, *dec_w, *dec_b)
     ff = [model.fea_fuse[il][t] for t in names]
     kmap = (2 * tarp, [(0, 0, tar), (tarp, tar, tar)])
-    y0 = BLinearFn.apply(cat, F, 'plain', kmap, None, prec, ('swtf0', il), *[m[0].weight for m in ff], *[m[0].bias for m in ff])
+    y0 = BLinearFn.apply(cat, F, 'plain', kmap, None, prec, ('swtf0', il), None, *[m[0].weight for m in ff], *[m[0].bias for m in ff])
     y0 = BilinearFn.apply(y0, (B, y0.shape[-1], h, w, 2 * h, 2 * w), prec.adt, False)
     y1 = Conv3x3Fn.apply(y0, (B, 2 * h, 2 * w, F, F), prec, ('swtf1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
     y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)

@@ -329,17 +329,28 @@ class TaskPrompter(nn.Module):
         for t in names:
             dec_w += [self.fea_decode_spa[il][t][0].weight, self.fea_decode_chan[il][t][0].weight]
             dec_b += [self.fea_decode_spa[il][t][0].bias, self.fea_decode_chan[il][t][0].bias]
-        Wdec = ops.pack_linear(dec_w, prec, ('dec', il))
         bdec = ops.stack_vec(dec_b, ('decb', il))
         f0 = [self.fea_fuse[il][t][0].weight for t in names]
         # fea_fuse[0] reads torch.cat([spa, chan], 1) (:471): its K = 2*tar columns land at 0 and pad8(tar) of the padded concatenation
-        W0 = ops.pack_kmap(f0, F, 2 * tarp, [(0, 0, tar), (tarp, tar, tar)], pf, ('f0', il))
+        if self._decoder_split():
+            Wdec = ops.pack_linear_split(dec_w, ('dec', il))
+            W0 = ops.pack_kmap_split(f0, F, 2 * tarp, [(0, 0, tar), (tarp, tar, tar)], ('f0', il))
+        else:
+            Wdec = ops.pack_linear(dec_w, prec, ('dec', il))
+            W0 = ops.pack_kmap(f0, F, 2 * tarp, [(0, 0, tar), (tarp, tar, tar)], pf, ('f0', il))
         b0 = ops.stack_vec([self.fea_fuse[il][t][0].bias for t in names], ('f0b', il))
         Wc = ops.pack_conv3([self.fea_fuse[il][t][1].weight for t in names], pf, ('f1', il))
         bc = ops.stack_vec([self.fea_fuse[il][t][1].bias for t in names], ('f1b', il))
         W4 = ops.pack_linear([self.fea_fuse[il][t][4].weight for t in names], pf, ('f4', il))
         b4 = ops.stack_vec([self.fea_fuse[il][t][4].bias for t in names], ('f4b', il))
         return Wdec, bdec, W0, b0, Wc, bc, W4, b4
+
+    def _decoder_split(self):
+        """x3f: fea_decode_* and fea_fuse[0] on the split-plane LDS-DMA kernel — `modulate` writes hi / lo planes, the fea_decode epilogue
+        writes the padded concatenation as planes (the register-staged x3 kernel split the fp32 operands of every tile while staging:
+        3.2 -> 2.3 ms and 1.2 -> 0.85 ms per tap at B = 63, profiles/r04_dec_x3_bench_g.log).  Needs whole 32-deep K steps."""
+        return (self.prec.split and self.gprec is None and ops.split_gemm_ok(self.embed_dim)
+                and ops.split_gemm_ok(2 * ops.pad8(self.p.embed_dim)))
 
     def _ctr_weights(self, rawlog, il, B, T):
         """[B, T, T] mixing weights: per-head MLP on the prompt<->prompt raw logits (:482-484); identity without ctr."""
@@ -373,10 +384,12 @@ class TaskPrompter(nn.Module):
         tarp, Fp = ops.pad8(tar), ops.pad8(F)
         nwin = int(math.isqrt(self.chan_nheads))
         Wdec, bdec, W0, b0, Wc, bc, W4, b4 = self._decoder_packs(il)
-        mod = ops.modulate(xview, C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec)
-        cat = torch.empty(T, B * hw, 2 * tarp, dtype=prec.adt, device=xsrc.device)
+        sp = self._decoder_split()
+        mod = ops.modulate(xview, C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec, split=sp)
+        cat = ops.Split.empty((T, B * hw, 2 * tarp), xsrc.device) if sp else torch.empty(T, B * hw, 2 * tarp, dtype=prec.adt, device=xsrc.device)
         ops.linear(mod, Wdec, tar, ps, bias=bdec, out=cat, batch_inner=2, d_z=(B * hw * 2 * tarp, tarp), ldd=2 * tarp,
                    n_store=tarp)
+        del mod
         y0 = ops.linear(cat, W0, F, pf, bias=b0, out_dtype=adt)
         bns = [self.fea_fuse[il][t][2] for t in names]
         if self.training:

@@ -73,7 +73,7 @@ def gemm(**kw):
     k = torch.arange(K)[None, :]
     a_split, b_split, d_split = g("a_dtype") == SPLIT, g("b_dtype") == SPLIT, g("d_dtype") == SPLIT
     if a_split or b_split:
-        assert a_split and b_split and prec == 1 and a_op == OP_K and b_op == OP_K and K % 64 == 0, "split operands: x3, both split, OP_K, K % 64 == 0"
+        assert a_split and b_split and prec == 1 and a_op == OP_K and b_op == OP_K and K % 32 == 0 and K >= 64, "split operands: x3, both split, OP_K, K % 32 == 0, K >= 64"
 
     def conv_taps(idx_tap, flip):
         ty, tx = idx_tap // 3, idx_tap % 3
@@ -332,6 +332,8 @@ def modulate(**kw):
         outs.append(x * (1 + rc[:, t][:, win]))
     y = torch.stack(outs, 0).reshape(-1)
     _wr(kw["out"], torch.arange(y.numel()), y)
+    if kw.get("out_lo") is not None:                 # MTT_SPLIT: out is the bf16 hi plane (rounded by the store), out_lo = bf16(v - hi)
+        _wr(kw["out_lo"], torch.arange(y.numel()), y - _bf16_round(y))
 
 
 def ctr_mix(**kw):

@@ -510,6 +510,10 @@ def row_cases():
             kw = dict(x=XT[:, T:], x_ld=C, x_bs=N * C, rawlog=rnd(g, B, C // 64, T, N), rawchan=rnd(g, B, T, nh * nh, C),
                       out=torch.zeros(2 * T, B * h * w, C, dtype=DT[dt]), B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nh, out_dtype=dt)
             cases.append((f"modulate_{dt}_win{nh}", "modulate", kw, TOL_ROW))
+            if dt == BF16:          # ABI 8: MTT_SPLIT output (hi / lo planes for the split-plane fea_decode GEMM)
+                ks = dict(kw, out=torch.zeros(2 * T, B * h * w, C, dtype=torch.bfloat16), out_lo=torch.zeros(2 * T, B * h * w, C, dtype=torch.bfloat16),
+                          out_dtype=SPLIT)
+                cases.append((f"modulate_split_win{nh}", "modulate", ks, dict(f32=1e-5, bf16=5e-3, split=1e-5, split_pairs=[("out", "out_lo")])))
         # several pixel splits per window (partials through the workspace, summed in split order): 16 x 16 patches
         B, T, C, h, w = 1, 3, 128, 16, 16
         N = T + h * w

@@ -119,9 +119,32 @@ def test_bench_under_torchrun_rccl_single_rank():
     port = 29900 + (os.getpid() % 90)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
-           "--no-cpu-baseline", "--no-ref-batch", "--no-parity", "--no-roofline", "--no-torch-baseline", "--no-parity-mode"]
+           "--no-cpu-baseline", "--no-ref-batch", "--no-parity", "--no-roofline", "--no-torch-baseline", "--no-fast-mode"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, r.stderr[-2000:]
     rec = json.loads(lines[-1])
     assert rec["config"]["rccl_ranks"] == 1 and rec["value"] > 0, rec
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_ddp_buckets_are_handed_to_rccl_while_backward_is_still_running():
+    """TaskPrompter/main.py:94 relies on DDP overlapping the gradient all-reduce with backward.  The hand-written backward must therefore
+    deliver parameter gradients PROGRESSIVELY (heads -> decoder -> blocks 23..0), not in one piece at the end: with an RCCL process group
+    (world size 1) and a comm hook that timestamps every bucket on the backward's stream (tools/ddp_overlap.py), all buckets but the
+    last ones are ready — i.e. their all-reduce is launched on ProcessGroupNCCL's stream — well before the backward's GPU work ends."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MASTER_PORT=str(29300 + (os.getpid() % 90)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_overlap.py"), "--batch", "4", "--bucket-mb", "100", "--json"],
+                       capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr[-2000:]
+    s = json.loads(lines[-1])
+    n = s["n_buckets"]
+    assert n >= 8, s                                               # 1.6 GB of fp32 gradients in 100 MB buckets
+    assert s["buckets_ready_before_97pct_of_backward"] >= n - 2, s
+    assert s["first_bucket_ready_frac"] < 0.35, s                  # the heads' / decoder's gradients leave long before the encoder's backward ends
+    fr = [b["ready_gpu_frac"] for b in s["buckets"]]
+    assert fr == sorted(fr), fr                                    # buckets arrive in order along the backward

@@ -107,8 +107,10 @@ def test_x3f_mode_forward_x3_on_split_planes_backward_bf16(emulated, monkeypatch
     assert max(fwd.values()) < 5e-5, fwd
     worst, med = train_check.summarize(errs, floor=1e-4)
     assert med < 3e-2, (worst, med)
-    n_blocks = 4
-    assert sum(1 for n, adt, pr, _ in seen if n == "gemm" and adt == 2 and pr == 1) == 4 * n_blocks          # qkv, proj, fc1, fc2 per block
+    n_blocks = n_taps = 4
+    # qkv, proj, fc1, fc2 per block + per tap fea_decode (on the planes `modulate` writes) and fea_fuse[0] (on the planes its epilogue writes)
+    assert sum(1 for n, adt, pr, _ in seen if n == "gemm" and adt == 2 and pr == 1) == 4 * n_blocks + 2 * n_taps
+    assert sum(1 for n, _, _, _ in seen if n == "modulate") == n_taps
     assert sum(1 for n, _, pr, dt in seen if n == "attn_fwd" and dt == 2 and pr == 1) == n_blocks
     assert sum(1 for n, *_ in seen if n == "attn_bwd") == n_blocks
     assert not any(n == "gemm" and pr == 1 for n, _, pr, _ in seen[len(seen) // 2 + 40:]), "x3 GEMMs in the backward half"
