@@ -20,6 +20,7 @@ it (1.5e-2) and x3f meets it (2.6e-5) — forward = 3 bf16 MFMAs per product on 
                  these images (the oracle runs inside the cpu_baseline subprocess)
   fast_mode    — the bf16 mode (BASELINE.json's configs and north_star's 40 % target are stated on it), measured in the same process with
                  the same steps / warm-up: images/s, fwd ms/img, its own roofline (gemm_ring_kernel) and its own parity (which fails 1e-3)
+  full_fp32_mode — the fully fp32-class step (x3 forward AND backward: gradients match the oracle's autograd to 6e-5), 3 steps
   torch_rocm_baseline — stock PyTorch-ROCm (the reference's op graph through hipBLASLt / MIOpen / ATen) on the same GPU, fp32 and bf16 autocast
   ref_batch    — the headline step at the reference's own per-GPU batch (trBatch: 2), eager and replayed from one hipGraph
   cpu_baseline — the CPU oracle (restatement of the reference, `kind: "port"`) timed on this box's host cores on a
@@ -96,6 +97,7 @@ def parse():
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg (the oracle's torch ops on the GPU)")
     ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency leg (profiling runs: every launch then belongs to a training step)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the bf16 sub-record (fast_mode) of a tolerance-compliant headline run")
+    ap.add_argument("--no-x3-mode", action="store_true", help="skip the fully fp32-class sub-record (full_fp32_mode: x3 forward and backward, 3 steps)")
     ap.add_argument("--torch-baseline-worker", default=None, help="(internal) subprocess leg of torch_rocm_baseline: 'fp32' or 'bf16'")
     ap.add_argument("--no-fuse-upsample", action="store_true",
                     help="A/B: materialise the x4-upsampled task features and run ConvHead's 3x3 conv on them (the reference's operation order)")
@@ -160,7 +162,7 @@ KERNELS = {
 }
 
 
-def roofline_of(gt_, v):
+def roofline_of(gt_, v, pmc_ok=True):
     """roofline record of GEMM variant v from the instrumented step: achieved = MFMA work the kernel's algorithm issues / HIP-event time."""
     flops, ms, n, byts = gt_.result(v)
     if n == 0 or ms <= 0:
@@ -168,7 +170,7 @@ def roofline_of(gt_, v):
     mfma_per_product = 3 if v == 8 else 1
     tf = mfma_per_product * flops / (ms * 1e-3) / 1e12
     kname, kdesc = KERNELS[v]
-    traffic = _pmc_traffic(kname)
+    traffic = _pmc_traffic(kname) if pmc_ok else dict(note="the committed PMC passes were taken on the default workload (ns6, per-GPU batch 63)")
     rec = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                traffic=traffic.get("hbm_bytes_per_launch"), traffic_source=traffic.get("source"), traffic_commit=traffic.get("commit"),
                traffic_note=traffic.get("note"), algorithmic_bytes_per_launch=int(byts / n), kernel=kdesc, launches=n,
@@ -562,9 +564,10 @@ def main():
         if not a.no_roofline and rank == 0:
             with GemmTimer(mtt_amd.ops, mtt_amd._lib.gemm_variant, variants=(3, 8)) as gt_:
                 step()
-                rec["roofline"] = roofline_of(gt_, 8 if prec == "x3f" else 3)
+                pmc_ok = a.config == "ns6" and batch == dflt_batch and prec == a.prec
+                rec["roofline"] = roofline_of(gt_, 8 if prec == "x3f" else 3, pmc_ok)
                 if prec == "x3f":                # its bf16 backward's input-gradient GEMMs run on the bf16 kernel
-                    rec["roofline_bwd_gemm"] = roofline_of(gt_, 3)
+                    rec["roofline_bwd_gemm"] = roofline_of(gt_, 3, pmc_ok)
 
         # the reference's own per-GPU batch (trBatch: 2, yml:8), same step, same process
         rec["ref_batch"] = None
@@ -603,6 +606,20 @@ def main():
             fast = run_mode("bf16", False)
         except Exception as e:  # noqa: BLE001
             fast = dict(mode="bf16", error=repr(e)[:300])
+    # the fully fp32-class step (x3: 3-MFMA products forward AND backward, fp32 storage) as a third record: the reference trains in fp32
+    # (no AMP), x3 is the mode whose GRADIENTS match the oracle's autograd to 6e-5 (tests/test_gpu_fullsize.py)
+    full = None
+    if solo and not a.no_x3_mode and a.prec != "x3":
+        keep = (a.steps, a.warmup, a.no_fwd, a.no_roofline)
+        try:
+            a.steps, a.warmup, a.no_fwd, a.no_roofline = min(3, a.steps), 1, True, True
+            r3 = run_mode("x3", False)
+            full = dict(mode="x3", dtype=MODE_DTYPE["x3"], arithmetic=MODE_TEXT["x3"], images_per_s=round(r3["images_per_s"], 3),
+                        ms_per_step=round(r3["ms_per_step"], 3), steps=r3["steps"], warmup=r3["warmup"], per_gpu_batch=batch, loss=r3["loss"],
+                        peak_hbm_gb=r3["peak_hbm_gb"])
+        except Exception as e:  # noqa: BLE001
+            full = dict(mode="x3", error=repr(e)[:300])
+        a.steps, a.warmup, a.no_fwd, a.no_roofline = keep
     saved.clear()
     torch.cuda.empty_cache()
     if head.get("ref_batch") is not None:
@@ -631,6 +648,8 @@ def main():
         except Exception as e:  # noqa: BLE001  (no oracle reference: cpu_baseline skipped or failed)
             for mode in outs:
                 parity[mode] = dict(mode=mode, error="no oracle reference: " + repr(e)[:200])
+    if full is not None and "error" not in full:
+        full["parity"] = parity.get("x3")
     if tmpd:
         import shutil
         shutil.rmtree(tmpd, ignore_errors=True)
@@ -679,7 +698,7 @@ def main():
                     fwd_ms_per_img=None if head["fwd_ms_per_img"] is None else round(head["fwd_ms_per_img"], 3),
                     peak_hbm_gb=head["peak_hbm_gb"], host=head["host"], model_tflops=flops_block(head),
                     roofline=head["roofline"], roofline_bwd_gemm=head["roofline_bwd_gemm"], parity=parity.get(a.prec),
-                    fast_mode=fast_rec, ref_batch=head["ref_batch"], torch_rocm_baseline=torch_base, cpu_baseline=cpu,
+                    fast_mode=fast_rec, full_fp32_mode=full, ref_batch=head["ref_batch"], torch_rocm_baseline=torch_base, cpu_baseline=cpu,
                     git=dict(head=_git("rev-parse", "--short", "HEAD"), dirty=bool(_git("status", "--porcelain", "--untracked-files=no"))))
         print(json.dumps(line), flush=True)
     if ddp_mode:

@@ -61,9 +61,11 @@ def _scaled_colsum(g, rowscale, mb, n_prompt, prec):
 
 
 def _to_bwd(t, prec):
-    """x3f backward on fp32-STORED decoder tensors: a bf16 copy, so that the backward GEMMs take the token-major / LDS-DMA kernels instead of
-    the register-staged kernel's fp32 modes (which round the operand to bf16 while staging: the same arithmetic at a third of the rate).
-    No-op in the bf16 mode (already bf16) and in x3 (its backward stays fp32-class)."""
+    """A bf16 copy of an fp32-STORED tensor wherever the backward's arithmetic is bf16 (`prec` = the backward's Prec): the backward GEMMs then
+    take the token-major / LDS-DMA kernels instead of the register-staged kernel's fp32 modes (which round the operand to bf16 while
+    staging: the same products at a third of the rate).  Concerns x3f's fp32-stored decoder tensors and any fp32 dy reaching a bf16-mode
+    layer (e.g. the fp32 head outputs); no-op for tensors that already are bf16 and in x3 (whose backward stays fp32-class).  NOTE the bias
+    gradients of these layers are column sums of the ROUNDED dy (bf16-class like the rest of that backward; tolerance 5e-3 in the tests)."""
     if prec.name != "bf16" or t.dtype != torch.float32 or not FAST_BWD:
         return t
     t2 = t.reshape(-1, t.shape[-1])
@@ -207,6 +209,11 @@ def _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, colsum
     GELU' epilogue dx IS the gradient of the previous Linear's output, so its column sums are that layer's bias gradient — taken in the
     GEMM epilogue (mtt_gemm_desc.colsum_out) instead of re-reading the [tokens, hidden] gradient."""
     if colsum:
+        # the epilogue column sums exist for bf16 x bf16 operands and for x3; fp32-stored operands under bf16 arithmetic (x3f with
+        # FAST_BWD off: gemm_kernel<.., 3>) take a separate column-sum pass over dx instead (mtt_gemm would return MTT_E_UNSUPPORTED)
+        if prec.name == "bf16" and (dy.dtype != torch.bfloat16 or wpack2d.dtype != torch.bfloat16):
+            dx = _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, **epi)
+            return dx, _colsum(dx, N_in)
         cs = torch.empty(N_in, dtype=torch.float32, device=dy.device)
         epi = dict(epi, colsum_out=cs, colsum_ws=ops.ws_for("gemm_colsum", dy.device, M=M, N=N_in))
         return _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, **epi), cs

@@ -13,11 +13,21 @@ import torch.nn as nn
 from . import ops
 
 
+def _group(bns):
+    """process group of a BatchNorm stage: nn.SyncBatchNorm.process_group (convert_sync_batchnorm(model, process_group=...)), default WORLD.
+    One collective serves the whole stage, so its holders must agree."""
+    gs = {id(getattr(bn, "process_group", None)): getattr(bn, "process_group", None) for bn in bns}
+    if len(gs) > 1:
+        raise ValueError("the SyncBatchNorm holders of one stage (one per task) must share a process group")
+    return next(iter(gs.values()))
+
+
 def _world(bns):
     bn = bns[0]
     sync = isinstance(bn, nn.SyncBatchNorm) or getattr(bn, "_mtt_sync", False)     # _mtt_sync: CPU/gloo tests (DDP rejects SyncBN on CPU)
-    if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.get_world_size()
+    if sync and dist.is_available() and dist.is_initialized():
+        w = dist.get_world_size(_group(bns))
+        return w if w > 1 else 1
     return 1
 
 
@@ -33,8 +43,9 @@ def train_stats(x, C, bns):
         # (sum with zeros is exact).  An all_reduce rather than an all_gather because it is the one collective every backend offers
         # on device tensors (gloo has no device all_gather; RCCL has both) — the table is a few KB.
         allp = torch.zeros(world, Z, 2 * C + 1, dtype=torch.float32, device=x.device)
-        allp[dist.get_rank()] = torch.cat([mean, m2, torch.full((Z, 1), float(rows), dtype=torch.float32, device=x.device)], 1)
-        dist.all_reduce(allp)
+        grp = _group(bns)
+        allp[dist.get_rank(grp)] = torch.cat([mean, m2, torch.full((Z, 1), float(rows), dtype=torch.float32, device=x.device)], 1)
+        dist.all_reduce(allp, group=grp)
         cnt = allp[:, :, 2 * C:]
         n = cnt.sum(0)                                                 # [Z, 1]
         mean = (allp[:, :, :C] * cnt).sum(0) / n
@@ -81,5 +92,5 @@ def train_forward(x, C, bns, act, gammas=None, betas=None):
 def sync_backward_sums(s, bns):
     """s [2, Z, C] local sums of du and du*xhat -> summed over ranks (one all_reduce per stage)."""
     if _world(bns) > 1:
-        dist.all_reduce(s)
+        dist.all_reduce(s, group=_group(bns))
     return s

@@ -182,6 +182,14 @@ def segment(src, src_off, dst, dst_off, n, s, d, dst_lo=None):
     return [sa, da, la, n[0] * n[1] * n[2], n[1], n[2], s[0], s[1], s[2], d[0], d[1], d[2], _lib.dtype_code(src), ddt, vec, 0]
 
 
+def _seg_elems(r):
+    """logical element count of a segment() row (its field 3 is the chunked WORK size: padded 64 x 64 tiles for a transposing segment)."""
+    if r[15]:
+        n1, n2 = r[4], r[5]
+        return r[3] // 4096 // (((n1 + 63) // 64) * ((n2 + 63) // 64)) * n1 * n2
+    return r[3]
+
+
 class SegProgram:
     """Device tables of an mtt_segcopy launch over a list of `segment(...)` rows (absolute addresses: the tensors must outlive it)."""
 
@@ -258,8 +266,15 @@ def _refresh_packs(device):
     live = _live_packs(device)
     _packs_program(device, live).run()
     pack_refreshes += 1
+    bumped = []
     for e, ps in live:
         e.ver = _pver(ps)
+        v = e.value
+        bumped += [v.hi, v.lo] if isinstance(v, Split) else [v]
+    # the packs were rewritten IN PLACE by a raw launch: tell autograd, so that a backward still holding one of them from an earlier
+    # forward (ctx.save_for_backward) raises "modified by an inplace operation" instead of silently using the new weights
+    if bumped and not _capturing(device):
+        torch.autograd.graph.increment_version(bumped)
 
 
 def _pver(params):
@@ -322,7 +337,7 @@ def unpack_grads(src, key, shapes, rows_of, partial=False):
         for r in rows:
             r[0] -= src.data_ptr()
             r[1] -= flat.data_ptr()
-        assert partial or sum(r[3] for r in rows) == sum(sizes), "gradient scatter must cover every parameter element exactly once"
+        assert partial or sum(_seg_elems(r) for r in rows) == sum(sizes), "gradient scatter must cover every parameter element exactly once"
         prog = _unpack_progs[k] = SegProgram(rows, src.device)
     assert src.data_ptr() % 16 == 0
     prog.run(src_base=src.data_ptr(), dst_base=flat.data_ptr())
