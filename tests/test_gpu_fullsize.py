@@ -275,3 +275,31 @@ def test_dma_gemm_and_conv_kernels_agree_with_x3_at_bench_shapes():
     e = pu.rel(y16[..., :F], y32[..., :F])
     pu.report("kernel_parity", kernel="conv3x3_bf16", shape="head conv 350ch 128x128", rel=e)
     assert e < 2e-5, e
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(2400)
+def test_swinb_fullsize_training_step_matches_oracle_autograd():
+    """TaskPrompter Swin-B at cs_swinB's FULL size (taskprompter_swin.py:120-774; cs_swinB_taskprompter.yml: 1024 x 2048 x 0.75, window 12,
+    depths 2-2-18-2, DEConvHead; B = 1): train-mode forward + the hand-written backward (shifted-window attention with prompt rows, channel
+    attention, patch merging of features / prompts / attention maps, decoder) vs the oracle's autograd.  Rounds 2-3 checked these gradients on
+    two miniatures only.  x3: fp32-class; bf16: bf16-class.  Parameters the reference leaves without a gradient must get none here."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    import train_check
+    cfg = pu.get_cfg("cs_swinB")
+    contract = pu.contract_of(cfg)
+    torch.set_num_threads(conftest.HOST_THREADS)
+    cache = {}
+    for prec, ftol, mtol in (("x3", 1e-3, 3e-3), ("bf16", 5e-2, 1.5e-1)):
+        t0 = time.time()
+        fwd, errs, dead = train_check.swin_grad_errors("cs_swinB", prec, "cuda", batch=1, contract=contract, ref_cache=cache)
+        worst, med = train_check.summarize(errs)
+        rels = sorted((e / max(n, 1e-30) for e, n in errs.values() if n > 1e-6), reverse=True)
+        pu.report("train_parity", config="cs_swinB", batch=1, prec=prec, fwd_worst=max(fwd.values()), grad_median=med, grad_worst=worst[0],
+                  grad_worst_param=worst[1], grad_p90=rels[len(rels) // 10], n_params=len(errs), n_dead=len(dead), per_head=fwd,
+                  seconds=round(time.time() - t0, 1))
+        assert max(fwd.values()) < ftol, fwd
+        assert med < mtol, (med, worst)
+        torch.cuda.empty_cache()

@@ -114,24 +114,32 @@ def swin_drop_masks(cfg, B, rate=0.3, seed=5):
     return {(il, ib): torch.bernoulli(torch.full((4, B), keep), generator=g) / keep for il, d in enumerate(cfg["depths"]) for ib in range(d)}
 
 
-def swin_grad_errors(name, prec, device, seed=0, drop=None):
+def swin_grad_errors(name, prec, device, seed=0, drop=None, batch=2, contract=None, ref_cache=None):
     """TaskPrompter-Swin: product training forward + backward (swin_autograd.py) vs the oracle's autograd (itself pinned against the
-    reference's gradient norms in tests/test_oracle_golden.py).  Parameters the reference leaves without a gradient must stay so."""
+    reference's gradient norms in tests/test_oracle_golden.py).  Parameters the reference leaves without a gradient must stay so.
+    contract: the state-dict contract [(name, shape)]; default = the one dumped from the unmodified reference for the miniatures (tests/golden)."""
     from oracle import swin_oracle as swo
     cfg = configs.swin(name)
-    meta, _ = conftest.load_golden(name)
-    sd = weights.synth_state_dict(meta["contract"], seed)
+    if contract is None:
+        contract = conftest.load_golden(name)[0]["contract"]
+    sd = weights.synth_state_dict(contract, seed)
     model = conftest.build_product_model(cfg, prec, device, drop_path_rate=0.3 if drop is not None else 0.0)
     model.load_state_dict({k: v.to(device) for k, v in sd.items()}, strict=False)
     model.train()
-    x = weights.synth_images(2, cfg["img_size"], 2)
+    x = weights.synth_images(batch, cfg["img_size"], 2)
     if drop is not None:
         model.backbone._drop_override = drop
     out = model(x.to(device))
     loss_of({k: v.cpu() for k, v in out.items()}).backward()
-    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
-    ref_out = swo.forward(dict(sd, **params), cfg, x, training=True, drop=drop)
-    loss_of(ref_out).backward()
+    if ref_cache is not None and "ref" in ref_cache:                # the oracle's step is the same for every arithmetic mode of the product
+        params, ref_out = ref_cache["ref"]
+    else:
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+        ref_out = swo.forward(dict(sd, **params), cfg, x, training=True, drop=drop)
+        loss_of(ref_out).backward()
+        ref_out = {k: v.detach() for k, v in ref_out.items()}
+        if ref_cache is not None:
+            ref_cache["ref"] = (params, ref_out)
     fwd = {t: float((out[t].detach().cpu() - ref_out[t].detach()).norm() / ref_out[t].detach().norm()) for t in ref_out}
     errs, dead = {}, []
     for k, prm in model.named_parameters():
