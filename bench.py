@@ -135,7 +135,7 @@ class GemmTimer:
                 byts = z * ((kw["M"] + kw["N"]) * kw["K"] * 2 * planes
                             + kw["M"] * kw["N"] * (out_b + (4 if kw.get("resid") is not None else 0)
                                                    + (2 if (kw.get("aux_out") is not None or kw.get("aux_in") is not None) else 0)))
-                self.rec[v].append((2.0 * kw["M"] * kw["N"] * kw["K"] * z, e0, e1, byts))
+                self.rec[v].append((2.0 * kw["M"] * kw["N"] * kw["K"] * z, e0, e1, byts, (kw["M"], kw["N"], kw["K"], z)))
             else:
                 self.orig(name, **kw)
         self.lib.call = hooked
@@ -149,6 +149,18 @@ class GemmTimer:
         torch.cuda.synchronize()
         rec = self.rec[v]
         return (sum(r[0] for r in rec), sum(r[1].elapsed_time(r[2]) for r in rec), len(rec), sum(r[3] for r in rec))
+
+    def by_shape(self, v, mfma_per_product, top=8):
+        """the launches of variant v grouped by (M, N, K, batch): launches, summed ms, TFLOP/s of MFMA work — the kernel's live per-shape table"""
+        agg = {}
+        for fl, e0, e1, _, shp in self.rec[v]:
+            a = agg.setdefault(shp, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += fl
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+        return [dict(M=k[0], N=k[1], K=k[2], batch=k[3], launches=a[0], ms=round(a[1], 3),
+                     tflops=round(mfma_per_product * a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None) for k, a in rows]
 
 
 KERNELS = {
@@ -174,7 +186,8 @@ def roofline_of(gt_, v, pmc_ok=True):
     rec = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                traffic=traffic.get("hbm_bytes_per_launch"), traffic_source=traffic.get("source"), traffic_commit=traffic.get("commit"),
                traffic_note=traffic.get("note"), algorithmic_bytes_per_launch=int(byts / n), kernel=kdesc, launches=n,
-               kernel_ms_per_step=round(ms, 3), algorithmic_tflop_per_step=round(mfma_per_product * flops / 1e12, 2))
+               kernel_ms_per_step=round(ms, 3), algorithmic_tflop_per_step=round(mfma_per_product * flops / 1e12, 2),
+               by_shape=gt_.by_shape(v, mfma_per_product))
     if v == 8:
         rec["flop_convention"] = ("achieved counts the bf16 MFMA work of the split-product algorithm (3 MFMAs per fp32-class product = 6 M N K); "
                                   "the fp32-class product rate is a third of it")

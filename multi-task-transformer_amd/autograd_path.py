@@ -682,10 +682,20 @@ class UpConv3x3Fn(Function):
         B, h, w, Co, Ci = geo
         Z = len(wb) // 2
         ws, bs = wb[:Z], wb[Z:]
-        w9 = ops.pack_upconv9(list(ws), prec, tag)
         xa = x if x.dtype == prec.adt else ops.cast_rows(x.reshape(-1, x.shape[-1]), prec.adt).view(x.shape)
-        y = ops.upconv3x3(xa, w9, Co, B, h, w, prec, bias=ops.stack_vec(list(bs), (tag, 'b')))
-        ctx.save_for_backward(xa, w9)
+        if prec.split and ops.split_gemm_ok(xa.shape[-1]):
+            # x3f: planes of the low-resolution task features + pre-split tap matrices -> the split-plane LDS-DMA kernel; the hi planes
+            # are the bf16 operands of the backward
+            Zs, M, Kp = xa.shape
+            sp = ops.split_cast(xa.reshape(Zs * M, Kp))
+            xs = ops.Split(sp.hi.view(Zs, M, Kp), sp.lo.view(Zs, M, Kp))
+            w9 = ops.pack_upconv9_split(list(ws), tag)
+            y = ops.upconv3x3(xs, w9, Co, B, h, w, prec, bias=ops.stack_vec(list(bs), (tag, 'b')))
+            ctx.save_for_backward(xs.hi, w9.hi)
+        else:
+            w9 = ops.pack_upconv9(list(ws), prec, tag)
+            y = ops.upconv3x3(xa, w9, Co, B, h, w, prec, bias=ops.stack_vec(list(bs), (tag, 'b')))
+            ctx.save_for_backward(xa, w9)
         ctx.meta = (geo, prec, Z, x.dtype)
         return y
 

@@ -424,6 +424,18 @@ def pack_upconv9(weights, prec, tag):
                     check=lambda: _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3)))
 
 
+def pack_upconv9_split(weights, tag):
+    """pack_upconv9 as pre-split planes (Split [Z, 9*pad8(Co), pad8(Ci)]) for the split-plane GEMM."""
+    Co, Ci = weights[0].shape[:2]
+    Cop, Kp, Z = pad8(Co), pad8(Ci), len(weights)
+    dev = weights[0].device
+    return seg_pack((tag, 'split', 'up9', tuple(id(w) for w in weights)), list(weights),
+                    lambda: Split(torch.zeros(Z, 9 * Cop, Kp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, 9 * Cop, Kp, dtype=torch.bfloat16, device=dev)),
+                    lambda sp: [segment(w, 0, sp.hi, z * 9 * Cop * Kp, (9, Co, Ci), (1, Ci * 9, 9), (Cop * Kp, Kp, 1), dst_lo=sp.lo)
+                                for z, w in enumerate(weights)],
+                    check=lambda: _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3)))
+
+
 def pack_kmap(weights, N, Kp, kmap, prec, tag):
     """List of Z parameters [N, K...] -> [Z, N, Kp] with the column ranges (dst0, src0, len) of `kmap` copied (inputs that are padded
     concatenations: taskprompter.py:471 torch.cat([spa, chan], 1) feeding fea_fuse[0])."""
@@ -583,7 +595,13 @@ def upconv4_gather(dy, C, B, h, w):
 def upconv3x3(x, w9, Co, B, h, w, prec, *, bias=None, colscale=None, act=ACT_NONE):
     """F.interpolate(x, scale_factor=4, 'bilinear') -> Conv2d(3x3, padding 1) on the LOW-resolution task stack x [Z, B*h*w, Cip]
     (taskprompter.py:420 -> :692) in its taps-first form: one GEMM with the nine stacked tap matrices, then the expansion kernel."""
-    z = linear(x, w9, w9.shape[1], prec)
+    if isinstance(w9, Split) and not isinstance(x, Split):
+        # x3f: the nine-tap GEMM (N = 9 * pad8(Co): whole 256-wide tiles) on the split-plane LDS-DMA kernel; the fp32 task features are
+        # split by one pass over the LOW-resolution stack (1 / 16 of the head maps)
+        Z, M, Kp = x.shape
+        x = split_cast(x.reshape(Z * M, Kp))
+        x = Split(x.hi.view(Z, M, Kp), x.lo.view(Z, M, Kp))
+    z = linear(x, w9, w9.shape[1], prec, out_dtype=torch.float32 if isinstance(w9, Split) else None)
     return upconv4_expand(z, Co, B, h, w, bias=bias, colscale=colscale, act=act)
 
 

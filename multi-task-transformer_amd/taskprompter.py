@@ -505,7 +505,8 @@ def run_heads(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False)
         if lowres:
             if fea.dtype != prec.adt:
                 fea = ops.cast_rows(fea.reshape(-1, fea.shape[-1]), prec.adt).view(fea.shape)
-            W9 = ops.pack_upconv9(conv_w, prec, 'hc9')
+            sp9 = prec.split and ops.split_gemm_ok(ops.pad8(conv_w[0].shape[1]))
+            W9 = ops.pack_upconv9_split(conv_w, 'hc9') if sp9 else ops.pack_upconv9(conv_w, prec, 'hc9')
 
             def conv(**epi):
                 return ops.upconv3x3(fea, W9, F, B, h4 // 4, w4 // 4, prec, **epi)

@@ -1,5 +1,12 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out; mkdir -p $O
-timeout 2400 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k swinb -s > $O/r04_pytest_k_swinb.log 2>&1; tail -25 $O/r04_pytest_k_swinb.log | cut -c1-400
-grep cs_swinB $O/parity_report.jsonl | tail -3 | cut -c1-600
+REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_train.py -m gpu -x -q > $O/r04_pytest_l.log 2>&1; tail -4 $O/r04_pytest_l.log
+timeout 900 python bench.py --steps 8 --warmup 3 --no-torch-baseline --no-ref-batch --no-x3-mode > $O/r04_bench_l.log 2>&1
+python - <<'P'
+import json
+l=[x for x in open('gpurun_out/r04_bench_l.log') if x.startswith('{')]
+if l:
+    d=json.loads(l[-1]); print('x3f', d['value'], d['ms_per_step'], d['fwd_ms_per_img'], d['parity']['worst_head_rel_err'], d['roofline']['frac']); print('bf16', d['fast_mode']['images_per_s'], d['fast_mode']['fwd_ms_per_img'])
+else: print(open('gpurun_out/r04_bench_l.log').read()[-2000:])
+P
