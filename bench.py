@@ -124,6 +124,7 @@ class GemmTimer:
             if name == "gemm" and getattr(self.lib, "GEMM_VARIANT", None) is not None and not kw.get("variant"):
                 kw["variant"] = self.lib.GEMM_VARIANT
             v = self.variant_of(**kw) if name == "gemm" else -1
+            v = 8 if v == 9 else v                                     # 9 = the same kernel's implicit-GEMM 3x3 form (gemm_ring3_kernel<true>)
             if v in self.rec:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -169,8 +170,9 @@ KERNELS = {
         "interior-tile epilogue; <0> = the same kernel with general addressing for calls with a K tail): every encoder Linear forward "
         "(bf16 mode) and input gradient of the step"),
     8: ("gemm_ring3_kernel", "gemm_ring3_kernel (the same tile on MTT_SPLIT operands: hi / lo bf16 planes of both operands staged once per 32-deep K step "
-        "into a part-recycled LDS ring with counted vmcnt, three MFMA products Ah Bh + Ah Bl + Al Bh per step, fp32 accumulate): every "
-        "encoder Linear of the fp32-class forward"),
+        "into a part-recycled LDS ring with counted vmcnt, three MFMA products Ah Bh + Ah Bl + Al Bh per step, fp32 accumulate; <true> = its "
+        "implicit-GEMM 3x3 form): every encoder Linear, fea_decode, fea_fuse[0], the fea_fuse 3x3 convs and the taps-first head GEMM of the "
+        "fp32-class forward"),
 }
 
 

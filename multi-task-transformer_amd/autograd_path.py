@@ -615,13 +615,19 @@ class Conv3x3Fn(Function):
 
     @staticmethod
     def forward(ctx, x, geo, prec, tag, *wb):
+        """geo may carry a 7th element: the lo plane of a split input (x is then its hi plane; x3f) — the conv runs on the split-plane
+        implicit-GEMM kernel with pre-split weights, and the hi plane is the bf16 operand of the backward."""
         B, H, W, Co, Ci = geo[:5]
         dil = geo[5] if len(geo) > 5 else 1
+        xlo = geo[6] if len(geo) > 6 else None
         Z = len(wb) // 2
         ws, bs = wb[:Z], wb[Z:]
         has_bias = bs[0] is not None
-        wpack = ops.pack_conv3(list(ws), prec, tag)
-        y = ops.conv3x3(x, wpack, Co, Ci, B, H, W, prec, dil=dil, bias=ops.stack_vec(list(bs), (tag, 'b')) if has_bias else None)
+        bias = ops.stack_vec(list(bs), (tag, 'b')) if has_bias else None
+        if xlo is not None:
+            y = ops.conv3x3(ops.Split(x, xlo), ops.pack_conv3_split(list(ws), tag), Co, Ci, B, H, W, prec, dil=dil, bias=bias, out_dtype=torch.float32)
+        else:
+            y = ops.conv3x3(x, ops.pack_conv3(list(ws), prec, tag), Co, Ci, B, H, W, prec, dil=dil, bias=bias)
         ctx.save_for_backward(x, *ws)
         ctx.meta = ((B, H, W, Co, Ci, dil), prec, tag, Z, has_bias)
         return y
@@ -925,8 +931,12 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
     del mod, mod_lo
     ff = [model.fea_fuse[il][t] for t in names]
     kmap = (2 * tarp, [(0, 0, tar), (tarp, tar, tar)])
-    y0 = BLinearFn.apply(cat, F, 'plain', kmap, torch.float32 if sp else None, prec, ('f0', il), cat_lo, *[m[0].weight for m in ff], *[m[0].bias for m in ff])
-    y1 = Conv3x3Fn.apply(y0, (B, h, w, F, F), prec, ('f1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
+    spc = model._decoder_conv_split()    # ... and fea_fuse[0]'s epilogue writes y0 as planes for the implicit-GEMM 3x3 on the same kernel
+    y0 = BLinearFn.apply(cat, F, 'plain', kmap, "split" if spc else (torch.float32 if sp else None), prec, ('f0', il), cat_lo,
+                         *[m[0].weight for m in ff], *[m[0].bias for m in ff])
+    y0, y0_lo = y0 if spc else (y0, None)
+    del cat, cat_lo
+    y1 = Conv3x3Fn.apply(y0, (B, h, w, F, F) + ((1, y0_lo) if spc else ()), prec, ('f1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
     y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)
     fea = BLinearFn.apply(y1, F, 'plain', None, None, prec, ('f4', il), None, *[m[4].weight for m in ff], *[m[4].bias for m in ff])
     wmix = model._ctr_weights(rawlog, il, B, T)

@@ -944,6 +944,12 @@ MTT_DEV void wait_vmcnt_dyn(int n) {
 //   awaited ones (10 / 12 / 10 in steady state, less in the last two steps).  Every wait precedes the barrier that closes the time slot
 //   before the first read of the awaited part by waves 0-3; every refill follows the barrier that closed the last read by waves 4-7.
 // ---------------------------------------------------------------------------------------------
+// CONV (MTT_OP_CONV_K on split planes: the 3x3 convs of the fp32-class forward, fea_fuse[1] / InvPT's 576-channel convs): the A operand is
+// the implicit im2col of the NHWC planes, k = tap * Cp + ci with Cp % 32 == 0, so a 32-deep K step lies inside ONE tap: per step the
+// scalar unit turns j into (tap, channel offset) and a signed row delta, and every lane redirects its 16-byte source to a zero page when
+// that tap falls outside the image for its output pixel (a 9-bit mask per lane and piece, computed once) — two v_cndmask + one 64-bit add
+// per LDS-DMA piece on top of the plain kernel.
+template <bool CONV>
 __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WAVES_N = 4, WAVES_M = 2, MT = 8, NT = 4;
@@ -968,20 +974,54 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
   const int nk = p.d.K >> 5;
 
   uint32_t aoff32[2], boff32[2];
+  unsigned tapmask[2] = {0x1ffu, 0x1ffu};                            // CONV: bit t set <=> tap t of this lane's output pixel reads inside the image
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (wave * 2 + i) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ring_swz(row);
     int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;
-    aoff32[i] = (uint32_t)(row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + c * 8) * 2u;
+    if constexpr (CONV) {
+      aoff32[i] = (uint32_t)((int64_t)ra * p.d.lda + c * 8) * 2u;    // the centre pixel's row (rows = B * H * W pixels, pitch lda)
+      const uint32_t q = fdiv((uint32_t)ra, p.divW);
+      const int px = ra - (int)q * p.d.conv.W;
+      const int py = (int)q - (int)fdiv(q, p.divH) * p.d.conv.H;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        int ty = t / 3, tx = t - 3 * (t / 3);
+        if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+        const int yy = py + (ty - 1) * p.d.conv.dil, xx = px + (tx - 1) * p.d.conv.dil;
+        if (yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W) mk |= 1u << t;
+      }
+      tapmask[i] = mk;
+    } else {
+      aoff32[i] = (uint32_t)(row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + c * 8) * 2u;
+    }
     int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
     boff32[i] = (uint32_t)((int64_t)rb * p.d.ldb + c * 8) * 2u;
   }
+  uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
+  asm volatile("" : "+s"(zpage));
+  const int cpt = CONV ? p.d.conv.Cp >> 5 : 1;                       // K steps per tap
+  const int cpt_inv = ((1 << 20) + cpt - 1) / cpt;                   // j / cpt == (j * cpt_inv) >> 20 for j < 9 * cpt, cpt <= 128 (checked exhaustively)
   // both pieces of part `part` (0 Ah, 1 Bh, 2 Bl, 3 Al) of K step j into slot j & 1
   auto issue_part = [&](int j, int part) {
     unsigned char* dst = smem + (j & 1) * SLOT + part * PART + wave * 2048;
-    const unsigned char* base = (part == 0 ? AbaseH : part == 1 ? BbaseH : part == 2 ? BbaseL : AbaseL) + (size_t)j * 64;
     const bool isA = part == 0 || part == 3;
+    if (CONV && isA) {
+      const int tap = (j * cpt_inv) >> 20;                            // wave-uniform: scalar unit
+      int ty = (tap * 11) >> 5, tx = tap - 3 * ((tap * 11) >> 5);     // tap / 3, tap % 3 for tap < 9
+      if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+      const int64_t delta = ((int64_t)((ty - 1) * p.d.conv.dil * p.d.conv.W + (tx - 1) * p.d.conv.dil) * p.d.lda + (int64_t)(j - tap * cpt) * 32) * 2;
+      const unsigned char* base = (part == 0 ? AbaseH : AbaseL) + delta;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint64_t src = (uint64_t)(uintptr_t)(base + aoff32[i]);
+        glds16((const bf16_t*)(uintptr_t)(((tapmask[i] >> tap) & 1u) ? src : zpage), dst + i * 1024);
+      }
+      return;
+    }
+    const unsigned char* base = (part == 0 ? AbaseH : part == 1 ? BbaseH : part == 2 ? BbaseL : AbaseL) + (size_t)j * 64;
     glds16((const bf16_t*)(base + (isA ? aoff32[0] : boff32[0])), dst);
     glds16((const bf16_t*)(base + (isA ? aoff32[1] : boff32[1])), dst + 1024);
   };
@@ -1069,13 +1109,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
   gemm_epilogue_auto<256, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
 }
 
+template <bool CONV>
 int launch_ring3(const GemmP& p, hipStream_t stream) {
   constexpr int smem = 2 * 4 * 16384;
   static std::atomic<unsigned long long> done{0};
-  if (int e = mtt_ensure_dyn_lds((const void*)gemm_ring3_kernel, smem, done)) return e;
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_ring3_kernel<CONV>, smem, done)) return e;
   const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + 255) / 256;
   dim3 grid(tm * tn, 1, p.d.batch);
-  hipLaunchKernelGGL(gemm_ring3_kernel, grid, dim3(512), smem, stream, p);
+  hipLaunchKernelGGL((gemm_ring3_kernel<CONV>), grid, dim3(512), smem, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -1464,7 +1505,8 @@ extern "C" size_t mtt_desc_size(int which) {
 //   3 LDS-DMA 256 x 256 phased / staggered (gemm_dma_kernel)
 //   4 LDS-DMA 128 x 128, two workgroups per CU (gemm_dma128_kernel)
 //   6 token-major weight-gradient kernel (gemm_tn_kernel): LDS-DMA + ds_read_b64_tr_b16 fragments
-//   8 gemm_dma_kernel<2>: MTT_SPLIT operands, fp32-class product as one K-concatenated bf16 GEMM
+//   8 gemm_ring3_kernel<false>: MTT_SPLIT operands, fp32-class product (three MFMA products per staged K step)
+//   9 gemm_ring3_kernel<true>: the same with the implicit im2col of a 3x3 conv as A operand (MTT_OP_CONV_K on planes)
 //  <0 MTT_E_* (no kernel takes this descriptor)
 // d.variant = MTT_GEMM_AUTO applies the policy; MTT_GEMM_GENERAL / MTT_GEMM_DMA256 force a kernel where it is applicable.
 // K % 64 == 0 and 32-bit per-lane byte offsets from the batch member's base: the fast source addressing of the LDS-DMA kernel
@@ -1478,9 +1520,13 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   const bool any_split = d.a_dtype == MTT_SPLIT || d.b_dtype == MTT_SPLIT;
   if (any_split) {
     // pre-split planes exist for ONE kernel: both operands split, reduction-contiguous, whole 32-deep K steps (at least two), fast addressing
-    const bool ok = d.prec == MTT_PREC_X3 && d.a_dtype == MTT_SPLIT && d.b_dtype == MTT_SPLIT && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K &&
-                    d.A_lo && d.B_lo && d.store_mode == MTT_STORE_ROWS && dma_fastaddr_ok(d, MTT_RING ? 32 : 64) && d.K >= 64 && d.K / 64 * 3 < 32768;
-    return ok ? 8 : MTT_E_UNSUPPORTED;
+    const bool both = d.prec == MTT_PREC_X3 && d.a_dtype == MTT_SPLIT && d.b_dtype == MTT_SPLIT && d.b_op == MTT_OP_K && d.A_lo && d.B_lo &&
+                      d.store_mode == MTT_STORE_ROWS;
+    if (both && d.a_op == MTT_OP_K && dma_fastaddr_ok(d, MTT_RING ? 32 : 64) && d.K >= 64 && d.K / 64 * 3 < 32768) return 8;
+    // ... and its implicit-GEMM form for the 3x3 convs: channel pitch a multiple of 32 (a K step inside one tap), pixel rows of pitch lda
+    if (both && d.a_op == MTT_OP_CONV_K && d.conv.Cp % 32 == 0 && d.conv.Cp <= 4096 && d.K == 9 * d.conv.Cp && d.a_mb <= 0 &&
+        (int64_t)d.M * d.lda < (1ll << 31) && (int64_t)(d.N - 1) * d.ldb + d.K < (1ll << 31)) return 9;
+    return MTT_E_UNSUPPORTED;
   }
   if (d.prec != MTT_PREC_BF16 || d.a_dtype != MTT_BF16 || d.b_dtype != MTT_BF16) return 0;
   // 6: token-major weight-gradient kernel (gemm_tn_kernel): both operands MTT_OP_R (B may be the implicit im2col^T), bf16
@@ -1567,7 +1613,7 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
     if (d.batch != 1 || d.store_mode != MTT_STORE_ROWS || v == 6) return MTT_E_UNSUPPORTED;
     const int rc = gemm_launch(p, s, v);
     if (rc) return rc;
-    const int tbm = (v == 3 || v == 8) ? 256 : BM;           // (the 128 x 128 LDS-DMA kernel has the general kernel's row block)
+    const int tbm = (v == 3 || v == 8 || v == 9) ? 256 : BM;           // (the 128 x 128 LDS-DMA kernel has the general kernel's row block)
     hipLaunchKernelGGL(mtt_colsum_final_kernel, dim3((d.N + 31) / 32, 1, 1), dim3(256), 0, s, (const float*)d.colsum_ws, d.colsum_out, d.N,
                        (d.M + tbm - 1) / tbm, (int64_t)0);
     return (int)hipGetLastError();
@@ -1582,8 +1628,9 @@ extern "C" size_t mtt_gemm_colsum_ws_floats(const mtt_gemm_desc* d) {
 
 static int gemm_launch(GemmP& p, hipStream_t s, int v) {
   mtt_gemm_desc& d = p.d;
+  if (v == 9) return launch_ring3<true>(p, s);
 #if MTT_RING
-  if (v == 8) return launch_ring3(p, s);
+  if (v == 8) return launch_ring3<false>(p, s);
 #else
   if (v == 8) return launch_dma<2>(p, s);
 #endif

@@ -412,6 +412,23 @@ def pack_conv3(weights, prec, tag, transpose=False):
                     check=lambda: _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3)))
 
 
+def pack_conv3_split(weights, tag):
+    """pack_conv3 as pre-split planes (Split [Z, Co, 9*pad8(Ci)], k = tap*Cip + ci) for the split-plane implicit-GEMM conv."""
+    Co, Ci = weights[0].shape[:2]
+    Cp, Z = pad8(Ci), len(weights)
+    dev = weights[0].device
+    return seg_pack((tag, 'split', 'conv3', tuple(id(w) for w in weights)), list(weights),
+                    lambda: Split(torch.zeros(Z, Co, 9 * Cp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, Co, 9 * Cp, dtype=torch.bfloat16, device=dev)),
+                    lambda sp: [segment(w, 0, sp.hi, z * Co * 9 * Cp, (Co, 9, Ci), (Ci * 9, 1, 9), (9 * Cp, Cp, 1), dst_lo=sp.lo)
+                                for z, w in enumerate(weights)],
+                    check=lambda: _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3)))
+
+
+def split_conv_ok(Ci):
+    """the split-plane implicit-GEMM conv (mtt_gemm variant 9) needs a channel pitch that is a multiple of 32 (a K step inside one tap)"""
+    return pad8(Ci) % 32 == 0
+
+
 def pack_upconv9(weights, prec, tag):
     """List of Z conv weights [Co, Ci, 3, 3] -> [Z, 9*pad8(Co), pad8(Ci)]: row (ky*3+kx)*pad8(Co) + co holds W[co, :, ky, kx] — the nine
     tap matrices of the "taps first" form of upsample x4 + 3x3 conv (mtt_upconv_desc) stacked as ONE linear layer; rows of the channel
@@ -557,12 +574,15 @@ def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=AC
     Implicit GEMM (no im2col buffer): A rows are gathered per 16-byte channel chunk."""
     Z, rows, Cp = x.shape
     assert rows == B * H * W and wpack.shape[-1] == 9 * Cp
+    assert isinstance(x, Split) == isinstance(wpack, Split), "split planes: both operands or neither"
     Cop = pad8(Co)
     out = torch.empty(Z, rows, Cop, dtype=out_dtype or prec.adt, device=x.device)
-    kw = dict(A=x, B=wpack, D=out, M=rows, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K,
+    kw = dict(A=_hi(x), B=_hi(wpack), D=out, M=rows, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K,
               a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
-              lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Z, batch_inner=1, a_zo=x.stride(0), b_zo=wpack.stride(0), d_zo=out.stride(0),
+              lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Z, batch_inner=1, a_zo=_hi(x).stride(0), b_zo=_hi(wpack).stride(0), d_zo=out.stride(0),
               conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, act=act, n_store=Cop)
+    if isinstance(x, Split):                     # implicit-GEMM form of the split-plane kernel (mtt_gemm variant 9): Cp % 32 == 0
+        kw.update(A_lo=x.lo, B_lo=wpack.lo)
     if bias is not None:
         kw.update(colshift=bias, col_zo=bias.stride(0))
     if colscale is not None:

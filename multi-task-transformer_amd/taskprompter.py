@@ -339,7 +339,8 @@ class TaskPrompter(nn.Module):
             Wdec = ops.pack_linear(dec_w, prec, ('dec', il))
             W0 = ops.pack_kmap(f0, F, 2 * tarp, [(0, 0, tar), (tarp, tar, tar)], pf, ('f0', il))
         b0 = ops.stack_vec([self.fea_fuse[il][t][0].bias for t in names], ('f0b', il))
-        Wc = ops.pack_conv3([self.fea_fuse[il][t][1].weight for t in names], pf, ('f1', il))
+        fc = [self.fea_fuse[il][t][1].weight for t in names]
+        Wc = ops.pack_conv3_split(fc, ('f1', il)) if self._decoder_conv_split() else ops.pack_conv3(fc, pf, ('f1', il))
         bc = ops.stack_vec([self.fea_fuse[il][t][1].bias for t in names], ('f1b', il))
         W4 = ops.pack_linear([self.fea_fuse[il][t][4].weight for t in names], pf, ('f4', il))
         b4 = ops.stack_vec([self.fea_fuse[il][t][4].bias for t in names], ('f4b', il))
@@ -351,6 +352,10 @@ class TaskPrompter(nn.Module):
         3.2 -> 2.3 ms and 1.2 -> 0.85 ms per tap at B = 63, profiles/r04_dec_x3_bench_g.log).  Needs whole 32-deep K steps."""
         return (self.prec.split and self.gprec is None and ops.split_gemm_ok(self.embed_dim)
                 and ops.split_gemm_ok(2 * ops.pad8(self.p.embed_dim)))
+
+    def _decoder_conv_split(self):
+        """... and fea_fuse[1] (3x3) on its implicit-GEMM form: fea_fuse[0]'s epilogue writes y0 as planes (channel pitch % 32 == 0)."""
+        return self._decoder_split() and ops.split_conv_ok(self.p.final_embed_dim)
 
     def _ctr_weights(self, rawlog, il, B, T):
         """[B, T, T] mixing weights: per-head MLP on the prompt<->prompt raw logits (:482-484); identity without ctr."""
@@ -390,7 +395,8 @@ class TaskPrompter(nn.Module):
         ops.linear(mod, Wdec, tar, ps, bias=bdec, out=cat, batch_inner=2, d_z=(B * hw * 2 * tarp, tarp), ldd=2 * tarp,
                    n_store=tarp)
         del mod
-        y0 = ops.linear(cat, W0, F, pf, bias=b0, out_dtype=adt)
+        y0 = ops.linear(cat, W0, F, pf, bias=b0, out_dtype="split" if self._decoder_conv_split() else adt)
+        del cat
         bns = [self.fea_fuse[il][t][2] for t in names]
         if self.training:
             y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, pf, bias=bc, out_dtype=adt)

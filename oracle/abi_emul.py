@@ -73,7 +73,11 @@ def gemm(**kw):
     k = torch.arange(K)[None, :]
     a_split, b_split, d_split = g("a_dtype") == SPLIT, g("b_dtype") == SPLIT, g("d_dtype") == SPLIT
     if a_split or b_split:
-        assert a_split and b_split and prec == 1 and a_op == OP_K and b_op == OP_K and K % 32 == 0 and K >= 64, "split operands: x3, both split, OP_K, K % 32 == 0, K >= 64"
+        assert a_split and b_split and prec == 1 and b_op == OP_K, "split operands: x3, both split, B reduction-contiguous"
+        if a_op == OP_K:
+            assert K % 32 == 0 and K >= 64, "split operands: K % 32 == 0, K >= 64"
+        else:                                             # variant 9: implicit-GEMM 3x3 on planes
+            assert a_op == OP_CONV_K and conv["Cp"] % 32 == 0 and K == 9 * conv["Cp"] and not g("a_mb"), "split conv: channel pitch % 32 == 0"
 
     def conv_taps(idx_tap, flip):
         ty, tx = idx_tap // 3, idx_tap % 3
@@ -100,6 +104,8 @@ def gemm(**kw):
             y, x = (m // W) % H, m % W
             ok = (y + dy >= 0) & (y + dy < H) & (x + dx >= 0) & (x + dx < W) & (ci < Cc)
             Am = _rd(A, za + (m + dy * W + dx) * lda + ci, ok)
+            if a_split:
+                Am = Am + _rd(kw["A_lo"], za + (m + dy * W + dx) * lda + ci, ok)
         else:
             raise ValueError("bad a_op")
         # ---- B [N, K] ----

@@ -257,6 +257,19 @@ def gemm_cases():
     kw = dict(A=Ah, A_lo=Al, B=Bh, B_lo=Bl, D=torch.zeros(Z, M, N), M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=SPLIT, b_dtype=SPLIT, d_dtype=F32, prec=1,
               lda=K, ldb=K, ldd=N, batch=Z, batch_inner=1, a_zo=M * K, b_zo=N * K, d_zo=M * N, alpha=1.0, colshift=rnd(g, Z, N), col_zo=N)
     cases.append(("gemm_split_batched", "gemm", kw, TOL_X3))
+    # 1e+. the implicit-GEMM 3x3 conv on MTT_SPLIT planes (mtt_gemm variant 9, gemm_ring3_kernel<true>): channel pitch 32 / 96 / 352 (the
+    #      fea_fuse width), dilation 1 / 2, mirrored taps, ragged M and N tiles, task batches, BN-folded GELU epilogue; K = 9 * Cp
+    for (Bc, H, W, Ci, Cp, Co, dil, flip, Zc) in ((2, 9, 11, 30, 32, 40, 1, 0, 1), (1, 16, 20, 90, 96, 300, 2, 0, 2), (3, 8, 8, 350, 352, 350, 1, 1, 1)):
+        rows = Bc * H * W
+        xa = rnd(g, Zc, rows, Cp); xa[..., Ci:] = 0
+        wa = rnd(g, Zc, Co, 9, Cp) * 0.2; wa[..., Ci:] = 0
+        Ah, Al = planes(xa); Bh, Bl = planes(wa.reshape(Zc, Co, 9 * Cp))
+        Cop = (Co + 7) // 8 * 8
+        kw = dict(A=Ah, A_lo=Al, B=Bh, B_lo=Bl, D=torch.full((Zc, rows, Cop), 7.0), M=rows, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K, a_dtype=SPLIT,
+                  b_dtype=SPLIT, d_dtype=F32, prec=1, lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Zc, batch_inner=1, a_zo=rows * Cp, b_zo=Co * 9 * Cp,
+                  d_zo=rows * Cop, conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, n_store=Cop, colshift=rnd(g, Zc, Co), col_zo=Co)
+        cases.append((f"conv3_split_{Bc}x{H}x{W}_c{Ci}_dil{dil}_flip{flip}", "gemm", kw, TOL_X3))
+        cases.append((f"conv3_split_bnfold_gelu_{Bc}x{H}x{W}_c{Ci}", "gemm", dict(kw, D=torch.full((Zc, rows, Cop), 7.0), colscale=rnd(g, Zc, Co), act=1), TOL_X3))
     # 1e''. bf16 arithmetic on fp32-STORED operands (rounded while staged: general kernel MODE 3 = f32 x f32, MODE 4 = bf16 x f32), in the
     #       layouts the bf16 backward of the x3-forward training mode uses them: dgrad (OP_K x OP_R), wgrad (OP_R x OP_R), conv dgrad / wgrad
     for tag, adt, bdt in (("f32f32", F32, F32), ("bf16f32", BF16, F32)):
