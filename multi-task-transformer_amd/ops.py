@@ -402,6 +402,9 @@ def pack_conv3(weights, prec, tag, transpose=False):
     """List of Z conv weights [Co, Ci, 3, 3] -> [Z, Co, 9*Cip] with k = tap*Cip + ci (taps row-major).
     transpose=True packs the dgrad operand [Z, Ci, 9*Cop] with k = tap*Cop + co."""
     Co, Ci = weights[0].shape[:2]
+    if prec.split and not transpose and split_conv_ok(Ci):
+        # x3f forward: pre-split planes -> conv3x3 runs the split-plane implicit-GEMM kernel (an fp32 input is split by one pass first)
+        return pack_conv3_split(weights, tag)
     R, Cin = (Ci, Co) if transpose else (Co, Ci)
     Cp, Z = pad8(Cin), len(weights)
     # logical box (r, tap, c): source W[co, ci, tap] has strides (Ci*9, 9, 1) over (co, ci, tap)
@@ -574,6 +577,12 @@ def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=AC
     Implicit GEMM (no im2col buffer): A rows are gathered per 16-byte channel chunk."""
     Z, rows, Cp = x.shape
     assert rows == B * H * W and wpack.shape[-1] == 9 * Cp
+    if isinstance(wpack, Split) and not isinstance(x, Split):
+        # x3f: the weights are pre-split planes (pack_conv3 under a split Prec); an fp32 input is split by one pass (8 bytes per element,
+        # against a kernel that runs 2-3x the register-staged x3 conv's rate)
+        x = x.float().contiguous()
+        sp = split_cast(x.view(Z * rows, Cp))
+        x = Split(sp.hi.view(Z, rows, Cp), sp.lo.view(Z, rows, Cp))
     assert isinstance(x, Split) == isinstance(wpack, Split), "split planes: both operands or neither"
     Cop = pad8(Co)
     out = torch.empty(Z, rows, Cop, dtype=out_dtype or prec.adt, device=x.device)
