@@ -46,6 +46,10 @@ def taskprompter(name):
                          chan_nheads=4, use_ctr=False, prompt_len=1, head="conv"),
         "mini_deconv": dict(backbone="tiny", img_size=(64, 64), tasks=CS2, embed_dim=30, final_embed_dim=36,
                             chan_nheads=1, use_ctr=True, prompt_len=1, head="deconv"),
+        # decoder widths that are multiples of 32 (as 352 = pad8(350), 1024, 768 of the BASELINE configs): the x3f mode then runs the
+        # fea_fuse 3x3 convs and the taps-first head GEMM on split planes.  No reference fixture: product vs oracle only.
+        "mini_p32": dict(backbone="tiny", img_size=(64, 96), tasks=NYUD4, embed_dim=48, final_embed_dim=64,
+                         chan_nheads=1, use_ctr=True, prompt_len=1, head="conv"),
     }[name]
     return dict(t, name=name, model="TaskPrompter")
 

@@ -116,6 +116,31 @@ def test_x3f_mode_forward_x3_on_split_planes_backward_bf16(emulated, monkeypatch
     assert not any(n == "gemm" and pr == 1 for n, _, pr, _ in seen[len(seen) // 2 + 40:]), "x3 GEMMs in the backward half"
 
 
+def test_x3f_decoder_convs_and_head_gemm_run_on_split_planes(emulated, monkeypatch):
+    """Decoder widths that are multiples of 32 (352 / 1024 / 768 in the BASELINE configs; 64 here): in x3f the fea_fuse 3x3 convs take the
+    split-plane implicit-GEMM kernel (mtt_gemm: MTT_OP_CONV_K on MTT_SPLIT operands, y0 written as planes by fea_fuse[0]'s epilogue) and the
+    taps-first head GEMM runs on planes of the low-resolution task features — whole model on the ABI emulator vs the oracle's autograd."""
+    import mtt_amd
+    import train_check
+    seen = []
+    inner = mtt_amd.ops.call
+
+    def spy(name, **kw):
+        seen.append((name, kw.get("a_op"), kw.get("a_dtype"), kw.get("d_dtype"), kw.get("prec"), kw.get("N")))
+        return inner(name, **kw)
+    monkeypatch.setattr(mtt_amd.ops, "call", spy)
+    fwd, errs = train_check.grad_errors("mini_p32", "x3f", "cpu")
+    assert max(fwd.values()) < 5e-5, fwd
+    worst, med = train_check.summarize(errs, floor=1e-4)
+    assert med < 3e-2, (worst, med)
+    n_taps = 4
+    convs = [s for s in seen if s[0] == "gemm" and s[1] == 2 and s[2] == 2 and s[4] == 1]             # OP_CONV_K on split planes, x3
+    assert len(convs) == n_taps, len(convs)
+    assert sum(1 for s in seen if s[0] == "gemm" and s[1] == 0 and s[2] == 2 and s[3] == 2 and s[5] == 64) == n_taps    # fea_fuse[0] -> planes
+    assert sum(1 for s in seen if s[0] == "gemm" and s[1] == 0 and s[2] == 2 and s[5] == 9 * 64) == 1                   # the nine-tap head GEMM
+    assert not any(s[0] == "gemm" and s[1] == 2 and s[2] == 0 and s[4] == 1 for s in seen), "a forward 3x3 conv still on the register-staged x3 kernel"
+
+
 def test_bf16_training_uses_flash_attention_backward(emulated, monkeypatch):
     """bf16 mode routes the attention backward to mtt_attn_bwd (flash, no N x N buffer); gradients stay bf16-accurate."""
     import mtt_amd
