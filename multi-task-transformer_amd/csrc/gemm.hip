@@ -1121,6 +1121,96 @@ int launch_ring3(const GemmP& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_f32n_kernel (round 4): D[M, N <= 32] = A[M, K] W[N, K]^T + bias in EXACT fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32: f32 in,
+// f32 accumulate, one rounding per product — bitwise a k-ordered fmaf chain, cdna_hip_programming.md §3).  For the fp32-class modes' tall
+// GEMMs with a handful of outputs (the heads' 1x1 predictions on the full-resolution maps: M = B 128 128 rows, K = 352, N = 1 .. 21): they
+// are HBM-bound on reading A once, and the split-product kernels spend three bf16 MFMA products on a 128-wide tile of which 21 columns are
+// real.  The f32 MFMA runs at 1 / 16 of the bf16 rate, but 32 columns at that rate are still 2x faster than A can be streamed.
+//   One wave = 32 rows; lane (r = l & 31, h = l >> 5) loads 16 bytes A[row r][8 i + 4 h .. + 3] per step i and feeds four MFMAs (the
+//   reduction order inside a step is permuted consistently on both operands: instruction (i, e) contracts k = 8 i + 4 h + e).  W sits in LDS as
+//   [K / 4][32][4] (chunk-major: the 32 lanes of a half read 512 contiguous bytes), rows >= N zero.  Workgroup = 4 waves x RB row blocks.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int F32N_RB = 4;            // 32-row blocks per wave
+__global__ __launch_bounds__(256, 2) void gemm_f32n_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* wl = (float4*)smem;                                        // [K / 4][32] chunks of 4 k
+  const mtt_gemm_desc& d = p.d;
+  const int z = blockIdx.z;
+  const int zo = z / d.batch_inner, zi = z - zo * d.batch_inner;
+  const float* A = (const float*)d.A + ((int64_t)zo * d.a_zo + (int64_t)zi * d.a_zi);
+  const float* W = (const float*)d.B + ((int64_t)zo * d.b_zo + (int64_t)zi * d.b_zi);
+  float* D = (float*)d.D + ((int64_t)zo * d.d_zo + (int64_t)zi * d.d_zi);
+  const int K4 = d.K >> 2;
+  for (int t = threadIdx.x; t < K4 * 32; t += 256) {
+    const int n = t & 31, q = t >> 5;
+    wl[t] = n < d.N ? *(const float4*)(W + (int64_t)n * d.ldb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_store = d.n_store > d.N ? d.n_store : d.N;
+  const float bias = (d.colshift && r < d.N) ? d.colshift[(int64_t)zo * d.col_zo + (int64_t)zi * d.col_zi + r] : 0.f;
+  const int steps = d.K >> 3;
+#pragma unroll 1
+  for (int rb = 0; rb < F32N_RB; ++rb) {
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 * F32N_RB + (int64_t)rb * 4 + wave) * 32;
+    if (m0 >= d.M) break;
+    int64_t row = m0 + r; if (row > d.M - 1) row = d.M - 1;
+    const float* ar = A + row * d.lda + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    int i = 0;
+    for (; i + 4 <= steps; i += 4) {                               // four 16-byte loads in flight per lane
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *(const float4*)(ar + 8 * (i + u));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = wl[(2 * (i + u) + h) * 32 + r];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+      }
+    }
+    for (; i < steps; ++i) {
+      const float4 a = *(const float4*)(ar + 8 * i), b = wl[(2 * i + h) * 32 + r];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    // acc[g] = D[row (g & 3) + 8 (g >> 2) + 4 h][col r]: lanes of a half write 32 consecutive columns of one row
+    if (r < n_store) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int64_t m = m0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (m < d.M) D[m * d.ldd + r] = r < d.N ? acc[g] + bias : 0.f;
+      }
+    }
+  }
+}
+
+static bool f32n_ok(const mtt_gemm_desc& d) {
+  return d.prec == MTT_PREC_X3 && d.a_dtype == MTT_F32 && d.b_dtype == MTT_F32 && d.d_dtype == MTT_F32 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K &&
+         d.N <= 32 && d.K % 8 == 0 && d.K <= 1024 && d.M >= 2048 && d.store_mode == MTT_STORE_ROWS && d.a_mb <= 0 && d.d_mb <= 0 && !d.resid &&
+         !d.aux_in && !d.aux_out && !d.colscale && !d.rowscale && !d.colsum_out && d.act == MTT_ACT_NONE && d.alpha == 1.0f &&
+         (d.variant == MTT_GEMM_AUTO) && d.lda % 4 == 0 && d.ldb % 4 == 0;
+}
+int launch_f32n(const GemmP& p, hipStream_t stream) {
+  const int smem = p.d.K * 32 * 4;
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_f32n_kernel, 1024 * 32 * 4, done)) return e;
+  const int64_t rows_per_wg = 4 * F32N_RB * 32;
+  dim3 grid((unsigned)((p.d.M + rows_per_wg - 1) / rows_per_wg), 1, p.d.batch);
+  hipLaunchKernelGGL(gemm_f32n_kernel, grid, dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_dma128_kernel<FASTADDR, NT>: 128 x (32 NT) x 64 tile, 4 waves (2 x 2, each 64 rows x 16 NT columns).  NT = 4: 128 x 128, 64 fp32 accumulators per lane,
 // operands streamed by LDS-DMA into 2 stages of 32 KiB — TWO workgroups per CU, so a SIMD alternates between a wave of each: while
 // one waits for its K tile the other issues MFMAs; NT = 1 / 2: 32 / 64-column tiles for outputs of a few channels (head predictions:
@@ -1507,6 +1597,7 @@ extern "C" size_t mtt_desc_size(int which) {
 //   6 token-major weight-gradient kernel (gemm_tn_kernel): LDS-DMA + ds_read_b64_tr_b16 fragments
 //   8 gemm_ring3_kernel<false>: MTT_SPLIT operands, fp32-class product (three MFMA products per staged K step)
 //   9 gemm_ring3_kernel<true>: the same with the implicit im2col of a 3x3 conv as A operand (MTT_OP_CONV_K on planes)
+//  11 gemm_f32n_kernel: fp32 operands, N <= 32, exact fp32 MFMA (the fp32-class modes' tall few-output GEMMs)
 //  <0 MTT_E_* (no kernel takes this descriptor)
 // d.variant = MTT_GEMM_AUTO applies the policy; MTT_GEMM_GENERAL / MTT_GEMM_DMA256 force a kernel where it is applicable.
 // K % 64 == 0 and 32-bit per-lane byte offsets from the batch member's base: the fast source addressing of the LDS-DMA kernel
@@ -1528,6 +1619,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
         (int64_t)d.M * d.lda < (1ll << 31) && (int64_t)(d.N - 1) * d.ldb + d.K < (1ll << 31)) return 9;
     return MTT_E_UNSUPPORTED;
   }
+  if (f32n_ok(d)) return 11;
   if (d.prec != MTT_PREC_BF16 || d.a_dtype != MTT_BF16 || d.b_dtype != MTT_BF16) return 0;
   // 6: token-major weight-gradient kernel (gemm_tn_kernel): both operands MTT_OP_R (B may be the implicit im2col^T), bf16
   const bool tn = d.a_op == MTT_OP_R && (d.b_op == MTT_OP_R || d.b_op == MTT_OP_CONV_R) && d.store_mode == MTT_STORE_ROWS;
@@ -1628,6 +1720,7 @@ extern "C" size_t mtt_gemm_colsum_ws_floats(const mtt_gemm_desc* d) {
 
 static int gemm_launch(GemmP& p, hipStream_t s, int v) {
   mtt_gemm_desc& d = p.d;
+  if (v == 11) return launch_f32n(p, s);
   if (v == 9) return launch_ring3<true>(p, s);
 #if MTT_RING
   if (v == 8) return launch_ring3<false>(p, s);

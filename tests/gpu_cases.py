@@ -270,6 +270,15 @@ def gemm_cases():
                   d_zo=rows * Cop, conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, n_store=Cop, colshift=rnd(g, Zc, Co), col_zo=Co)
         cases.append((f"conv3_split_{Bc}x{H}x{W}_c{Ci}_dil{dil}_flip{flip}", "gemm", kw, TOL_X3))
         cases.append((f"conv3_split_bnfold_gelu_{Bc}x{H}x{W}_c{Ci}", "gemm", dict(kw, D=torch.full((Zc, rows, Cop), 7.0), colscale=rnd(g, Zc, Co), act=1), TOL_X3))
+    # 1e++. tall GEMMs with a handful of outputs in the fp32-class modes (mtt_gemm variant 11, gemm_f32n_kernel: exact fp32 MFMA): the head
+    #       predictions' shapes (K = 352, N = 1 / 21), N = 32, K = 8 and 1024, ragged M (not a multiple of 32 / of a workgroup's 512 rows),
+    #       channel padding columns (n_store), task batches
+    for (M, N, K, Zc) in ((5000, 21, 352, 1), (2049, 1, 352, 1), (4096, 32, 8, 1), (3000, 7, 1024, 2)):
+        ldd = (N + 7) // 8 * 8 + 8
+        kw = dict(A=rnd(g, Zc, M, K + 8), B=rnd(g, Zc, N, K), D=torch.full((Zc, M, ldd), 7.0), M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=F32, b_dtype=F32,
+                  d_dtype=F32, prec=1, lda=K + 8, ldb=K, ldd=ldd, batch=Zc, batch_inner=1, a_zo=M * (K + 8), b_zo=N * K, d_zo=M * ldd, alpha=1.0,
+                  colshift=rnd(g, Zc, N), col_zo=N, n_store=(N + 7) // 8 * 8)
+        cases.append((f"gemm_f32n_{M}x{N}x{K}_z{Zc}", "gemm", kw, TOL_X3))
     # 1e''. bf16 arithmetic on fp32-STORED operands (rounded while staged: general kernel MODE 3 = f32 x f32, MODE 4 = bf16 x f32), in the
     #       layouts the bf16 backward of the x3-forward training mode uses them: dgrad (OP_K x OP_R), wgrad (OP_R x OP_R), conv dgrad / wgrad
     for tag, adt, bdt in (("f32f32", F32, F32), ("bf16f32", BF16, F32)):
