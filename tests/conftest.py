@@ -23,7 +23,7 @@ def pytest_configure(config):
     # them) THRASHES on these workloads — measured in round 2: the NS-6 oracle forward took 220 s on 256 threads vs 5 s on 8.
     torch.set_num_threads(HOST_THREADS)
     # A/B of kernel variants under the model-level parity tests (a test-harness switch, not a library one): every mtt_gemm call that
-    # leaves its descriptor at AUTO gets this variant, e.g. MTT_TEST_GEMM_VARIANT=12 = policy + persistent LDS-DMA kernel
+    # leaves its descriptor at AUTO gets this variant, e.g. MTT_TEST_GEMM_VARIANT=1 = the register-staged general kernel everywhere
     if os.environ.get("MTT_TEST_GEMM_VARIANT"):
         import mtt_amd
         mtt_amd.ops.GEMM_VARIANT = int(os.environ["MTT_TEST_GEMM_VARIANT"])

@@ -15,11 +15,19 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = {
-    # name: (kind, config, image shares per rank)
+    # name: (kind, config, image shares per rank[, arithmetic mode, bound on the worst gradient error])
     "taskprompter_2ranks": ("TP", "mini_ctr", [[0], [1]]),
     "taskprompter_3ranks_unequal": ("TP", "mini_ctr", [[0, 1], [2], [3]]),
     "invpt_4ranks": ("IP", "mini8", [[0], [1], [2], [3]]),
+    # the DEFAULT mode (x3f) on decoder widths % 32: its Functions hand split planes to each other (two outputs, the lo plane without a
+    # gradient) — DDP with find_unused_parameters=False must still see every parameter's gradient; bf16-class gradients
+    "taskprompter_x3f_planes_2ranks": ("TP", "mini_p32", [[0], [1, 2]], "x3f", 1.5e-1),
 }
+
+
+def _mode(case):
+    c = CASES[case]
+    return (c[3], c[4]) if len(c) > 3 else ("x3", 1e-3)
 
 
 def _loss(out, rows, n_total, world, seed=7):
@@ -56,9 +64,9 @@ def _worker_body(rank, world, port, case, q):
     import mtt_amd
     from oracle import abi_emul, configs, weights
     mtt_amd.ops.call = abi_emul.call
-    kind, name, shares = CASES[case]
+    kind, name, shares = CASES[case][:3]
     cfg = configs.taskprompter(name) if kind == "TP" else configs.invpt(name)
-    model = conftest.build_product_model(cfg, "x3")
+    model = conftest.build_product_model(cfg, _mode(case)[0])
     contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
     model.load_state_dict(weights.synth_state_dict(contract, 0), strict=True)
     model.train()
@@ -101,7 +109,7 @@ def _worker_body(rank, world, port, case, q):
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_ddp_ranks_match_single_process(case):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    kind, name, shares = CASES[case]
+    kind, name, shares = CASES[case][:3]
     world = len(shares)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -129,14 +137,19 @@ def test_ddp_ranks_match_single_process(case):
         from oracle import invpt_oracle as orc
     out = orc.forward(dict(sd, **params), cfg, x, training=True)
     _loss(out, list(range(n_total)), n_total, 1).backward()
-    worst = 0.0
+    worst, errs = 0.0, []
     for k, ref in params.items():
-        if ref.grad is None or float(ref.grad.norm()) < 1e-6:
+        if ref.grad is None or float(ref.grad.norm()) < (1e-6 if _mode(case)[0] == "x3" else 1e-4):
             continue
         assert got[k] is not None, k
         e = float((torch.from_numpy(got[k]) - ref.grad).norm() / ref.grad.norm())
         worst = max(worst, e)
-    assert worst < 1e-3, worst
+        errs.append(e)
+    errs.sort()
+    if _mode(case)[0] == "x3":
+        assert worst < _mode(case)[1], worst
+    else:                                   # bf16 backward: bound the median (single near-zero gradients can be off by more)
+        assert errs[len(errs) // 2] < 3e-2 and errs[int(len(errs) * 0.9)] < _mode(case)[1], (errs[len(errs) // 2], worst)
     # SyncBN statistics: one all_gather per BatchNorm STAGE (a stage = all tasks' BatchNorms at one point of the network), not one
     # per BatchNorm layer: TaskPrompter has 4 taps + 1 head stage; InvPT's decoder has 2 + 3*... stages (fewer than its 2*T*... layers)
     n_layers = sum(1 for k in sd if k.endswith("running_mean"))
