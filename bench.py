@@ -714,7 +714,8 @@ def main():
                     peak_hbm_gb=head["peak_hbm_gb"], host=head["host"], model_tflops=flops_block(head),
                     roofline=head["roofline"], roofline_bwd_gemm=head["roofline_bwd_gemm"], parity=parity.get(a.prec),
                     fast_mode=fast_rec, full_fp32_mode=full, ref_batch=head["ref_batch"], torch_rocm_baseline=torch_base, cpu_baseline=cpu,
-                    git=dict(head=_git("rev-parse", "--short", "HEAD"), dirty=bool(_git("status", "--porcelain", "--untracked-files=no"))))
+                    git=dict(head=_git("rev-parse", "--short", "HEAD") or os.environ.get("MTT_COMMIT") or None,      # (no .git on a gpurun box)
+                             dirty=bool(_git("status", "--porcelain", "--untracked-files=no"))))
         print(json.dumps(line), flush=True)
     if ddp_mode:
         dist.barrier()                            # rank 0's extra legs (second mode, JSON line) end before any rank tears the group down
