@@ -586,3 +586,24 @@ def test_persistent_packs_match_torch_relayouts_on_emulator(emulated):
     pack_check.check_packs("cpu")
     pack_check.check_refresh("cpu")
     pack_check.check_unpack("cpu")
+
+
+def test_bench_pmc_traffic_record_is_refused_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    """bench.py reports roofline.traffic from the committed PMC passes only while csrc/gemm.hip is the file they were measured on."""
+    import hashlib
+    import json as _json
+    import bench
+    (tmp_path / "profiles").mkdir()
+    src = tmp_path / "multi-task-transformer_amd" / "csrc"
+    src.mkdir(parents=True)
+    (src / "gemm.hip").write_text("// kernel source, version A\n")
+    sha = hashlib.sha256((src / "gemm.hip").read_bytes()).hexdigest()[:16]
+    rec = {"gemm_ring3_kernel": dict(hbm_bytes_per_launch=123, commit="abc1234", csrc_sha=sha, source="pmc")}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(_json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench._pmc_traffic("gemm_ring3_kernel")
+    assert got["hbm_bytes_per_launch"] == 123 and got["commit"] == "abc1234"
+    assert bench._pmc_traffic("gemm_dma_kernel<1>").get("hbm_bytes_per_launch") is None        # no record for that kernel
+    (src / "gemm.hip").write_text("// kernel source, version B\n")
+    stale = bench._pmc_traffic("gemm_ring3_kernel")
+    assert stale.get("hbm_bytes_per_launch") is None and "STALE" in stale["note"] and stale["commit"] == "abc1234"
