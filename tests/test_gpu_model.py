@@ -20,7 +20,7 @@ def _rel(a, b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv"])
-@pytest.mark.parametrize("prec,tol", [("x3", REL_TOL_X3), ("bf16", REL_TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("x3", REL_TOL_X3), ("x3f", REL_TOL_X3), ("bf16", REL_TOL_BF16)])
 def test_forward_matches_reference_golden(name, prec, tol):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -72,7 +72,7 @@ def test_forward_matches_oracle_on_fresh_inputs_larger_batch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec,tol", [("x3", REL_TOL_X3), ("bf16", REL_TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("x3", REL_TOL_X3), ("x3f", REL_TOL_X3), ("bf16", REL_TOL_BF16)])
 def test_invpt_forward_matches_reference_golden(prec, tol):
     """InvPT (ViT taps + TransformerDecoder + InvPT stages + MLPHead): eval and train-mode forward vs the unmodified reference."""
     if not torch.cuda.is_available():

@@ -181,7 +181,7 @@ def _invpt_outputs_vs_golden(model, cfg, meta, gold, tol, device="cpu"):
         assert float((out[t].cpu()[:, :, ::2, ::2] - g).norm() / g.norm()) < tol * 2, t
 
 
-@pytest.mark.parametrize("prec,tol", [("x3", 2e-5), ("bf16", 4e-2)])
+@pytest.mark.parametrize("prec,tol", [("x3", 2e-5), ("x3f", 2e-5), ("bf16", 4e-2)])
 def test_invpt_contract_and_wiring_on_emulator(emulated, prec, tol):
     cfg = configs.invpt("mini")
     meta, gold = conftest.load_golden("mini")
