@@ -19,7 +19,7 @@ it (1.5e-2) and x3f meets it (2.6e-5) — forward = 3 bf16 MFMAs per product on 
   parity       — the headline mode's worst per-head relative error against the CPU ORACLE's eval forward on this model's weights and 2 of
                  these images (the oracle runs inside the cpu_baseline subprocess)
   fast_mode    — the bf16 mode (BASELINE.json's configs and north_star's 40 % target are stated on it), measured in the same process with
-                 the same steps / warm-up: images/s, fwd ms/img, its own roofline (gemm_ring_kernel) and its own parity (which fails 1e-3)
+                 the same steps / warm-up: images/s, fwd ms/img, its own roofline (gemm_dma_kernel<1>) and its own parity (which fails 1e-3)
   full_fp32_mode — the fully fp32-class step (x3 forward AND backward: gradients match the oracle's autograd to 6e-5), 3 steps
   torch_rocm_baseline — stock PyTorch-ROCm (the reference's op graph through hipBLASLt / MIOpen / ATen) on the same GPU, fp32 and bf16 autocast
   ref_batch    — the headline step at the reference's own per-GPU batch (trBatch: 2), eager and replayed from one hipGraph
@@ -47,6 +47,11 @@ PASCAL5 = ["semseg", "human_parts", "sal", "normals", "edge"]
 PASCAL6 = ["semseg", "depth", "human_parts", "sal", "normals", "edge"]      # TaskPrompter/utils/config.py:30-87 order
 # name -> (description, make_p kwargs, image size, default per-GPU batch, algorithmic forward GFLOP / image (SURVEY.md §8d closed form))
 CONFIGS = {
+    # test-only miniature (oracle/configs.py "mini_ctr": same code path, 64x96, ViT-tiny): the launcher / DDP tests on CPU
+    "mini": ("TaskPrompter ViT-tiny miniature, 6 tasks, 64x96 (launcher / host-logic tests only)",
+             dict(tasks=PASCAL6, backbone=(128, 4, 2, (1, 2, 3)), head="conv", embed_dim=44, final_embed_dim=52, chan_nheads=1, use_ctr=True,
+                  drop_path_rate=0.0),
+             (64, 96), 2, 0.217),
     "ns6": ("TaskPrompter ViT-L/16 (taskprompter_vit_large_patch16_384), PASCAL-Context 5 tasks + depth = 6 tasks, 512x512, ConvHead, "
             "embed 300/350, ctr; random-init weights",
             dict(tasks=PASCAL6, backbone="TaskPrompter_vitL", head="conv", embed_dim=300, final_embed_dim=350, chan_nheads=1, use_ctr=True),
@@ -77,7 +82,15 @@ CONFIGS = {
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--tree-sha", action="store_true", help="print the source-tree hash the bench line reports as git.tree_sha and exit")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks of ONE node, one process per GPU.  N > 1 without RANK in the environment: this process becomes the launcher "
+                         "(python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 <this script> <same flags>), "
+                         "as TaskPrompter/run_taskprompter_*.sh:1 launches main.py; under an external torch.distributed.run the flag must "
+                         "equal WORLD_SIZE")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu = host-logic runs of the launcher / DDP path (gloo); the C-ABI library has NO CPU implementation — a cpu run "
+                         "only works under tests/bench_emulated.py, which routes ops.call to the test emulator")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="ns6", choices=sorted(CONFIGS))
@@ -161,7 +174,8 @@ class GemmTimer:
             a[2] += fl
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
         return [dict(M=k[0], N=k[1], K=k[2], batch=k[3], launches=a[0], ms=round(a[1], 3),
-                     tflops=round(mfma_per_product * a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None) for k, a in rows]
+                     tflops=round(a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None,
+                     tflops_mfma_issued=round(mfma_per_product * a[2] / (a[1] * 1e-3) / 1e12, 1) if a[1] > 0 else None) for k, a in rows]
 
 
 KERNELS = {
@@ -182,19 +196,23 @@ def roofline_of(gt_, v, pmc_ok=True):
     if n == 0 or ms <= 0:
         return None
     mfma_per_product = 3 if v == 8 else 1
-    tf = mfma_per_product * flops / (ms * 1e-3) / 1e12
+    tf = flops / (ms * 1e-3) / 1e12                      # ALGORITHMIC rate: 2 M N K per product whatever the kernel issues for it
+    tf_issued = mfma_per_product * tf
     kname, kdesc = KERNELS[v]
     traffic = _pmc_traffic(kname) if pmc_ok else dict(note="the committed PMC passes were taken on the default workload (ns6, per-GPU batch 63)")
     rec = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+               achieved_mfma_issued=round(tf_issued, 2), frac_mfma_issued=round(tf_issued / MFMA_BF16_PEAK_TFLOPS, 4),
                traffic=traffic.get("hbm_bytes_per_launch"), traffic_source=traffic.get("source"), traffic_commit=traffic.get("commit"),
+               traffic_csrc_sha=traffic.get("csrc_sha"),
                traffic_note=traffic.get("note"), algorithmic_bytes_per_launch=int(byts / n), kernel=kdesc, launches=n,
-               kernel_ms_per_step=round(ms, 3), algorithmic_tflop_per_step=round(mfma_per_product * flops / 1e12, 2),
+               kernel_ms_per_step=round(ms, 3), avg_launch_us=round(ms / n * 1e3, 1), algorithmic_tflop_per_step=round(flops / 1e12, 2),
+               mfma_issued_tflop_per_step=round(mfma_per_product * flops / 1e12, 2),
+               flop_convention=("achieved / frac = ALGORITHMIC FLOPs (2 M N K per GEMM, SURVEY.md 8d) / HIP-event time / the dense bf16 MFMA peak; "
+                                "achieved_mfma_issued / frac_mfma_issued = the bf16 MFMA work the kernel's algorithm issues for them (%d MFMA "
+                                "product%s per algorithmic product)" % (mfma_per_product, "s" if mfma_per_product > 1 else "")),
                by_shape=gt_.by_shape(v, mfma_per_product))
     if v == 8:
-        rec["flop_convention"] = ("achieved counts the bf16 MFMA work of the split-product algorithm (3 MFMAs per fp32-class product = 6 M N K); "
-                                  "the fp32-class product rate is a third of it")
-        rec["fp32_class_tflops"] = round(tf / 3, 2)
-        rec["fp32_class_vs_fp32_matrix_peak_157"] = round(tf / 3 / 157.3, 2)
+        rec["fp32_class_vs_fp32_matrix_peak_157"] = round(tf / 157.3, 2)
     return rec
 
 
@@ -205,7 +223,7 @@ def build(cfg_name, prec, mtt_amd):
     return p, mtt_amd.factory.get_model(p)
 
 
-def _cpu_baseline_worker(cfg_name, batch, threads, q, ref_in=None, ref_out=None):
+def _cpu_baseline_worker(cfg_name, batch, threads, q, ref_in=None, ref_out=None, timed_steps=4):
     """Runs in a subprocess: oracle (CPU restatement of the reference) forward + loss + backward on a bounded sample.
     ref_in / ref_out: additionally run the oracle's EVAL forward on the state dict + images saved in `ref_in` (the bench model's own
     weights) and save its per-task outputs to `ref_out` — the reference the bench line's parity records are measured against."""
@@ -231,7 +249,7 @@ def _cpu_baseline_worker(cfg_name, batch, threads, q, ref_in=None, ref_out=None)
     else:
         from oracle import taskprompter_oracle as orc
     times = []
-    for _ in range(4):                                            # one warm-up (allocator, thread pool), three timed
+    for _ in range(timed_steps):                                  # one warm-up (allocator, thread pool), three timed
         for v in params.values():
             v.grad = None
         t0 = time.time()
@@ -248,14 +266,20 @@ def _cpu_baseline_worker(cfg_name, batch, threads, q, ref_in=None, ref_out=None)
     q.put(times)
 
 
-def cpu_baseline(cfg_name, batch, threads=16, limit_s=300, ref_in=None, ref_out=None):
-    """images/s of one oracle training step on `threads` host cores; bounded by a subprocess timeout."""
+def cpu_baseline(cfg_name, batch, threads=16, limit_s=300, ref_in=None, ref_out=None, parity_only=False):
+    """images/s of one oracle training step on `threads` host cores; bounded by a subprocess timeout.  parity_only: no timed steps, only the
+    oracle's eval forward on `ref_in` (the parity reference of a --no-cpu-baseline run)."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    pr = ctx.Process(target=_cpu_baseline_worker, args=(cfg_name, batch, threads, q, ref_in, ref_out))
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(cfg_name, batch, threads, q, ref_in, ref_out, 0 if parity_only else 4))
     pr.start()
     pr.join(limit_s)
+    if parity_only:
+        if pr.is_alive():
+            pr.terminate()
+            pr.join()
+        return None
     host = dict(host_cores=os.cpu_count(), host_cpu=_cpu_model())
     if pr.is_alive():
         pr.terminate()
@@ -372,6 +396,30 @@ def _git(*args):
         return ""
 
 
+def source_tree_sha():
+    """sha256 over the product's sources (package .py / .hip / .h, include/, bench.py), path-sorted: identifies the tree on a box that has
+    no .git (gpurun / driver snapshots).  `python bench.py --tree-sha` prints it for any checkout."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "bench.py")]
+    for top in ("multi-task-transformer_amd", "include"):
+        for d, _, fs in os.walk(os.path.join(ROOT, top)):
+            files += [os.path.join(d, f) for f in fs if f.endswith((".py", ".hip", ".h"))]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _source_id():
+    """git.head: the commit when .git travels with the tree, else MTT_COMMIT, else `tree-<source_tree_sha>` (never null: the driver's
+    box is a snapshot without .git); tree_sha is always present and can be recomputed on any checkout with `bench.py --tree-sha`."""
+    tree = source_tree_sha()
+    head = _git("rev-parse", "--short", "HEAD")
+    return dict(head=head or os.environ.get("MTT_COMMIT") or f"tree-{tree}", tree_sha=tree,
+                dirty=bool(_git("status", "--porcelain", "--untracked-files=no")) if head else None)
+
+
 def _pmc_traffic(kernel_name):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/pmc_traffic.json, written by tools/pmc_traffic.py):
     {kernel name: {hbm_bytes_per_launch, source, commit, csrc_sha}}.  The record names the commit and the hash of the kernel sources it
@@ -447,22 +495,63 @@ MODE_TEXT = {
 }
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv=None, script=None):
+    """`bench.py --gpus N` started as ONE process: become the launcher of N ranks on this node, one process per GPU, exactly the command the
+    task contract names (and what TaskPrompter/run_taskprompter_*.sh:1 does for main.py with torch.distributed.launch):
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P <script> <same flags>
+    Rank 0's JSON line passes through on stdout; returns the launcher's exit code."""
+    import subprocess
+    script = script or os.path.abspath(sys.argv[0])
+    argv = list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 1) // max(1, n)))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.tree_sha:
+        return print(source_tree_sha())
     if a.graphed_worker:
         return _graphed_worker(a.config, a.prec)
     if a.torch_baseline_worker:
         return _torch_baseline_worker(a.config, a.torch_baseline_worker)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if "RANK" in os.environ and a.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs and what n_gpus reports", file=sys.stderr)
+    on_gpu = a.device == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:                                 # host-logic runs only (tests/bench_emulated.py): everything GPU-specific is skipped
+        dev = torch.device("cpu")
+        a.no_roofline = a.no_ref_batch = a.no_torch_baseline = a.no_cpu_baseline = a.no_fast_mode = a.no_x3_mode = a.no_parity = True
+        torch.cuda.synchronize = lambda *x, **k: None
+        torch.cuda.reset_peak_memory_stats = lambda *x, **k: None
+        torch.cuda.max_memory_allocated = lambda *x, **k: 0
+        torch.cuda.empty_cache = lambda *x, **k: None
     # launched by torch.distributed.run (RANK / MASTER_ADDR in the env): RCCL process group + DDP even at world size 1, so that a
     # one-GPU box exercises the same communicator / bucketed all-reduce code path the 8-GPU run takes
     ddp_mode = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if ddp_mode:
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        if on_gpu:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", init_method="env://")
     import mtt_amd
 
     desc, _, (H, W), dflt_batch, gflop_fwd = CONFIGS[a.config]
@@ -489,8 +578,12 @@ def main():
         nonlocal outs
         torch.manual_seed(0)
         p, model = build(a.config, prec, mtt_amd)
-        if ddp_mode and headline:
+        if ddp_mode and headline and on_gpu:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)          # TaskPrompter/main.py:92
+        elif ddp_mode and headline:         # DDP refuses nn.SyncBatchNorm on CPU modules: plain holders flagged for the same cross-rank code path
+            for m in model.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                    m._mtt_sync = True
         model = model.to(dev)
         if not headline and "sd" in saved:                 # the second mode starts from the weights the parity reference was taken on
             model.load_state_dict(saved["sd"])
@@ -501,7 +594,7 @@ def main():
         model.train()
         net = model
         if ddp_mode and headline:
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=a.config == "cfg4",
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if on_gpu else None, find_unused_parameters=a.config == "cfg4",
                                                             gradient_as_bucket_view=True, bucket_cap_mb=a.bucket_mb)
             if a.grad_comm == "bf16":
                 from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
@@ -650,6 +743,8 @@ def main():
             cpu = cpu_baseline(a.config, a.cpu_sample_batch, a.cpu_threads, ref_in=ref_paths[0] if outs else None, ref_out=ref_paths[1])
         except Exception as e:  # noqa: BLE001
             cpu = dict(value=None, unit="images/s", cores=a.cpu_threads, kind="port", host_cores=os.cpu_count(), sample=f"failed: {e!r}")
+    elif solo and outs:                           # --no-cpu-baseline: the parity reference alone (the oracle's eval forward, untimed)
+        cpu_baseline(a.config, a.cpu_sample_batch, a.cpu_threads, ref_in=ref_paths[0], ref_out=ref_paths[1], parity_only=True)
     parity = {}
     if rank == 0 and outs:
         ref_txt = ("the CPU oracle's eval forward (fp32, %d host threads) on this model's weights and 2 of the bench images; per-head relative "
@@ -709,13 +804,13 @@ def main():
                                 mode=a.prec, arithmetic=MODE_TEXT[a.prec],
                                 optimizer="clip_grad_norm 10 + Adam (mtt_grad_sqnorm / mtt_adam_step)", loss=head["loss"],
                                 grad_comm=a.grad_comm if ddp_mode else None, bucket_mb=a.bucket_mb if ddp_mode else None,
-                                rccl_ranks=world if ddp_mode else None),
+                                rccl_ranks=world if (ddp_mode and on_gpu) else None, gloo_ranks=None if on_gpu or not ddp_mode else world,
+                                device=a.device),
                     fwd_ms_per_img=None if head["fwd_ms_per_img"] is None else round(head["fwd_ms_per_img"], 3),
                     peak_hbm_gb=head["peak_hbm_gb"], host=head["host"], model_tflops=flops_block(head),
                     roofline=head["roofline"], roofline_bwd_gemm=head["roofline_bwd_gemm"], parity=parity.get(a.prec),
                     fast_mode=fast_rec, full_fp32_mode=full, ref_batch=head["ref_batch"], torch_rocm_baseline=torch_base, cpu_baseline=cpu,
-                    git=dict(head=_git("rev-parse", "--short", "HEAD") or os.environ.get("MTT_COMMIT") or None,      # (no .git on a gpurun box)
-                             dirty=bool(_git("status", "--porcelain", "--untracked-files=no"))))
+                    git=_source_id())
         print(json.dumps(line), flush=True)
     if ddp_mode:
         dist.barrier()                            # rank 0's extra legs (second mode, JSON line) end before any rank tears the group down

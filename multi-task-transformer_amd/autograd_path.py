@@ -624,20 +624,28 @@ class Conv3x3Fn(Function):
         ws, bs = wb[:Z], wb[Z:]
         has_bias = bs[0] is not None
         bias = ops.stack_vec(list(bs), (tag, 'b')) if has_bias else None
+        xdt = x.dtype
         if xlo is not None:
             y = ops.conv3x3(ops.Split(x, xlo), ops.pack_conv3_split(list(ws), tag), Co, Ci, B, H, W, prec, dil=dil, bias=bias, out_dtype=torch.float32)
+        elif prec.split and x.dtype == torch.float32 and ops.split_conv_ok(Ci, Co):
+            # x3f on an fp32 input (head convs, Swin, InvPT): split it HERE, so that the hi plane — the bf16 operand the backward needs
+            # anyway — is what gets saved instead of the fp32 activation plus a second cast pass in the backward
+            Zx, rows, Cp = x.shape
+            sp = ops.split_cast(x.contiguous().view(Zx * rows, Cp))
+            xs = ops.Split(sp.hi.view(Zx, rows, Cp), sp.lo.view(Zx, rows, Cp))
+            y = ops.conv3x3(xs, ops.pack_conv3_split(list(ws), tag), Co, Ci, B, H, W, prec, dil=dil, bias=bias)
+            x = xs.hi
         else:
             y = ops.conv3x3(x, ops.pack_conv3(list(ws), prec, tag), Co, Ci, B, H, W, prec, dil=dil, bias=bias)
         ctx.save_for_backward(x, *ws)
-        ctx.meta = ((B, H, W, Co, Ci, dil), prec, tag, Z, has_bias)
+        ctx.meta = ((B, H, W, Co, Ci, dil), prec, tag, Z, has_bias, xdt)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        (B, H, W, Co, Ci, dil), prec, tag, Z, has_bias = ctx.meta
+        (B, H, W, Co, Ci, dil), prec, tag, Z, has_bias, xdt = ctx.meta
         prec = prec.bwd
-        xdt = x.dtype
         x, dy = _to_bwd(x, prec), _to_bwd(dy.contiguous(), prec)
         rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
         wd = ops.pack_conv3(list(ws), prec, tag, transpose=True)                     # [Z, Ci, 9*Cop]

@@ -119,6 +119,38 @@ def load_flax_vit_npz(model, checkpoint, prefix=""):
     return done
 
 
+# `pretrained=True` (what the reference's get_backbone passes, TaskPrompter/utils/common_config.py:22,29; InvPT/utils/common_config.py:17):
+# timm 0.5.4's build_model_with_cfg -> load_custom_pretrained fetches default_cfg['url'] into the torch hub cache
+# (<torch.hub.get_dir()>/checkpoints/<file name of the URL>) and hands the file to model.load_pretrained.  This box has no network, so the
+# native path takes the SAME cache location and fails with the path to fill when the file is not there.
+_AUGREG = "https://storage.googleapis.com/vit_models/augreg/"
+PRETRAINED_URLS = {            # default_cfgs of taskprompter.py:83-91 / vit.py (the variants the reference's factories construct)
+    "vit_base_patch16_384": _AUGREG + "B_16-i21k-300ep-lr_0.001-aug_medium1-wd_0.1-do_0.0-sd_0.0--imagenet2012-steps_20k-lr_0.01-res_384.npz",
+    "vit_large_patch16_384": _AUGREG + "L_16-i21k-300ep-lr_0.001-aug_medium1-wd_0.1-do_0.1-sd_0.1--imagenet2012-steps_20k-lr_0.01-res_384.npz",
+    "vit_small_patch16_384": _AUGREG + "S_16-i21k-300ep-lr_0.001-aug_light1-wd_0.03-do_0.0-sd_0.0--imagenet2012-steps_20k-lr_0.03-res_384.npz",
+}
+
+
+def cached_pretrained_path(variant):
+    """Where timm's download_cached_file keeps the variant's checkpoint: <hub dir>/checkpoints/<basename of the URL>."""
+    import os
+    from urllib.parse import urlparse
+    url = PRETRAINED_URLS[variant]
+    return os.path.join(torch.hub.get_dir(), "checkpoints", os.path.basename(urlparse(url).path))
+
+
+def load_cached_pretrained(model, variant):
+    """pretrained=True: load the variant's Flax `.npz` from the torch hub cache (never downloads)."""
+    import os
+    if variant not in PRETRAINED_URLS:
+        raise RuntimeError(f"no pretrained checkpoint is defined for variant {variant!r}")
+    path = cached_pretrained_path(variant)
+    if not os.path.isfile(path):
+        raise RuntimeError(f"pretrained=True needs {path} (timm's cache of {PRETRAINED_URLS[variant]}); this library never downloads — "
+                           "place the file there, or construct with pretrained=False and load a checkpoint with load_state_dict")
+    return model.load_pretrained(path)
+
+
 def filter_state_dict(state_dict, model):
     """A torch checkpoint made for another input size / an old linear patch embedding, adapted to `model`: unwraps {'model': ...},
     reshapes a flattened patch-embedding weight to OIHW and resizes `pos_embed`."""

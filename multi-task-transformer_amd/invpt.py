@@ -130,11 +130,12 @@ class VisionTransformer(nn.Module):
 
 
 def _create_vision_transformer(variant, pretrained=False, default_cfg=None, **kwargs):
-    if pretrained:
-        raise RuntimeError('pretrained ImageNet weights need network access (vit.py:541 downloads them)')
     kwargs.pop('representation_size', None)
     model = VisionTransformer(**kwargs)
     model.default_cfg = dict(default_cfg or {}, variant=variant)
+    if pretrained:                       # vit.py:541: from the torch hub cache only (checkpoints.load_cached_pretrained), never the network
+        from .checkpoints import load_cached_pretrained
+        load_cached_pretrained(model, variant)
     return model
 
 

@@ -268,9 +268,11 @@ def _refresh_packs(device):
     pack_refreshes += 1
     bumped = []
     for e, ps in live:
-        e.ver = _pver(ps)
-        v = e.value
-        bumped += [v.hi, v.lo] if isinstance(v, Split) else [v]
+        new = _pver(ps)
+        if e.ver[1] != new[1]:           # this pack's own parameters moved on (the epoch alone also changes when ANOTHER model in the
+            v = e.value                  # process stepped: its bytes are rewritten identically, its pending backward stays valid — ADVICE r04)
+            bumped += [v.hi, v.lo] if isinstance(v, Split) else [v]
+        e.ver = new
     # the packs were rewritten IN PLACE by a raw launch: tell autograd, so that a backward still holding one of them from an earlier
     # forward (ctx.save_for_backward) raises "modified by an inplace operation" instead of silently using the new weights
     if bumped and not _capturing(device):
@@ -402,7 +404,7 @@ def pack_conv3(weights, prec, tag, transpose=False):
     """List of Z conv weights [Co, Ci, 3, 3] -> [Z, Co, 9*Cip] with k = tap*Cip + ci (taps row-major).
     transpose=True packs the dgrad operand [Z, Ci, 9*Cop] with k = tap*Cop + co."""
     Co, Ci = weights[0].shape[:2]
-    if prec.split and not transpose and split_conv_ok(Ci):
+    if prec.split and not transpose and split_conv_ok(Ci, Co):
         # x3f forward: pre-split planes -> conv3x3 runs the split-plane implicit-GEMM kernel (an fp32 input is split by one pass first)
         return pack_conv3_split(weights, tag)
     R, Cin = (Ci, Co) if transpose else (Co, Ci)
@@ -427,9 +429,13 @@ def pack_conv3_split(weights, tag):
                     check=lambda: _check_sources(weights, lambda w: tuple(w.shape) == (Co, Ci, 3, 3)))
 
 
-def split_conv_ok(Ci):
-    """the split-plane implicit-GEMM conv (mtt_gemm variant 9) needs a channel pitch that is a multiple of 32 (a K step inside one tap)"""
-    return pad8(Ci) % 32 == 0
+def split_conv_ok(Ci, Co=None):
+    """the split-plane implicit-GEMM conv (mtt_gemm variant 9, gemm_variant_for in csrc/gemm.hip) needs a channel pitch that is a multiple
+    of 32 (a K step inside one tap), at most 4096 channels, and a weight operand within 32-bit element offsets; the pixel-row limit
+    (M * pitch < 2^31) is met by conv3x3 through batch chunks.  Outside these the caller keeps the non-split pack and the register-staged
+    x3 kernel."""
+    Cp = pad8(Ci)
+    return Cp % 32 == 0 and Cp <= 4096 and (Co is None or Co * 9 * Cp < 2 ** 31)
 
 
 def pack_upconv9(weights, prec, tag):
@@ -572,6 +578,9 @@ def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=No
     return out
 
 
+SPLIT_CONV_MAX_ELEMS = 2 ** 31 - 1          # gemm_variant_for: (int64) M * lda < 2^31 for variant 9 (tests lower it to force chunks)
+
+
 def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=ACT_NONE, dil=1, flip=0, out_dtype=None):
     """x [Z, B*H*W, Cp] -> [Z, B*H*W, pad8(Co)]; wpack [Z, Co, 9*Cp]; bias/colscale [Z, Co] fp32.
     Implicit GEMM (no im2col buffer): A rows are gathered per 16-byte channel chunk."""
@@ -586,17 +595,24 @@ def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=AC
     assert isinstance(x, Split) == isinstance(wpack, Split), "split planes: both operands or neither"
     Cop = pad8(Co)
     out = torch.empty(Z, rows, Cop, dtype=out_dtype or prec.adt, device=x.device)
-    kw = dict(A=_hi(x), B=_hi(wpack), D=out, M=rows, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K,
-              a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
-              lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Z, batch_inner=1, a_zo=_hi(x).stride(0), b_zo=_hi(wpack).stride(0), d_zo=out.stride(0),
-              conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, act=act, n_store=Cop)
-    if isinstance(x, Split):                     # implicit-GEMM form of the split-plane kernel (mtt_gemm variant 9): Cp % 32 == 0
-        kw.update(A_lo=x.lo, B_lo=wpack.lo)
-    if bias is not None:
-        kw.update(colshift=bias, col_zo=bias.stride(0))
-    if colscale is not None:
-        kw.update(colscale=colscale)
-    call("gemm", **kw)
+    # the split-plane kernel addresses a batch member's pixel rows with 32-bit element offsets (M * pitch < 2^31): larger batches go
+    # in chunks of whole images (a conv never mixes images); the general kernel has no such limit
+    per = max(1, SPLIT_CONV_MAX_ELEMS // (H * W * Cp)) if isinstance(x, Split) else B
+    for b0 in range(0, B, per):
+        nb = min(per, B - b0)
+        r0, r1 = b0 * H * W, (b0 + nb) * H * W
+        xa, xl = _hi(x)[:, r0:r1], (x.lo[:, r0:r1] if isinstance(x, Split) else None)
+        kw = dict(A=xa, B=_hi(wpack), D=out[:, r0:r1], M=r1 - r0, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K,
+                  a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
+                  lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Z, batch_inner=1, a_zo=_hi(x).stride(0), b_zo=_hi(wpack).stride(0), d_zo=out.stride(0),
+                  conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, act=act, n_store=Cop)
+        if isinstance(x, Split):                     # implicit-GEMM form of the split-plane kernel (mtt_gemm variant 9): Cp % 32 == 0
+            kw.update(A_lo=xl, B_lo=wpack.lo)
+        if bias is not None:
+            kw.update(colshift=bias, col_zo=bias.stride(0))
+        if colscale is not None:
+            kw.update(colscale=colscale)
+        call("gemm", **kw)
     return out
 
 

@@ -422,12 +422,14 @@ def bn_fold(bns, conv_biases, tag):
 
 
 def _create_task_prompter(variant, pretrained=False, default_cfg=None, **kwargs):
-    if pretrained:
-        raise RuntimeError('pretrained ImageNet weights need network access (taskprompter.py:661 downloads them); '
-                           'construct with pretrained=False and load a checkpoint with load_state_dict')
+    """taskprompter.py:646-668.  pretrained=True (what the reference's get_backbone passes) loads the variant's ImageNet `.npz` from
+    the torch hub cache, where timm's build_model_with_cfg would have downloaded it; never touches the network."""
     kwargs.setdefault('in_chans', 3)
     model = TaskPrompter(**kwargs)
     model.default_cfg = dict(default_cfg or {}, variant=variant)
+    if pretrained:
+        from .checkpoints import load_cached_pretrained
+        load_cached_pretrained(model, variant)
     return model
 
 

@@ -37,8 +37,19 @@ def build_model_with_cfg(model_cls, variant, pretrained, default_cfg, model_cfg=
     if kwargs_filter:
         for k in kwargs_filter:
             kwargs.pop(k, None)
-    if pretrained:
-        raise RuntimeError('pretrained weights cannot be downloaded offline; call with pretrained=False')
     model = model_cls(**kwargs) if model_cfg is None else model_cls(cfg=model_cfg, **kwargs)
     model.default_cfg = default_cfg
+    if pretrained:
+        # timm 0.5.4: pretrained_custom_load -> load_custom_pretrained(model): download_cached_file(url) keeps the file under
+        # <torch.hub.get_dir()>/checkpoints/<basename of the URL> and re-uses it when present, then model.load_pretrained(file).
+        # Offline stand-in: the cached file only.
+        import os
+        from urllib.parse import urlparse
+        import torch
+        if not pretrained_custom_load:
+            raise RuntimeError('torch (.pth) pretrained weights cannot be downloaded offline; call with pretrained=False')
+        cached = os.path.join(torch.hub.get_dir(), 'checkpoints', os.path.basename(urlparse(default_cfg['url']).path))
+        if not os.path.isfile(cached):
+            raise RuntimeError('pretrained weights cannot be downloaded offline and %s is not cached' % cached)
+        model.load_pretrained(cached)
     return model

@@ -45,6 +45,13 @@ def _ref_up9(ws, dtype):
     return torch.stack(out).to(dtype)
 
 
+def same_split(sp, ref32):
+    """a Split pack against the fp32 reference layout: hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even"""
+    hi = ref32.to(torch.bfloat16)
+    same(sp.hi, hi)
+    same(sp.lo, (ref32 - hi.float()).to(torch.bfloat16))
+
+
 def same(a, b):
     assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
     assert torch.equal(a.cpu(), b.cpu()), float((a.float().cpu() - b.float().cpu()).abs().max())
@@ -70,6 +77,14 @@ def check_packs(device):
         same(ops.pack_conv3(ws, prec, 'c'), _ref_conv3(ws, prec.adt, False))
         same(ops.pack_conv3(ws, prec, 'c', transpose=True), _ref_conv3(ws, prec.adt, True))
         same(ops.pack_upconv9(ws, prec, 'u'), _ref_up9(ws, prec.adt))
+    # the same layouts as pre-split planes (x3f: the split-plane implicit-GEMM conv and the nine-tap head GEMM)
+    same_split(ops.pack_conv3_split(ws, 'cs'), _ref_conv3(ws, torch.float32, False))
+    same_split(ops.pack_upconv9_split(ws, 'us'), _ref_up9(ws, torch.float32))
+    w32 = _params(device, [(24, 64, 3, 3)] * 2, 8)                # channel pitch % 32 == 0: pack_conv3 itself picks the split layout under x3f
+    got = ops.pack_conv3(w32, ops.Prec("x3f"), 'c32')
+    assert isinstance(got, ops.Split)
+    same_split(got, _ref_conv3(w32, torch.float32, False))
+    assert not isinstance(ops.pack_conv3(w32, ops.Prec("x3f"), 'c32', transpose=True), ops.Split)      # the dgrad operand stays one bf16 plane
     # padded concatenation (fea_fuse[0]) and bias stacks
     ws = _params(device, [(52, 88, 1, 1)] * 2, 2)
     got = ops.pack_kmap(ws, 52, 96, [(0, 0, 44), (48, 44, 44)], bf, 'k')
@@ -79,6 +94,7 @@ def check_packs(device):
         ref[z, :, :44] = w2[:, :44]
         ref[z, :, 48:92] = w2[:, 44:]
     same(got, ref.to(torch.bfloat16))
+    same_split(ops.pack_kmap_split(ws, 52, 96, [(0, 0, 44), (48, 44, 44)], 'ks'), ref)
     bs = _params(device, [(301,)] * 4, 3)
     same(ops.stack_vec(bs, 'b'), torch.stack([b.detach() for b in bs]))
     # transposed packs: tiles with ragged edges, several tiles per chunk, and the small-matrix fallback
@@ -117,6 +133,18 @@ def check_refresh(device):
     same(ops.pack_linear(ws, bf, 'r'), _ref_linear(ws, torch.bfloat16))
     ops.bump_param_epoch()
     same(ops.pack_conv3(cs, bf, 'rc'), _ref_conv3(cs, torch.bfloat16, False))
+    same(ops.pack_linear(ws, bf, 'r'), _ref_linear(ws, torch.bfloat16))
+    # two models in one process: a step on the parameters of ONE pack must not invalidate a pending backward that saved
+    # the OTHER pack — the refresh rewrites every pack, but only the packs whose own parameters moved get their autograd version bumped
+    a, c = ops.pack_linear(ws, bf, 'r'), ops.pack_conv3(cs, bf, 'rc')
+    va, vc = a._version, c._version
+    with torch.no_grad():
+        for p in ws:
+            p.mul_(0.5)
+    ops.bump_param_epoch()
+    n1 = ops.pack_refreshes
+    assert ops.pack_conv3(cs, bf, 'rc') is c and ops.pack_refreshes == n1 + 1     # the epoch moved: refreshed (identical bytes) ...
+    assert c._version == vc and a._version > va                                  # ... but only the changed pack's version moved
     same(ops.pack_linear(ws, bf, 'r'), _ref_linear(ws, torch.bfloat16))
 
 

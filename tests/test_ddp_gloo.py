@@ -137,7 +137,8 @@ def test_ddp_ranks_match_single_process(case):
         from oracle import invpt_oracle as orc
     out = orc.forward(dict(sd, **params), cfg, x, training=True)
     _loss(out, list(range(n_total)), n_total, 1).backward()
-    worst, errs = 0.0, []
+    worst, errs, big = 0.0, [], []
+    gmax = max(float(p_.grad.norm()) for p_ in params.values() if p_.grad is not None)
     for k, ref in params.items():
         if ref.grad is None or float(ref.grad.norm()) < (1e-6 if _mode(case)[0] == "x3" else 1e-4):
             continue
@@ -145,12 +146,49 @@ def test_ddp_ranks_match_single_process(case):
         e = float((torch.from_numpy(got[k]) - ref.grad).norm() / ref.grad.norm())
         worst = max(worst, e)
         errs.append(e)
+        if float(ref.grad.norm()) > 1e-2 * gmax:
+            big.append((e, k))
     errs.sort()
     if _mode(case)[0] == "x3":
         assert worst < _mode(case)[1], worst
-    else:                                   # bf16 backward: bound the median (single near-zero gradients can be off by more)
+    else:
+        # bf16 backward: the median and the 90th percentile over all parameters (single near-zero gradients can be off by more), AND a
+        # worst-case bound on every gradient of non-negligible norm (> 1 % of the largest): one wrong parameter gradient must not pass
         assert errs[len(errs) // 2] < 3e-2 and errs[int(len(errs) * 0.9)] < _mode(case)[1], (errs[len(errs) // 2], worst)
+        assert big and max(big)[0] < 8e-2, sorted(big, reverse=True)[:5]
     # SyncBN statistics: one all_gather per BatchNorm STAGE (a stage = all tasks' BatchNorms at one point of the network), not one
     # per BatchNorm layer: TaskPrompter has 4 taps + 1 head stage; InvPT's decoder has 2 + 3*... stages (fewer than its 2*T*... layers)
     n_layers = sum(1 for k in sd if k.endswith("running_mean"))
     assert 0 < n_stage_collectives < n_layers, (n_stage_collectives, n_layers)
+
+
+def _run_bench_emulated(*flags, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "bench_emulated.py"), "--device", "cpu", "--config", "mini",
+                        "--steps", "2", "--warmup", "1", "--no-fwd"] + list(flags), capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus N` (the driver's form, no torchrun around it) must start N ranks itself (TaskPrompter/main.py:32,92-94 under
+    run_taskprompter_*.sh:1): here N = 2 over gloo on the CPU emulator, miniature config.  The line reports n_gpus = 2, a global batch of
+    2 x the per-GPU batch (weak scaling) and whole-job throughput; --gpus 1 stays a single process without a process group."""
+    two = _run_bench_emulated("--gpus", "2")
+    assert two["n_gpus"] == 2 and two["config"]["gloo_ranks"] == 2 and two["config"]["parallelism"] == "dp2"
+    assert two["config"]["global_batch"] == 2 * two["config"]["per_gpu_batch"] and two["scaling"] == "weak"
+    assert abs(two["value"] - two["config"]["global_batch"] / (two["ms_per_step"] * 1e-3)) < 1e-2 * two["value"]
+    assert two["git"]["head"] and two["git"]["tree_sha"]
+    one = _run_bench_emulated("--gpus", "1")
+    assert one["n_gpus"] == 1 and one["config"]["gloo_ranks"] is None and one["config"]["parallelism"] == "dp1"
+    # the same seeded weights, rank 0's batch is the single process's batch; SyncBN + the gradient mean change the trajectory, not the scale
+    assert abs(two["config"]["loss"] - one["config"]["loss"]) < 0.5 * abs(one["config"]["loss"])

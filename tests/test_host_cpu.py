@@ -141,6 +141,34 @@ def test_x3f_decoder_convs_and_head_gemm_run_on_split_planes(emulated, monkeypat
     assert not any(s[0] == "gemm" and s[1] == 2 and s[2] == 0 and s[4] == 1 for s in seen), "a forward 3x3 conv still on the register-staged x3 kernel"
 
 
+def test_split_plane_conv_chunks_the_batch_at_the_kernels_row_limit(emulated, monkeypatch):
+    """mtt_gemm variant 9 addresses a batch member's pixel rows with 32-bit element offsets (M * pitch < 2^31, gemm_variant_for); beyond
+    it ops.conv3x3 launches chunks of whole images instead of raising MTT_E_UNSUPPORTED.  With the limit lowered to one
+    image the result must be bitwise the unchunked one; the pack falls back to the non-split layout outside the kernel's other limits."""
+    import mtt_amd
+    ops = mtt_amd.ops
+    g = torch.Generator().manual_seed(0)
+    Z, B, H, W, Ci, Co = 2, 3, 5, 4, 32, 24
+    prec = ops.Prec("x3f")
+    ws = [torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, generator=g) * 0.1) for _ in range(Z)]
+    wp = ops.pack_conv3(ws, prec, "chunk_test")
+    assert isinstance(wp, ops.Split)
+    x = torch.randn(Z, B * H * W, Ci, generator=g)
+    bias = torch.randn(Z, Co, generator=g)
+    whole = ops.conv3x3(x, wp, Co, Ci, B, H, W, prec, bias=bias, out_dtype=torch.float32)
+    calls = []
+    inner = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, **kw: (calls.append((name, kw.get("M"))), inner(name, **kw))[1])
+    monkeypatch.setattr(ops, "SPLIT_CONV_MAX_ELEMS", H * W * Ci)
+    chunked = ops.conv3x3(x, wp, Co, Ci, B, H, W, prec, bias=bias, out_dtype=torch.float32)
+    assert [c for c in calls if c[0] == "gemm"] == [("gemm", H * W)] * B
+    assert torch.equal(whole, chunked)
+    ref = torch.nn.functional.conv2d(x[0].view(B, H, W, Ci).permute(0, 3, 1, 2), ws[0].detach(), bias[0], padding=1).permute(0, 2, 3, 1)
+    assert float((whole[0].view(B, H, W, -1)[..., :Co] - ref).norm() / ref.norm()) < 1e-4
+    assert ops.split_conv_ok(352, 352) and not ops.split_conv_ok(300) and not ops.split_conv_ok(8192, 64) and not ops.split_conv_ok(4096, 60000)
+    ops.clear_pack_cache()
+
+
 def test_bf16_training_uses_flash_attention_backward(emulated, monkeypatch):
     """bf16 mode routes the attention backward to mtt_attn_bwd (flash, no N x N buffer); gradients stay bf16-accurate."""
     import mtt_amd
@@ -387,6 +415,17 @@ def test_flax_vit_checkpoint_import_matches_reference_loader():
             filt = mtt_amd.checkpoints.filter_state_dict(raw, model.backbone)
             for k, v in filt.items():
                 assert np.abs(v.numpy() - gold[f"TP/filter_out/{k}"]).max() < 1e-5, k
+
+
+def test_training_trajectory_harness_on_emulator(emulated):
+    """The harness of tests/test_gpu_train.py::test_mixed_precision_training_trajectory_... (200 steps on the device) run for 8 steps on
+    the emulator: x3f and x3 against the oracle's fp32 training from the same state, the reference's criterion, clip + Adam."""
+    import train_check
+    curves = train_check.trajectory_check("mini_ctr", ["x3f", "x3"], "cpu", steps=8, lr=2e-4)
+    gaps = train_check.trajectory_gaps(curves, window=4)
+    assert curves["x3"][0] == pytest.approx(curves["oracle"][0], rel=1e-5) and curves["x3f"][0] == pytest.approx(curves["oracle"][0], rel=1e-5)
+    assert gaps["x3"][0] < 2e-3 and gaps["x3f"][0] < 5e-3, gaps
+    assert curves["oracle"][-1] < curves["oracle"][0]
 
 
 def test_multi_step_training_rebuilds_weight_packs(emulated):

@@ -154,3 +154,72 @@ def swin_grad_errors(name, prec, device, seed=0, drop=None, batch=2, contract=No
         assert prm.grad is not None, f"{k}: no gradient"
         errs[k] = (float((prm.grad.cpu() - rg).norm()), float(rg.norm()))
     return fwd, errs, dead
+
+
+def trajectory_check(name, modes, device, steps=200, lr=2e-4, n_batches=4, batch=2, seed=0):
+    """`steps` optimizer steps of the whole training iteration — forward (train-mode BatchNorm), the reference's criterion
+    (MultiTaskLoss; the product uses its fused HIP form), backward, clip_grad_norm_(10) + Adam (train_utils.py:32-51) — from the same
+    state on the same cycle of `n_batches` synthetic batches: the CPU oracle (fp32 autograd, torch.optim.Adam) and the product in every
+    arithmetic mode of `modes`.  Returns {"oracle": [loss per step], mode: [...]}: what bounds how far mixed-precision training
+    (x3f: fp32-class forward, bf16 backward) drifts from the reference's fp32 training over a few hundred steps."""
+    import mtt_amd
+    cfg = configs.taskprompter(name)
+    meta, _ = conftest.load_golden(name)
+    sd = weights.synth_state_dict(meta["contract"], seed)
+    H, W = cfg["img_size"]
+    xs = [weights.synth_images(batch, cfg["img_size"], 20 + i) for i in range(n_batches)]
+    curves = {}
+    p = None
+    for mode in modes:
+        model = conftest.build_product_model(cfg, mode, device)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        p = model.backbone.p
+        crit = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES).to(device)
+        gts = [mtt_amd.losses.synthetic_targets(p, batch, H, W, device, seed=30 + i) for i in range(n_batches)]
+        opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=lr, weight_decay=1e-6, max_norm=10.0)
+        xd = [x.to(device) for x in xs]
+        ls = []
+        for it in range(steps):
+            loss = crit(model(xd[it % n_batches]), gts[it % n_batches])["total"]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            ls.append(loss.detach())
+        curves[mode] = [float(v) for v in torch.stack(ls).cpu()]
+        del model, opt, crit
+        mtt_amd.ops.clear_pack_cache()
+    ref = {k: v.clone() for k, v in sd.items()}
+    params = {k: ref[k].requires_grad_(True) for k in ref if ref[k].dtype.is_floating_point and "running_" not in k}
+    ropt = torch.optim.Adam(list(params.values()), lr=lr, weight_decay=1e-6)
+    rcrit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)
+    rgts = [mtt_amd.losses.synthetic_targets(p, batch, H, W, "cpu", seed=30 + i) for i in range(n_batches)]
+    ls = []
+    for it in range(steps):
+        # BatchNorm running statistics are state too: the oracle returns the updated buffers through `ref` (in place)
+        loss = rcrit(tpo.forward(ref, cfg, xs[it % n_batches], training=True), rgts[it % n_batches])["total"]
+        ropt.zero_grad(set_to_none=True)
+        loss.backward()
+        for q in params.values():
+            if q.grad is None:
+                q.grad = torch.zeros_like(q)
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 10.0)
+        ropt.step()
+        ls.append(float(loss.detach()))
+    curves["oracle"] = ls
+    return curves
+
+
+def trajectory_gaps(curves, window=10):
+    """per mode: (max over steps of |loss - oracle| / oracle, the same on `window`-step running means, final-window relative gap)"""
+    import numpy as np
+    o = np.asarray(curves["oracle"])
+    res = {}
+    for m, c in curves.items():
+        if m == "oracle":
+            continue
+        c = np.asarray(c)
+        k = np.ones(window) / window
+        os_, cs_ = np.convolve(o, k, "valid"), np.convolve(c, k, "valid")
+        res[m] = (float(np.max(np.abs(c - o) / np.abs(o))), float(np.max(np.abs(cs_ - os_) / np.abs(os_))), float(abs(cs_[-1] - os_[-1]) / abs(os_[-1])))
+    return res
