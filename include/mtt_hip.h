@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 8
+#define MTT_ABI_VERSION 9
 
 /* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
  * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
@@ -259,6 +259,8 @@ typedef struct {
   float* dsum; float* dsumxh;
   int64_t rows; int32_t C; int64_t ld; int32_t dtype; int32_t act;
   int32_t Z; int64_t x_zs; int64_t p_zs;
+  int32_t g_dtype;   /* ABI 9, bwd_reduce / bwd_apply: storage of dy and dx = MTT_* dtype code + 1 (same pitch and map stride in ELEMENTS as
+                      * x); 0 = the dtype of x.  Lets a bf16-arithmetic backward keep its gradient maps in bf16 next to an fp32-stored x */
 } mtt_bn_desc;
 size_t mtt_bn_reduce_ws_floats(int64_t rows, int32_t C, int32_t Z);
 int mtt_bn_stats(const mtt_bn_desc* d, float* ws, void* stream);

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -105,7 +105,7 @@ class BnDesc(C.Structure):
                 ("mean_out", ptr), ("m2_out", ptr), ("mean", ptr), ("rstd", ptr), ("gamma", ptr), ("beta", ptr),
                 ("dsum", ptr), ("dsumxh", ptr),
                 ("rows", i64), ("C", i32), ("ld", i64), ("dtype", i32), ("act", i32),
-                ("Z", i32), ("x_zs", i64), ("p_zs", i64)]
+                ("Z", i32), ("x_zs", i64), ("p_zs", i64), ("g_dtype", i32)]
 
 
 class DwconvDesc(C.Structure):

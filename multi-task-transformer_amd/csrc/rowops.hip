@@ -879,8 +879,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const mtt_bn_desc d, int
   const int c8 = threadIdx.x % C8, rl = threadIdx.x / C8;
   const int z = blockIdx.y;
   const int es = d.dtype == MTT_F32 ? 4 : 2;
+  const int gdt = d.g_dtype ? d.g_dtype - 1 : d.dtype, ges = gdt == MTT_F32 ? 4 : 2;       // dy may be stored narrower than x (ABI 9)
   const unsigned char* xz = (const unsigned char*)d.x + (int64_t)z * d.x_zs * es;
-  const unsigned char* dyz = (const unsigned char*)d.dy + (int64_t)z * d.x_zs * es;
+  const unsigned char* dyz = (const unsigned char*)d.dy + (int64_t)z * d.x_zs * ges;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
   float a0[8], a1[8], sh[8];
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const mtt_bn_desc d, int
       for (int64_t r = r0 + rl; r < r1; r += lanes) {
         float x[8], v[8];
         ld8(xz, r * d.ld + c8 * 8, d.dtype, x);
-        ld8(dyz, r * d.ld + c8 * 8, d.dtype, v);
+        ld8(dyz, r * d.ld + c8 * 8, gdt, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = (x[j] - mu[j]) * rs[j];
@@ -993,10 +994,11 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
   if (rl >= lanes) return;
   const int z = blockIdx.y;
   const int es = d.dtype == MTT_F32 ? 4 : 2;
-  const int64_t zoff = (int64_t)z * d.x_zs * es, pz = (int64_t)z * d.p_zs;
+  const int gdt = (BWD && d.g_dtype) ? d.g_dtype - 1 : d.dtype, ges = gdt == MTT_F32 ? 4 : 2;    // BWD: dy / dx may be stored narrower than x (ABI 9)
+  const int64_t zoff = (int64_t)z * d.x_zs * es, goff = (int64_t)z * d.x_zs * ges, pz = (int64_t)z * d.p_zs;
   const unsigned char* xz = (const unsigned char*)d.x + zoff;
-  const unsigned char* dyz = (const unsigned char*)d.dy + zoff;
-  unsigned char* oz = (unsigned char*)(BWD ? d.dx : d.y) + zoff;
+  const unsigned char* dyz = (const unsigned char*)d.dy + goff;
+  unsigned char* oz = (unsigned char*)(BWD ? d.dx : d.y) + (BWD ? goff : zoff);
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
   const float invn = 1.0f / (float)d.rows;
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
       ld8(xz, r * d.ld + c8 * 8, d.dtype, x);
       if (BWD) {
         float g[8];
-        ld8(dyz, r * d.ld + c8 * 8, d.dtype, g);
+        ld8(dyz, r * d.ld + c8 * 8, gdt, g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = (x[j] - mu[j]) * rs[j];
@@ -1032,7 +1034,7 @@ __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (c8 * 8 + j >= d.C) o[j] = 0.f;
       }
-      st8(oz, r * d.ld + c8 * 8, d.dtype, o);
+      st8(oz, r * d.ld + c8 * 8, BWD ? gdt : d.dtype, o);
     }
   }
 }

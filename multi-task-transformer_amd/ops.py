@@ -842,16 +842,19 @@ def bn_bwd_reduce(x, dy, C, mean, rstd, gamma, beta, act):
     x, dy = _as3(x), _as3(dy)
     Z, rows, ld = x.shape
     s = torch.empty(2, Z, C, dtype=torch.float32, device=x.device)
+    assert dy.shape == x.shape and dy.stride() == x.stride()
     call("bn_bwd_reduce", x=x, dy=dy, mean=mean, rstd=rstd, gamma=gamma, beta=beta, dsum=s[0], dsumxh=s[1], rows=rows, C=C, ld=ld,
-         dtype=dtype_code(x), act=act, Z=Z, x_zs=x.stride(0), p_zs=C, xargs=[_bn_ws(rows, C, Z, x.device)])
+         dtype=dtype_code(x), g_dtype=dtype_code(dy) + 1, act=act, Z=Z, x_zs=x.stride(0), p_zs=C, xargs=[_bn_ws(rows, C, Z, x.device)])
     return s
 
 
 def bn_bwd_apply(x, dy, C, mean, rstd, gamma, beta, act, red):
-    """dx from the (rank-summed, pre-scaled to the local row count) sums `red` [2, Z, C]."""
+    """dx from the (rank-summed, pre-scaled to the local row count) sums `red` [2, Z, C]; dx is stored like dy (which may be bf16 next
+    to an fp32-stored x: the gradient maps of a bf16-arithmetic backward, mtt_bn_desc.g_dtype)."""
     x3, dy3 = _as3(x), _as3(dy)
     Z, rows, ld = x3.shape
-    dx = torch.empty_like(x)
+    assert dy3.shape == x3.shape and dy3.stride() == x3.stride()
+    dx = torch.empty_like(dy)
     call("bn_bwd_apply", x=x3, dy=dy3, dx=dx, mean=mean, rstd=rstd, gamma=gamma, beta=beta, dsum=red[0], dsumxh=red[1], rows=rows, C=C,
-         ld=ld, dtype=dtype_code(x3), act=act, Z=Z, x_zs=x3.stride(0), p_zs=C)
+         ld=ld, dtype=dtype_code(x3), g_dtype=dtype_code(dy3) + 1, act=act, Z=Z, x_zs=x3.stride(0), p_zs=C)
     return dx

@@ -658,6 +658,16 @@ def row_cases():
         kw = dict(x=xs, dy=dys, dx=torch.full((Zs, rows2, ld), 5.0, dtype=DT[dt]), mean=means, rstd=rstds, gamma=gams, beta=bets,
                   dsum=rnd(g, Zs, C), dsumxh=rnd(g, Zs, C), rows=rows2, C=C, ld=ld, dtype=dt, act=2, Z=Zs, x_zs=rows2 * ld, p_zs=C)
         cases.append((f"bn_bwd_apply_stack_{dt}", "bn_bwd_apply", kw, TOL_ROW))
+        if dt == F32:
+            # ABI 9 (mtt_bn_desc.g_dtype): x fp32, dy / dx bf16 with the same pitch and map stride in elements — the gradient maps of a
+            # bf16-arithmetic backward next to the fp32-stored conv output of the x3f forward (ConvHeadFn)
+            dyb = dys.to(torch.bfloat16)
+            kw = dict(x=xs, dy=dyb, mean=means, rstd=rstds, gamma=gams, beta=bets, dsum=torch.zeros(Zs, C), dsumxh=torch.zeros(Zs, C),
+                      rows=rows2, C=C, ld=ld, dtype=F32, g_dtype=BF16 + 1, act=1, Z=Zs, x_zs=rows2 * ld, p_zs=C, xargs=[scratch(1 << 18)])
+            cases.append(("bn_bwd_reduce_stack_x32_g16", "bn_bwd_reduce", kw, TOL_ROW))
+            kw = dict(x=xs, dy=dyb, dx=torch.full((Zs, rows2, ld), 5.0, dtype=torch.bfloat16), mean=means, rstd=rstds, gamma=gams, beta=bets,
+                      dsum=rnd(g, Zs, C), dsumxh=rnd(g, Zs, C), rows=rows2, C=C, ld=ld, dtype=F32, g_dtype=BF16 + 1, act=1, Z=Zs, x_zs=rows2 * ld, p_zs=C)
+            cases.append(("bn_bwd_apply_stack_x32_g16", "bn_bwd_apply", kw, TOL_ROW))
         cases.append((f"cast2d_{dt}", "cast2d", dict(args=[rnd(g, 30, 20), torch.full((30, 24), 4.0, dtype=DT[dt]), 30, 18, 20, 24, F32, dt, 1]), TOL_ROW))
         cases.append((f"colsum_{dt}", "colsum", dict(args=[rnd(g, 300, 56, dtype=DT[dt]), torch.full((52,), 3.0), 300, 52, 56, dt, scratch(300 * 56)]), TOL_ROW))
         for (r_, c_, ld_) in ((5000, 4104, 4112), (1031, 350, 352), (70, 1024, 1024)):     # two column chunks + ragged tail / row lanes / few rows

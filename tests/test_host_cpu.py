@@ -169,6 +169,42 @@ def test_split_plane_conv_chunks_the_batch_at_the_kernels_row_limit(emulated, mo
     ops.clear_pack_cache()
 
 
+def test_conv_head_as_one_node_keeps_its_gradient_maps_in_the_backwards_dtype(emulated, monkeypatch):
+    """ConvHeadFn (conv -> BatchNorm -> predictions as ONE autograd node): in x3f the head's gradient maps are bf16 tensors next to the
+    fp32-stored conv output (mtt_bn_desc.g_dtype, the gather kernel's bf16 input) and the gradients equal the three-node form's within
+    bf16 storage rounding; in x3 the two forms are the same arithmetic."""
+    import importlib
+    import mtt_amd
+    import train_check
+    ap = importlib.import_module("multi-task-transformer_amd.autograd_path")
+    seen = []
+    inner = mtt_amd.ops.call
+
+    def spy(name, **kw):
+        if name in ("bn_bwd_reduce", "bn_bwd_apply", "upconv4_gather"):
+            seen.append((name, kw.get("g_dtype"), kw.get("y_dtype"), kw.get("z_dtype"), kw["dy"].dtype if "dy" in kw else None, kw["x"].dtype if "x" in kw else None))
+        return inner(name, **kw)
+    monkeypatch.setattr(mtt_amd.ops, "call", spy)
+    _, fused = train_check.grad_errors("mini_ctr", "x3f", "cpu")
+    head = [s_ for s_ in seen if s_[0] == "bn_bwd_reduce"][0]            # the first BatchNorm backward of the step is the heads'
+    assert head[1] == 2 and head[4] == torch.bfloat16 and head[5] == torch.float32, head
+    gath = [s_ for s_ in seen if s_[0] == "upconv4_gather"][0]
+    assert gath[2] == 1 and gath[3] == 1, gath                             # bf16 in, bf16 out: no cast pass before the tap GEMMs
+    monkeypatch.setattr(ap, "FUSE_HEAD_NODE", False)
+    seen.clear()
+    _, plain = train_check.grad_errors("mini_ctr", "x3f", "cpu")
+    assert [s_ for s_ in seen if s_[0] == "bn_bwd_reduce"][0][4] == torch.float32
+    wf, mf = train_check.summarize(fused, floor=1e-4)
+    wp, mp = train_check.summarize(plain, floor=1e-4)
+    assert mf < 3e-2 and mf < 1.5 * mp + 1e-3, (mf, mp)                    # against the oracle's autograd: the same bf16-class accuracy
+    for prec_name in ("x3",):
+        monkeypatch.setattr(ap, "FUSE_HEAD_NODE", True)
+        _, a = train_check.grad_errors("mini_ctr", prec_name, "cpu")
+        monkeypatch.setattr(ap, "FUSE_HEAD_NODE", False)
+        _, b = train_check.grad_errors("mini_ctr", prec_name, "cpu")
+        assert all(abs(a[k][0] - b[k][0]) <= 1e-6 * max(a[k][1], 1e-12) + 1e-12 for k in a), "x3: the node fusion must not change the arithmetic"
+
+
 def test_bf16_training_uses_flash_attention_backward(emulated, monkeypatch):
     """bf16 mode routes the attention backward to mtt_attn_bwd (flash, no N x N buffer); gradients stay bf16-accurate."""
     import mtt_amd

@@ -13,6 +13,10 @@ import torch  # noqa: E402
 import mtt_amd  # noqa: E402
 from mtt_amd import ops  # noqa: E402
 
+if "--lib" in sys.argv:                      # A/B builds (python multi-task-transformer_amd/_build.py --variant NAME -D...): one library per process
+    mtt_amd._lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+print(f"library: {mtt_amd._lib.LIB_PATH}", flush=True)
+
 x3, x3f = ops.Prec("x3"), ops.Prec("x3f")
 M = 63 * 1024
 
@@ -53,3 +57,15 @@ for name, Z, N, K, pair in (("fea_decode", 12, 300, 1024, True), ("fea_fuse0", 6
     err_sp = float((osp.hi.float() + osp.lo.float() - o32).norm() / o32.norm())
     print(f"{name:10s} Z={Z} M={M} N={N} K={K}: register-staged x3 {t_reg:7.1f} us | ring3 on planes {t_ring:7.1f} us (fp32 out; split out {t_ring_sp:7.1f} us), "
           f"split_cast of A {t_cast:6.1f} us | rel diff {err:.1e} / {err_sp:.1e}", flush=True)
+
+# the fea_fuse 3x3 conv (6 x [63 * 32 * 32, 352] -> 350, K = 9 * 352) and the nine-tap head GEMM (N = 9 * 352) on planes
+Z, Ci, Co, B, H, W = 6, 350, 350, 63, 32, 32
+Cp = ops.pad8(Ci)
+xs = ops.Split.empty((Z, B * H * W, Cp), "cuda")
+xs.hi.normal_(); xs.lo.normal_(std=1e-3)
+ws = [torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05) for _ in range(Z)]
+wc = ops.pack_conv3_split(ws, "bconv")
+t_conv = timed(lambda: ops.conv3x3(xs, wc, Co, Ci, B, H, W, x3f, out_dtype=torch.float32))
+w9 = ops.pack_upconv9_split(ws, "b9")
+t_nine = timed(lambda: ops.linear(xs, w9, w9.shape[1], x3f, out_dtype=torch.float32))
+print(f"conv3x3 on planes (N = 350, K = 3168, z = 6): {t_conv:7.1f} us | nine-tap head GEMM (N = {w9.shape[1]}, K = 352, z = 6): {t_nine:7.1f} us", flush=True)
