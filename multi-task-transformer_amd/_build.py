@@ -58,7 +58,12 @@ def build_variant(name, defines, source="gemm.hip"):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python _build.py --variant NAME -DFOO=1 ...
-        print(build_variant(sys.argv[2], sys.argv[3:]))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python _build.py --variant NAME [--source attn_fast.hip] -DFOO=1 ...
+        rest, src = sys.argv[3:], "gemm.hip"
+        if "--source" in rest:
+            i = rest.index("--source")
+            src = rest[i + 1]
+            del rest[i:i + 2]
+        print(build_variant(sys.argv[2], rest, source=src))
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

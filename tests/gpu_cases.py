@@ -439,8 +439,9 @@ def attn_cases():
                   xargs=[rnd(g, B * N, C, dtype=DT[BF16]), rnd(g, B, nH, T, N) * 0.05, torch.zeros(B * N, 3 * C, dtype=DT[BF16]),
                          torch.zeros(B, nH, 2, (N + 3) // 4 * 4)])
         cases.append((f"attn_bwd_B{B}N{N}T{T}_variant{variant}", "attn_bwd", kb, dict(f32=5e-3, bf16=1.5e-2)))
-    # x3 attention on split planes (qkv hi / lo in, out hi / lo + lse + raw prompt logits out): the x3f mode's forward
-    for (B, N, nH, T) in ((2, 150, 2, 6), (1, 257, 1, 0)):
+    # x3 attention on split planes (qkv hi / lo in, out hi / lo + lse + raw prompt logits out): the x3f mode's forward.  Ragged ends:
+    # N = 257 / 70 / 1030 end in a key tile of <= 16 keys and in a 16-row sub-block without query rows; 150 in neither
+    for (B, N, nH, T) in ((2, 150, 2, 6), (1, 257, 1, 0), (1, 70, 2, 3), (1, 1030, 1, 6)):
         C = nH * 64
         q = rnd(g, B * N, 3 * C)
         qh = q.to(torch.bfloat16)
