@@ -833,40 +833,43 @@ class _SubCtx:
 
 
 class ConvHeadFn(Function):
-    """ConvHead of ALL tasks as ONE autograd node (taskprompter.py:688-698 behind the x4 resize of :420): UpConv3x3Fn -> BnActStackFn ->
-    TaskHeadsFn, the same kernels in the same order.  What the fusion of the NODE buys is the backward's storage: between separate
-    nodes a gradient must have its tensor's dtype, and in the x3f mode (fp32-class forward on fp32-stored head maps, bf16 backward)
-    that made every gradient map of the head — 6 tasks x B x 128 x 128 x 352 fp32 = 8.7 GB at the benchmark's batch — an fp32 tensor
-    that the bf16-arithmetic backward rounded while reading.  Inside one node the maps are stored in the backward's own dtype
-    (`prec.bwd.adt`): the prediction dgrad writes bf16, BatchNorm's reduce / apply read and write bf16 next to the fp32 conv output
-    (mtt_bn_desc.g_dtype), the gather kernel reads bf16 and writes the bf16 operand of the tap GEMMs directly (no cast pass).
-    geo = (B, h, w, F); params = Z conv weights, Z conv biases, Z BN weights, Z BN biases, Z prediction weights, Z prediction biases."""
+    """A conv head of ALL tasks as ONE autograd node: [up4 +] Conv3x3 -> BatchNorm (batch statistics) + activation -> the per-task 1x1
+    predictions — ConvHead behind the x4 resize (taskprompter.py:420, :688-698: UpConv3x3Fn -> BnActStackFn -> TaskHeadsFn) and InvPT's
+    mt_proj + MLPHead (invpt.py:538-541, transformer_decoder.py:124-131: Conv3x3Fn -> BnActStackFn -> TaskHeadsFn); the same kernels in the
+    same order.  What the fusion of the NODE buys is the backward's storage: between separate nodes a gradient must have its tensor's
+    dtype, and in the x3f mode (fp32-class forward on fp32-stored head maps, bf16 backward) that made every gradient map of the head —
+    6 tasks x B x 128 x 128 x 352 fp32 = 8.7 GB at the benchmark's batch — an fp32 tensor that the bf16-arithmetic backward rounded while
+    reading.  Inside one node the maps are stored in the backward's own dtype (`prec.bwd.adt`): the prediction dgrad writes bf16,
+    BatchNorm's reduce / apply read and write bf16 next to the fp32 conv output (mtt_bn_desc.g_dtype), the gather kernel / conv dgrad
+    read bf16 (no cast pass).  spec = (first stage 'up' | 'conv', its geo, its tag, C, act, prediction tag);
+    params = Z conv weights, Z conv biases (or None), Z BN weights, Z BN biases, Z prediction weights, Z prediction biases."""
 
     @staticmethod
-    def forward(ctx, fea, geo, prec, training, bns, *params):
-        B, h, w, F = geo
+    def forward(ctx, fea, spec, prec, training, bns, *params):
+        kind, geo, tag1, C, act, ptag = spec
         Z = len(params) // 6
         cw, cb, bg, bb, pw, pb = (params[i * Z:(i + 1) * Z] for i in range(6))
         c1, c2, c3 = _SubCtx(), _SubCtx(), _SubCtx()
-        y = UpConv3x3Fn.forward(c1, fea, (B, h, w, F, F), prec, 'hc9', *cw, *cb)
-        ya = BnActStackFn.forward(c2, y, F, ACT_GELU, training, bns, *bg, *bb)
-        preds = TaskHeadsFn.forward(c3, ya, prec, 'hp', *pw, *pb)
+        Stage1 = UpConv3x3Fn if kind == 'up' else Conv3x3Fn
+        y = Stage1.forward(c1, fea, geo, prec, tag1, *cw, *cb)
+        ya = BnActStackFn.forward(c2, y, C, act, training, bns, *bg, *bb)
+        preds = TaskHeadsFn.forward(c3, ya, prec, ptag, *pw, *pb)
         n1, n2 = len(c1.saved_tensors), len(c2.saved_tensors)
         ctx.save_for_backward(*c1.saved_tensors, *c2.saved_tensors, *c3.saved_tensors)
-        ctx.sub = (n1, n2, c1.meta, c2.meta, c3.meta, Z)
+        ctx.sub = (n1, n2, c1.meta, c2.meta, c3.meta, Z, Stage1)
         ctx.grad_dtype = prec.bwd.adt
         return preds
 
     @staticmethod
     def backward(ctx, *dps):
-        n1, n2, m1, m2, m3, Z = ctx.sub
+        n1, n2, m1, m2, m3, Z, Stage1 = ctx.sub
         sv = ctx.saved_tensors
         c1, c2, c3 = _SubCtx(sv[:n1]), _SubCtx(sv[n1:n1 + n2]), _SubCtx(sv[n1 + n2:])
         c1.meta, c2.meta, c3.meta = m1, m2, m3
         c3.grad_dtype = ctx.grad_dtype
         g3 = TaskHeadsFn.backward(c3, *dps)                 # (dya in grad_dtype, None, None, dW_pred x Z, db_pred x Z)
         g2 = BnActStackFn.backward(c2, g3[0])               # (dy in grad_dtype, None x 4, dgamma x Z, dbeta x Z)
-        g1 = UpConv3x3Fn.backward(c1, g2[0])                # (dfea in fea's dtype, None x 3, dW_conv x Z, db_conv x Z)
+        g1 = Stage1.backward(c1, g2[0])                     # (dfea in fea's dtype, None x 3, dW_conv x Z, db_conv x Z)
         return (g1[0], None, None, None, None) + tuple(g1[4:]) + tuple(g2[5:]) + tuple(g3[3:])
 
 
@@ -1052,8 +1055,8 @@ def heads_forward(kind, heads, fea, B, h4, w4, target, prec, training, lowres=Fa
         pred_w, pred_b = [hd.linear_pred.weight for hd in heads], [hd.linear_pred.bias for hd in heads]
         if lowres and FUSE_HEAD_NODE:
             bns = [hd.mt_proj[1] for hd in heads]
-            preds = ConvHeadFn.apply(fea, (B, h4 // 4, w4 // 4, F), prec, training, bns, *conv_w, *conv_b, *[bn.weight for bn in bns],
-                                     *[bn.bias for bn in bns], *pred_w, *pred_b)
+            preds = ConvHeadFn.apply(fea, ('up', (B, h4 // 4, w4 // 4, F, F), 'hc9', F, ACT_GELU, 'hp'), prec, training, bns,
+                                     *conv_w, *conv_b, *[bn.weight for bn in bns], *[bn.bias for bn in bns], *pred_w, *pred_b)
         else:
             if lowres:
                 y = UpConv3x3Fn.apply(fea, (B, h4 // 4, w4 // 4, F, F), prec, 'hc9', *conv_w, *conv_b)

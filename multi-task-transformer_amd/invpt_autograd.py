@@ -16,7 +16,8 @@ from torch.autograd import Function
 
 from . import ops
 from ._lib import ACT_NONE, ACT_RELU, F32, OP_K, OP_R, dtype_code
-from .autograd_path import (AttnHalfFn, MlpHalfFn, BLinearFn, BilinearFn, Conv3x3Fn, LayerNormFn, TaskHeadsFn, _bn_act,
+from . import autograd_path
+from .autograd_path import (AttnHalfFn, MlpHalfFn, BLinearFn, BilinearFn, Conv3x3Fn, ConvHeadFn, LayerNormFn, TaskHeadsFn, _bn_act,
                             _colsum, _dgrad, _gemm, _wgrad)
 
 pad8 = ops.pad8
@@ -274,6 +275,42 @@ class FuseAttnFn(Function):
 
 
 # =================================================================================================
+class MultiScaleSumFn(Function):
+    """acc = sum_i bilinear(y_i -> (th, tw)) over the InvPT stages' task stacks y_i [T, B*gh_i*gw_i, ld] (invpt.py:531-536: every stage's
+    normalised features resized to the target resolution and summed) as ONE node: the first resize writes the fp32 sum buffer, the others
+    accumulate into it inside the kernel (mtt_resize_desc.accumulate) — no separate [T, B*th*tw, ld] tensor per stage and no add passes
+    (2 x 21.6 GB of traffic at the cfg4 batch); a stage that already has the target resolution is added / differentiated as the identity
+    it is (its backward hands the incoming gradient through instead of running the adjoint resize)."""
+
+    @staticmethod
+    def forward(ctx, geo, *ys):
+        B, C, th, tw, sizes = geo
+        T, _, ld = ys[0].shape
+        acc = torch.empty(T, B * th * tw, ld, dtype=torch.float32, device=ys[0].device)
+        for i, (y, (gh, gw)) in enumerate(zip(ys, sizes)):
+            assert y.shape[0] == T and y.shape[2] == ld and y.is_contiguous()
+            ops.call("bilinear_fwd", **{"in": y}, out=acc, B=T * B, C=ld, Hin=gh, Win=gw, Hout=th, Wout=tw, ld_in=ld, ld_out=ld,
+                     in_dtype=dtype_code(y), out_dtype=F32, out_nchw=0, accumulate=1 if i else 0)
+        ctx.meta = (geo, [(tuple(y.shape), y.dtype) for y in ys])
+        return acc
+
+    @staticmethod
+    def backward(ctx, dacc):
+        (B, C, th, tw, sizes), metas = ctx.meta
+        dacc = dacc.contiguous()
+        outs = []
+        for (shape, dtype), (gh, gw) in zip(metas, sizes):
+            ld = shape[2]
+            if (gh, gw) == (th, tw):
+                outs.append(dacc if dtype == torch.float32 else ops.cast2d(dacc.view(-1, ld), dacc.numel() // ld, ld, ld, dtype, ldd=ld).view(shape))
+                continue
+            din = torch.zeros(shape, dtype=torch.float32, device=dacc.device)
+            ops.call("bilinear_bwd", **{"in": dacc}, out=din, B=shape[0] * B, C=ld, Hin=gh, Win=gw, Hout=th, Wout=tw, ld_in=ld, ld_out=ld,
+                     in_dtype=F32, out_dtype=F32, out_nchw=0, accumulate=1)
+            outs.append(din if dtype == torch.float32 else ops.cast2d(din.view(-1, ld), din.numel() // ld, ld, ld, dtype, ldd=ld).view(shape))
+        return (None,) + tuple(outs)
+
+
 def _check8(*dims):
     if any(d % 8 for d in dims):
         raise NotImplementedError(f"InvPT training path needs channel / head dims that are multiples of 8, got {dims}")
@@ -345,8 +382,9 @@ def _block(dec, blk, si, Xf, B, T, D, gh, gw, prev_score):
     return X3.view(T, rows, D), S
 
 
-def decoder_forward(dec, taps, B):
-    """Autograd twin of TransformerDecoder.forward_nhwc -> (features [T, B*8mh*8mw, E], {task: inter_pred [1, B*mh*mw, pad8(n)] fp32})."""
+def decoder_forward(dec, taps, B, heads=None):
+    """Autograd twin of TransformerDecoder.forward_nhwc -> (features [T, B*8mh*8mw, E], {task: inter_pred [1, B*mh*mw, pad8(n)] fp32});
+    heads (the MLPHeads, in task order): -> (their predictions [1, B*8mh*8mw, pad8(n)] fp32 per task, inter_preds) instead of the features."""
     p, prec = dec.p, dec.prec
     names = p.TASKS.NAMES
     T = len(names)
@@ -383,7 +421,7 @@ def decoder_forward(dec, taps, B):
     Xf = torch.stack(xs, 0)                                                                # fp32 [T, rows0, E]
 
     th, tw = mh * 8, mw * 8
-    acc = None
+    scales, scale_sizes = [], []
     prev_score = None
     gh, gw = mh, mw
     for i in range(3):
@@ -409,11 +447,22 @@ def decoder_forward(dec, taps, B):
         if i > 0:
             rc = dec.invpt.redu_chan[i]
             yn = BLinearFn.apply(yn, E, 'plain', None, None, prec, ('rc', i), None, *[m.weight for m in rc], *[m.bias for m in rc])
-        r = BilinearFn.apply(yn, (B, E, gh, gw, th, tw), torch.float32, False)
-        acc = r if acc is None else acc + r
+        scales.append(yn)
+        scale_sizes.append((gh, gw))
+    acc = MultiScaleSumFn.apply((B, E, th, tw, tuple(scale_sizes)), *scales)
     mps = [dec.invpt.mt_proj[t] for t in names]
+    if heads is not None and autograd_path.FUSE_HEAD_NODE:
+        # mt_proj (Conv3x3 + BatchNorm + ReLU, invpt.py:538-541) and the MLPHeads' 1x1 predictions as ONE node: the 128 x 128 gradient maps
+        # of the six tasks stay in the backward's dtype (autograd_path.ConvHeadFn)
+        bns = [m[1] for m in mps]
+        preds = ConvHeadFn.apply(acc.to(prec.adt), ('conv', (B, th, tw, E, E), 'mtp', E, ACT_RELU, 'iph'), prec, training, bns,
+                                 *[m[0].weight for m in mps], *[m[0].bias for m in mps], *[bn.weight for bn in bns], *[bn.bias for bn in bns],
+                                 *[hd.linear_pred.weight for hd in heads], *[hd.linear_pred.bias for hd in heads])
+        return preds, inter
     f = Conv3x3Fn.apply(acc.to(prec.adt), (B, th, tw, E, E), prec, 'mtp', *[m[0].weight for m in mps], *[m[0].bias for m in mps])
     f = _bn_act(f, [m[1] for m in mps], E, ACT_RELU, training)
+    if heads is not None:
+        return TaskHeadsFn.apply(f, prec, 'iph', *[hd.linear_pred.weight for hd in heads], *[hd.linear_pred.bias for hd in heads]), inter
     return f, inter
 
 
@@ -424,12 +473,11 @@ def net_forward(net, x):
     dec = net.multi_task_decoder
     prec = dec.prec
     taps = vit_taps(net.backbone, x)
-    feats, inter = decoder_forward(dec, taps, B)
+    hds = [net.heads[t] for t in net.tasks]
+    preds, inter = decoder_forward(dec, taps, B, heads=hds)
     mh, mw = net.p.mtt_resolution
     th, tw = 8 * mh, 8 * mw
     out = {}
-    hds = [net.heads[t] for t in net.tasks]
-    preds = TaskHeadsFn.apply(feats, prec, 'iph', *[hd.linear_pred.weight for hd in hds], *[hd.linear_pred.bias for hd in hds])
     for t, hd, pred in zip(net.tasks, hds, preds):
         out[t] = BilinearFn.apply(pred, (B, hd.linear_pred.weight.shape[0], th, tw, img_size[0], img_size[1]), torch.float32, True)
     out['inter_preds'] = {t: BilinearFn.apply(inter[t], (B, net.p.TASKS.NUM_OUTPUT[t], mh, mw, img_size[0], img_size[1]),
