@@ -12,20 +12,36 @@ SOURCES = ["gemm.hip", "attn.hip", "attn_fast.hip", "attn_bwd.hip", "rowops.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
-def _newer(a, b):
-    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+def _stamp(src, deps):
+    """what an object was compiled from: sha256 over the source, the two shared headers and the flags (NOT mtimes: a snapshot copied to
+    another box keeps its contents, not its timestamps)"""
+    import hashlib
+    h = hashlib.sha256(" ".join(f for f in FLAGS if not f.startswith("-I")).encode())
+    for f in [src] + deps:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def build(force=False, verbose=False):
+    """Compile what is stale and link.  An object is up to date when the stamp next to it (<name>.o.sha) equals the hash of its source +
+    headers + flags, so shipped binaries are reused exactly when they correspond to the shipped sources; `force=True` (or MTT_FORCE_BUILD=1)
+    recompiles everything."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    force = force or os.environ.get("MTT_FORCE_BUILD") == "1"
     deps = [os.path.join(CSRC, "mtt_device.h"), os.path.join(ROOT, "include", "mtt_hip.h")]
-    objs, jobs = [], []
+    objs, jobs, stamps = [], [], {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+        want = _stamp(s, deps)
+        try:
+            have = open(o + ".sha").read().strip()
+        except OSError:
+            have = None
+        if force or not os.path.exists(o) or have != want:
             jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            stamps[o] = want
 
     def run(cmd):
         if verbose:
@@ -37,6 +53,9 @@ def build(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(run, jobs))
+        for o, st in stamps.items():
+            with open(o + ".sha", "w") as f:
+                f.write(st + "\n")
     if jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB

@@ -1147,6 +1147,165 @@ int launch_ring3(const GemmP& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_ringc_kernel (round 5): the implicit-GEMM 3x3 conv in bf16 on the LDS-DMA tile — gemm_dma_kernel<1>'s tile, wave layout, staggered
+// R | C phases and epilogue with the operands in a RING of S = 4 slots of 32-deep K sub-tiles (the round-4 ring of the bf16 kernel,
+// measured equal to gemm_dma_kernel<1> on plain GEMMs; what it adds here is the 32-deep step that lies inside ONE tap whenever the channel
+// pitch is a multiple of 32) and gemm_ring3_kernel<true>'s per-step tap addressing: the scalar unit turns the step index into (tap, channel
+// offset) and a signed row delta, every lane redirects its 16-byte source to a zero page when that tap leaves the image for its output
+// pixel.  Takes the bf16 3x3 convs that gemm_kernel<MTT_OP_CONV_K, ., 0> (register-staged, 640-720 TFLOP/s) ran: the input gradients of
+// every 3x3 conv in the bf16 / x3f backward (mirrored taps on the transposed pack), and the forward convs of the bf16 mode.
+// A slot = [A 256 x 32 | B 256 x 32] bf16 = 32 KiB; sub-tile j + 3 is issued in R(j) into the slot sub-tile j - 1 left; waits are counted:
+// after the 4 pieces of sub-tile j + 1 a wave has issued those of j + 2 and j + 3 (8) in steady state.
+// ---------------------------------------------------------------------------------------------
+// EDGE: an N-edge tile of <= 128 columns (350 = 256 + 94 + 2 of padding) runs the waves 4 x 2 with 64 x 64 wave tiles — half the MFMAs — and
+// stages 128 B rows (one piece per wave: 3 pieces per sub-tile instead of 4), as gemm_ring3_kernel does.
+template <bool EDGE>
+MTT_DEV void ringc_tile(const GemmP& p, unsigned char* smem, int m0, int n0, int zo, int zi) {
+  constexpr int WAVES_N = EDGE ? 2 : 4, WAVES_M = EDGE ? 4 : 2, MT = EDGE ? 4 : 8, NT = 4, S = 4;
+  constexpr int NP = EDGE ? 3 : 4;                                   // LDS-DMA pieces a wave issues per sub-tile
+  constexpr int PART = 256 * 64, SLOT = 2 * PART;                    // [256 rows][32 k] bf16 per operand
+  const unsigned char* Abase = (const unsigned char*)((const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi));
+  const unsigned char* Bbase = (const unsigned char*)((const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi));
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int late = wave >> 2;
+  const int nk = p.d.K >> 5;                                          // 32-deep sub-tiles: K = 9 * Cp, Cp % 32 == 0
+
+  uint32_t aoff32[2], boff32[2];
+  unsigned tapmask[2];                                                // bit t set <=> tap t of this lane's output pixel reads inside the image
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ring_swz(row);
+    int ra = m0 + row; if (ra > p.d.M - 1) ra = p.d.M - 1;
+    aoff32[i] = (uint32_t)((int64_t)ra * p.d.lda + c * 8) * 2u;      // the centre pixel's row (rows = B * H * W pixels, pitch lda)
+    const uint32_t q = fdiv((uint32_t)ra, p.divW);
+    const int px = ra - (int)q * p.d.conv.W;
+    const int py = (int)q - (int)fdiv(q, p.divH) * p.d.conv.H;
+    unsigned mk = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      int ty = t / 3, tx = t - 3 * (t / 3);
+      if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+      const int yy = py + (ty - 1) * p.d.conv.dil, xx = px + (tx - 1) * p.d.conv.dil;
+      if (yy >= 0 && yy < p.d.conv.H && xx >= 0 && xx < p.d.conv.W) mk |= 1u << t;
+    }
+    tapmask[i] = mk;
+    const int brow = EDGE ? wave * 16 + (lane >> 2) : row;            // EDGE: rows [16 w, 16 w + 16) of the 128 B rows, one piece
+    const int cb = (lane & 3) ^ ring_swz(brow);
+    int rb = n0 + brow; if (rb > p.d.N - 1) rb = p.d.N - 1;
+    boff32[i] = (uint32_t)((int64_t)rb * p.d.ldb + cb * 8) * 2u;
+  }
+  uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
+  asm volatile("" : "+s"(zpage));
+  const int cpt = p.d.conv.Cp >> 5;                                   // K steps per tap
+  const int cpt_inv = ((1 << 20) + cpt - 1) / cpt;                    // j / cpt == (j * cpt_inv) >> 20 for j < 9 * cpt, cpt <= 128
+  // the four pieces (A rows 2 w, 2 w + 1 of 16; B likewise) of sub-tile j into ring slot `slot`
+  auto issue_tile = [&](int j, int slot) {
+    unsigned char* dst = smem + slot * SLOT + wave * 2048;
+    const int tap = (j * cpt_inv) >> 20;                              // wave-uniform: scalar unit
+    int ty = (tap * 11) >> 5, tx = tap - 3 * ((tap * 11) >> 5);       // tap / 3, tap % 3 for tap < 9
+    if (p.d.conv.flip) { ty = 2 - ty; tx = 2 - tx; }
+    const int64_t delta = ((int64_t)((ty - 1) * p.d.conv.dil * p.d.conv.W + (tx - 1) * p.d.conv.dil) * p.d.lda + (int64_t)(j - tap * cpt) * 32) * 2;
+    const unsigned char* abase = Abase + delta;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint64_t src = (uint64_t)(uintptr_t)(abase + aoff32[i]);
+      glds16((const bf16_t*)(uintptr_t)(((tapmask[i] >> tap) & 1u) ? src : zpage), dst + i * 1024);
+    }
+    const unsigned char* bbase = Bbase + (size_t)j * 64;
+    if constexpr (EDGE) {
+      glds16((const bf16_t*)(bbase + boff32[0]), smem + slot * SLOT + PART + wave * 1024);
+    } else {
+      glds16((const bf16_t*)(bbase + boff32[0]), dst + PART);
+      glds16((const bf16_t*)(bbase + boff32[1]), dst + PART + 1024);
+    }
+  };
+  const int fsw = ((lg ^ ring_swz(li)) << 4) + li * 64;
+  const int fragA = wm * (MT * 16) * 64 + fsw, fragB = PART + wn * (NT * 16) * 64 + fsw;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int npro = nk < S - 1 ? nk : S - 1;                           // nk >= 9
+  for (int j = 0; j < npro; ++j) issue_tile(j, j);
+  wait_vmcnt_dyn(NP * (npro - 1));
+  __builtin_amdgcn_s_barrier();                    // sub-tile 0 is in LDS
+  if (late) __builtin_amdgcn_s_barrier();          // stagger: waves 4-7 start one slot later
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto main_loop = [&](auto late_tag) {
+  constexpr bool LATE = decltype(late_tag)::value;
+  int rslot = 0, wslot = (S - 1) % S;
+  for (int j = 0; j < nk; ++j) {
+    const unsigned char* sb = smem + rslot * SLOT;
+    const bool more = j + S - 1 < nk;              // this step issues sub-tile j + S - 1
+    // the wait of this step covers sub-tile j + 1: behind its pieces the wave has issued sub-tiles j + 2 .. min(j + S - 1, nk - 1)
+    const int newer = more ? S - 2 : (nk - j - 2 > 0 ? nk - j - 2 : 0);
+    // ---- R phase ----
+    if (more) issue_tile(j + S - 1, wslot);
+    u32x4 fa[MT], fb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[t] = *(const u32x4*)(sb + fragB + t * 1024);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[t] = *(const u32x4*)(sb + fragA + t * 1024);
+    if (LATE) { if (more) wait_vmcnt_imm<2 * NP>(); else wait_vmcnt_dyn(NP * newer); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C phase ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+    __builtin_amdgcn_s_setprio(0);
+    if (!LATE) { if (more) wait_vmcnt_imm<2 * NP>(); else wait_vmcnt_dyn(NP * newer); }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    rslot = rslot + 1 == S ? 0 : rslot + 1;
+    wslot = wslot + 1 == S ? 0 : wslot + 1;
+  }
+  };
+  if (late) main_loop(std::true_type{}); else main_loop(std::false_type{});
+  if (!late) __builtin_amdgcn_s_barrier();         // waves 0-3 wait one slot for the late half
+  __syncthreads();                                 // everyone is past its last LDS read: the epilogue may reuse the ring
+  if constexpr (EDGE) gemm_epilogue<128, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  else gemm_epilogue_auto<256, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_ringc_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + BM2 - 1) / BM2;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * BM2, n0 = tile_n * 256;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  const int ncols = (p.d.n_store > p.d.N ? p.d.n_store : p.d.N) - n0;
+  if (MTT_R3_EDGE && ncols <= 128) ringc_tile<true>(p, smem, m0, n0, zo, zi);
+  else ringc_tile<false>(p, smem, m0, n0, zo, zi);
+}
+
+int launch_ringc(const GemmP& p, hipStream_t stream) {
+  constexpr int smem = 4 * 32768;
+  static std::atomic<unsigned long long> done{0};
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_ringc_kernel, smem, done)) return e;
+  const int tm = (p.d.M + BM2 - 1) / BM2, tn = (p.d.N + 255) / 256;
+  dim3 grid(tm * tn, 1, p.d.batch);
+  hipLaunchKernelGGL(gemm_ringc_kernel, grid, dim3(512), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_f32n_kernel (round 4): D[M, N <= 32] = A[M, K] W[N, K]^T + bias in EXACT fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32: f32 in,
 // f32 accumulate, one rounding per product — bitwise a k-ordered fmaf chain, cdna_hip_programming.md §3).  For the fp32-class modes' tall
 // GEMMs with a handful of outputs (the heads' 1x1 predictions on the full-resolution maps: M = B 128 128 rows, K = 352, N = 1 .. 21): they
@@ -1624,6 +1783,7 @@ extern "C" size_t mtt_desc_size(int which) {
 //   8 gemm_ring3_kernel<false>: MTT_SPLIT operands, fp32-class product (three MFMA products per staged K step)
 //   9 gemm_ring3_kernel<true>: the same with the implicit im2col of a 3x3 conv as A operand (MTT_OP_CONV_K on planes)
 //  11 gemm_f32n_kernel: fp32 operands, N <= 32, exact fp32 MFMA (the fp32-class modes' tall few-output GEMMs)
+//  12 gemm_ringc_kernel: bf16 implicit-GEMM 3x3 conv on the LDS-DMA ring (channel pitch % 32 == 0)
 //  <0 MTT_E_* (no kernel takes this descriptor)
 // d.variant = MTT_GEMM_AUTO applies the policy; MTT_GEMM_GENERAL / MTT_GEMM_DMA256 force a kernel where it is applicable.
 // K % 64 == 0 and 32-bit per-lane byte offsets from the batch member's base: the fast source addressing of the LDS-DMA kernel
@@ -1647,6 +1807,12 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
   }
   if (f32n_ok(d)) return 11;
   if (d.prec != MTT_PREC_BF16 || d.a_dtype != MTT_BF16 || d.b_dtype != MTT_BF16) return 0;
+  // 12: the bf16 implicit-GEMM 3x3 conv on the LDS-DMA ring (gemm_ringc_kernel): channel pitch a multiple of 32, pixel rows of pitch lda,
+  // 32-bit element offsets; enough rows and columns for 256 x 256 tiles (small maps stay on the register-staged 128 x 128 kernel)
+  if (d.a_op == MTT_OP_CONV_K && d.b_op == MTT_OP_K && d.variant != MTT_GEMM_GENERAL && d.store_mode == MTT_STORE_ROWS && d.conv.Cp % 32 == 0 &&
+      d.conv.Cp <= 4096 && d.K == 9 * d.conv.Cp && d.lda == d.conv.Cp && d.a_mb <= 0 && (int64_t)d.M * d.lda < (1ll << 31) &&
+      (int64_t)(d.N - 1) * d.ldb + d.K < (1ll << 31) && !d.colsum_out &&
+      (d.variant == MTT_GEMM_DMA256 || (d.M >= 2048 && d.N >= 128))) return 12;
   // 6: token-major weight-gradient kernel (gemm_tn_kernel): both operands MTT_OP_R (B may be the implicit im2col^T), bf16
   const bool tn = d.a_op == MTT_OP_R && (d.b_op == MTT_OP_R || d.b_op == MTT_OP_CONV_R) && d.store_mode == MTT_STORE_ROWS;
   if (tn && d.variant != MTT_GEMM_GENERAL) {
@@ -1747,6 +1913,7 @@ extern "C" size_t mtt_gemm_colsum_ws_floats(const mtt_gemm_desc* d) {
 static int gemm_launch(GemmP& p, hipStream_t s, int v) {
   mtt_gemm_desc& d = p.d;
   if (v == 11) return launch_f32n(p, s);
+  if (v == 12) return launch_ringc(p, s);
   if (v == 9) return launch_ring3<true>(p, s);
 #if MTT_RING
   if (v == 8) return launch_ring3<false>(p, s);

@@ -272,6 +272,22 @@ def gemm_cases():
                   d_zo=rows * Cop, conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, n_store=Cop, colshift=rnd(g, Zc, Co), col_zo=Co)
         cases.append((f"conv3_split_{Bc}x{H}x{W}_c{Ci}_dil{dil}_flip{flip}", "gemm", kw, TOL_X3))
         cases.append((f"conv3_split_bnfold_gelu_{Bc}x{H}x{W}_c{Ci}", "gemm", dict(kw, D=torch.full((Zc, rows, Cop), 7.0), colscale=rnd(g, Zc, Co), act=1), TOL_X3))
+    # 1e+b. the same implicit-GEMM conv in bf16 on the LDS-DMA ring (mtt_gemm variant 12, gemm_ringc_kernel; round 5): forced by variant 3 on
+    #       these small maps (AUTO takes it from 2048 pixel rows), channel pitch 32 / 96 / 352, dilation, mirrored taps (the dgrad form),
+    #       ragged M and N tiles, task batches, bias / BN-folded GELU epilogues, bf16 and fp32 outputs
+    for (Bc, H, W, Ci, Cp, Co, dil, flip, Zc) in ((2, 9, 11, 30, 32, 40, 1, 0, 1), (1, 16, 20, 90, 96, 300, 2, 0, 2), (3, 8, 8, 350, 352, 350, 1, 1, 1),
+                                                  (5, 24, 20, 64, 64, 264, 1, 1, 1)):
+        rows = Bc * H * W
+        xa = rnd(g, Zc, rows, Cp, dtype=torch.bfloat16); xa[..., Ci:] = 0
+        wa = (rnd(g, Zc, Co, 9, Cp) * 0.2).to(torch.bfloat16); wa[..., Ci:] = 0
+        Cop = (Co + 7) // 8 * 8
+        kw = dict(A=xa, B=wa.reshape(Zc, Co, 9 * Cp), D=torch.full((Zc, rows, Cop), 7.0, dtype=torch.bfloat16), M=rows, N=Co, K=9 * Cp, a_op=OP_CONV_K,
+                  b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Zc, batch_inner=1, a_zo=rows * Cp,
+                  b_zo=Co * 9 * Cp, d_zo=rows * Cop, conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, n_store=Cop,
+                  colshift=rnd(g, Zc, Co), col_zo=Co, variant=3)
+        cases.append((f"conv3_ring_bf16_{Bc}x{H}x{W}_c{Ci}_dil{dil}_flip{flip}", "gemm", kw, TOL_BF))
+        cases.append((f"conv3_ring_bf16_bnfold_gelu_f32out_{Bc}x{H}x{W}_c{Ci}", "gemm",
+                      dict(kw, D=torch.full((Zc, rows, Cop), 7.0), d_dtype=F32, colscale=rnd(g, Zc, Co), act=1), TOL_BF))
     # 1e++. tall GEMMs with a handful of outputs in the fp32-class modes (mtt_gemm variant 11, gemm_f32n_kernel: exact fp32 MFMA): the head
     #       predictions' shapes (K = 352, N = 1 / 21), N = 32, K = 8 and 1024, ragged M (not a multiple of 32 / of a workgroup's 512 rows),
     #       channel padding columns (n_store), task batches
