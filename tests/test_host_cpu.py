@@ -682,3 +682,21 @@ def test_bench_pmc_traffic_record_is_refused_when_the_kernel_source_changed(tmp_
     (src / "gemm.hip").write_text("// kernel source, version B\n")
     stale = bench._pmc_traffic("gemm_ring3_kernel")
     assert stale.get("hbm_bytes_per_launch") is None and "STALE" in stale["note"] and stale["commit"] == "abc1234"
+
+
+def test_pmc_record_was_measured_on_this_trees_gemm_source():
+    """the committed PMC traffic record (profiles/pmc_traffic.json, the source of the bench line's roofline.traffic) must have
+    been measured on the gemm.hip of THIS tree — the re-measurement is the last GPU step of a round that touched the file.  A stale record
+    is caught here instead of surfacing as `traffic: null` in the driver's line."""
+    import hashlib
+    import json as _json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = hashlib.sha256(open(os.path.join(root, "multi-task-transformer_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+    rec = _json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    for kernel in ("gemm_ring3_kernel", "gemm_dma_kernel<1>"):
+        assert rec[kernel]["csrc_sha"] == sha, (kernel, rec[kernel]["csrc_sha"], sha)
+        assert rec[kernel]["hbm_bytes_per_launch"] > 0 and rec[kernel]["launches"] > 0
+    import bench
+    assert bench._pmc_traffic("gemm_ring3_kernel")["hbm_bytes_per_launch"] == rec["gemm_ring3_kernel"]["hbm_bytes_per_launch"]
+    ident = bench._source_id()
+    assert ident["head"] and ident["tree_sha"] == bench.source_tree_sha()
