@@ -22,7 +22,7 @@ PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 STORE_ROWS, STORE_PIXSHUF2 = 0, 1
-GEMM_AUTO, GEMM_GENERAL, GEMM_DMA256, GEMM_GENERAL_EPILOGUE = 0, 1, 3, 11
+GEMM_AUTO, GEMM_GENERAL, GEMM_DMA256, GEMM_DMA128, GEMM_GENERAL_EPILOGUE = 0, 1, 3, 4, 11
 ATTN_AUTO, ATTN_PLAIN = 0, 1
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p

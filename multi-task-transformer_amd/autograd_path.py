@@ -20,6 +20,7 @@ from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, 
 
 pad8 = ops.pad8
 SPLITK_MIN_ROWS = 4096      # reduction length from which few-tile weight gradients are split over the batch dimension
+WGRAD_MAX_SLICES, WGRAD_TARGET_WGS = 192, 512        # _wgrad's split-K: up to two workgroups per CU (round 4: 64, 256)
 
 
 def _gemm(A, B, D, M, N, K, prec, **kw):
@@ -82,7 +83,9 @@ def _wgrad(dy, x, N, Kp, prec, rows=None, lda=None, ldb=None):
     lda, ldb = lda or dy.stride(0), ldb or x.stride(0)
     tiles = -(-N // 128) * -(-Kp // 128)
     if tiles < 96 and rows >= SPLITK_MIN_ROWS:
-        Z = max(2, min(64, 256 // tiles, max(2, rows // 512)))
+        # two workgroups per CU (the kernel's LDS allows it): a handful of output tiles over a million pixel rows (the head predictions'
+        # weight gradients: 3 tiles) is pure streaming of x — 64 slices left three quarters of the CUs without a workgroup
+        Z = max(2, min(WGRAD_MAX_SLICES, WGRAD_TARGET_WGS // tiles, max(2, rows // 512)))
         c = rows // Z
         rem = rows - c * Z
         slabs = torch.empty(Z + (1 if rem else 0), N, Kp, dtype=torch.float32, device=dy.device)
@@ -280,6 +283,7 @@ def attention_bwd(qkv, dao, drawlog, B, N, nH, T, prec):
     return dqkv
 
 
+HEAD_DGRAD_DMA = True   # TaskHeadsFn: the prediction dgrad on the LDS-DMA kernel (tests / A-B runs set it to False)
 FLASH_BWD = True        # bf16: mtt_attn_bwd (tests set it to False to exercise the materialised batched-GEMM backward in bf16)
 
 
@@ -812,7 +816,17 @@ class TaskHeadsFn(Function):
             n = wshapes[z][0]
             g = dps[z].contiguous().view(rows, -1)
             Kp = packs[z].shape[-1]
-            _gemm(g, packs[z][0], dy[z], rows, ld, n, prec, b_op=OP_R, lda=g.shape[1], ldb=Kp, ldd=ld, n_store=ld)
+            if prec.name == "bf16" and FAST_BWD and HEAD_DGRAD_DMA and dy.dtype == torch.bfloat16 and rows >= FAST_MIN_ROWS and g.shape[1] % 8 == 0:
+                # dya = g W is an outer-product-like GEMM (K = n <= 21 classes, a million rows): bound by the 0.7 GB it writes.  bf16 copies of
+                # the two small operands (g [rows, pad8(n)], W^T [ld, pad8(n)]) put it on the 128-row LDS-DMA kernel instead of the
+                # register-staged one (423 us per task at the benchmark's batch); padding columns of g are zeros (BilinearFn.backward)
+                npad = g.shape[1]
+                g16 = ops.cast_rows(g, torch.bfloat16)
+                assert Kp == ld
+                wT = _pad_last(packs[z][0].t(), npad).to(torch.bfloat16)                         # [ld, pad8(n)] (tiny)
+                _gemm(g16, wT, dy[z], rows, ld, npad, prec, lda=npad, ldb=npad, ldd=ld, n_store=ld, variant=_lib.GEMM_DMA128)
+            else:
+                _gemm(g, packs[z][0], dy[z], rows, ld, n, prec, b_op=OP_R, lda=g.shape[1], ldb=Kp, ldd=ld, n_store=ld)
             dW = _wgrad(g, y[z], n, Kp, prec)
             dws.append(dW[:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
             dbs.append(_colsum(g, n))

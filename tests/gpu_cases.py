@@ -272,6 +272,12 @@ def gemm_cases():
                   d_zo=rows * Cop, conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, n_store=Cop, colshift=rnd(g, Zc, Co), col_zo=Co)
         cases.append((f"conv3_split_{Bc}x{H}x{W}_c{Ci}_dil{dil}_flip{flip}", "gemm", kw, TOL_X3))
         cases.append((f"conv3_split_bnfold_gelu_{Bc}x{H}x{W}_c{Ci}", "gemm", dict(kw, D=torch.full((Zc, rows, Cop), 7.0), colscale=rnd(g, Zc, Co), act=1), TOL_X3))
+    # 1e+a. the prediction dgrad of TaskHeadsFn on the 128-row LDS-DMA kernel (forced variant 4): K = pad8(n) = 8 / 24 — less than one 64-deep K
+    #       step, chunks past K read the zero page — a tall M, N = 352 / 176, bf16 output with n_store = pitch
+    for (M, N, K) in ((5000, 352, 24), (3001, 176, 8)):
+        kw = dict(A=rnd(g, M, K, dtype=torch.bfloat16), B=rnd(g, N, K, dtype=torch.bfloat16), D=torch.full((M, N), 7.0, dtype=torch.bfloat16), M=M, N=N, K=K,
+                  a_op=OP_K, b_op=OP_K, a_dtype=BF16, b_dtype=BF16, d_dtype=BF16, prec=0, lda=K, ldb=K, ldd=N, batch=1, batch_inner=1, alpha=1.0, n_store=N, variant=4)
+        cases.append((f"gemm_dma128_shortk_{M}x{N}x{K}", "gemm", kw, TOL_BF))
     # 1e+b. the same implicit-GEMM conv in bf16 on the LDS-DMA ring (mtt_gemm variant 12, gemm_ringc_kernel; round 5): forced by variant 3 on
     #       these small maps (AUTO takes it from 2048 pixel rows), channel pitch 32 / 96 / 352, dilation, mirrored taps (the dgrad form),
     #       ragged M and N tiles, task batches, bias / BN-folded GELU epilogues, bf16 and fp32 outputs
