@@ -76,7 +76,7 @@ CONFIGS = {
               "the 3ddet task), 1024x2048 x 0.75, window 12, level 256 / final 450, DEConvHead; SURVEY.md §8f rank 3",
               dict(tasks=["semseg", "depth"], backbone="TaskPrompter_swinB", head="deconv", final_embed_dim=450, chan_nheads=1, img_ds_ratio=0.75,
                    level_embed_dim=256, chan_embed_dim=256, prompt_len=1, num_output=dict(semseg=19)),
-              (1024, 2048), 2, 3678.8),
+              (1024, 2048), 8, 3678.8),
 }
 
 
