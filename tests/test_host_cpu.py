@@ -700,3 +700,50 @@ def test_pmc_record_was_measured_on_this_trees_gemm_source():
     assert bench._pmc_traffic("gemm_ring3_kernel")["hbm_bytes_per_launch"] == rec["gemm_ring3_kernel"]["hbm_bytes_per_launch"]
     ident = bench._source_id()
     assert ident["head"] and ident["tree_sha"] == bench.source_tree_sha()
+
+
+def test_gemm_policy_routes_the_round5_kernels():
+    """mtt_gemm_variant (the library's dispatch policy, a pure function of the descriptor; no GPU needed): the bf16 3x3 convs of the
+    benchmark's shapes go to the LDS-DMA ring kernel (12), the split-plane ones to gemm_ring3_kernel<true> (9); channel pitches that are
+    not multiples of 32, small maps and forced-general calls stay on the register-staged kernel (0)."""
+    import mtt_amd
+    gv = mtt_amd._lib.gemm_variant
+    def conv(M, N, Cp, **kw):
+        d = dict(M=M, N=N, K=9 * Cp, a_op=2, b_op=0, a_dtype=1, b_dtype=1, d_dtype=1, prec=0, lda=Cp, ldb=9 * Cp, ldd=(N + 7) // 8 * 8, batch=6,
+                 conv=dict(H=32, W=32, C=Cp - 2, Cp=Cp, dil=1, flip=1))
+        d.update(kw)
+        return gv(**d)
+    assert conv(63 * 1024, 350, 352) == 12                     # fea_fuse 3x3 input gradient (x3f / bf16 backward)
+    assert conv(32 * 16384, 576, 576, conv=dict(H=128, W=128, C=576, Cp=576, dil=1, flip=0)) == 12      # InvPT mt_proj, bf16 forward
+    assert conv(63 * 1024, 300, 304) == 0                      # pitch 304: a 32-deep K step would straddle two taps
+    assert conv(1024, 350, 352) == 0                           # small map: 128 x 128 tiles fill the chip better
+    assert conv(63 * 1024, 350, 352, variant=1) == 0           # MTT_GEMM_GENERAL
+    assert conv(1024, 40, 32, variant=3) == 12                 # forced (the op tests' small shapes)
+    assert conv(63 * 1024, 350, 352, a_dtype=2, b_dtype=2, prec=1, A_lo=torch.zeros(1), B_lo=torch.zeros(1), d_dtype=0) == 9
+    # the prediction dgrad of TaskHeadsFn: K = pad8(n) on the 128-row LDS-DMA kernel when forced, the general kernel otherwise
+    head = dict(M=63 * 16384, N=352, K=24, a_op=0, b_op=0, a_dtype=1, b_dtype=1, d_dtype=1, prec=0, lda=24, ldb=24, ldd=352, batch=1)
+    assert gv(**head, variant=4) == 4 and gv(**head) in (0, 4)
+
+
+def test_multi_scale_sum_node_equals_the_separate_resizes(emulated):
+    """invpt_autograd.MultiScaleSumFn (the stage outputs resized and summed in ONE node: in-kernel accumulation, identity scale handed
+    through) against BilinearFn per stage + adds: same values, same input gradients."""
+    import importlib
+    ia = importlib.import_module("multi-task-transformer_amd.invpt_autograd")
+    ap = importlib.import_module("multi-task-transformer_amd.autograd_path")
+    g = torch.Generator().manual_seed(3)
+    T, B, C, th, tw = 2, 2, 16, 8, 12
+    sizes = ((2, 3), (4, 6), (8, 12))
+    ys = [torch.randn(T, B * h * w, C, generator=g).requires_grad_(True) for h, w in sizes]
+    ys2 = [y.detach().clone().requires_grad_(True) for y in ys]
+    acc = ia.MultiScaleSumFn.apply((B, C, th, tw, sizes), *ys)
+    ref = None
+    for y, (h, w) in zip(ys2, sizes):
+        r = ap.BilinearFn.apply(y, (B, C, h, w, th, tw), torch.float32, False)
+        ref = r if ref is None else ref + r
+    assert torch.allclose(acc, ref, rtol=1e-6, atol=1e-6)
+    wgt = torch.randn(acc.shape, generator=g)
+    (acc * wgt).sum().backward()
+    (ref * wgt).sum().backward()
+    for a, b in zip(ys, ys2):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)
