@@ -594,7 +594,12 @@ def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=AC
         x = Split(sp.hi.view(Z, rows, Cp), sp.lo.view(Z, rows, Cp))
     assert isinstance(x, Split) == isinstance(wpack, Split), "split planes: both operands or neither"
     Cop = pad8(Co)
-    out = torch.empty(Z, rows, Cop, dtype=out_dtype or prec.adt, device=x.device)
+    if out_dtype == "split":                     # the output as hi / lo planes (the split-plane kernel's epilogue kinds 5 / 6): feeds a split-plane GEMM
+        assert isinstance(x, Split), "a split conv output needs the split-plane conv kernel"
+        out = Split.empty((Z, rows, Cop), x.device)
+    else:
+        out = torch.empty(Z, rows, Cop, dtype=out_dtype or prec.adt, device=x.device)
+    oh = _hi(out)
     # the split-plane kernel addresses a batch member's pixel rows with 32-bit element offsets (M * pitch < 2^31): larger batches go
     # in chunks of whole images (a conv never mixes images); the general kernel has no such limit
     per = max(1, SPLIT_CONV_MAX_ELEMS // (H * W * Cp)) if isinstance(x, Split) else B
@@ -602,12 +607,14 @@ def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=AC
         nb = min(per, B - b0)
         r0, r1 = b0 * H * W, (b0 + nb) * H * W
         xa, xl = _hi(x)[:, r0:r1], (x.lo[:, r0:r1] if isinstance(x, Split) else None)
-        kw = dict(A=xa, B=_hi(wpack), D=out[:, r0:r1], M=r1 - r0, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K,
+        kw = dict(A=xa, B=_hi(wpack), D=oh[:, r0:r1], M=r1 - r0, N=Co, K=9 * Cp, a_op=OP_CONV_K, b_op=OP_K,
                   a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,
-                  lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Z, batch_inner=1, a_zo=_hi(x).stride(0), b_zo=_hi(wpack).stride(0), d_zo=out.stride(0),
+                  lda=Cp, ldb=9 * Cp, ldd=Cop, batch=Z, batch_inner=1, a_zo=_hi(x).stride(0), b_zo=_hi(wpack).stride(0), d_zo=oh.stride(0),
                   conv=dict(H=H, W=W, C=Ci, Cp=Cp, dil=dil, flip=flip), alpha=1.0, act=act, n_store=Cop)
         if isinstance(x, Split):                     # implicit-GEMM form of the split-plane kernel (mtt_gemm variant 9): Cp % 32 == 0
             kw.update(A_lo=xl, B_lo=wpack.lo)
+        if isinstance(out, Split):
+            kw.update(D_lo=out.lo[:, r0:r1])
         if bias is not None:
             kw.update(colshift=bias, col_zo=bias.stride(0))
         if colscale is not None:

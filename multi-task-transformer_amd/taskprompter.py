@@ -342,7 +342,10 @@ class TaskPrompter(nn.Module):
         fc = [self.fea_fuse[il][t][1].weight for t in names]
         Wc = ops.pack_conv3_split(fc, ('f1', il)) if self._decoder_conv_split() else ops.pack_conv3(fc, pf, ('f1', il))
         bc = ops.stack_vec([self.fea_fuse[il][t][1].bias for t in names], ('f1b', il))
-        W4 = ops.pack_linear([self.fea_fuse[il][t][4].weight for t in names], pf, ('f4', il))
+        f4 = [self.fea_fuse[il][t][4].weight for t in names]
+        # inference (BatchNorm folded into the conv's epilogue): the conv writes GELU(BN(.)) as planes, so fea_fuse[4] runs on the split-plane
+        # kernel too (880 -> 490 us per tap at B = 63, profiles/r05_dec_x3_bench_b_edge.log); in training BatchNorm's apply writes fp32
+        W4 = ops.pack_linear_split(f4, ('f4', il)) if self._fuse4_split() else ops.pack_linear(f4, pf, ('f4', il))
         b4 = ops.stack_vec([self.fea_fuse[il][t][4].bias for t in names], ('f4b', il))
         return Wdec, bdec, W0, b0, Wc, bc, W4, b4
 
@@ -356,6 +359,10 @@ class TaskPrompter(nn.Module):
     def _decoder_conv_split(self):
         """... and fea_fuse[1] (3x3) on its implicit-GEMM form: fea_fuse[0]'s epilogue writes y0 as planes (channel pitch % 32 == 0)."""
         return self._decoder_split() and ops.split_conv_ok(self.p.final_embed_dim)
+
+    def _fuse4_split(self):
+        """... and, in eval mode only, fea_fuse[4] on planes written by the BN-folded conv epilogue (K = pad8(F) a multiple of 32)."""
+        return (not self.training) and self._decoder_conv_split() and ops.split_gemm_ok(ops.pad8(self.p.final_embed_dim))
 
     def _ctr_weights(self, rawlog, il, B, T):
         """[B, T, T] mixing weights: per-head MLP on the prompt<->prompt raw logits (:482-484); identity without ctr."""
@@ -403,7 +410,7 @@ class TaskPrompter(nn.Module):
             y1 = self._bn_train(y1, bns, F, ACT_GELU)
         else:
             sc, sh = self._bn_fold(bns, [self.fea_fuse[il][t][1].bias for t in names], ('f2', il))
-            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, pf, bias=sh, colscale=sc, act=ACT_GELU, out_dtype=adt)
+            y1 = ops.conv3x3(y0, Wc, F, F, B, h, w, pf, bias=sh, colscale=sc, act=ACT_GELU, out_dtype="split" if self._fuse4_split() else adt)
         fea = ops.linear(y1, W4, F, pf, bias=b4, out_dtype=adt)
         wmix = self._ctr_weights(rawlog, il, B, T).detach()
         return ops.ctr_mix(fea, wmix, B, F, acc)
