@@ -568,7 +568,7 @@ class BLinearFn(Function):
             lda = Np
         xz = x.stride(0) if (x.dim() == 3 and x.shape[0] > 1) else 0
         bi = az['batch_inner']
-        dx = torch.empty(Z, M, Kp, dtype=xdt, device=x.device)
+        dx = torch.empty(Z, M, Kp, dtype=getattr(ctx, "grad_dtype", None) or xdt, device=x.device)       # (a stage of FuseTailFn: the backward's dtype)
         if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and M >= FAST_MIN_ROWS and Kp >= 128:
             # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T.  The reduction runs over pad8(N) columns of dy:
             # the padding columns [N, pad8(N)) meet zero rows of W^T, but 0 * NaN is NaN, so they must hold FINITE values.  Invariant of
@@ -887,6 +887,47 @@ class ConvHeadFn(Function):
         return (g1[0], None, None, None, None) + tuple(g1[4:]) + tuple(g2[5:]) + tuple(g3[3:])
 
 
+class FuseTailFn(Function):
+    """fea_fuse[1..4] of all tasks at one tap as ONE autograd node (taskprompter.py:362, :472-474): Conv3x3 -> BatchNorm (batch statistics)
+    + GELU -> Conv1x1 — Conv3x3Fn -> BnActStackFn -> BLinearFn, the same kernels in the same order, with what the single node allows:
+    the gradient maps between the stages are stored in the backward's dtype (bf16 in x3f instead of fp32: no cast passes, half the
+    traffic), and in x3f the activated map is handed to the 1x1 as hi / lo planes (one split pass; 880 -> 490 + 218 us per tap on the
+    split-plane kernel at the benchmark's batch) whose hi plane is the bf16 operand the backward needs — the fp32 map is not kept.
+    geo = Conv3x3Fn's geo (with the lo plane of a split input as 7th element); params = Z conv weights, Z conv biases, Z BN weights,
+    Z BN biases, Z 1x1 weights, Z 1x1 biases."""
+
+    @staticmethod
+    def forward(ctx, y0, geo, tags, C, prec, training, bns, *params):
+        Z = len(params) // 6
+        cw, cb, bg, bb, w4, b4 = (params[i * Z:(i + 1) * Z] for i in range(6))
+        c1, c2, c3 = _SubCtx(), _SubCtx(), _SubCtx()
+        y1 = Conv3x3Fn.forward(c1, y0, geo, prec, tags[0], *cw, *cb)
+        ya = BnActStackFn.forward(c2, y1, C, ACT_GELU, training, bns, *bg, *bb)
+        if prec.split and ya.dtype == torch.float32 and ops.split_gemm_ok(ya.shape[-1]):
+            Zs, M, Kp = ya.shape
+            sp = ops.split_cast(ya.view(Zs * M, Kp))
+            fea = BLinearFn.forward(c3, sp.hi.view(Zs, M, Kp), C, 'plain', None, None, prec, tags[1], sp.lo.view(Zs, M, Kp), *w4, *b4)
+        else:
+            fea = BLinearFn.forward(c3, ya, C, 'plain', None, None, prec, tags[1], None, *w4, *b4)
+        n1, n2 = len(c1.saved_tensors), len(c2.saved_tensors)
+        ctx.save_for_backward(*c1.saved_tensors, *c2.saved_tensors, *c3.saved_tensors)
+        ctx.sub = (n1, n2, c1.meta, c2.meta, c3.meta, Z)
+        ctx.grad_dtype = prec.bwd.adt
+        return fea
+
+    @staticmethod
+    def backward(ctx, dfea):
+        n1, n2, m1, m2, m3, Z = ctx.sub
+        sv = ctx.saved_tensors
+        c1, c2, c3 = _SubCtx(sv[:n1]), _SubCtx(sv[n1:n1 + n2]), _SubCtx(sv[n1 + n2:])
+        c1.meta, c2.meta, c3.meta = m1, m2, m3
+        c3.grad_dtype = ctx.grad_dtype
+        g3 = BLinearFn.backward(c3, dfea)                   # (dya in grad_dtype, None x 7, dW4 x Z, db4 x Z)
+        g2 = BnActStackFn.backward(c2, g3[0])               # (dy1 in grad_dtype, None x 4, dgamma x Z, dbeta x Z)
+        g1 = Conv3x3Fn.backward(c1, g2[0])                  # (dy0 in y0's dtype, None x 3, dW_conv x Z, db_conv x Z)
+        return (g1[0], None, None, None, None, None, None) + tuple(g1[4:]) + tuple(g2[5:]) + tuple(g3[8:])
+
+
 class CtrMixFn(Function):
     """acc (+)= sum_s wmix[b,t,s] * fea[s]  — cross-task reweighting fused with the 4-tap sum (taskprompter.py:411,484)."""
 
@@ -1014,9 +1055,16 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
                          *[m[0].weight for m in ff], *[m[0].bias for m in ff])
     y0, y0_lo = y0 if spc else (y0, None)
     del cat, cat_lo
-    y1 = Conv3x3Fn.apply(y0, (B, h, w, F, F) + ((1, y0_lo) if spc else ()), prec, ('f1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
-    y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)
-    fea = BLinearFn.apply(y1, F, 'plain', None, None, prec, ('f4', il), None, *[m[4].weight for m in ff], *[m[4].bias for m in ff])
+    geo1 = (B, h, w, F, F) + ((1, y0_lo) if spc else ())
+    if FUSE_HEAD_NODE:
+        bns = [m[2] for m in ff]
+        fea = FuseTailFn.apply(y0, geo1, (('f1', il), ('f4', il)), F, prec, model.training, bns, *[m[1].weight for m in ff],
+                               *[m[1].bias for m in ff], *[bn.weight for bn in bns], *[bn.bias for bn in bns],
+                               *[m[4].weight for m in ff], *[m[4].bias for m in ff])
+    else:
+        y1 = Conv3x3Fn.apply(y0, geo1, prec, ('f1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
+        y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)
+        fea = BLinearFn.apply(y1, F, 'plain', None, None, prec, ('f4', il), None, *[m[4].weight for m in ff], *[m[4].bias for m in ff])
     wmix = model._ctr_weights(rawlog, il, B, T)
     return CtrMixFn.apply(fea, wmix, acc, B, F)
 
