@@ -1558,23 +1558,18 @@ MTT_DEV u32x2 ds_read_tr16(unsigned addr) {
   return r;
 }
 
-template <bool CONVB>
-__global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int MT = 8, NT = 4, WAVES_N = 4;
+// MEDGE (round 5): an M-edge tile with at most 128 output rows (the decoder layers' 300 / 350 outputs leave 44 / 94 rows in their second row
+// tile, InvPT's 576 leave 64) runs the waves as 1 x 8 — each wave all 128 rows x 32 columns (8 x 2 MFMA tiles) instead of 128 x 64 — so the
+// tile issues half the MFMAs and half the B fragment reads; the staging is unchanged (chunks of A beyond M read the zero page as before).
+template <bool CONVB, bool MEDGE>
+MTT_DEV void tn_tile(const GemmP& p, unsigned char* smem, int m0, int n0, int zo, int zi) {
+  constexpr int MT = 8, NT = MEDGE ? 2 : 4, WAVES_N = MEDGE ? 8 : 4, WAVES_M = MEDGE ? 1 : 2;
   constexpr int TILE = BK * 256 * 2, STAGE = 2 * TILE;          // 32 KiB per operand tile, 64 KiB per stage
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + 255) / 256;
-  int tile_m, tile_n;
-  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
-  const int z = blockIdx.z;
-  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
   const bf16_t* Abase = (const bf16_t*)p.d.A + ((int64_t)zo * p.d.a_zo + (int64_t)zi * p.d.a_zi);
   const bf16_t* Bbase = (const bf16_t*)p.d.B + ((int64_t)zo * p.d.b_zo + (int64_t)zi * p.d.b_zi);
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = MEDGE ? 0 : wave >> 2, wn = MEDGE ? wave : wave & 3;
   const int late = wave >> 2;
   const int K = p.d.K;
   uint64_t zpage = (uint64_t)(uintptr_t)g_zero_page;
@@ -1645,7 +1640,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const GemmP p) {
   for (int t = 0; t < MT; ++t) a_addr[t] = lbase + (unsigned)((wm * 8 + (t ^ fr)) * 32);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int unit = wn * 4 + t;
+    const int unit = wn * NT + t;
     b_addr[t] = lbase + (unsigned)TILE + (unsigned)(((unit & 8) | ((unit & 7) ^ fr)) * 32);
   }
 
@@ -1676,16 +1671,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const GemmP p) {
       for (int t = 0; t < MT; ++t) { al[t] = ds_read_tr16(a_addr[t] + off); ah[t] = ds_read_tr16(a_addr[t] + off + 4 * 512); }
       // the wait names every destination as an in/out operand: no use (not even a register copy) can be scheduled above it
 #define TNW(x) "+v"(x)
-      if (kh == 1)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : TNW(bl[0]), TNW(bl[1]), TNW(bl[2]), TNW(bl[3]), TNW(bh[0]), TNW(bh[1]), TNW(bh[2]), TNW(bh[3]),
-                       TNW(al[0]), TNW(al[1]), TNW(al[2]), TNW(al[3]), TNW(al[4]), TNW(al[5]), TNW(al[6]), TNW(al[7]),
-                       TNW(ah[0]), TNW(ah[1]), TNW(ah[2]), TNW(ah[3]), TNW(ah[4]), TNW(ah[5]), TNW(ah[6]), TNW(ah[7]) :: "memory");
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : TNW(bl[0]), TNW(bl[1]), TNW(bl[2]), TNW(bl[3]), TNW(bh[0]), TNW(bh[1]), TNW(bh[2]), TNW(bh[3]),
-                       TNW(al[0]), TNW(al[1]), TNW(al[2]), TNW(al[3]), TNW(al[4]), TNW(al[5]), TNW(al[6]), TNW(al[7]),
-                       TNW(ah[0]), TNW(ah[1]), TNW(ah[2]), TNW(ah[3]), TNW(ah[4]), TNW(ah[5]), TNW(ah[6]), TNW(ah[7]) :: "memory");
+#define TNW_A TNW(al[0]), TNW(al[1]), TNW(al[2]), TNW(al[3]), TNW(al[4]), TNW(al[5]), TNW(al[6]), TNW(al[7]), \
+              TNW(ah[0]), TNW(ah[1]), TNW(ah[2]), TNW(ah[3]), TNW(ah[4]), TNW(ah[5]), TNW(ah[6]), TNW(ah[7])
+      if constexpr (MEDGE) {
+        if (kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : TNW(bl[0]), TNW(bl[1]), TNW(bh[0]), TNW(bh[1]), TNW_A :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : TNW(bl[0]), TNW(bl[1]), TNW(bh[0]), TNW(bh[1]), TNW_A :: "memory");
+      } else {
+        if (kh == 1)
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                       : TNW(bl[0]), TNW(bl[1]), TNW(bl[2]), TNW(bl[3]), TNW(bh[0]), TNW(bh[1]), TNW(bh[2]), TNW(bh[3]), TNW_A :: "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : TNW(bl[0]), TNW(bl[1]), TNW(bl[2]), TNW(bl[3]), TNW(bh[0]), TNW(bh[1]), TNW(bh[2]), TNW(bh[3]), TNW_A :: "memory");
+      }
+#undef TNW_A
 #undef TNW
       u32x4 fa[MT], fb[NT];
 #pragma unroll
@@ -1709,7 +1708,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const GemmP p) {
   }
   if (!late) __builtin_amdgcn_s_barrier();
   __syncthreads();
-  gemm_epilogue_auto<256, 2, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+  if constexpr (MEDGE) gemm_epilogue<256, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);      // 128 x 256 tile, ragged rows: general epilogue
+  else gemm_epilogue_auto<256, WAVES_M, WAVES_N, MT, NT>(p, acc, smem, m0, n0, zo, zi);
+}
+
+template <bool CONVB>
+__global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_n = (p.d.N + 255) / 256, tiles_m = (p.d.M + 255) / 256;
+  int tile_m, tile_n;
+  grouped_tile(wg, tiles_m, tiles_n, p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int z = blockIdx.z;
+  const int zo = z / p.d.batch_inner, zi = z - zo * p.d.batch_inner;
+  if (MTT_R3_EDGE && p.d.M - m0 <= 128 && !p.d.colsum_out && p.d.store_mode == MTT_STORE_ROWS) tn_tile<CONVB, true>(p, smem, m0, n0, zo, zi);
+  else tn_tile<CONVB, false>(p, smem, m0, n0, zo, zi);
 }
 
 template <bool CONVB>
