@@ -816,13 +816,13 @@ class TaskHeadsFn(Function):
             n = wshapes[z][0]
             g = dps[z].contiguous().view(rows, -1)
             Kp = packs[z].shape[-1]
-            if prec.name == "bf16" and FAST_BWD and HEAD_DGRAD_DMA and dy.dtype == torch.bfloat16 and rows >= FAST_MIN_ROWS and g.shape[1] % 8 == 0:
+            if (prec.name == "bf16" and FAST_BWD and HEAD_DGRAD_DMA and dy.dtype == torch.bfloat16 and rows >= FAST_MIN_ROWS and g.shape[1] % 8 == 0
+                    and Kp == ld):
                 # dya = g W is an outer-product-like GEMM (K = n <= 21 classes, a million rows): bound by the 0.7 GB it writes.  bf16 copies of
                 # the two small operands (g [rows, pad8(n)], W^T [ld, pad8(n)]) put it on the 128-row LDS-DMA kernel instead of the
                 # register-staged one (423 us per task at the benchmark's batch); padding columns of g are zeros (BilinearFn.backward)
                 npad = g.shape[1]
                 g16 = ops.cast_rows(g, torch.bfloat16)
-                assert Kp == ld
                 wT = _pad_last(packs[z][0].t(), npad).to(torch.bfloat16)                         # [ld, pad8(n)] (tiny)
                 _gemm(g16, wT, dy[z], rows, ld, npad, prec, lda=npad, ldb=npad, ldd=ld, n_store=ld, variant=_lib.GEMM_DMA128)
             else:
