@@ -196,6 +196,8 @@ typedef struct {
   const void* q; const void* xn; float* rawchan;
   int32_t B, T, N, C, h, w, nh, nw; int32_t dtype; int64_t ldq;
   float* ws;                     /* forward: workspace of mtt_chan_logits_ws_floats(d) floats (may be NULL when that is 0) */
+  const void* xn_lo;             /* ABI 9, forward only: dtype == MTT_SPLIT reads the normalised tokens as hi (xn) + lo (xn_lo) bf16 planes — the
+                                    LayerNorm output the split-plane GEMMs stream, so no fp32 copy of it is written for this kernel; q is then fp32 */
 } mtt_chanlogit_desc;
 /* rawchan is WRITTEN.  Reductions over the pixels of a window that are split across workgroups go through per-split partials in the
  * caller-owned workspace and are summed in split order (deterministic; no atomics — as every reduction of this library since ABI 6). */

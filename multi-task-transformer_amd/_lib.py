@@ -81,7 +81,7 @@ class LnDesc(C.Structure):
 class ChanLogitDesc(C.Structure):
     _fields_ = [("q", ptr), ("xn", ptr), ("rawchan", ptr),
                 ("B", i32), ("T", i32), ("N", i32), ("C", i32), ("h", i32), ("w", i32), ("nh", i32), ("nw", i32),
-                ("dtype", i32), ("ldq", i64), ("ws", ptr)]
+                ("dtype", i32), ("ldq", i64), ("ws", ptr), ("xn_lo", ptr)]
 
 
 class ModulateDesc(C.Structure):

@@ -323,13 +323,13 @@ class AttnHalfFn(Function):
         chan = Wtt is not None
         split = prec.split                       # x3f: x3 products on pre-split planes (LDS-DMA kernel), bf16 backward on the hi planes
         if split:
-            xn, mean, rstd = ops.layernorm(XT, g1, b1, eps, prec, save_stats=True, out_dtype="split", want32=chan)
-            xs, xn32 = xn if chan else (xn, None)
+            xs, mean, rstd = ops.layernorm(XT, g1, b1, eps, prec, save_stats=True, out_dtype="split")
+            xp32 = ops.prompt_rows32(xs, B, N, T, C) if chan else None      # the prompt rows (fp32-class) of the channel attention's Linears
             wq = ops.pack_linear_split([Wqkv], tag + ('qkv',))
             wp = ops.pack_linear_split([Wproj], tag + ('proj',))
             qkv = ops.linear(xs, wq, 3 * C, prec, bias=bqkv[None], out_dtype="split")[0]
             ao, rawlog, lse = ops.attention(qkv, B, N, nH, T, prec, want_lse=True)
-            xn_b, xn_c = xs.hi, xn32                # backward operands: bf16 hi plane (weight gradients), fp32 rows (channel attention)
+            xn_b, xn_c = xs.hi, xs                  # backward operand: the bf16 hi plane; the channel attention reads the planes (no fp32 copy)
         else:
             xn, mean, rstd = ops.layernorm(XT, g1, b1, eps, prec, save_stats=True)
             wq = ops.pack_linear([Wqkv], prec, tag + ('qkv',))
@@ -345,13 +345,16 @@ class AttnHalfFn(Function):
         if chan:
             wt = ops.pack_linear([Wtt], prec, tag + ('tt',))
             wt1 = ops.pack_linear([Wtt1], prec, tag + ('tt1',))
-            cq = ops.linear(xn_c, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
+            if split:
+                cq = ops.linear(xp32, wt, hw, prec, bias=btt[None], M=B * T)[0]
+            else:
+                cq = ops.linear(xn_c, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
             rawchan = ops.chan_logits(cq, xn_c, B, T, N, C, (h, w), (nwin, nwin))
             pr = XT2.view(B, N, C)[:, :T]
             ops.linear(cq, wt1, C, prec, bias=btt1[None], out=pr, d_rows=(T, N * C, C), resid=pr, rowscale=rowscale, n_prompt=T,
                        M=B * T)
         ctx.save_for_backward(XT, g1, mean, rstd, xn_b, ops._hi(qkv), ops._hi(ao), ops._hi(wq), ops._hi(wp), rowscale, lse, cq, wt, wt1,
-                              xn_c if chan and split else None)
+                              xp32 if chan and split else None)
         ctx.geo, ctx.prec, ctx.eps, ctx.chan = geo, prec, eps, chan
         ctx.params = (Wqkv, Wproj, Wtt, Wtt1)
         z = torch.zeros(0, device=XT.device)
@@ -359,11 +362,11 @@ class AttnHalfFn(Function):
 
     @staticmethod
     def backward(ctx, dXT2, drawlog, drawchan):
-        XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1, xn32 = ctx.saved_tensors
+        XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1, xp32 = ctx.saved_tensors
         Wqkv_, Wproj_, Wtt_, Wtt1_ = ctx.params
         B, N, nH, T, h, w, nwin = ctx.geo
         prec, C, M, hw = ctx.prec.bwd, nH * 64, B * N, h * w
-        xn_c = xn32 if xn32 is not None else xn                    # the rows the channel attention read (fp32 in the x3f mode)
+        xn_c = xn              # the rows the channel attention's backward reads: the bf16 hi plane in the x3f mode (its backward IS bf16)
         dXT2 = dXT2.contiguous()
         # ---- spatial attention ---------------------------------------------------------------------------------
         g, dbproj = _scaled_colsum(dXT2, rowscale, N, T, prec)
@@ -395,10 +398,12 @@ class AttnHalfFn(Function):
                 dcq = _dgrad(gp, wt1[0], B * T, hwp, C, prec, torch.float32)
             if drawchan is not None and drawchan.numel():
                 dq2 = torch.zeros(B * T, hwp, dtype=torch.float32, device=xn.device)
-                ops.call("chan_logits_bwd", q=cq, xn=xn_c, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
+                # one storage type for q and the tokens: in the x3f mode q (fp32, [B*T, hw]: tiny) is rounded to the hi plane's bf16
+                cqb = cq if cq.dtype == xn_c.dtype else ops.cast_rows(cq, xn_c.dtype)
+                ops.call("chan_logits_bwd", q=cqb, xn=xn_c, rawchan=None, B=B, T=T, N=N, C=C, h=h, w=w, nh=nwin, nw=nwin,
                          dtype=dtype_code(xn_c), ldq=hwp, xargs=[drawchan.contiguous(), dq2, F32, dxn])
                 dcq = dcq + dq2                                                # [B*T, hwp] fp32 (tiny)
-            xnp = xn_c.view(B, N, C)[:, :T].reshape(B * T, C)
+            xnp = xp32 if xp32 is not None else xn_c.view(B, N, C)[:, :T].reshape(B * T, C)
             dWtt = _wgrad(dcq, xnp, hw, C, prec)[:, :C]
             dbtt = _colsum(dcq, hw)
             dp = dxn.view(B, N, C)[:, :T]

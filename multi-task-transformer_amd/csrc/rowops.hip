@@ -377,6 +377,19 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* img, void* c
 // grid (C/8/32 column groups, pixel splits, B*nwin); block = 32 column chunks x 8 pixel lanes.
 // ------------------------------------------------------------------------------------------------
 constexpr int CL_MAXT = 8;
+// the normalised tokens of the forward: one storage type, or MTT_SPLIT = hi + lo bf16 planes (q is then fp32)
+MTT_DEV void cl_ld8_x(const mtt_chanlogit_desc& d, int64_t off, float (&v)[8]) {
+  if (d.dtype == MTT_SPLIT) {
+    float lo[8];
+    ld8(d.xn, off, MTT_BF16, v);
+    ld8(d.xn_lo, off, MTT_BF16, lo);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += lo[j];
+  } else {
+    ld8(d.xn, off, d.dtype, v);
+  }
+}
+MTT_DEV int cl_qdtype(const mtt_chanlogit_desc& d) { return d.dtype == MTT_SPLIT ? MTT_F32 : d.dtype; }
 // grid (C/64 column groups, pixel splits, B*nwin); block = 8 column chunks (64 channels, 128 B per pixel) x 32 pixel lanes.
 // Pixel lanes are reduced with wave shuffles, the 4 waves through LDS; gridDim.y == 1 -> the result is stored, else pixel split s
 // stores its partial sums as plane s of the workspace (summed in split order by mtt_reduce_few_kernel: deterministic, no atomics).
@@ -402,11 +415,11 @@ __global__ __launch_bounds__(256) void chanlogit_kernel(const mtt_chanlogit_desc
       const int y = wy * wh + pi / ww, x = wx * ww + pi % ww;
       const int pix = y * d.w + x;
       float xv[8];
-      ld8(d.xn, ((int64_t)b * d.N + d.T + pix) * d.C + cchunk * 8, d.dtype, xv);
+      cl_ld8_x(d, ((int64_t)b * d.N + d.T + pix) * d.C + cchunk * 8, xv);
 #pragma unroll
       for (int t = 0; t < CL_MAXT; ++t) {
         if (t < nT) {
-          const float qv = ld_elem(d.q, ((int64_t)b * d.T + tbase + t) * d.ldq + pix, d.dtype);
+          const float qv = ld_elem(d.q, ((int64_t)b * d.T + tbase + t) * d.ldq + pix, cl_qdtype(d));
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[t][j] += qv * xv[j];
         }
@@ -463,11 +476,11 @@ __global__ __launch_bounds__(256) void chanlogit_px8_kernel(const mtt_chanlogit_
       float qv[CL_MAXT][8];
 #pragma unroll
       for (int t = 0; t < CL_MAXT; ++t)
-        if (t < nT) ld8(d.q, ((int64_t)b * d.T + tbase + t) * d.ldq + pix, d.dtype, qv[t]);
+        if (t < nT) ld8(d.q, ((int64_t)b * d.T + tbase + t) * d.ldq + pix, cl_qdtype(d), qv[t]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float xv[8];
-        ld8(d.xn, ((int64_t)b * d.N + d.T + pix + k) * d.C + cchunk * 8, d.dtype, xv);
+        cl_ld8_x(d, ((int64_t)b * d.N + d.T + pix + k) * d.C + cchunk * 8, xv);
 #pragma unroll
         for (int t = 0; t < CL_MAXT; ++t)
           if (t < nT) {
@@ -1584,6 +1597,7 @@ extern "C" size_t mtt_ctr_dw_ws_floats(const mtt_ctr_desc* d) {
 extern "C" int mtt_chan_logits(const mtt_chanlogit_desc* d, void* stream) {
   if (!d || !d->q || !d->xn || !d->rawchan) return MTT_E_BADARG;
   if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
+  if (d->dtype == MTT_SPLIT && !d->xn_lo) return MTT_E_BADARG;
   const int splits = chanlogit_splits(d);
   if (splits > 1 && !d->ws) return MTT_E_BADARG;
   const int64_t n = (int64_t)d->B * d->T * d->nh * d->nw * d->C;
@@ -1765,6 +1779,7 @@ extern "C" int mtt_chan_logits_bwd(const mtt_chanlogit_desc* d, const float* dra
   if (!d || !d->q || !d->xn || !drawchan || !dq || !dxn) return MTT_E_BADARG;
   if (d->nh <= 0 || d->nw <= 0 || (d->h % d->nh) || (d->w % d->nw) || (d->C % 8)) return MTT_E_BADARG;
   if (d->T > 2 * CL_MAXT) return MTT_E_UNSUPPORTED;
+  if (d->dtype == MTT_SPLIT) return MTT_E_UNSUPPORTED;          // the backward reads ONE storage type (bf16 hi plane or fp32 rows)
   const int64_t toks = (int64_t)d->B * d->h * d->w;
   if (d->T <= CL_MAXT && ((d->w / d->nw) % 4) == 0 && (d->w % 4) == 0)
     hipLaunchKernelGGL(chanlogit_bwd_tok4_kernel, dim3((unsigned)((toks / 4 + 3) / 4)), dim3(256), 0, S_, *d, drawchan, dq, dq_dtype, dxn);

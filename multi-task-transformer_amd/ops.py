@@ -716,12 +716,23 @@ def patchify(img, prec):
 
 
 def chan_logits(cq, xn, B, T, N, C, grid, nwin_hw):
-    """cq [B*T, ldq] (token_trans output), xn [B*N, C] (norm1 output) -> rawchan fp32 [B, T, nwin, C]."""
+    """cq [B*T, ldq] (token_trans output), xn [B*N, C] (norm1 output; a Split: its hi / lo planes are read and summed, cq is then fp32)
+    -> rawchan fp32 [B, T, nwin, C]."""
     nh, nw = nwin_hw
     rawchan = torch.empty(B, T, nh * nw, C, dtype=torch.float32, device=xn.device)
-    call("chan_logits", q=cq, xn=xn, rawchan=rawchan, B=B, T=T, N=N, C=C, h=grid[0], w=grid[1], nh=nh, nw=nw,
-         dtype=dtype_code(xn), ldq=cq.shape[-1], ws=ws_for("chan_logits", xn.device, B=B, T=T, C=C, h=grid[0], w=grid[1], nh=nh, nw=nw))
+    kw = {}
+    if isinstance(xn, Split):
+        assert cq.dtype == torch.float32
+        kw["xn_lo"] = xn.lo
+    call("chan_logits", q=cq, xn=_hi(xn), rawchan=rawchan, B=B, T=T, N=N, C=C, h=grid[0], w=grid[1], nh=nh, nw=nw,
+         dtype=dtype_code(xn), ldq=cq.shape[-1], ws=ws_for("chan_logits", xn.device, B=B, T=T, C=C, h=grid[0], w=grid[1], nh=nh, nw=nw), **kw)
     return rawchan
+
+
+def prompt_rows32(xs, B, N, T, C):
+    """The T prompt rows of every image of a Split token matrix [B*N, C] as fp32 [B*T, C] (hi + lo): the A operand of the prompt-row
+    Linears of the channel attention (B*T rows: a few hundred KB — torch ops, not worth a kernel)."""
+    return (xs.hi.view(B, N, C)[:, :T].float() + xs.lo.view(B, N, C)[:, :T].float()).reshape(B * T, C)
 
 
 def modulate(x, x_ld, x_bs, rawlog, rawchan, B, T, N, C, grid, nwin_hw, prec, hg=0, split=False):

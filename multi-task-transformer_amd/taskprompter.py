@@ -298,15 +298,17 @@ class TaskPrompter(nn.Module):
         prec, C, nH = self.prec, self.embed_dim, self.num_heads
         hw = grid[0] * grid[1]
         a = blk.attn
-        (xs, xn32), _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec, out_dtype="split", want32=True)
+        xs, _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec, out_dtype="split")
         qkv = ops.linear(xs, ops.pack_linear_split([a.qkv.weight], tag + ('qkv',)), 3 * C, prec, bias=a.qkv.bias.detach()[None],
                          out_dtype="split")[0]
         ao, rawlog, _ = ops.attention(qkv, B, N, nH, T, prec)
         XT2 = torch.empty_like(XT)
         ops.linear(ao, ops.pack_linear_split([a.proj.weight], tag + ('proj',)), C, prec, bias=a.proj.bias.detach()[None], out=XT2, resid=XT)
-        cq = ops.linear(xn32, ops.pack_linear([a.token_trans.weight], prec, tag + ('tt',)), hw, prec,
-                        bias=a.token_trans.bias.detach()[None], a_rows=(T, N * C, C), M=B * T)[0]
-        rawchan = ops.chan_logits(cq, xn32, B, T, N, C, grid, (nwin, nwin))
+        # channel attention: its patch rows are read as the planes LayerNorm wrote (no fp32 copy of the normalised tokens), its T prompt rows
+        # per image are gathered into a small fp32 matrix
+        cq = ops.linear(ops.prompt_rows32(xs, B, N, T, C), ops.pack_linear([a.token_trans.weight], prec, tag + ('tt',)), hw, prec,
+                        bias=a.token_trans.bias.detach()[None], M=B * T)[0]
+        rawchan = ops.chan_logits(cq, xs, B, T, N, C, grid, (nwin, nwin))
         pr = XT2.view(B, N, C)[:, :T]
         ops.linear(cq, ops.pack_linear([a.token_trans1.weight], prec, tag + ('tt1',)), C, prec,
                    bias=a.token_trans1.bias.detach()[None], out=pr, d_rows=(T, N * C, C), resid=pr, M=B * T)

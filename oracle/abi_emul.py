@@ -309,6 +309,9 @@ def chan_logits(**kw):
     B, T, N, Cn, h, w, nh, nw = (kw[k] for k in ("B", "T", "N", "C", "h", "w", "nh", "nw"))
     f, o = flat(kw["xn"])
     xn = f[o:o + B * N * Cn].double().view(B, N, Cn)[:, T:]
+    if kw.get("dtype") == 2:                                          # MTT_SPLIT: hi + lo planes of the normalised tokens (q fp32)
+        fl, ol = flat(kw["xn_lo"])
+        xn = xn + fl[ol:ol + B * N * Cn].double().view(B, N, Cn)[:, T:]
     qi = (torch.arange(B)[:, None, None] * T + torch.arange(T)[None, :, None]) * kw["ldq"] + torch.arange(h * w)[None, None, :]
     q = _rd(kw["q"], qi)                                              # [B,T,hw]
     wh, ww = h // nh, w // nw

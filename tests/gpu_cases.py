@@ -574,6 +574,16 @@ def row_cases():
             kw = dict(q=rnd(g, B * T, ldq, dtype=DT[dt]), xn=rnd(g, B * N, C, dtype=DT[dt]), rawchan=torch.full((B, T, nh * nw, C), 9.0),
                       B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nw, dtype=dt, ldq=ldq, ws=scratch(64 * B * T * nh * nw * C))
             cases.append((f"chanlogit_px8_{dt}_{h}x{w}_win{nh}x{nw}", "chan_logits", kw, TOL_ROW))
+    # ABI 9: the normalised tokens as hi / lo planes (MTT_SPLIT; q fp32) — what LayerNorm wrote for the split-plane GEMMs, no fp32 copy:
+    # the one-pixel kernel (6 x 4 windows) and the eight-pixel kernel (32 x 32, one window; 16 x 16 in 2 x 2 windows; padded query pitch)
+    for (B, T, h, w, nh, nw, C) in ((2, 3, 6, 4, 1, 1, 128), (2, 6, 32, 32, 1, 1, 128), (1, 5, 16, 16, 2, 2, 64)):
+        N = T + h * w
+        ldq = h * w + 8
+        x32 = rnd(g, B * N, C)
+        xh = x32.to(torch.bfloat16)
+        kw = dict(q=rnd(g, B * T, ldq), xn=xh, xn_lo=(x32 - xh.float()).to(torch.bfloat16), rawchan=torch.full((B, T, nh * nw, C), 9.0),
+                  B=B, T=T, N=N, C=C, h=h, w=w, nh=nh, nw=nw, dtype=SPLIT, ldq=ldq, ws=scratch(64 * B * T * nh * nw * C))
+        cases.append((f"chanlogit_split_{h}x{w}_win{nh}x{nw}", "chan_logits", kw, TOL_ROW))
     # backward-only kernels ((8, 8, *): window widths that are multiples of 4 take the token-grouped chan_logits_bwd kernel)
     for dt in (F32, BF16):
         for (h, w, nh) in ((4, 6, 1), (4, 6, 2), (8, 8, 1), (8, 8, 2)):
