@@ -1,13 +1,10 @@
 #!/bin/bash
 # GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
+# round 5: the whole -m gpu suite and smoke() on the FINAL tree.
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-timeout 300 python -m pytest tests/test_gpu_ops.py -x -q -k "chanlogit or ln_fwd" > $O/r05_pytest_p_ops.log 2>&1; tail -3 $O/r05_pytest_p_ops.log
-timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_model.py tests/test_gpu_train.py tests/test_gpu_fullsize.py -x -q -k "(x3f or ns6 or gradients or bitwise) and not swin and not invpt and not cfg4 and not cfg1 and not cfg5 and not trajectory" > $O/r05_pytest_p_models.log 2>&1; tail -3 $O/r05_pytest_p_models.log
-timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-torch-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-roofline > $O/r05_bench_p_chan.log 2> $O/r05_bench_p_chan.err; echo "bench rc $?"
-python - <<'PY'
-import json
-l=[x for x in open('gpurun_out/r05_bench_p_chan.log') if x.startswith('{')][-1]
-d=json.loads(l)
-print({k:d[k] for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')}, d['parity']['worst_head_rel_err'])
-PY
+rm -f $O/parity_report.jsonl
+timeout 900 python -m pytest tests -m gpu -x -q > $O/r05_pytest_final.log 2>&1; echo "pytest rc $?" >> $O/r05_pytest_final.log
+tail -5 $O/r05_pytest_final.log
+cp $O/parity_report.jsonl $O/r05_parity_report_final.jsonl 2>/dev/null
+timeout 200 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/r05_smoke_final.log 2>&1; tail -1 $O/r05_smoke_final.log
