@@ -747,3 +747,20 @@ def test_multi_scale_sum_node_equals_the_separate_resizes(emulated):
     (ref * wgt).sum().backward()
     for a, b in zip(ys, ys2):
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_pretrained_true_reads_timms_cache_and_never_downloads(tmp_path, monkeypatch):
+    """`pretrained=True` is what the reference's get_backbone passes (TaskPrompter/utils/common_config.py:22): the constructors look for
+    the variant's `.npz` where timm 0.5.4's download_cached_file keeps it (<torch hub dir>/checkpoints/<file name of the URL>) and fail with
+    that path when it is not there — no network access, no silent random initialisation."""
+    import mtt_amd
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path))
+    path = mtt_amd.checkpoints.cached_pretrained_path("vit_base_patch16_384")
+    assert path.startswith(str(tmp_path)) and path.endswith("res_384.npz") and "B_16" in os.path.basename(path)
+    p = mtt_amd.factory.make_p(["semseg", "depth"], (64, 64), backbone="TaskPrompter_vitB", head="conv", embed_dim=24, final_embed_dim=24,
+                               num_output=dict(semseg=5))
+    with pytest.raises(RuntimeError) as e:
+        mtt_amd.taskprompter.taskprompter_vit_base_patch16_384(p=p, pretrained=True, drop_path_rate=0.0, img_size=(64, 64))
+    assert path in str(e.value) and "never downloads" in str(e.value)
+    with pytest.raises(RuntimeError):
+        mtt_amd.checkpoints.load_cached_pretrained(object(), "no_such_variant")
