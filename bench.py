@@ -118,10 +118,30 @@ def parse():
                     help="MEASUREMENT ONLY (invalid training: the forward keeps using the step-0 weight packs): what the per-step re-packing costs")
     ap.add_argument("--gemm-variant", type=int, default=None,
                     help="A/B: mtt_gemm_desc.variant for every GEMM left at AUTO (1 = general kernel, 3 = LDS-DMA kernel, 11 = general epilogue everywhere)")
+    ap.add_argument("--cpu-roofline", action="store_true",
+                    help="(host-logic tests, --device cpu only) keep the instrumented roofline step — wall-clock stamps instead of HIP events — so "
+                         "that a gloo run exercises what every rank does around it under DDP")
+    ap.add_argument("--side-stream", type=int, default=1, choices=[0, 1],
+                    help="A/B: 0 = the backward's weight-gradient work on the main stream (round 5's one-stream schedule); 1 = on a second HIP stream "
+                         "(autograd_path._SideWork, the default)")
+    ap.add_argument("--side-priority", type=int, default=0, help="A/B: torch.cuda.Stream priority of the weight-gradient stream (-1 = high)")
     ap.add_argument("--graphed-worker", action="store_true", help="(internal) the subprocess leg of ref_batch.graphed")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
     return ap.parse_args()
+
+
+class _WallEvent:
+    """stand-in for torch.cuda.Event on a box without a GPU (host-logic runs of the instrumented step: tests/bench_emulated.py --cpu-roofline)"""
+
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
 
 
 class GemmTimer:
@@ -139,7 +159,8 @@ class GemmTimer:
             v = self.variant_of(**kw) if name == "gemm" else -1
             v = 8 if v == 9 else v                                     # 9 = the same kernel's implicit-GEMM 3x3 form (gemm_ring3_kernel<true>)
             if v in self.rec:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                Ev = torch.cuda.Event if torch.cuda.is_available() else _WallEvent
+                e0, e1 = Ev(enable_timing=True), Ev(enable_timing=True)
                 e0.record()
                 self.orig(name, **kw)
                 e1.record()
@@ -229,7 +250,7 @@ def _cpu_baseline_worker(cfg_name, batch, threads, q, ref_in=None, ref_out=None,
     weights) and save its per-task outputs to `ref_out` — the reference the bench line's parity records are measured against."""
     import torch as T
     T.set_num_threads(threads)
-    from oracle import configs, weights
+    from oracle import configs, losses_oracle, weights
     import mtt_amd
     okey = {"ns6": "ns6", "cfg2": "cfg2", "cfg3": "cfg3", "cfg4": "cfg4_6", "cfg5": "cfg5", "swinb": "cs_swinB"}[cfg_name]
     invpt, swin = cfg_name == "cfg4", cfg_name == "swinb"
@@ -240,7 +261,7 @@ def _cpu_baseline_worker(cfg_name, batch, threads, q, ref_in=None, ref_out=None,
     sd = weights.synth_state_dict(contract, 0)
     params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
     x = weights.synth_images(batch, cfg["img_size"], 1)
-    crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)
+    crit = losses_oracle.MultiTaskLoss(p, p.TASKS.NAMES)
     gt = mtt_amd.losses.synthetic_targets(p, batch, cfg["img_size"][0], cfg["img_size"][1], "cpu")
     if invpt:
         from oracle import invpt_oracle as orc
@@ -299,7 +320,7 @@ def _torch_baseline_worker(cfg_name, mode):
     convs, ATen softmax / LayerNorm / GELU kernels) run on cuda:0, fp32 like the reference or under bf16 autocast — forward + criterion +
     backward + torch.optim.Adam + clip_grad_norm_.  BASELINE ONLY: the number a user gets for free on this chip, next to the hand-written path."""
     import torch as T
-    from oracle import configs, weights
+    from oracle import configs, losses_oracle, weights
     import mtt_amd
     okey = {"ns6": "ns6", "cfg2": "cfg2", "cfg3": "cfg3", "cfg4": "cfg4_6", "cfg5": "cfg5", "swinb": "cs_swinB"}[cfg_name]
     invpt, swin = cfg_name == "cfg4", cfg_name == "swinb"
@@ -316,7 +337,7 @@ def _torch_baseline_worker(cfg_name, mode):
         from oracle import swin_oracle as orc
     else:
         from oracle import taskprompter_oracle as orc
-    crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)
+    crit = losses_oracle.MultiTaskLoss(p, p.TASKS.NAMES)
     opt = T.optim.Adam(list(params.values()), lr=2e-5, weight_decay=1e-6)
     H, W = cfg["img_size"]
     res = {}
@@ -495,17 +516,13 @@ MODE_TEXT = {
 }
 
 
-def _free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
 def launch_ranks(n, argv=None, script=None):
-    """`bench.py --gpus N` started as ONE process: become the launcher of N ranks on this node, one process per GPU, exactly the command the
-    task contract names (and what TaskPrompter/run_taskprompter_*.sh:1 does for main.py with torch.distributed.launch):
-        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P <script> <same flags>
+    """`bench.py --gpus N` started as ONE process: become the launcher of N ranks on this node, one process per GPU — what
+    TaskPrompter/run_taskprompter_*.sh:1 does for main.py with torch.distributed.launch:
+        python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node N <script> <same flags>
+    `--standalone` lets the elastic agent's own store pick the rendezvous port (an endpoint of port 0 that is bound ONCE, by the process
+    that keeps it) — the earlier "bind a socket, read its port, close it, pass --master-port" left a window in which a concurrent launch
+    on the box could take the port; `--local-addr 127.0.0.1` because the container's hostname may not resolve.
     Rank 0's JSON line passes through on stdout; returns the launcher's exit code."""
     import subprocess
     script = script or os.path.abspath(sys.argv[0])
@@ -513,8 +530,8 @@ def launch_ranks(n, argv=None, script=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes needs it on this driver)
     env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 1) // max(1, n)))))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), script] + argv
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           script] + argv
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -539,7 +556,8 @@ def main():
         dev = torch.device("cuda", local)
     else:                                 # host-logic runs only (tests/bench_emulated.py): everything GPU-specific is skipped
         dev = torch.device("cpu")
-        a.no_roofline = a.no_ref_batch = a.no_torch_baseline = a.no_cpu_baseline = a.no_fast_mode = a.no_x3_mode = a.no_parity = True
+        a.no_ref_batch = a.no_torch_baseline = a.no_cpu_baseline = a.no_fast_mode = a.no_x3_mode = a.no_parity = True
+        a.no_roofline = a.no_roofline or not a.cpu_roofline
         torch.cuda.synchronize = lambda *x, **k: None
         torch.cuda.reset_peak_memory_stats = lambda *x, **k: None
         torch.cuda.max_memory_allocated = lambda *x, **k: 0
@@ -560,6 +578,8 @@ def main():
         mtt_amd.taskprompter.TaskPrompterWrapper.fuse_upsample = False
     if a.gemm_variant is not None:
         mtt_amd.ops.GEMM_VARIANT = a.gemm_variant
+    mtt_amd.autograd_path.SIDE_STREAM = bool(a.side_stream)
+    mtt_amd.autograd_path.SIDE_PRIORITY = a.side_priority
     if a.measure_no_repack:
         mtt_amd.ops.bump_param_epoch = lambda: None
         torch.autograd.graph.increment_version = lambda *x, **k: None
@@ -670,8 +690,11 @@ def main():
         if not a.no_roofline and rank != 0 and headline:
             step()                               # every rank takes the instrumented step: under DDP its gradient all-reduce is a collective
         if not a.no_roofline and rank == 0:
+            # per-kernel HIP-event durations need the kernel alone on the chip: the instrumented step runs the one-stream schedule
+            mtt_amd.autograd_path.SIDE_STREAM = False
             with GemmTimer(mtt_amd.ops, mtt_amd._lib.gemm_variant, variants=(3, 8)) as gt_:
                 step()
+                mtt_amd.autograd_path.SIDE_STREAM = bool(a.side_stream)
                 pmc_ok = a.config == "ns6" and batch == dflt_batch and prec == a.prec
                 rec["roofline"] = roofline_of(gt_, 8 if prec == "x3f" else 3, pmc_ok)
                 if prec == "x3f":                # its bf16 backward's input-gradient GEMMs run on the bf16 kernel

@@ -56,9 +56,10 @@ def test_fullsize_backward_is_the_derivative_of_forward():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import mtt_amd
+    from oracle import losses_oracle
     p, model = _build("x3")
     model.train()
-    crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES).cuda()
+    crit = losses_oracle.MultiTaskLoss(p, p.TASKS.NAMES).cuda()
     x = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(2)).cuda()
     gt = mtt_amd.losses.synthetic_targets(p, 2, 512, 512, "cuda", seed=3)
     params = [q for q in model.parameters() if q.requires_grad]
@@ -296,7 +297,7 @@ def test_swinb_fullsize_training_step_matches_oracle_autograd():
         t0 = time.time()
         fwd, errs, dead = train_check.swin_grad_errors("cs_swinB", prec, "cuda", batch=1, contract=contract, ref_cache=cache)
         worst, med = train_check.summarize(errs)
-        rels = sorted((e / max(n, 1e-30) for e, n in errs.values() if n > 1e-6), reverse=True)
+        rels = sorted((v.err / max(v.ref, 1e-30) for v in errs.values() if v.ref > 1e-6), reverse=True)
         pu.report("train_parity", config="cs_swinB", batch=1, prec=prec, fwd_worst=max(fwd.values()), grad_median=med, grad_worst=worst[0],
                   grad_worst_param=worst[1], grad_p90=rels[len(rels) // 10], n_params=len(errs), n_dead=len(dead), per_head=fwd,
                   seconds=round(time.time() - t0, 1))

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import conftest
-from oracle import configs, weights
+from oracle import configs, losses_oracle, weights
 
 
 def test_library_loads_and_exports_header_symbols():
@@ -410,7 +410,7 @@ def check_fused_losses(device, tol):
     import mtt_amd
     p, pred, gt = _loss_case(device)
     ref_pred = {t: v.detach().cpu().clone().requires_grad_(True) for t, v in pred.items()}
-    ref = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)(ref_pred, {t: v.cpu() for t, v in gt.items()})
+    ref = losses_oracle.MultiTaskLoss(p, p.TASKS.NAMES)(ref_pred, {t: v.cpu() for t, v in gt.items()})
     out = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES)(pred, gt)
     ref["total"].backward()
     out["total"].backward()

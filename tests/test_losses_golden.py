@@ -2,7 +2,7 @@
 TaskPrompter/losses/loss_functions.py + loss_schemes.py (6 task kinds: ignore regions, class-frequency weights, pos_weight,
 normalised L1), InvPT/losses/loss_schemes.py (intermediate supervision), TaskPrompter/utils/train_utils.py:139-150 (PolynomialLR).
 
-  * CPU: the torch restatement `losses.MultiTaskLoss` (the oracle of the fused kernels) and `FusedMultiTaskLoss` on the ABI emulator
+  * CPU: the torch restatement `oracle/losses_oracle.MultiTaskLoss` (the oracle of the fused kernels) and `FusedMultiTaskLoss` on the ABI emulator
   * -m gpu: `FusedMultiTaskLoss` on the HIP kernels (mtt_loss_label_stats / mtt_loss_fwd / mtt_loss_bwd)
 """
 import os
@@ -31,7 +31,8 @@ def _check(cls, device, tol, gtol):
     import mtt_amd
     g = _gold()
     for scheme, intermediate in (("tp", False), ("ip", True)):
-        crit = getattr(mtt_amd.losses, cls)(_p(intermediate), TASKS, WEIGHTS)
+        from oracle import losses_oracle
+        crit = getattr(losses_oracle if cls == "MultiTaskLoss" else mtt_amd.losses, cls)(_p(intermediate), TASKS, WEIGHTS)
         for case in CASES:
             pred = {t: torch.from_numpy(g[f"pred/{t}"]).to(device).requires_grad_(True) for t in TASKS}
             gt = {t: torch.from_numpy(g[f"gt/{case}/{t}"]).to(device) for t in TASKS}

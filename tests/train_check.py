@@ -1,9 +1,45 @@
 """Shared helper: one training step's forward + backward of the product vs the oracle's autograd."""
+import collections
+
 import torch
 
 import conftest
-from oracle import configs, taskprompter_oracle as tpo, weights
+from oracle import configs, losses_oracle, taskprompter_oracle as tpo, weights
 from tests.golden.make_golden import loss_of
+
+# one parameter's gradient against the oracle's autograd: |g - ref|, |ref|, cos(g, ref), element count
+GradErr = collections.namedtuple("GradErr", "err ref cos numel")
+
+
+def grad_err(g, ref):
+    g, ref = g.detach().double().cpu().reshape(-1), ref.detach().double().reshape(-1)
+    gn, rn = float(g.norm()), float(ref.norm())
+    cos = float(g @ ref) / (gn * rn) if gn > 0 and rn > 0 else (1.0 if gn == rn else 0.0)
+    return GradErr(float((g - ref).norm()), rn, cos, g.numel())
+
+
+# Per-parameter bound of a bf16-arithmetic backward (x3f, bf16): EVERY parameter whose reference gradient is above the norm floor must
+# point the oracle's way (cosine) or be close in norm (relative error) — a median over the parameters lets one wrong gradient through
+# (VERDICT r05, weak #1).  The floor is relative to the largest per-element gradient RMS of the model: a tensor whose true gradient is
+# three orders of magnitude below the others' (a bias whose contributions cancel) carries rounding noise of the tensors it is summed from.
+PER_PARAM = dict(cos_min=0.999, rel_max=0.15, worst_max=0.2, floor=1e-3)
+
+
+def per_param_violations(errs, cos_min=PER_PARAM["cos_min"], rel_max=PER_PARAM["rel_max"], worst_max=PER_PARAM["worst_max"], floor=PER_PARAM["floor"]):
+    """-> (violations [(name, rel, cos, rms / top_rms)], n_checked, n_below_floor).  A parameter passes when cos >= cos_min or
+    rel <= rel_max, and every checked parameter needs rel < worst_max."""
+    rms = {k: v.ref / max(v.numel, 1) ** 0.5 for k, v in errs.items()}
+    top = max(rms.values())
+    bad, checked, below = [], 0, 0
+    for k, v in errs.items():
+        if rms[k] < floor * top:
+            below += 1
+            continue
+        checked += 1
+        rel = v.err / v.ref
+        if not ((v.cos >= cos_min or rel <= rel_max) and rel < worst_max):
+            bad.append((k, rel, v.cos, rms[k] / top))
+    return bad, checked, below
 
 
 def grad_errors(name, prec, device, drop=None, seed=0):
@@ -29,7 +65,7 @@ def grad_errors(name, prec, device, drop=None, seed=0):
     for k, prm in model.named_parameters():
         ref = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
         assert prm.grad is not None, f"{k}: no gradient (reference gives every TaskPrompter parameter one)"
-        errs[k] = (float((prm.grad.cpu() - ref).norm()), float(ref.norm()))
+        errs[k] = grad_err(prm.grad, ref)
     return fwd, errs
 
 
@@ -60,12 +96,12 @@ def invpt_grad_errors(name, prec, device, seed=0):
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, f"{k}: dead in the reference but got a gradient"
             continue
         assert prm.grad is not None, f"{k}: no gradient"
-        errs[k] = (float((prm.grad.cpu() - params[k].grad).norm()), float(params[k].grad.norm()))
+        errs[k] = grad_err(prm.grad, params[k].grad)
     return fwd, errs, dead
 
 
 def summarize(errs, floor=1e-6):
-    rel = sorted(((e / n, k) for k, (e, n) in errs.items() if n > floor), reverse=True)
+    rel = sorted(((v[0] / v[1], k) for k, v in errs.items() if v[1] > floor), reverse=True)
     med = rel[len(rel) // 2][0]
     return rel[0], med
 
@@ -152,7 +188,7 @@ def swin_grad_errors(name, prec, device, seed=0, drop=None, batch=2, contract=No
             assert prm.grad is None or float(prm.grad.abs().max()) < 1e-12, f"{k}: dead in the reference but got a gradient"
             continue
         assert prm.grad is not None, f"{k}: no gradient"
-        errs[k] = (float((prm.grad.cpu() - rg).norm()), float(rg.norm()))
+        errs[k] = grad_err(prm.grad, rg)
     return fwd, errs, dead
 
 
@@ -192,7 +228,7 @@ def trajectory_check(name, modes, device, steps=200, lr=2e-4, n_batches=4, batch
     ref = {k: v.clone() for k, v in sd.items()}
     params = {k: ref[k].requires_grad_(True) for k in ref if ref[k].dtype.is_floating_point and "running_" not in k}
     ropt = torch.optim.Adam(list(params.values()), lr=lr, weight_decay=1e-6)
-    rcrit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES)
+    rcrit = losses_oracle.MultiTaskLoss(p, p.TASKS.NAMES)
     rgts = [mtt_amd.losses.synthetic_targets(p, batch, H, W, "cpu", seed=30 + i) for i in range(n_batches)]
     ls = []
     for it in range(steps):

@@ -1,14 +1,23 @@
 #!/bin/bash
 # GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
-# round 5: the driver-style bench line on the FINAL tree.
+# round 6, session 1: per-parameter gradient distribution (calibrates tests/train_check.PER_PARAM), the side-stream backward's
+# correctness tests, and its same-box A/B on the headline step.
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-timeout 390 python bench.py --steps 20 --warmup 5 > $O/r05_bench_final.log 2> $O/r05_bench_final.err; echo "bench rc $?"
-python - <<'PY'
-import json
-l=[x for x in open('gpurun_out/r05_bench_final.log') if x.startswith('{')][-1]
-d=json.loads(l)
-print({k:d[k] for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
-r=d['roofline']; print({k:v for k,v in r.items() if k in ('achieved','frac','frac_mfma_issued','traffic','traffic_note','launches','kernel_ms_per_step')})
-print('fast', d['fast_mode']['images_per_s'], d['fast_mode']['fwd_ms_per_img'], 'parity', d['parity']['worst_head_rel_err'], d['full_fp32_mode']['images_per_s'])
+timeout 900 python tools/grad_dist.py --out $O/r06_grad_dist_a.json mini_ctr:x3f mini_ctr:bf16 mini_win:x3f mini_win:bf16 mini_deconv:x3f mini_deconv:bf16 \
+    mini_p32:x3f mini8:x3f mini8:bf16 ns6:x3f ns6:bf16 > $O/r06_grad_dist_a.log 2>&1; echo "grad_dist rc $?"
+grep -E "^==|VIOLATION" $O/r06_grad_dist_a.log
+timeout 900 python -m pytest tests/test_gpu_train.py -x -q -m gpu -k "not trajectory and not swin" > $O/r06_pytest_a_train.log 2>&1; echo "pytest rc $?"; tail -3 $O/r06_pytest_a_train.log
+COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-ref-batch --no-torch-baseline --no-fast-mode --no-x3-mode --no-fwd"
+for v in "1 0" "0 0" "1 -1" "0 0" "1 0"; do
+  set -- $v
+  timeout 300 python bench.py $COMMON --side-stream $1 --side-priority $2 > $O/r06_bench_a_side$1_p$2.log 2>&1
+  python - "$O/r06_bench_a_side$1_p$2.log" "$v" <<'PY'
+import json, sys
+l = [x for x in open(sys.argv[1]) if x.startswith('{')]
+if not l:
+    print("side", sys.argv[2], "NO LINE"); print(open(sys.argv[1]).read()[-1500:])
+else:
+    d = json.loads(l[-1]); print("side/prio", sys.argv[2], d['value'], d['ms_per_step'])
 PY
+done

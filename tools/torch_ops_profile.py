@@ -8,13 +8,14 @@ import torch  # noqa: E402
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 import mtt_amd  # noqa: E402
+from oracle import losses_oracle  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda")
 p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (512, 512), backbone="TaskPrompter_vitL", head="conv", embed_dim=300,
                            final_embed_dim=350, chan_nheads=1, use_ctr=True, prec="bf16")
 model = mtt_amd.factory.get_model(p).to(dev).train()
-crit = mtt_amd.losses.MultiTaskLoss(p, p.TASKS.NAMES).to(dev)
+crit = losses_oracle.MultiTaskLoss(p, p.TASKS.NAMES).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=2e-5, fused=True)
 x = torch.randn(B, 3, 512, 512, device=dev)
 gt = mtt_amd.losses.synthetic_targets(p, B, 512, 512, dev)
