@@ -121,10 +121,6 @@ def parse():
     ap.add_argument("--cpu-roofline", action="store_true",
                     help="(host-logic tests, --device cpu only) keep the instrumented roofline step — wall-clock stamps instead of HIP events — so "
                          "that a gloo run exercises what every rank does around it under DDP")
-    ap.add_argument("--side-stream", type=int, default=1, choices=[0, 1],
-                    help="A/B: 0 = the backward's weight-gradient work on the main stream (round 5's one-stream schedule); 1 = on a second HIP stream "
-                         "(autograd_path._SideWork, the default)")
-    ap.add_argument("--side-priority", type=int, default=0, help="A/B: torch.cuda.Stream priority of the weight-gradient stream (-1 = high)")
     ap.add_argument("--graphed-worker", action="store_true", help="(internal) the subprocess leg of ref_batch.graphed")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
@@ -578,8 +574,6 @@ def main():
         mtt_amd.taskprompter.TaskPrompterWrapper.fuse_upsample = False
     if a.gemm_variant is not None:
         mtt_amd.ops.GEMM_VARIANT = a.gemm_variant
-    mtt_amd.autograd_path.SIDE_STREAM = bool(a.side_stream)
-    mtt_amd.autograd_path.SIDE_PRIORITY = a.side_priority
     if a.measure_no_repack:
         mtt_amd.ops.bump_param_epoch = lambda: None
         torch.autograd.graph.increment_version = lambda *x, **k: None
@@ -690,11 +684,8 @@ def main():
         if not a.no_roofline and rank != 0 and headline:
             step()                               # every rank takes the instrumented step: under DDP its gradient all-reduce is a collective
         if not a.no_roofline and rank == 0:
-            # per-kernel HIP-event durations need the kernel alone on the chip: the instrumented step runs the one-stream schedule
-            mtt_amd.autograd_path.SIDE_STREAM = False
             with GemmTimer(mtt_amd.ops, mtt_amd._lib.gemm_variant, variants=(3, 8)) as gt_:
                 step()
-                mtt_amd.autograd_path.SIDE_STREAM = bool(a.side_stream)
                 pmc_ok = a.config == "ns6" and batch == dflt_batch and prec == a.prec
                 rec["roofline"] = roofline_of(gt_, 8 if prec == "x3f" else 3, pmc_ok)
                 if prec == "x3f":                # its bf16 backward's input-gradient GEMMs run on the bf16 kernel

@@ -230,56 +230,6 @@ def _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, colsum
 FAST_BWD = True
 FAST_MIN_DIM, FAST_MIN_ROWS = 256, 1024      # below these the general (transposing-stager) kernels are used
 
-SIDE_STREAM = True          # weight gradients (GEMMs, slab sums, bias column sums, scatter copies) of a backward node on a second HIP stream
-SIDE_PRIORITY = 0           # torch.cuda.Stream priority of that stream (0 = the main stream's; tests / A-B runs change it)
-_side_streams = {}
-
-
-def _flat_tensors(o):
-    if isinstance(o, torch.Tensor):
-        yield o
-    elif isinstance(o, (tuple, list)):
-        for v in o:
-            yield from _flat_tensors(v)
-
-
-class _SideWork:
-    """The off-chain part of ONE backward node on a second stream.  A weight gradient depends on the node's incoming gradient and on
-    saved activations, and nothing downstream of the node waits for it: `run(fn, ...)` launches it on the side stream behind everything
-    the main stream has queued so far (its operands), while the main stream goes on with the input-gradient chain; `join()` — before
-    the node returns, because autograd's AccumulateGrad and DDP's bucket hooks read the results on the main stream — makes the main
-    stream wait for the side stream and tells the caching allocator that the side-allocated results are used on the main stream.
-    What it buys: the HBM-bound kernels of the chain (LayerNorm / BatchNorm backward, casts, modulate) and the tails of its GEMM launches
-    no longer leave the matrix pipes idle, and the bias column sums / slab sums / scatter copies of the weight gradients run under the
-    chain's GEMMs.  No atomics, fixed summation orders: results are bitwise those of the one-stream schedule.  Capturable (the side stream
-    forks from and joins the capturing stream).  Workspaces are per stream (ops.workspace)."""
-
-    def __init__(self, device):
-        self.on = SIDE_STREAM and device.type == "cuda"
-        self.outs = []
-        if self.on:
-            self.main = torch.cuda.current_stream(device)
-            key = (device.index, SIDE_PRIORITY)
-            self.side = _side_streams.get(key)
-            if self.side is None:
-                self.side = _side_streams[key] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
-
-    def run(self, fn, *a, **k):
-        if not self.on:
-            return fn(*a, **k)
-        self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
-            out = fn(*a, **k)
-        self.outs.append(out)
-        return out
-
-    def join(self):
-        if self.on and self.outs:
-            self.main.wait_stream(self.side)
-            for t in _flat_tensors(self.outs):
-                t.record_stream(self.main)
-            self.outs = []
-
 
 def _dgrad(dy, wpack2d, M, N_in, K_out, prec, out_dtype, **epi):
     """dx[M, N_in] = dy[M, :K_out] @ W[K_out, N_in]   (W stored [K_out, ldw], read transposed)."""
@@ -419,16 +369,15 @@ class AttnHalfFn(Function):
         xn_c = xn              # the rows the channel attention's backward reads: the bf16 hi plane in the x3f mode (its backward IS bf16)
         dXT2 = dXT2.contiguous()
         # ---- spatial attention ---------------------------------------------------------------------------------
-        sw = _SideWork(dXT2.device)
         g, dbproj = _scaled_colsum(dXT2, rowscale, N, T, prec)
-        dWproj, _ = sw.run(_enc_wgrad, g, ao, C, C, prec, bias=False)
+        dWproj, _ = _enc_wgrad(g, ao, C, C, prec, bias=False)
         dao = _enc_dgrad(g, Wproj_, wp[0], M, C, C, prec, prec.adt, 'proj')
         dl = drawlog.contiguous() if (T > 0 and drawlog is not None and drawlog.numel()) else None
         if lse is not None:
             dqkv = attention_bwd_flash(qkv, ao, lse, dao, dl, B, N, nH, T, prec)
         else:
             dqkv = attention_bwd(qkv, dao, dl, B, N, nH, T, prec)
-        dWqkv, dbqkv = sw.run(_enc_wgrad, dqkv, xn, 3 * C, C, prec)
+        dWqkv, dbqkv = _enc_wgrad(dqkv, xn, 3 * C, C, prec)
         dxn = _enc_dgrad(dqkv, Wqkv_, wq[0], M, C, 3 * C, prec, torch.float32, 'qkv')
         # ---- channel attention: accumulates onto dxn -------------------------------------------------------------
         dWtt = dbtt = dWtt1 = dbtt1 = None
@@ -468,7 +417,6 @@ class AttnHalfFn(Function):
                       resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
         # ---- norm1 backward accumulated into the residual gradient ------------------------------------------------
         dXT, dg1, db1 = _ln_bwd_join(dXT2, XT, dxn, g1, mean, rstd, ctx.eps)
-        sw.join()
         return (dXT, dg1, db1, None, dWqkv, dbqkv, dWproj, dbproj, dWtt, dbtt, dWtt1, dbtt1, None, None, None, None)
 
 
@@ -500,16 +448,14 @@ class MlpHalfFn(Function):
         prec, M = ctx.prec.bwd, B * N
         C, Hd = xn2.shape[1], z.shape[1]
         dXT3 = dXT3.contiguous()
-        sw = _SideWork(dXT3.device)
         g, db2 = _scaled_colsum(dXT3, rowscale, N, T, prec)
         W1_, W2_ = ctx.params
-        dW2, _ = sw.run(_enc_wgrad, g, hmid, C, Hd, prec, bias=False)
+        dW2, _ = _enc_wgrad(g, hmid, C, Hd, prec, bias=False)
         dz, db1 = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', colsum=True, act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z),
                              ldaux=Hd)
-        dW1, _ = sw.run(_enc_wgrad, dz, xn2, Hd, C, prec, bias=False)
+        dW1, _ = _enc_wgrad(dz, xn2, Hd, C, prec, bias=False)
         dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
         dXT2, dg2, dbn2 = _ln_bwd_join(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps)
-        sw.join()
         return dXT2, dg2, dbn2, None, dW1, db1, dW2, db2, None, None, None, None
 
 
@@ -627,34 +573,6 @@ class BLinearFn(Function):
             lda = Np
         xz = x.stride(0) if (x.dim() == 3 and x.shape[0] > 1) else 0
         bi = az['batch_inner']
-
-        def weight_part():
-            if Z == 1 and layout == 'plain':
-                dW = _wgrad(dy.view(M, lda), x.reshape(M, x.shape[-1]), N, Kp, prec)[None]
-            elif layout == 'catpair':
-                # z = 2t + s: dy[t][:, s*Np:], x[z]; one (task, slice)-batched launch per s
-                halves = [_wgrad_batched(dy, x, N, Kp, M, prec, Z // 2, lda, x.shape[-1], M * lda, 2 * xz, a0=sft * Np, b0=sft * xz) for sft in (0, 1)]
-                dW = torch.stack(halves, 1).reshape(Z, N, Kp)
-            else:
-                dW = _wgrad_batched(dy, x, N, Kp, M, prec, Z, lda, x.shape[-1], M * lda, xz)
-            dys = dy.view(-1, M, lda)
-            # bias gradients of all Z layers in one launch pair (catpair: one per half, the half's columns start s * Np into every row)
-            if layout == 'catpair':
-                h0, h1 = (ops.colsum_batched(dys, N, Z // 2, M * lda, col_off=sft * Np) for sft in (0, 1))
-                dball = torch.stack([h0, h1], 1).reshape(Z, N)
-            else:
-                dball = ops.colsum_batched(dys, N, Z, M * lda)
-            K = math.prod(wshapes[0][1:])
-            cols = [(0, 0, K)] if kmap is None else kmap[1]
-            dW = dW.contiguous()
-            dws = ops.unpack_grads(dW, ('blinear', N, Kp, tuple(cols)), wshapes,
-                                   lambda src, flat, offs: [ops.segment(src, z * N * Kp + d0, flat, offs[z] + s0, (1, N, ln), (0, Kp, 1), (0, K, 1))
-                                                            for z in range(Z) for (d0, s0, ln) in cols],
-                                   partial=sum(c[2] for c in cols) != K)      # a column range of a shared weight (InvPT mix projections)
-            return dws, list(dball.unbind(0))
-
-        sw = _SideWork(dy.device)
-        dws, dbs = sw.run(weight_part)
         dx = torch.empty(Z, M, Kp, dtype=getattr(ctx, "grad_dtype", None) or xdt, device=x.device)       # (a stage of FuseTailFn: the backward's dtype)
         if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and M >= FAST_MIN_ROWS and Kp >= 128:
             # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T.  The reduction runs over pad8(N) columns of dy:
@@ -669,11 +587,33 @@ class BLinearFn(Function):
         else:
             _gemm(dy, wpack, dx, M, Kp, N, prec, b_op=OP_R, lda=lda, ldb=Kp, ldd=Kp, b_zo=wpack.stride(0) * bi,
                   b_zi=wpack.stride(0) if bi > 1 else 0, d_zo=M * Kp * bi, d_zi=M * Kp if bi > 1 else 0, n_store=Kp, **az)
+        if Z == 1 and layout == 'plain':
+            dW = _wgrad(dy.view(M, lda), x.reshape(M, x.shape[-1]), N, Kp, prec)[None]
+        elif layout == 'catpair':
+            # z = 2t + s: dy[t][:, s*Np:], x[z]; one (task, slice)-batched launch per s
+            halves = [_wgrad_batched(dy, x, N, Kp, M, prec, Z // 2, lda, x.shape[-1], M * lda, 2 * xz, a0=sft * Np, b0=sft * xz) for sft in (0, 1)]
+            dW = torch.stack(halves, 1).reshape(Z, N, Kp)
+        else:
+            dW = _wgrad_batched(dy, x, N, Kp, M, prec, Z, lda, x.shape[-1], M * lda, xz)
+        dys = dy.view(-1, M, lda)
+        # bias gradients of all Z layers in one launch pair (catpair: one per half, the half's columns start s * Np into every row)
+        if layout == 'catpair':
+            h0, h1 = (ops.colsum_batched(dys, N, Z // 2, M * lda, col_off=sft * Np) for sft in (0, 1))
+            dball = torch.stack([h0, h1], 1).reshape(Z, N)
+        else:
+            dball = ops.colsum_batched(dys, N, Z, M * lda)
+        dbs = list(dball.unbind(0))
+        K = math.prod(wshapes[0][1:])
+        cols = [(0, 0, K)] if kmap is None else kmap[1]
+        dW = dW.contiguous()
+        dws = ops.unpack_grads(dW, ('blinear', N, Kp, tuple(cols)), wshapes,
+                               lambda src, flat, offs: [ops.segment(src, z * N * Kp + d0, flat, offs[z] + s0, (1, N, ln), (0, Kp, 1), (0, K, 1))
+                                                        for z in range(Z) for (d0, s0, ln) in cols],
+                               partial=sum(c[2] for c in cols) != K)      # a column range of a shared weight (InvPT mix projections)
         if x.dim() == 3 and x.shape[0] == 1 and Z > 1:
             dx = dx.sum(0, keepdim=True)
         elif x.dim() == 2:
             dx = dx.sum(0)
-        sw.join()
         return (dx, None, None, None, None, None, None, None) + tuple(dws) + tuple(dbs)
 
 
@@ -718,17 +658,7 @@ class Conv3x3Fn(Function):
         x, dy = _to_bwd(x, prec), _to_bwd(dy.contiguous(), prec)
         rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
         wd = ops.pack_conv3(list(ws), prec, tag, transpose=True)                     # [Z, Ci, 9*Cop]
-        sw = _SideWork(dy.device)
-        dws, dbs = sw.run(Conv3x3Fn._weight_part, x, dy, (B, H, W, Co, Ci, dil), prec, Z, has_bias)
         dx = ops.conv3x3(dy, wd, Ci, Co, B, H, W, prec, flip=1, dil=dil, out_dtype=xdt)
-        sw.join()
-        return (dx, None, None, None) + tuple(dws) + tuple(dbs)
-
-    @staticmethod
-    def _weight_part(x, dy, geo, prec, Z, has_bias):
-        """weight and bias gradients of the Z convs (the off-chain part of the backward: _SideWork)"""
-        B, H, W, Co, Ci, dil = geo
-        rows, Cip, Cop = x.shape[1], x.shape[2], dy.shape[2]
         conv = dict(H=H, W=W, C=Ci, Cp=Cip, dil=dil, flip=0)
         tiles = Z * (-(-Co // 128)) * (-(-9 * Cip // 128))
         S = _n_splits(tiles, B)                                          # slices = whole images (the gather decomposes pixel -> (y, x))
@@ -761,7 +691,7 @@ class Conv3x3Fn(Function):
                                lambda src, flat, offs: [ops.segment(src, z * Co * 9 * Cip, flat, offs[z], (Co, 9, Ci), (9 * Cip, Cip, 1), (Ci * 9, 1, 9))
                                                         for z in range(Z)])
         dbs = list(ops.colsum_batched(dy, Co, Z, dy.stride(0)).unbind(0)) if has_bias else [None] * Z
-        return dws, dbs
+        return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 
 class UpConv3x3Fn(Function):
@@ -801,17 +731,6 @@ class UpConv3x3Fn(Function):
         M, Kp, N9 = xa.shape[1], xa.shape[2], w9.shape[1]
         dz = _to_bwd(ops.upconv4_gather(dy, Co, B, h, w), prec)          # [Z, M, N9]
         xa = _to_bwd(xa, prec)
-        Cop = N9 // 9
-
-        def weight_part():
-            dW9 = _wgrad_batched(dz, xa, N9, Kp, M, prec, Z, N9, Kp, M * N9, M * Kp)              # [Z, N9, Kp] fp32
-            dws = ops.unpack_grads(dW9, 'upconv9', [(Co, Ci, 3, 3)] * Z,    # dW9[z][tap*Cop + co, ci] -> W[co, ci, tap]
-                                   lambda src, flat, offs: [ops.segment(src, z * N9 * Kp, flat, offs[z], (9, Co, Ci), (Cop * Kp, Kp, 1), (1, Ci * 9, 9))
-                                                            for z in range(Z)])
-            return dws, list(ops.colsum_batched(dy, Co, Z, dy.stride(0)).unbind(0))
-
-        sw = _SideWork(dy.device)
-        dws, dbs = sw.run(weight_part)
         dx = torch.empty(Z, M, Kp, dtype=xdtype, device=dy.device)
         if prec.name == "bf16" and FAST_BWD and M >= FAST_MIN_ROWS and Kp >= 128:
             wT = w9.transpose(1, 2).contiguous().to(torch.bfloat16)      # [Z, Kp, N9]: reduction-contiguous dgrad operand (x3f: fp32 pack)
@@ -819,7 +738,12 @@ class UpConv3x3Fn(Function):
         else:
             _gemm(dz, w9, dx, M, Kp, N9, prec, b_op=OP_R, lda=N9, ldb=Kp, ldd=Kp, batch=Z, a_zo=M * N9, b_zo=N9 * Kp, d_zo=M * Kp,
                   n_store=Kp)
-        sw.join()
+        dW9 = _wgrad_batched(dz, xa, N9, Kp, M, prec, Z, N9, Kp, M * N9, M * Kp)              # [Z, N9, Kp] fp32
+        Cop = N9 // 9
+        dws = ops.unpack_grads(dW9, 'upconv9', [(Co, Ci, 3, 3)] * Z,    # dW9[z][tap*Cop + co, ci] -> W[co, ci, tap]
+                               lambda src, flat, offs: [ops.segment(src, z * N9 * Kp, flat, offs[z], (9, Co, Ci), (Cop * Kp, Kp, 1), (1, Ci * 9, 9))
+                                                        for z in range(Z)])
+        dbs = list(ops.colsum_batched(dy, Co, Z, dy.stride(0)).unbind(0))
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 
@@ -893,12 +817,10 @@ class TaskHeadsFn(Function):
         # autograd requires the dtype of y
         dy = torch.empty(y.shape, dtype=getattr(ctx, "grad_dtype", None) or y.dtype, device=y.device)
         dws, dbs = [], []
-        sw = _SideWork(y.device)
         for z in range(Z):
             n = wshapes[z][0]
             g = dps[z].contiguous().view(rows, -1)
             Kp = packs[z].shape[-1]
-            dW, db = sw.run(lambda: (_wgrad(g, y[z], n, Kp, prec), _colsum(g, n)))
             if (prec.name == "bf16" and FAST_BWD and HEAD_DGRAD_DMA and dy.dtype == torch.bfloat16 and rows >= FAST_MIN_ROWS and g.shape[1] % 8 == 0
                     and Kp == ld):
                 # dya = g W is an outer-product-like GEMM (K = n <= 21 classes, a million rows): bound by the 0.7 GB it writes.  bf16 copies of
@@ -910,9 +832,9 @@ class TaskHeadsFn(Function):
                 _gemm(g16, wT, dy[z], rows, ld, npad, prec, lda=npad, ldb=npad, ldd=ld, n_store=ld, variant=_lib.GEMM_DMA128)
             else:
                 _gemm(g, packs[z][0], dy[z], rows, ld, n, prec, b_op=OP_R, lda=g.shape[1], ldb=Kp, ldd=ld, n_store=ld)
+            dW = _wgrad(g, y[z], n, Kp, prec)
             dws.append(dW[:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
-            dbs.append(db)
-        sw.join()
+            dbs.append(_colsum(g, n))
         return (dy, None, None) + tuple(dws) + tuple(dbs)
 
 

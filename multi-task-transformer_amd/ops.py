@@ -780,13 +780,10 @@ _ws_retired = []         # outgrown workspaces are kept alive: a captured hipGra
 
 
 def workspace(nfloats, device):
-    """Grow-only fp32 scratch buffer per device AND stream for the kernels' workspaces (launches are stream-ordered, so one buffer serves
-    all kernels of a stream).
+    """Grow-only fp32 scratch buffer per device for the kernels' workspaces (launches are stream-ordered, so one buffer serves all).
     An outgrown buffer is never freed (a recorded graph may still write its partial sums there), and growing while a stream is
     capturing is an error (the allocation would land in the graph's private pool and die with it)."""
-    # one buffer per (device, stream): the backward runs its weight-gradient work on a second stream (autograd_path._SideWork), and two
-    # kernels of different streams must never share partial-sum scratch
-    key = (device.type, device.index, torch.cuda.current_stream(device).stream_id if device.type == "cuda" else 0)
+    key = (device.type, device.index)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         if device.type == "cuda" and torch.cuda.is_current_stream_capturing():

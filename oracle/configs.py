@@ -42,6 +42,10 @@ def taskprompter(name):
         # miniatures for fast CPU parity (same code paths: odd dims, windows, ctr, deconv)
         "mini_ctr": dict(backbone="tiny", img_size=(64, 96), tasks=PASCAL6, embed_dim=44, final_embed_dim=52,
                          chan_nheads=1, use_ctr=True, prompt_len=1, head="conv"),
+        # the wrapper's `dd_label_map_size` branch (taskprompter_wrapper.py:17-27): mini_ctr with predictions resized to 40 x 56 instead of
+        # the 64 x 96 input (fixture tests/golden/mini_ctr_dd.npz from the unmodified reference; same state-dict contract as mini_ctr)
+        "mini_ctr_dd": dict(backbone="tiny", img_size=(64, 96), tasks=PASCAL6, embed_dim=44, final_embed_dim=52,
+                            chan_nheads=1, use_ctr=True, prompt_len=1, head="conv", dd_label_map_size=(40, 56), contract_of="mini_ctr"),
         "mini_win": dict(backbone="tiny", img_size=(64, 96), tasks=NYUD4, embed_dim=48, final_embed_dim=40,
                          chan_nheads=4, use_ctr=False, prompt_len=1, head="conv"),
         "mini_deconv": dict(backbone="tiny", img_size=(64, 64), tasks=CS2, embed_dim=30, final_embed_dim=36,

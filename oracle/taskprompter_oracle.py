@@ -181,10 +181,12 @@ def head_forward(sd, pre, kind, f, training=False, bn_updates=None):
 
 
 def forward(sd, cfg, img, training=False, drop=None, bn_updates=None, return_features=False):
-    """TaskPrompterWrapper.forward (taskprompter_wrapper.py:22-40): {task: [B,n_out,H,W]} fp32."""
+    """TaskPrompterWrapper.forward (taskprompter_wrapper.py:22-40): {task: [B,n_out,H,W]} fp32; (H, W) = the input size, or
+    cfg["dd_label_map_size"] when the config carries one (taskprompter_wrapper.py:17-20, :26)."""
     feats = backbone_forward(sd, cfg, img, "backbone", training, drop, bn_updates)
     out = {}
+    target = tuple(cfg["dd_label_map_size"]) if cfg.get("dd_label_map_size") is not None else tuple(img.shape[-2:])
     for task, _ in cfg["tasks"]:
         y = head_forward(sd, f"heads.{task}", cfg["head"], feats[task], training, bn_updates)
-        out[task] = F.interpolate(y, size=tuple(img.shape[-2:]), mode="bilinear", align_corners=False)
+        out[task] = F.interpolate(y, size=target, mode="bilinear", align_corners=False)
     return (out, feats) if return_features else out

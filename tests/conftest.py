@@ -58,9 +58,10 @@ def build_product_model(cfg, prec, device="cpu", drop_path_rate=0.0):
                                    PRED_OUT_NUM_CONSTANT=cfg["pred_const"], mtt_resolution_downsample_rate=cfg["mtt_down"],
                                    drop_path_rate=drop_path_rate)
         return mtt_amd.factory.get_model(p).to(device)
+    extra = dict(dd_label_map_size=tuple(cfg["dd_label_map_size"])) if cfg.get("dd_label_map_size") is not None else {}
     p = mtt_amd.factory.make_p([t for t, _ in cfg["tasks"]], cfg["img_size"], backbone=(C, depth, nH, sel), head=cfg["head"],
                                embed_dim=cfg["embed_dim"], final_embed_dim=cfg["final_embed_dim"], chan_nheads=cfg["chan_nheads"],
-                               use_ctr=cfg["use_ctr"], num_output=dict(cfg["tasks"]), prec=prec, drop_path_rate=drop_path_rate)
+                               use_ctr=cfg["use_ctr"], num_output=dict(cfg["tasks"]), prec=prec, drop_path_rate=drop_path_rate, **extra)
     return mtt_amd.factory.get_model(p).to(device)
 
 

@@ -99,6 +99,7 @@ def test_ns6_training_step_bf16_matches_oracle_autograd():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import time
+    import train_check
     from oracle import taskprompter_oracle as tpo
     from tests.golden.make_golden import loss_of
     cfg, sd, x, _ = pu.oracle_eval("ns6", 2)
@@ -115,19 +116,23 @@ def test_ns6_training_step_bf16_matches_oracle_autograd():
         out = model(x.cuda())
         loss_of({k: v.cpu() for k, v in out.items()}).backward()
         fwd = {t: pu.rel(out[t].detach(), ref_out[t].detach()) for t in ref_out}
-        rels = []
+        rels, errs = [], {}
         for k, prm in model.named_parameters():
             ref = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
             assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
-            n = float(ref.norm())
-            if n > 1e-6:
-                rels.append((float((prm.grad.cpu() - ref).norm()) / n, k))
+            errs[k] = train_check.grad_err(prm.grad, ref)
+            if errs[k].ref > 1e-6:
+                rels.append((errs[k].err / errs[k].ref, k))
         rels.sort(reverse=True)
         med = rels[len(rels) // 2][0]
+        bad, checked, below = train_check.per_param_violations(errs, "x3f" if prec != "bf16" else "bf16")
         pu.report("train_parity", config="ns6", batch=2, prec=prec, fwd_worst=max(fwd.values()), grad_median=med, grad_worst=rels[0][0],
-                  grad_worst_param=rels[0][1], grad_p90=rels[len(rels) // 10][0], per_head=fwd)
+                  grad_worst_param=rels[0][1], grad_p90=rels[len(rels) // 10][0], per_head=fwd, per_param_checked=checked,
+                  per_param_below_floor=below, per_param_violations=len(bad), worst_cos=min(v.cos for v in errs.values() if v.numel >= 8 and v.ref > 1e-6))
         assert max(fwd.values()) < ftol, fwd
         assert med < mtol, (med, rels[:3])
+        # every parameter of the benchmarked model, not the median (bounds and calibration: train_check.PER_PARAM)
+        train_check.assert_per_param(errs, "x3f" if prec != "bf16" else "bf16")
         del model, out
         torch.cuda.empty_cache()
 

@@ -53,6 +53,41 @@ def test_forward_matches_reference_golden(name, prec, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("x3", REL_TOL_X3), ("x3f", REL_TOL_X3), ("bf16", REL_TOL_BF16)])
+def test_wrapper_dd_label_map_size_on_the_device(prec, tol):
+    """TaskPrompterWrapper with `p.dd_label_map_size` (taskprompter_wrapper.py:17-27): the heads' predictions are resized to the configured
+    label-map size (40 x 56 from a 64 x 96 input: not the input size, not a multiple of the 16 x 24 head maps — the fused resize kernel's
+    general scale path) — eval outputs against the fixture of the UNMODIFIED reference wrapper (tests/golden/make_dd_golden.py), and in the
+    fp32-class mode the training step's gradients through that resize against the oracle's autograd."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import numpy as np
+    cfg = configs.taskprompter("mini_ctr_dd")
+    meta, _ = conftest.load_golden("mini_ctr")
+    gold = np.load(os.path.join(conftest.GOLDEN, "mini_ctr_dd.npz"))
+    model = conftest.build_product_model(cfg, prec, "cuda")
+    assert tuple(model.target_size) == (40, 56)
+    model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=True)
+    model.eval()
+    with torch.no_grad():
+        out = model(weights.synth_images(2, cfg["img_size"], 1).cuda())
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        assert out[t].shape == g.shape, (t, out[t].shape)
+        assert _rel(out[t].cpu(), g) < tol, (t, _rel(out[t].cpu(), g))
+    if prec != "bf16":
+        import train_check
+        fwd, errs = train_check.grad_errors("mini_ctr_dd", prec, "cuda")
+        worst, med = train_check.summarize(errs, floor=1e-6 if prec == "x3" else 1e-4)
+        assert max(fwd.values()) < 1e-3, fwd
+        if prec == "x3":
+            assert worst[0] < 1e-2 and med < 1e-3, (worst, med)
+        else:
+            train_check.assert_per_param(errs, "x3f")
+
+
+@pytest.mark.gpu
 def test_forward_matches_oracle_on_fresh_inputs_larger_batch():
     """oracle (CPU restatement) vs HIP path on inputs that are not in the fixtures; B = 3, ragged tiles."""
     if not torch.cuda.is_available():
@@ -107,3 +142,51 @@ def test_swin_forward_matches_reference_golden(name, prec, tol):
         e = _rel(out[t].cpu()[:, :, ::es, ::es], g)
         print(f"PARITY swin {name} {prec} {t} {e:.3e}")
         assert e < tol, (t, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,name,seed", [("TP", "mini_ctr", 1), ("IP", "mini", 2)])
+def test_imported_flax_checkpoint_runs_on_the_device(kind, name, seed):
+    """SURVEY.md 8 f2 on the device: a Flax-layout ViT `.npz` (the format of the reference's pretrained backbones, taskprompter.py:525-602 /
+    vit.py:410-488) imported by checkpoints.load_flax_vit_npz INTO A MODEL THAT LIVES ON THE GPU (position embedding resized from a 3 x 3
+    source grid, q / k / v packed, patch kernel transposed), then (1) the imported device tensors equal what the UNMODIFIED reference loader
+    produced (tests/golden/ckpt_import.npz) and (2) the device forward with those weights matches the CPU oracle run on the same state
+    dict in all three arithmetic modes — a wrong layout rule that the host-only importer test could not see as a forward difference, or a
+    stale weight pack after the in-place import, fails here."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import numpy as np
+    import mtt_amd
+    from tests.golden.make_ckpt_golden import STRIDE, fake_flax_vit
+    gold = np.load(os.path.join(conftest.GOLDEN, "ckpt_import.npz"))
+    cfg = dict(configs.taskprompter(name) if kind == "TP" else configs.invpt(name), backbone="nano")
+    C, depth, heads, _ = configs.VIT["nano"]
+    x = weights.synth_images(2, cfg["img_size"], 3)
+    ref = None
+    # bf16 bound 0.25 here (not 4e-2): the synthetic checkpoint's weights are unit-variance randn (no 1/sqrt(fan_in)), which amplifies
+    # operand rounding ~10x over trained / synthetic-model weights (0.13 on the emulator); the modes that carry the tolerance keep 1e-3
+    for prec, tol in (("x3", REL_TOL_X3), ("x3f", REL_TOL_X3), ("bf16", 0.25)):
+        model = conftest.build_product_model(cfg, prec, "cuda")
+        contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+        model.load_state_dict({k: v.cuda() for k, v in weights.synth_state_dict(contract, 4).items()}, strict=True)
+        model.eval()
+        with torch.no_grad():
+            model(x.cuda())                                           # builds the weight packs of the PRE-import parameters
+        loaded = mtt_amd.checkpoints.load_flax_vit_npz(model.backbone, fake_flax_vit(C, depth, heads, 3, seed=seed))
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        for k in loaded:
+            got = sd["backbone." + k].numpy() if k == "pos_embed" else sd["backbone." + k].numpy().reshape(-1)[::STRIDE]
+            assert np.abs(got - gold[f"{kind}/expect/{k}"]).max() < 1e-5, (kind, k)
+        if ref is None:
+            with torch.no_grad():
+                if kind == "TP":
+                    ref = tpo.forward(sd, cfg, x)
+                else:
+                    from oracle import invpt_oracle as ipo
+                    ref = ipo.forward(sd, cfg, x)
+        with torch.no_grad():
+            out = model(x.cuda())                                     # must see the imported weights (packs rebuilt)
+        for t, _ in cfg["tasks"]:
+            assert _rel(out[t].cpu(), ref[t]) < tol, (kind, prec, t, _rel(out[t].cpu(), ref[t]))
+

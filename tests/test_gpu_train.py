@@ -17,13 +17,15 @@ def test_gradients_x3(name):
 
 
 @pytest.mark.gpu
-def test_gradients_bf16_are_bf16_accurate():
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv"])
+def test_gradients_bf16_are_bf16_accurate(name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    fwd, errs = train_check.grad_errors("mini_ctr", "bf16", "cuda")
+    fwd, errs = train_check.grad_errors(name, "bf16", "cuda")
     assert max(fwd.values()) < 4e-2
     worst, med = train_check.summarize(errs, floor=1e-4)
     assert med < 6e-2, (worst, med)
+    train_check.assert_per_param(errs, "bf16")              # EVERY parameter, not the median (bounds: train_check.PER_PARAM)
 
 
 @pytest.mark.gpu
@@ -37,6 +39,10 @@ def test_gradients_x3f_forward_exact_backward_bf16(name):
     assert max(fwd.values()) < 1e-3, fwd
     worst, med = train_check.summarize(errs, floor=1e-4)
     assert med < 3e-2, (worst, med)
+    # the DEFAULT mode's backward bounded per parameter: cosine >= 0.999 with the oracle's autograd or relative error <= 0.15 for every
+    # parameter above the norm floor, none beyond 0.2 (train_check.PER_PARAM) — this is what executes ConvHeadFn / FuseTailFn /
+    # TaskHeadsFn with bf16 gradient maps, which the x3 case above does not
+    train_check.assert_per_param(errs, "x3f")
 
 
 @pytest.mark.gpu
@@ -49,6 +55,7 @@ def test_invpt_x3f_runs_and_matches_forward():
     assert max(fwd.values()) < 1e-3, fwd
     worst, med = train_check.summarize(errs, floor=1e-4)
     assert med < 2e-1, (worst, med)
+    train_check.assert_per_param(errs, "x3f")
 
 
 def _two_steps_bitwise(cfg, prec, B, kind):
@@ -128,6 +135,8 @@ def test_invpt_gradients(prec, ftol, mtol):
     assert max(fwd.values()) < ftol, fwd
     worst, med = train_check.summarize(errs, floor=1e-6 if prec == "x3" else 1e-4)
     assert med < mtol and (prec != "x3" or worst[0] < 3e-2), (worst, med)
+    if prec == "bf16":
+        train_check.assert_per_param(errs, "bf16")
     assert len(dead) == 10
 
 

@@ -90,6 +90,31 @@ def test_training_gradients_on_emulator(emulated, name):
     assert worst[0] < 1e-3, worst
 
 
+def test_wrapper_dd_label_map_size_on_the_emulator(emulated):
+    """taskprompter_wrapper.py:17-27 through the product's wrapper and the ABI emulator: predictions at `p.dd_label_map_size` (40 x 56 from
+    a 64 x 96 input) against the unmodified reference wrapper's fixture, and the gradients through that resize against the oracle's autograd
+    (the -m gpu twin: tests/test_gpu_model.py::test_wrapper_dd_label_map_size_on_the_device)."""
+    import numpy as np
+    import train_check
+    from oracle import taskprompter_oracle as tpo
+    cfg = configs.taskprompter("mini_ctr_dd")
+    meta, _ = conftest.load_golden("mini_ctr")
+    gold = np.load(os.path.join(conftest.GOLDEN, "mini_ctr_dd.npz"))
+    model = conftest.build_product_model(cfg, "x3", "cpu")
+    assert tuple(model.target_size) == (40, 56)
+    model.load_state_dict(weights.synth_state_dict(meta["contract"], 0), strict=True)
+    model.eval()
+    with torch.no_grad():
+        out = model(weights.synth_images(2, cfg["img_size"], 1))
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        assert out[t].shape == g.shape, (t, out[t].shape)
+        assert float((out[t] - g).norm() / g.norm()) < 5e-5, t
+    fwd, errs = train_check.grad_errors("mini_ctr_dd", "x3", "cpu")
+    worst, med = train_check.summarize(errs)
+    assert max(fwd.values()) < 5e-5 and worst[0] < 1e-2 and med < 1e-3, (fwd, worst, med)
+
+
 def test_x3f_mode_forward_x3_on_split_planes_backward_bf16(emulated, monkeypatch):
     """x3f: the four encoder Linears of every block (and the attention between them) run on MTT_SPLIT planes in x3 arithmetic, the
     backward is the bf16 one (flash attention backward, bf16 weight / input gradients on the hi planes); outputs stay fp32-class,
@@ -107,6 +132,7 @@ def test_x3f_mode_forward_x3_on_split_planes_backward_bf16(emulated, monkeypatch
     assert max(fwd.values()) < 5e-5, fwd
     worst, med = train_check.summarize(errs, floor=1e-4)
     assert med < 3e-2, (worst, med)
+    train_check.assert_per_param(errs, "x3f")              # every parameter, not the median (the -m gpu twin asserts the same on the device)
     n_blocks = n_taps = 4
     # qkv, proj, fc1, fc2 per block + per tap fea_decode (on the planes `modulate` writes) and fea_fuse[0] (on the planes its epilogue writes)
     assert sum(1 for n, adt, pr, _ in seen if n == "gemm" and adt == 2 and pr == 1) == 4 * n_blocks + 2 * n_taps
@@ -133,6 +159,7 @@ def test_x3f_decoder_convs_and_head_gemm_run_on_split_planes(emulated, monkeypat
     assert max(fwd.values()) < 5e-5, fwd
     worst, med = train_check.summarize(errs, floor=1e-4)
     assert med < 3e-2, (worst, med)
+    train_check.assert_per_param(errs, "x3f")
     n_taps = 4
     convs = [s for s in seen if s[0] == "gemm" and s[1] == 2 and s[2] == 2 and s[4] == 1]             # OP_CONV_K on split planes, x3
     assert len(convs) == n_taps, len(convs)
@@ -194,6 +221,8 @@ def test_conv_head_as_one_node_keeps_its_gradient_maps_in_the_backwards_dtype(em
     seen.clear()
     _, plain = train_check.grad_errors("mini_ctr", "x3f", "cpu")
     assert [s_ for s_ in seen if s_[0] == "bn_bwd_reduce"][0][4] == torch.float32
+    train_check.assert_per_param(fused, "x3f")
+    train_check.assert_per_param(plain, "x3f")
     wf, mf = train_check.summarize(fused, floor=1e-4)
     wp, mp = train_check.summarize(plain, floor=1e-4)
     assert mf < 3e-2 and mf < 1.5 * mp + 1e-3, (mf, mp)                    # against the oracle's autograd: the same bf16-class accuracy

@@ -25,6 +25,23 @@ def test_oracle_forward_eval(name):
         assert float((out[t] - g).norm() / g.norm()) < 2e-5, t
 
 
+def test_oracle_dd_label_map_size_matches_reference_wrapper():
+    """taskprompter_wrapper.py:17-27: with `dd_label_map_size` in the config the predictions are resized to THAT size instead of the
+    input's.  Fixture from the unmodified reference wrapper (tests/golden/make_dd_golden.py): mini_ctr, 64 x 96 input -> 40 x 56 maps."""
+    import os
+    cfg = configs.taskprompter("mini_ctr_dd")
+    meta, _ = conftest.load_golden("mini_ctr")
+    gold = np.load(os.path.join(conftest.GOLDEN, "mini_ctr_dd.npz"))
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    x = weights.synth_images(2, cfg["img_size"], 1)
+    with torch.no_grad():
+        out = tpo.forward(sd, cfg, x)
+    for t, _ in cfg["tasks"]:
+        g = torch.from_numpy(gold[f"eval/{t}"])
+        assert out[t].shape == g.shape and tuple(g.shape[-2:]) == (40, 56)
+        assert float((out[t] - g).norm() / g.norm()) < 2e-5, t
+
+
 @pytest.mark.parametrize("name", TP_CASES)
 def test_oracle_train_forward_backward(name):
     cfg = configs.taskprompter(name)

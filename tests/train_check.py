@@ -18,35 +18,49 @@ def grad_err(g, ref):
     return GradErr(float((g - ref).norm()), rn, cos, g.numel())
 
 
-# Per-parameter bound of a bf16-arithmetic backward (x3f, bf16): EVERY parameter whose reference gradient is above the norm floor must
-# point the oracle's way (cosine) or be close in norm (relative error) — a median over the parameters lets one wrong gradient through
-# (VERDICT r05, weak #1).  The floor is relative to the largest per-element gradient RMS of the model: a tensor whose true gradient is
-# three orders of magnitude below the others' (a bias whose contributions cancel) carries rounding noise of the tensors it is summed from.
-PER_PARAM = dict(cos_min=0.999, rel_max=0.15, worst_max=0.2, floor=1e-3)
+# Per-parameter bound of a bf16-arithmetic backward: EVERY parameter whose reference gradient is above the norm floor must point the
+# oracle's way (cosine; tensors of >= 8 elements — for a scalar the cosine is just the sign) or be close in norm (relative error), and no
+# checked parameter may be further than `worst_max` — a median over the parameters lets one wrong gradient through.
+# The floor is relative to the largest per-element gradient RMS of the model: a tensor whose true gradient is three orders of magnitude
+# below the others' (a conv bias in front of BatchNorm: mathematically zero; a bias whose contributions cancel) carries the rounding noise
+# of the tensors it is summed from.  Calibrated on MI355X (profiles/r06_grad_dist_a.log; the step is bitwise reproducible, so these are
+# not noisy): x3f (fp32-class forward, bf16 backward) worst relative error 0.05 on the miniatures and 0.12 at full size (one scalar
+# bias of the cross-task MLP), worst cosine 0.9994; bf16 (forward AND backward bf16: the activations differ too) 0.29 / 0.30, cosine 0.968.
+PER_PARAM = {"x3f": dict(cos_min=0.999, rel_max=0.15, worst_max=0.2, floor=1e-3),
+             "bf16": dict(cos_min=0.95, rel_max=0.35, worst_max=0.5, floor=1e-3)}
 
 
-def per_param_violations(errs, cos_min=PER_PARAM["cos_min"], rel_max=PER_PARAM["rel_max"], worst_max=PER_PARAM["worst_max"], floor=PER_PARAM["floor"]):
-    """-> (violations [(name, rel, cos, rms / top_rms)], n_checked, n_below_floor).  A parameter passes when cos >= cos_min or
-    rel <= rel_max, and every checked parameter needs rel < worst_max."""
+def per_param_violations(errs, mode="x3f"):
+    """-> (violations [(name, rel, cos, rms / top_rms)], n_checked, n_below_floor) under PER_PARAM[mode]: a parameter above the floor passes
+    when (cos >= cos_min and numel >= 8) or rel <= rel_max, and needs rel < worst_max."""
+    b = PER_PARAM[mode]
     rms = {k: v.ref / max(v.numel, 1) ** 0.5 for k, v in errs.items()}
     top = max(rms.values())
     bad, checked, below = [], 0, 0
     for k, v in errs.items():
-        if rms[k] < floor * top:
+        if rms[k] < b["floor"] * top:
             below += 1
             continue
         checked += 1
         rel = v.err / v.ref
-        if not ((v.cos >= cos_min or rel <= rel_max) and rel < worst_max):
+        if not (((v.cos >= b["cos_min"] and v.numel >= 8) or rel <= b["rel_max"]) and rel < b["worst_max"]):
             bad.append((k, rel, v.cos, rms[k] / top))
     return bad, checked, below
+
+
+def assert_per_param(errs, mode, min_checked_frac=0.6):
+    """the per-parameter gradient bound of `mode`; also refuses a floor that would exempt most of the model"""
+    bad, checked, below = per_param_violations(errs, mode)
+    assert checked >= min_checked_frac * (checked + below), (checked, below)
+    assert not bad, (len(bad), bad[:6])
+    return checked, below
 
 
 def grad_errors(name, prec, device, drop=None, seed=0):
     cfg = configs.taskprompter(name)
     model = conftest.build_product_model(cfg, prec, device, drop_path_rate=0.3 if drop is not None else 0.0)
     try:                                   # the state-dict contract dumped from the unmodified reference, where a fixture exists
-        contract = conftest.load_golden(name)[0]["contract"]
+        contract = conftest.load_golden(cfg.get("contract_of", name))[0]["contract"]
     except OSError:
         contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
     sd = weights.synth_state_dict(contract, seed)

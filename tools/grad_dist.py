@@ -63,9 +63,9 @@ def main():
         top = max(rms.values())
         rows = sorted(((v.err / max(v.ref, 1e-300), v.cos, rms[k] / top, v.numel, k) for k, v in errs.items()), reverse=True)
         rec[c] = [dict(rel=r[0], cos=r[1], rms_frac=r[2], numel=r[3], name=r[4]) for r in rows]
-        bad, checked, below = train_check.per_param_violations(errs)
+        bad, checked, below = train_check.per_param_violations(errs, "bf16" if prec == "bf16" else "x3f")
         print(f"== {c}: {len(rows)} parameters, {checked} above the floor, {below} below, violations {len(bad)}")
-        floor = train_check.PER_PARAM["floor"]
+        floor = train_check.PER_PARAM["x3f"]["floor"]
         live = [r for r in rows if r[2] >= floor]
         for r in live[:10]:
             print("   rel %.3e  cos %.6f  rms/top %.2e  n %8d  %s" % r)
