@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 9
+#define MTT_ABI_VERSION 10
 
 /* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
  * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
@@ -235,6 +235,40 @@ int mtt_ctr_mix(const mtt_ctr_desc* d, void* stream);
  * floats of per-workgroup partials, summed in workgroup order) */
 size_t mtt_ctr_dw_ws_floats(const mtt_ctr_desc* d);
 int mtt_ctr_dw(const mtt_ctr_desc* d, const float* dout, float* dwmix, float* ws, void* stream);
+
+/* Cross-task reweighting WEIGHTS (taskprompter.py:482-484; modules defined at :364 `ctr_attn_conv`): for every image b and task pair
+ * (t, s) the nH prompt<->prompt raw logits z[h] = rawlog[b, h, t, s] (the first T columns of the prompt rows' logits) go through task t's
+ * 1x1-conv MLP over the head dimension:   wmix[b, t, s] = b2[t] + sum_j w2[t, j] * gelu(b0[t, j] + sum_h w0[t, j, h] * z[h])   (exact-erf GELU).
+ * rawlog fp32 [B, nH, T, N] (row pitch N >= T); w0 [T, nH, nH], b0 [T, nH], w2 [T, nH], b2 [T] fp32 contiguous (ops.stack_vec packs);
+ * wmix fp32 [B, T, T] written.  nH <= 32.
+ * bwd: given dwmix [B, T, T]: drawlog[b, h, t, s] for s < T is WRITTEN (the other columns of drawlog are not touched: the caller zeroes
+ * them), dw0 / db0 / dw2 / db2 are WRITTEN; the sums over (b, s) run inside one workgroup per (t, j) in a fixed order (deterministic,
+ * no atomics, no workspace). */
+typedef struct {
+  const float* rawlog; const float* w0; const float* b0; const float* w2; const float* b2; float* wmix;
+  int32_t B, T, nH; int64_t N;
+} mtt_ctrw_desc;
+int mtt_ctr_weights(const mtt_ctrw_desc* d, void* stream);
+int mtt_ctr_weights_bwd(const mtt_ctrw_desc* d, const float* dwmix, float* drawlog, float* dw0, float* db0, float* dw2, float* db2, void* stream);
+
+/* Losses of the 3-D detection branch (TaskPrompter/detection_toolbox/det_losses.py): element-wise loss on [N, C] with the
+ * reference's weighting (weight_reduce_loss, :28-54) and a deterministic sum.
+ *   kind 0  sigmoid focal loss (:226-345; mmcv-full 1.6.2 `sigmoid_focal_loss` on the device, py_sigmoid_focal_loss on the host, :183-224):
+ *           target = int64 labels [N] in [0, C], C = background (no positive class);  p = sigmoid(x);
+ *           loss[n, c] = -alpha (1 - p)^gamma log p            if c == target[n]
+ *                        -(1 - alpha) p^gamma log(1 - p)        otherwise
+ *   kind 1  smooth L1 (:102-123): target fp32 [N, C];  d = |x - y|;  loss = 0.5 d^2 / beta if d < beta else d - 0.5 beta
+ * weight: NULL, [N] per sample (wmode 1) or [N, C] per element (wmode 2).  fwd: out[n, c] = w * loss (skipped when NULL), sum[0] = the sum of
+ * out over all elements (skipped when NULL; ws: mtt_detloss_ws_floats(d) floats of per-workgroup partials summed in workgroup order).
+ * bwd: dpred[n, c] = w * d loss / d x * (gelem ? gelem[n, c] : gscale[0]) * scale   (gelem: the upstream gradient of reduction 'none';
+ * gscale: the upstream scalar of 'mean' / 'sum', read on the device; scale = loss_weight / avg_factor etc., a host constant). */
+typedef struct {
+  const float* pred; const void* target; const float* weight; float* out; float* sum; float* ws;
+  int64_t N; int32_t C; int32_t kind; int32_t wmode; float gamma, alpha, beta;
+} mtt_detloss_desc;
+size_t mtt_detloss_ws_floats(const mtt_detloss_desc* d);
+int mtt_detloss_fwd(const mtt_detloss_desc* d, void* stream);
+int mtt_detloss_bwd(const mtt_detloss_desc* d, const float* gscale, const float* gelem, float scale, float* dpred, void* stream);
 
 /* Bilinear resize, align_corners=False (F.interpolate at taskprompter.py:420, taskprompter_wrapper.py:36,
  * invpt.py:221,303,537, transformer_net.py:35-36).  NHWC in -> NHWC out or NCHW fp32 out.

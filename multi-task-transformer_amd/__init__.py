@@ -3,7 +3,7 @@
 The directory name carries a hyphen (it mirrors the reference repository's name), so import it through
 `importlib.import_module("multi-task-transformer_amd")` or the `mtt_amd` alias module at the repo root.
 """
-from . import _lib, ops, autograd_path, factory, losses, optim, checkpoints, iou3d, taskprompter_swin, graphs  # noqa: F401
+from . import _lib, ops, autograd_path, factory, losses, det_losses, optim, checkpoints, iou3d, taskprompter_swin, graphs  # noqa: F401
 from .taskprompter import (ConvHead, DEConvHead, TaskPrompter, TaskPrompterWrapper,  # noqa: F401
                            taskprompter_vit_base_patch16_384, taskprompter_vit_large_patch16_384)
 from .invpt import (MLPHead, TransformerDecoder, TransformerNet, VisionTransformer, vit_large_patch16_384)  # noqa: F401,E402

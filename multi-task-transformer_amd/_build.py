@@ -29,12 +29,12 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     force = force or os.environ.get("MTT_FORCE_BUILD") == "1"
     deps = [os.path.join(CSRC, "mtt_device.h"), os.path.join(ROOT, "include", "mtt_hip.h")]
-    objs, jobs, stamps = [], [], {}
+    objs, jobs, stamps, wants = [], [], {}, {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        want = _stamp(s, deps)
+        want = wants[o] = _stamp(s, deps)
         try:
             have = open(o + ".sha").read().strip()
         except OSError:
@@ -51,13 +51,28 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
     if jobs:
+        for o in stamps:                  # an object being rebuilt has no valid stamp until the LINK that contains it succeeded
+            try:
+                os.remove(o + ".sha")
+            except OSError:
+                pass
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(run, jobs))
-        for o, st in stamps.items():
+    # the library's own stamp = hash of the stamps of the objects it was linked from: a link that failed or was interrupted after the
+    # compile step leaves it stale and the next build() relinks instead of returning the old library
+    import hashlib
+    lib_want = hashlib.sha256("".join(wants[o] for o in objs).encode()).hexdigest()
+    try:
+        lib_have = open(LIB + ".sha").read().strip()
+    except OSError:
+        lib_have = None
+    if jobs or not os.path.exists(LIB) or lib_have != lib_want:
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+        for o, st in stamps.items():      # stamps only after the successful link
             with open(o + ".sha", "w") as f:
                 f.write(st + "\n")
-    if jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+        with open(LIB + ".sha", "w") as f:
+            f.write(lib_want + "\n")
     return LIB
 
 

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -150,6 +150,15 @@ class LossDesc(C.Structure):
                 ("C", i32), ("Cl", i32), ("kind", i32), ("ignore", f32), ("pos_weight", f32), ("ws", ptr)]
 
 
+class CtrwDesc(C.Structure):
+    _fields_ = [("rawlog", ptr), ("w0", ptr), ("b0", ptr), ("w2", ptr), ("b2", ptr), ("wmix", ptr), ("B", i32), ("T", i32), ("nH", i32), ("N", i64)]
+
+
+class DetLossDesc(C.Structure):
+    _fields_ = [("pred", ptr), ("target", ptr), ("weight", ptr), ("out", ptr), ("sum", ptr), ("ws", ptr), ("N", i64), ("C", i32), ("kind", i32),
+                ("wmode", i32), ("gamma", f32), ("alpha", f32), ("beta", f32)]
+
+
 class GatherDesc(C.Structure):
     _fields_ = [("src", ptr), ("dst", ptr), ("idx", ptr), ("rows", i64), ("C", i32), ("ld_src", i64), ("ld_dst", i64),
                 ("src_dtype", i32), ("dst_dtype", i32), ("B", i32), ("src_bs", i64), ("dst_bs", i64), ("idx_bs", i64), ("skip_neg", i32)]
@@ -188,10 +197,11 @@ DESCS = {
     "upconv4_expand": UpconvDesc, "upconv4_gather": UpconvDesc,
     "gather_rows": GatherDesc, "winattn_fwd": WinAttnDesc, "chanattn_fwd": ChanAttnDesc, "conv3s2_nchw": Conv3s2Desc,
     "segcopy": SegcopyDesc,
+    "ctr_weights": CtrwDesc, "detloss_fwd": DetLossDesc,
 }
 _SIZE_INDEX = [GemmDesc, AttnDesc, SoftmaxDesc, LnDesc, ChanLogitDesc, ModulateDesc, CtrDesc, ResizeDesc, BnDesc, ConvGeom,
                DwconvDesc, PoolDesc, LnMtDesc, AttnMsgDesc, ConvtDesc, AdamDesc, LossDesc, UpconvDesc,
-               GatherDesc, WinAttnDesc, ChanAttnDesc, Conv3s2Desc, SegcopyDesc]
+               GatherDesc, WinAttnDesc, ChanAttnDesc, Conv3s2Desc, SegcopyDesc, CtrwDesc, DetLossDesc]
 POSITIONAL = {
     "patchify16": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, ptr],
     "patchify": [ptr, ptr, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int, ptr],
@@ -214,6 +224,8 @@ DESC_EXTRA = {
     "modulate_bwd": (ModulateDesc, [ptr, ptr, ptr, ptr, ptr]),
     "chan_logits_bwd": (ChanLogitDesc, [ptr, ptr, C.c_int, ptr]),
     "ctr_dw": (CtrDesc, [ptr, ptr, ptr]),
+    "ctr_weights_bwd": (CtrwDesc, [ptr, ptr, ptr, ptr, ptr, ptr]),
+    "detloss_bwd": (DetLossDesc, [ptr, ptr, f32, ptr]),
     "attn_bwd": (AttnDesc, [ptr, ptr, ptr, ptr]),
     "winattn_bwd": (WinAttnDesc, [ptr, ptr, ptr, ptr]),
     "chanattn_bwd": (ChanAttnDesc, [ptr, ptr, ptr, ptr, i64, ptr]),
@@ -229,7 +241,7 @@ DESC_EXTRA = {
 
 # workspace-size queries mtt_<entry>_ws_floats(const desc*) of the entry points whose cross-workgroup reductions go through caller-owned partials
 WS_QUERIES = {"gemm_colsum": GemmDesc, "chan_logits": ChanLogitDesc, "modulate_bwd": ModulateDesc, "ctr_dw": CtrDesc, "attn_msg_bwd": AttnMsgDesc, "loss": LossDesc,
-              "chanattn_bwd": ChanAttnDesc}
+              "chanattn_bwd": ChanAttnDesc, "detloss": DetLossDesc}
 EXPORTS = ["mtt_abi_version", "mtt_desc_size", "mtt_gemm_variant", "mtt_adam_chunk", "mtt_segcopy_chunk", "mtt_bn_reduce_ws_floats", "mtt_colsum_ws_floats", "mtt_rowscale_cast_colsum_ws_floats", "mtt_layernorm_bwd_ws_floats", "mtt_nms_ws_bytes"] + ["mtt_%s_ws_floats" % n for n in WS_QUERIES] + ["mtt_" + n for n in list(DESCS) + list(POSITIONAL) + list(DESC_EXTRA)]
 
 _lib = None

@@ -826,8 +826,10 @@ class TaskHeadsFn(Function):
                 # dya = g W is an outer-product-like GEMM (K = n <= 21 classes, a million rows): bound by the 0.7 GB it writes.  bf16 copies of
                 # the two small operands (g [rows, pad8(n)], W^T [ld, pad8(n)]) put it on the 128-row LDS-DMA kernel instead of the
                 # register-staged one (423 us per task at the benchmark's batch); padding columns of g are zeros (BilinearFn.backward)
+                # only the n real columns are copied, the padding columns [n, pad8(n)) are written as zeros by the cast itself: the reduction
+                # runs over pad8(n) columns and 0 * NaN is NaN, so the K padding must not depend on what the producer left there
                 npad = g.shape[1]
-                g16 = ops.cast_rows(g, torch.bfloat16)
+                g16 = ops.cast2d(g, rows, n, g.stride(0), torch.bfloat16, ldd=npad, zero_pad=True)
                 wT = _pad_last(packs[z][0].t(), npad).to(torch.bfloat16)                         # [ld, pad8(n)] (tiny)
                 _gemm(g16, wT, dy[z], rows, ld, npad, prec, lda=npad, ldb=npad, ldd=ld, n_store=ld, variant=_lib.GEMM_DMA128)
             else:
@@ -847,7 +849,17 @@ class _SubCtx:
     def save_for_backward(self, *ts):
         self.saved_tensors = ts
 
+    # what a stage may call on a real ctx and has no meaning inside the larger node (its outputs' flags are set by the outer forward,
+    # every stage gradient is computed: the outer node owns needs_input_grad)
+    needs_input_grad = (True,) * 64
+
     def mark_dirty(self, *ts):
+        pass
+
+    def mark_non_differentiable(self, *ts):
+        pass
+
+    def set_materialize_grads(self, value):
         pass
 
 
@@ -956,6 +968,35 @@ class CtrMixFn(Function):
         ops.call("ctr_dw", fea=fea, out=None, wmix=None, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C, fea_dtype=dtype_code(fea),
                  accumulate=0, xargs=[dout, dw, ops.ws_for("ctr_dw", dout.device, T=T, B=B, rows_per_b=rows // B)])
         return dfea, dw, (dout if had_acc else None), None, None
+
+
+class CtrWeightsFn(Function):
+    """The [B, T, T] mixing weights of the cross-task reweighting: task t's two 1x1 convs over the head dimension (GELU between) applied to
+    the prompt<->prompt raw logits (taskprompter.py:482-484) — mtt_ctr_weights / mtt_ctr_weights_bwd.  params = T first-conv weights
+    [nH, nH, 1, 1], T biases [nH], T second-conv weights [1, nH, 1, 1], T biases [1]."""
+
+    @staticmethod
+    def forward(ctx, rawlog, B, T, tag, *params):
+        w0s, b0s, w2s, b2s = (list(params[i * T:(i + 1) * T]) for i in range(4))
+        W0, b0 = ops.stack_vec(w0s, (tag, 'w0')), ops.stack_vec(b0s, (tag, 'b0'))
+        W2, b2 = ops.stack_vec(w2s, (tag, 'w2')), ops.stack_vec(b2s, (tag, 'b2'))
+        rawlog = rawlog.contiguous()
+        wmix = ops.ctr_weights(rawlog, W0, b0, W2, b2, B, T)
+        ctx.save_for_backward(rawlog, W0, b0, W2, b2)
+        ctx.meta = (B, T, [tuple(w.shape) for w in w0s], [tuple(w.shape) for w in w2s])
+        return wmix
+
+    @staticmethod
+    def backward(ctx, dwmix):
+        rawlog, W0, b0, W2, b2 = ctx.saved_tensors
+        B, T, sh0, sh2 = ctx.meta
+        nH, N = rawlog.shape[1], rawlog.shape[3]
+        drawlog = torch.zeros_like(rawlog)                   # the kernel writes the first T columns; the patch columns get no gradient here
+        dW0, db0, dW2, db2 = torch.empty_like(W0), torch.empty_like(b0), torch.empty_like(W2), torch.empty_like(b2)
+        ops.call("ctr_weights_bwd", rawlog=rawlog, w0=W0, b0=b0, w2=W2, b2=b2, wmix=None, B=B, T=T, nH=nH, N=N,
+                 xargs=[dwmix.contiguous(), drawlog, dW0, db0, dW2, db2])
+        return ((drawlog, None, None, None) + tuple(dW0[t].view(sh0[t]) for t in range(T)) + tuple(db0.unbind(0))
+                + tuple(dW2[t].view(sh2[t]) for t in range(T)) + tuple(db2[t].view(1) for t in range(T)))
 
 
 class Deconv2x2Fn(Function):

@@ -16,9 +16,6 @@ namespace {
 constexpr int KV = 64, HD = 64;
 constexpr int KTILE = KV * HD * 2;   // 8 KiB per bf16 tile
 constexpr float LOG2E = 1.4426950408889634f;
-#ifndef MTT_ATTN_ABL
-#define MTT_ATTN_ABL 0          // experiment builds (timing ablations of attn_fwd_x3_kernel; the outputs are then wrong): 1 no DMA after tile 0, 2 no exp2, 16 no barrier
-#endif
 
 struct AttnP { mtt_attn_desc d; };
 
@@ -506,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const AttnP p) {
   auto tile = [&](auto stage_tag, int j) {
     constexpr int ST = decltype(stage_tag)::value;
     const bool more = j + 1 < nkv;
-    if (more && !(MTT_ATTN_ABL & 1)) dma_issue(smem + (1 - ST) * STAGE, (j + 1) * KV);
+    if (more) dma_issue(smem + (1 - ST) * STAGE, (j + 1) * KV);
     const int kv0 = j * KV;
     if (active) {
       // ---- S^T = Kh Qh^T + Kh Ql^T + Kl Qh^T ----------------------------------------------------------------------------
@@ -565,15 +562,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const AttnP p) {
               if ((kv0 + kt * 16 + lg * 4 + r) >= N) s[sub][kt][r] = -INFINITY;
       }
       u32x4 pbh[2][2], pbl[2][2];
-      if (MTT_ATTN_ABL & 4) {                        // ablation: no softmax at all (the MFMA + LDS + DMA floor)
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            pbh[sub][ks] = __builtin_bit_cast(u32x4, s[sub][2 * ks]);
-            pbl[sub][ks] = __builtin_bit_cast(u32x4, s[sub][2 * ks + 1]);
-          }
-      } else
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         float mx = s[sub][0][0];
@@ -597,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const AttnP p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = (MTT_ATTN_ABL & 2) ? s[sub][kt][r] : __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sc2, -m_new));
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sc2, -m_new));
             s[sub][kt][r] = pv;
             rs += pv;
           }
@@ -671,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const AttnP p) {
 #undef ATW
     }
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(MTT_ATTN_ABL & 16)) __syncthreads();
+    __syncthreads();
   };
   for (int j = 0; j < nkv; j += 2) {
     tile(std::integral_constant<int, 0>{}, j);
@@ -699,414 +687,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const AttnP p) {
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// attn_fwd_x3p_kernel (round 6): attn_fwd_x3_kernel as a TWO-TILE SOFTWARE PIPELINE inside every wave.  The kernel above runs its three
-// phases one after the other in each wave — 48 S MFMAs, then ~250 VALU instructions of softmax (max, exp2, sums, the hi / lo split of P),
-// then 48 P V MFMAs — and relies on the second wave of the SIMD to fill the idle pipe; measured (profiles/r05_pmc_sq_attn.txt) the matrix
-// pipe is busy 41 % of the time.  MFMA and VALU instructions share the SIMD's issue port but not its execution pipes: a 16x16x32 MFMA
-// occupies the matrix pipe ~17 cycles and leaves ~3 issue slots in its shadow (MI355X_MICROARCH.md, per-instruction constants).  Here an
-// iteration j holds TWO score tiles:
-//   block A:  S(j+1) = K(j+1) Q^T on the matrix pipe      ||  exp2 / sums / hi-lo split of P(j) on the VALU (independent registers)
-//   block B:  O^T += V(j)^T P(j)^T on the matrix pipe      ||  the running-max of S(j+1) on the VALU
-// each block is ONE basic block (no control flow), so the compiler's scheduler interleaves the two instruction streams; the rescale of
-// O^T (when some lane's running max moved), the prompt-row raw-logit stores and the masking of the ragged last tile are branches BETWEEN
-// the blocks.  Order of the online softmax (cdna_hip_programming.md T13: a rescale must never split a pending tile's P V): P V(j) is
-// complete at the end of block B; the decision for tile j + 1 (m_new from block B's maxima) is taken at the top of iteration j + 1,
-// rescales o and l once, and only then is P(j + 1) exponentiated against the new maximum.
-// LDS: the same two 32-KiB slots (K hi, K lo, V hi, V lo), but K runs ONE TILE AHEAD of V: K(j) and V(j) live in slot j & 1; at the top
-// of iteration j the DMA of K(j+2) goes to slot j & 1 (K(j) was consumed by block A of iteration j - 1) and V(j+1) to the other slot's V
-// part (V(j-1) was consumed by block B of iteration j - 1); one vmcnt(0) + barrier per tile as before.
-// ---------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_x3p_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = 4 * KTILE;                  // K hi, K lo, V hi, V lo
-  const mtt_attn_desc& d = p.d;
-  const int nqb = (d.N + 127) / 128;
-  const int wi = xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = wi % nqb, bh = wi / nqb;
-  const int h = bh % d.nH, b = bh / d.nH;
-  const int N = d.N, C = d.nH * HD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int64_t tok0 = (int64_t)b * N;
-  const bf16_t* qh_ = (const bf16_t*)d.qkv;
-  const bf16_t* ql_ = (const bf16_t*)d.qkv_lo;
-  const int q0 = qb * 128 + wave * 32;
-  const bool active = q0 < N;
-
-  u32x4 qfh[2][2], qfl[2][2];
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    const int qrow = q0 + sub * 16 + li;
-    const bool ok = qrow < N;
-    const int64_t qi = (tok0 + (ok ? qrow : 0)) * 3 * C + h * HD + lg * 8;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
-      qfh[sub][kh] = ok ? *(const u32x4*)(qh_ + qi + kh * 32) : z;
-      qfl[sub][kh] = ok ? *(const u32x4*)(ql_ + qi + kh * 32) : z;
-    }
-  }
-
-  int dma_off[4], dma_row[2];
-  uint64_t zpage = (uint64_t)(uintptr_t)g_attn_zero_page;
-  asm volatile("" : "+s"(zpage));
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wave * 16 + i * 8 + (lane >> 3), pc = lane & 7;
-    dma_row[i] = r;
-    dma_off[i] = r * 3 * C + C + ((pc ^ (r >> 1)) & 7) * 8;
-    dma_off[2 + i] = r * 3 * C + 2 * C + (((((pc >> 1) ^ (r >> 1)) & 3) << 1) | (pc & 1)) * 8;
-  }
-  // kv = 0: the K tile of both planes, kv = 1: the V tile of both planes (wave w moves key rows [16 w, 16 w + 16) as two 1-KiB pieces)
-  auto dma_issue = [&](unsigned char* st, int kv0, int kv) {
-    const int64_t boff = (tok0 + kv0) * 3 * C + h * HD;
-    const bool full = kv0 + KV <= N;
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      const bf16_t* base = (pl ? ql_ : qh_) + boff;
-      unsigned char* dst = st + (kv * 2 + pl) * KTILE + wave * 2048;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool ok = full || kv0 + dma_row[i] < N;
-        attn_glds16((const bf16_t*)(uintptr_t)(ok ? (uint64_t)(uintptr_t)(base + dma_off[kv * 2 + i]) : zpage), dst + i * 1024);
-      }
-    }
-  };
-  const int vrow = 4 * lg + (li >> 2);
-  const int vf_ = (vrow >> 1) & 3;
-  unsigned vaddr[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) vaddr[dt] = (unsigned)(uintptr_t)smem + (unsigned)(2 * KTILE + vrow * 128 + (li & 3) * 8 + ((dt ^ vf_) & 3) * 32);
-  const unsigned char* kaddr[2];
-#pragma unroll
-  for (int kh = 0; kh < 2; ++kh) kaddr[kh] = smem + li * 128 + (((kh * 4 + lg) ^ (li >> 1)) & 7) * 16;
-
-  f32x4 o[2][4];
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) o[sub][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY}, m_new[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
-  const float sc2 = d.scale * LOG2E;
-  const bool write_raw = d.rawlog != nullptr && d.T > 0 && qb == 0 && wave == 0 && li < d.T;
-  const int nkv = (N + KV - 1) / KV;
-
-  // S^T of one key tile from LDS slot SK: 48 MFMAs (Kh against Ql and Qh, then Kl against Qh), the K fragments in halves of two 16-key
-  // tiles (16 registers live instead of 32: block A also holds both score tiles, O^T and the Q planes)
-  auto scores = [&](auto slot_tag, f32x4 (&s)[2][4], f32x4 zacc) {
-    constexpr int SK = decltype(slot_tag)::value;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      u32x4 kf[2][2];
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) kf[k2][kh] = *(const u32x4*)(kaddr[kh] + SK * STAGE + (2 * half + k2) * 2048);
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int kt = 2 * half + k2;
-        s[0][kt] = zacc;
-        s[1][kt] = zacc;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-          s[0][kt] = mfma16(kf[k2][kh], qfl[0][kh], s[0][kt]);
-          s[1][kt] = mfma16(kf[k2][kh], qfl[1][kh], s[1][kt]);
-          s[0][kt] = mfma16(kf[k2][kh], qfh[0][kh], s[0][kt]);
-          s[1][kt] = mfma16(kf[k2][kh], qfh[1][kh], s[1][kt]);
-        }
-      }
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) kf[k2][kh] = *(const u32x4*)(kaddr[kh] + SK * STAGE + KTILE + (2 * half + k2) * 2048);
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int kt = 2 * half + k2;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-          s[0][kt] = mfma16(kf[k2][kh], qfh[0][kh], s[0][kt]);
-          s[1][kt] = mfma16(kf[k2][kh], qfh[1][kh], s[1][kt]);
-        }
-      }
-    }
-  };
-  // the ragged last tile: keys >= N score -inf (block-uniform branch around it)
-  auto mask_tail = [&](f32x4 (&s)[2][4], int kv0) {
-    if (kv0 + KV > N) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if ((kv0 + kt * 16 + lg * 4 + r) >= N) s[sub][kt][r] = -INFINITY;
-    }
-  };
-  // running-max candidate of a score tile: m_new[sub] = max(m_run[sub], max_keys(s) * sc2) (every lane of a query column gets it)
-  auto tile_max = [&](const f32x4 (&s)[2][4]) {
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      float mx = s[sub][0][0];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][kt][r]);
-      mx = groups_max(mx);
-      m_new[sub] = fmaxf(m_run[sub], mx * sc2);
-    }
-  };
-
-  if (active || true) {                              // (inactive waves still take part in the staging and the barriers)
-    dma_issue(smem, 0, 0);
-    dma_issue(smem, 0, 1);
-    if (nkv > 1) dma_issue(smem + STAGE, KV, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x4 sA[2][4], sB[2][4];
-  if (active) {
-    scores(std::integral_constant<int, 0>{}, sA, (f32x4){0.f, 0.f, 0.f, 0.f});
-    mask_tail(sA, 0);
-    tile_max(sA);
-  }
-  __syncthreads();                                   // every wave has read K(0): iteration 0 refills that part of slot 0
-
-  // one iteration: ST = j & 1 (the slot of V(j); K(j+1) sits in the other slot).  The body is a HAND-BUILT interleave: groups of two MFMAs
-  // (one fragment against the two 16-row query sub-blocks: different accumulators) each followed by a slice of the VALU work, with
-  // __builtin_amdgcn_sched_barrier(0) between the groups so that the compiler keeps it (left alone it clusters most of the MFMAs again:
-  // its scheduler balances register pressure, not the two pipes).  Budget per pair of MFMAs (~34 matrix-pipe cycles = ~8 issue slots):
-  // block A: 24 pairs, 16 exp slices of 7 instructions (2 x fma, exp2, add; one cvt_pk) + 8 lo-split slices of 10;
-  // block B: 24 pairs, the DMA of the next tiles (8 pieces) and the running max of S(j+1) (~40 instructions).
-#define MTT_SB() __builtin_amdgcn_sched_barrier(0)
-  auto tile = [&](auto stage_tag, auto kind_tag, int j, f32x4 (&sc)[2][4], f32x4 (&sn)[2][4]) {
-    constexpr int ST = decltype(stage_tag)::value;
-    constexpr int KIND = decltype(kind_tag)::value;          // 0: a tile j + 1 follows; 1: ... and it is the (possibly ragged) last one; 2: tile j is the last
-    constexpr bool MORE = KIND != 2;
-    constexpr int SK = 1 - ST;
-    const int kv0 = j * KV;
-    const bool dma_k = j + 2 < nkv;
-    if (active) {
-      if (write_raw) {
-        float* rl = d.rawlog + (((int64_t)b * d.nH + h) * d.T + li) * N;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kv0 + kt * 16 + lg * 4 + r;
-            if (key < N) rl[key] = sc[0][kt][r];
-          }
-      }
-      // the decision for tile j (m_new from the previous iteration's block B): all of P V(j - 1) is in o
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        if (__builtin_amdgcn_ballot_w64(m_new[sub] != m_run[sub]) != 0) {
-          const float alpha = __builtin_amdgcn_exp2f(m_run[sub] - m_new[sub]);
-          l_part[sub] *= alpha;
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[sub][t][r] *= alpha;
-          m_run[sub] = m_new[sub];
-        }
-      }
-      u32x4 pbh[2][2], pbl[2][2];
-      // exp slice e (0..15): two scores of sub-block e >> 3, key tile (e >> 1) & 3, rows 2 (e & 1), 2 (e & 1) + 1 -> P, row sum, one hi word
-      auto exp_slice = [&](int e) {
-        const int sub = e >> 3, kt = (e >> 1) & 3, r0 = (e & 1) * 2;
-        float p0 = __builtin_amdgcn_exp2f(fmaf(sc[sub][kt][r0], sc2, -m_run[sub]));
-        float p1 = __builtin_amdgcn_exp2f(fmaf(sc[sub][kt][r0 + 1], sc2, -m_run[sub]));
-        unsigned w = pack2(p0, p1);
-        float l = l_part[sub] + (p0 + p1);
-        // an empty volatile asm over the slice's results: volatile asms keep their program order (also against sched_barrier), so the slice
-        // is COMPUTED here — without it instruction selection lets half of the (side-effect-free) slices sink towards their users
-        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(w), "+v"(l));
-        sc[sub][kt][r0] = p0;
-        sc[sub][kt][r0 + 1] = p1;
-        l_part[sub] = l;
-        pbh[sub][kt >> 1][(kt & 1) * 2 + (e & 1)] = w;
-      };
-      // lo slice q (0..7): the two lo words of sub-block q >> 2, key tile q & 3
-      auto lo_slice = [&](int q) {
-        const int sub = q >> 2, kt = q & 3;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-          const unsigned ph = pbh[sub][kt >> 1][(kt & 1) * 2 + w];
-          unsigned lw = pack2(sc[sub][kt][2 * w] - lo_of(ph), sc[sub][kt][2 * w + 1] - hi_of(ph));
-          asm volatile("" : "+v"(lw));
-          pbl[sub][kt >> 1][(kt & 1) * 2 + w] = lw;
-        }
-      };
-      if constexpr (MORE) {
-        // ---- block A: S(j+1) = Kh Ql^T + Kh Qh^T + Kl Qh^T on the matrix pipe || P(j) on the VALU ------------------------------------
-        f32x4 zacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        asm volatile("" : "+v"(zacc));               // pins the score MFMAs below the rescale branches (see above)
-        u32x4 kA[2][2], kB[2][2];
-        auto kread = [&](u32x4 (&kf)[2][2], int half, int plane) {
-#pragma unroll
-          for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) kf[k2][kh] = *(const u32x4*)(kaddr[kh] + SK * STAGE + plane * KTILE + (2 * half + k2) * 2048);
-        };
-        kread(kA, 0, 0);
-        kread(kB, 0, 1);
-        MTT_SB();
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-          for (int g = 0; g < 8; ++g) {              // Kh of this half against Ql, Qh: pair g = (k2, kh, which Q plane)
-            const int k2 = g >> 2, kh = (g >> 1) & 1, kt = 2 * half + k2;
-            if ((g & 3) == 0) { sn[0][kt] = zacc; sn[1][kt] = zacc; }
-            const u32x4 q0f = (g & 1) ? qfh[0][kh] : qfl[0][kh], q1f = (g & 1) ? qfh[1][kh] : qfl[1][kh];
-            sn[0][kt] = mfma16(kA[k2][kh], q0f, sn[0][kt]);
-            sn[1][kt] = mfma16(kA[k2][kh], q1f, sn[1][kt]);
-            exp_slice(half * 8 + g);
-            MTT_SB();
-          }
-          if (half == 0) kread(kA, 1, 0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {              // Kl of this half against Qh
-            const int k2 = g >> 1, kh = g & 1, kt = 2 * half + k2;
-            sn[0][kt] = mfma16(kB[k2][kh], qfh[0][kh], sn[0][kt]);
-            sn[1][kt] = mfma16(kB[k2][kh], qfh[1][kh], sn[1][kt]);
-            lo_slice(half * 4 + g);
-            MTT_SB();
-          }
-          if (half == 0) kread(kB, 1, 1);
-        }
-        if constexpr (KIND == 1) {
-          // keys >= N of the last tile score -inf (branch-free, only in this instantiation: a branch here would split the iteration)
-#pragma unroll
-          for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sn[sub][kt][r] = (kv0 + KV + kt * 16 + lg * 4 + r) >= N ? -INFINITY : sn[sub][kt][r];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) exp_slice(e);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lo_slice(q);
-      }
-      // ---- block B: O^T += Vh^T Ph^T, + Vl^T Ph^T, + Vh^T Pl^T on the matrix pipe || the next tiles' DMA and the running max of S(j+1).
-      // Six half-groups of 8 transpose reads (32 keys) alternate between two fragment sets; a set is re-read right after its MFMAs.
-      const bool skip1 = !MORE && !(kv0 + 32 < N);   // block-uniform, last tile only: its second 32 keys may be all padding (P = 0, V = 0)
-      u32x2 vAl[4], vAh[4], vBl[4], vBh[4];
-      float mxs[2] = {-INFINITY, -INFINITY};
-#define ATW(x) "+v"(x)
-#define VREAD(L, H, HG)                                                                                                             \
-  _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                                                \
-    constexpr int PL_ = ((HG) >> 1) == 1 ? KTILE : 0, KO_ = ((HG) & 1) * 32 * 128;                                                  \
-    L[dt] = attn_ds_read_tr16<ST * STAGE + PL_ + KO_>(vaddr[dt]);                                                                   \
-    H[dt] = attn_ds_read_tr16<ST * STAGE + PL_ + KO_ + 16 * 128>(vaddr[dt]);                                                        \
-  }
-#define VWAIT(N_, L, H) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : ATW(L[0]), ATW(L[1]), ATW(L[2]), ATW(L[3]), ATW(H[0]), ATW(H[1]), ATW(H[2]), ATW(H[3]) :: "memory")
-      auto pv_half = [&](const u32x2 (&L)[4], const u32x2 (&H)[4], int hg) {
-        const int grp = hg >> 1, ks = hg & 1;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const u32x4 vf = (u32x4){L[dt][0], L[dt][1], H[dt][0], H[dt][1]};
-          o[0][dt] = mfma16(vf, grp == 2 ? pbl[0][ks] : pbh[0][ks], o[0][dt]);
-          o[1][dt] = mfma16(vf, grp == 2 ? pbl[1][ks] : pbh[1][ks], o[1][dt]);
-          const int f = hg * 4 + dt;                 // filler slot 0..23
-          if (f < 8) {                               // the next tiles' DMA, one 1-KiB piece per slot: K(j+2) planes, then V(j+1) planes
-            const int kv = f >> 2, pl = (f >> 1) & 1, i = f & 1;
-            const int t = kv == 0 ? j + 2 : j + 1;
-            if (kv == 0 ? dma_k : MORE) {
-              const int64_t boff = (tok0 + (int64_t)t * KV) * 3 * C + h * HD;
-              const bool ok = (t * KV + KV <= N) || (t * KV + dma_row[i] < N);
-              const bf16_t* base = (pl ? ql_ : qh_) + boff;
-              unsigned char* dst = smem + (kv == 0 ? ST : 1 - ST) * STAGE + (kv * 2 + pl) * KTILE + wave * 2048;
-              attn_glds16((const bf16_t*)(uintptr_t)(ok ? (uint64_t)(uintptr_t)(base + dma_off[kv * 2 + i]) : zpage), dst + i * 1024);
-            }
-          } else if (MORE && f < 16) {               // running max of S(j+1): 8 slices of 4 scores
-            const int sub = (f - 8) >> 2, kt = (f - 8) & 3;
-            float mx = fmaxf(fmaxf(mxs[sub], fmaxf(sn[sub][kt][0], sn[sub][kt][1])), fmaxf(sn[sub][kt][2], sn[sub][kt][3]));
-            asm volatile("" : "+v"(mx));
-            mxs[sub] = mx;
-          } else if (MORE && (f == 16 || f == 18)) {
-            const int sub = (f - 16) >> 1;
-            float mn = fmaxf(m_run[sub], groups_max(mxs[sub]) * sc2);
-            asm volatile("" : "+v"(mn));
-            m_new[sub] = mn;
-          }
-          MTT_SB();
-        }
-      };
-      VREAD(vAl, vAh, 0)
-      VREAD(vBl, vBh, 1)
-      VWAIT(8, vAl, vAh);
-      pv_half(vAl, vAh, 0);
-      VREAD(vAl, vAh, 2)
-      VWAIT(8, vBl, vBh);
-      if (!skip1) pv_half(vBl, vBh, 1);
-      VREAD(vBl, vBh, 3)
-      VWAIT(8, vAl, vAh);
-      pv_half(vAl, vAh, 2);
-      VREAD(vAl, vAh, 4)
-      VWAIT(8, vBl, vBh);
-      if (!skip1) pv_half(vBl, vBh, 3);
-      VREAD(vBl, vBh, 5)
-      VWAIT(8, vAl, vAh);
-      pv_half(vAl, vAh, 4);
-      VWAIT(0, vBl, vBh);
-      if (!skip1) pv_half(vBl, vBh, 5);
-#undef VREAD
-#undef VWAIT
-#undef ATW
-    } else {
-      if (dma_k) dma_issue(smem + ST * STAGE, (j + 2) * KV, 0);
-      if (MORE) dma_issue(smem + (1 - ST) * STAGE, (j + 1) * KV, 1);
-    }
-    if (MORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
-#undef MTT_SB
-  {
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using Plain = std::integral_constant<int, 0>;
-    using Mask = std::integral_constant<int, 1>;
-    using Last = std::integral_constant<int, 2>;
-    int j = 0;
-    for (; j + 4 <= nkv; j += 2) {
-      tile(S0{}, Plain{}, j, sA, sB);
-      tile(S1{}, Plain{}, j + 1, sB, sA);
-    }
-    if (nkv - j == 3) {
-      tile(S0{}, Plain{}, j, sA, sB);
-      tile(S1{}, Mask{}, j + 1, sB, sA);
-      tile(S0{}, Last{}, j + 2, sA, sB);
-    } else if (nkv - j == 2) {
-      tile(S0{}, Mask{}, j, sA, sB);
-      tile(S1{}, Last{}, j + 1, sB, sA);
-    } else {
-      tile(S0{}, Last{}, j, sA, sB);
-    }
-  }
-
-  bf16_t* outh = (bf16_t*)d.out;
-  bf16_t* outl = (bf16_t*)d.out_lo;
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    const float l = groups_sum(l_part[sub]);
-    const int qrow = q0 + sub * 16 + li;
-    if (qrow >= N) continue;
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const float v0 = o[sub][dt][0] * inv, v1 = o[sub][dt][1] * inv, v2 = o[sub][dt][2] * inv, v3 = o[sub][dt][3] * inv;
-      const u32x2 hi = (u32x2){pack2(v0, v1), pack2(v2, v3)};
-      const int64_t oi = (tok0 + qrow) * C + h * HD + dt * 16 + lg * 4;
-      *(u32x2*)(outh + oi) = hi;
-      *(u32x2*)(outl + oi) = (u32x2){pack2(v0 - lo_of(hi.x), v1 - hi_of(hi.x)), pack2(v2 - lo_of(hi.y), v3 - hi_of(hi.y))};
-    }
-    if (d.lse && lg == 0) d.lse[((int64_t)b * d.nH + h) * N + qrow] = (m_run[sub] + log2f(l)) * 0.6931471805599453f;
-  }
-}
-
 }  // namespace
 
 // called by mtt_attn_fwd (attn.hip) for MTT_SPLIT storage + MTT_PREC_X3
@@ -1114,12 +694,9 @@ int mtt_attn_fwd_x3_split(const mtt_attn_desc* dd, hipStream_t s) {
   constexpr int smem = 2 * 4 * KTILE;
   static std::atomic<unsigned long long> done{0};
   if (int e = mtt_ensure_dyn_lds((const void*)attn_fwd_x3_kernel, smem, done)) return e;
-  static std::atomic<unsigned long long> done_p{0};
-  if (int e = mtt_ensure_dyn_lds((const void*)attn_fwd_x3p_kernel, smem, done_p)) return e;
   AttnP p; p.d = *dd;
   dim3 grid((unsigned)(((dd->N + 127) / 128) * dd->nH * dd->B));
-  if (dd->variant == MTT_ATTN_FAST_V1) hipLaunchKernelGGL(attn_fwd_x3_kernel, grid, dim3(256), smem, s, p);      // A/B: the three-phase kernel of round 5
-  else hipLaunchKernelGGL(attn_fwd_x3p_kernel, grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL(attn_fwd_x3_kernel, grid, dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }
 

@@ -1785,6 +1785,8 @@ extern "C" size_t mtt_desc_size(int which) {
     case 20: return sizeof(mtt_chanattn_desc);
     case 21: return sizeof(mtt_conv3s2_desc);
     case 22: return sizeof(mtt_segcopy_desc);
+    case 23: return sizeof(mtt_ctrw_desc);
+    case 24: return sizeof(mtt_detloss_desc);
     default: return 0;
   }
 }

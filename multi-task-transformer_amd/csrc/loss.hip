@@ -130,6 +130,70 @@ __global__ __launch_bounds__(256) void loss_kernel(const mtt_loss_desc d, const 
   }
 }
 
+// ---- detection-branch losses (det_losses.py): element-wise on [N, C], weights, deterministic sum -----------------------------------
+// log(sigmoid(x)) = -softplus(-x), log(1 - sigmoid(x)) = -softplus(x): the stable forms of the reference's BCE-with-logits host path
+// (py_sigmoid_focal_loss, det_losses.py:183-224); mmcv's device kernel clamps log at FLT_MIN instead, the same values to fp32 rounding
+// wherever |x| < 87.
+MTT_DEV void focal_terms(float x, bool pos, float gamma, float alpha, float& loss, float& grad) {
+  const float p = 1.0f / (1.0f + __expf(-x));
+  const float lp = -softplus_neg(x), ln = -softplus_neg(-x);         // log p, log (1 - p)
+  if (pos) {
+    const float q = 1.0f - p, m = gamma == 2.0f ? q * q : __powf(fmaxf(q, 1e-38f), gamma);
+    loss = -alpha * m * lp;
+    // d/dx [-(1-p)^g log p] = (1-p)^g (g p log p - (1 - p))
+    grad = alpha * m * (gamma * p * lp - q);
+  } else {
+    const float m = gamma == 2.0f ? p * p : __powf(fmaxf(p, 1e-38f), gamma);
+    loss = -(1.0f - alpha) * m * ln;
+    // d/dx [-p^g log(1-p)] = p^g (p - g (1 - p) log(1 - p))
+    grad = (1.0f - alpha) * m * (p - gamma * (1.0f - p) * ln);
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void detloss_kernel(const mtt_detloss_desc d, const float* gscale, const float* gelem, float scale, float* dpred) {
+  const int64_t total = d.N * d.C;
+  const float gs = BWD ? (gelem ? scale : gscale[0] * scale) : 0.f;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / d.C;
+    const int c = (int)(i - n * d.C);
+    const float x = d.pred[i];
+    const float w = d.wmode == 0 ? 1.f : (d.wmode == 1 ? d.weight[n] : d.weight[i]);
+    float loss, grad;
+    if (d.kind == 0) {
+      focal_terms(x, ((const int64_t*)d.target)[n] == (int64_t)c, d.gamma, d.alpha, loss, grad);
+    } else {
+      const float df = x - ((const float*)d.target)[i], a = fabsf(df);
+      loss = a < d.beta ? 0.5f * a * a / d.beta : a - 0.5f * d.beta;
+      grad = a < d.beta ? df / d.beta : (df > 0.f ? 1.f : -1.f);
+    }
+    if (!BWD) {
+      const float v = w * loss;
+      if (d.out) d.out[i] = v;
+      acc += v;
+    } else {
+      dpred[i] = w * grad * (gelem ? gelem[i] * gs : gs);
+    }
+  }
+  if (!BWD && d.sum) {
+    acc = block_sum256(acc);
+    if (threadIdx.x == 0) d.ws[blockIdx.x] = acc;
+  }
+}
+
+unsigned detloss_blocks(const mtt_detloss_desc* d) {
+  const int64_t g = (d->N * d->C + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+int detloss_check(const mtt_detloss_desc* d) {
+  if (!d || !d->pred || !d->target || d->N <= 0 || d->C <= 0 || d->kind < 0 || d->kind > 1 || d->wmode < 0 || d->wmode > 2) return MTT_E_BADARG;
+  if (d->wmode != 0 && !d->weight) return MTT_E_BADARG;
+  if (d->kind == 1 && !(d->beta > 0.f)) return MTT_E_BADARG;
+  return 0;
+}
+
 dim3 loss_grid(const mtt_loss_desc* d) {
   int64_t g = (d->HW + 255) / 256;
   const int64_t cap = (8192 + d->B - 1) / d->B;
@@ -171,5 +235,24 @@ extern "C" int mtt_loss_bwd(const mtt_loss_desc* d, const float* gout, void* str
   if (int e = loss_check(d)) return e;
   if (!d->stats || !d->dpred || !gout) return MTT_E_BADARG;
   hipLaunchKernelGGL(loss_kernel<true>, loss_grid(d), dim3(256), 0, (hipStream_t)stream, *d, gout);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t mtt_detloss_ws_floats(const mtt_detloss_desc* d) {
+  if (!d || d->N <= 0 || d->C <= 0) return 0;
+  return (size_t)detloss_blocks(d);
+}
+extern "C" int mtt_detloss_fwd(const mtt_detloss_desc* d, void* stream) {
+  if (int e = detloss_check(d)) return e;
+  if ((!d->out && !d->sum) || (d->sum && !d->ws)) return MTT_E_BADARG;
+  const unsigned g = detloss_blocks(d);
+  hipLaunchKernelGGL(detloss_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, *d, (const float*)nullptr, (const float*)nullptr, 1.0f, (float*)nullptr);
+  if (d->sum) hipLaunchKernelGGL(mtt_reduce_many_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)d->ws, (int)g, 1, d->sum, 1.0f, 0);
+  return (int)hipGetLastError();
+}
+extern "C" int mtt_detloss_bwd(const mtt_detloss_desc* d, const float* gscale, const float* gelem, float scale, float* dpred, void* stream) {
+  if (int e = detloss_check(d)) return e;
+  if (!dpred || (!gscale && !gelem)) return MTT_E_BADARG;
+  hipLaunchKernelGGL(detloss_kernel<true>, dim3(detloss_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d, gscale, gelem, scale, dpred);
   return (int)hipGetLastError();
 }

@@ -1836,3 +1836,128 @@ extern "C" int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32
   return LAUNCH_OK();
 }
 
+
+// ---- cross-task reweighting weights: per-task 1x1-conv MLP over the head dimension of the prompt<->prompt raw logits (taskprompter.py:482-484)
+namespace {
+constexpr int CTRW_MAXH = 32;
+
+// one thread per (b, t, s): z[h] = rawlog[b, h, t, s] -> wmix[b, t, s]; bwd (DZ): dz[h] -> drawlog[b, h, t, s]
+template <bool DZ>
+__global__ __launch_bounds__(256) void ctrw_item_kernel(const mtt_ctrw_desc d, const float* dwmix, float* drawlog) {
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  const int T = d.T, nH = d.nH;
+  if (item >= d.B * T * T) return;
+  const int s = item % T, t = (item / T) % T, b = item / (T * T);
+  float z[CTRW_MAXH];
+#pragma unroll
+  for (int h = 0; h < CTRW_MAXH; ++h)
+    if (h < nH) z[h] = d.rawlog[(((int64_t)b * nH + h) * T + t) * d.N + s];
+  const float* w0 = d.w0 + (int64_t)t * nH * nH;
+  float out = DZ ? 0.f : d.b2[t];
+  float dz[CTRW_MAXH];
+  const float g = DZ ? dwmix[item] : 0.f;
+  if (DZ) {
+#pragma unroll
+    for (int h = 0; h < CTRW_MAXH; ++h) dz[h] = 0.f;
+  }
+  for (int j = 0; j < nH; ++j) {
+    float pre = d.b0[t * nH + j];
+#pragma unroll
+    for (int h = 0; h < CTRW_MAXH; ++h)
+      if (h < nH) pre = fmaf(w0[j * nH + h], z[h], pre);
+    if (!DZ) {
+      out = fmaf(d.w2[t * nH + j], gelu_f(pre), out);
+    } else {
+      const float dpre = g * d.w2[t * nH + j] * gelu_grad_f(pre);
+#pragma unroll
+      for (int h = 0; h < CTRW_MAXH; ++h)
+        if (h < nH) dz[h] = fmaf(dpre, w0[j * nH + h], dz[h]);
+    }
+  }
+  if (!DZ) {
+    d.wmix[item] = out;
+  } else {
+#pragma unroll
+    for (int h = 0; h < CTRW_MAXH; ++h)
+      if (h < nH) drawlog[(((int64_t)b * nH + h) * T + t) * d.N + s] = dz[h];
+  }
+}
+
+// one workgroup per (t, j): the (b, s) items in thread order, per-thread partial sums, then a fixed-order tree through LDS
+__global__ __launch_bounds__(256) void ctrw_wgrad_kernel(const mtt_ctrw_desc d, const float* dwmix, float* dw0, float* db0, float* dw2, float* db2) {
+  __shared__ float red[256];
+  const int T = d.T, nH = d.nH;
+  const int j = blockIdx.x % nH, t = blockIdx.x / nH;
+  const float* w0 = d.w0 + ((int64_t)t * nH + j) * nH;
+  float aw0[CTRW_MAXH];
+#pragma unroll
+  for (int h = 0; h < CTRW_MAXH; ++h) aw0[h] = 0.f;
+  float ab0 = 0.f, aw2 = 0.f, ab2 = 0.f;
+  const int items = d.B * T;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int s = it % T, b = it / T;
+    float z[CTRW_MAXH];
+    float pre = d.b0[t * nH + j];
+#pragma unroll
+    for (int h = 0; h < CTRW_MAXH; ++h)
+      if (h < nH) {
+        z[h] = d.rawlog[(((int64_t)b * nH + h) * T + t) * d.N + s];
+        pre = fmaf(w0[h], z[h], pre);
+      }
+    const float g = dwmix[((int64_t)b * T + t) * T + s];
+    const float dpre = g * d.w2[t * nH + j] * gelu_grad_f(pre);
+    aw2 = fmaf(g, gelu_f(pre), aw2);
+    ab2 += g;
+    ab0 += dpre;
+#pragma unroll
+    for (int h = 0; h < CTRW_MAXH; ++h)
+      if (h < nH) aw0[h] = fmaf(dpre, z[h], aw0[h]);
+  }
+  auto block_sum = [&](float v) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+#pragma unroll
+  for (int h = 0; h < CTRW_MAXH; ++h)
+    if (h < nH) {
+      const float r = block_sum(aw0[h]);
+      if (threadIdx.x == 0) dw0[((int64_t)t * nH + j) * nH + h] = r;
+    }
+  const float rb0 = block_sum(ab0), rw2 = block_sum(aw2), rb2 = block_sum(ab2);
+  if (threadIdx.x == 0) {
+    db0[t * nH + j] = rb0;
+    dw2[t * nH + j] = rw2;
+    if (j == 0) db2[t] = rb2;
+  }
+}
+
+int ctrw_check(const mtt_ctrw_desc* d) {
+  if (!d || !d->rawlog || !d->w0 || !d->b0 || !d->w2 || !d->b2 || d->B <= 0 || d->T <= 0 || d->nH <= 0 || d->N < d->T) return MTT_E_BADARG;
+  if (d->nH > CTRW_MAXH || (int64_t)d->B * d->T * d->T >= (1ll << 31)) return MTT_E_UNSUPPORTED;
+  return 0;
+}
+}  // namespace
+
+extern "C" int mtt_ctr_weights(const mtt_ctrw_desc* d, void* stream) {
+  if (int e = ctrw_check(d)) return e;
+  if (!d->wmix) return MTT_E_BADARG;
+  const int items = d->B * d->T * d->T;
+  hipLaunchKernelGGL(ctrw_item_kernel<false>, dim3((items + 255) / 256), dim3(256), 0, S_, *d, (const float*)nullptr, (float*)nullptr);
+  return LAUNCH_OK();
+}
+extern "C" int mtt_ctr_weights_bwd(const mtt_ctrw_desc* d, const float* dwmix, float* drawlog, float* dw0, float* db0, float* dw2, float* db2,
+                                   void* stream) {
+  if (int e = ctrw_check(d)) return e;
+  if (!dwmix || !drawlog || !dw0 || !db0 || !dw2 || !db2) return MTT_E_BADARG;
+  const int items = d->B * d->T * d->T;
+  hipLaunchKernelGGL(ctrw_item_kernel<true>, dim3((items + 255) / 256), dim3(256), 0, S_, *d, dwmix, drawlog);
+  hipLaunchKernelGGL(ctrw_wgrad_kernel, dim3(d->T * d->nH), dim3(256), 0, S_, *d, dwmix, dw0, db0, dw2, db2);
+  return LAUNCH_OK();
+}

@@ -110,12 +110,30 @@ _pack_cache = {}
 _param_epoch = 0
 
 
-def bump_param_epoch():
+_epoch_origin = {}           # epoch -> data_ptrs of the parameters that bump named, or None = unknown writer (assume any parameter)
+
+
+def bump_param_epoch(params=None):
     """Invalidate every cached pack: called by optimizers that write parameters through raw device pointers (optim.FusedClipAdam),
     where torch's own `_version` counter cannot see the update.  (FusedClipAdam also bumps `_version`; the epoch is the second,
-    independent line of defence so that a stale pack can never be served after a step.)"""
+    independent line of defence so that a stale pack can never be served after a step.)  `params`: the tensors that were written, when
+    the caller knows them — the next refresh then bumps the autograd versions of exactly the packs built from them (plus those whose
+    `_version` moved); without it the origin of the update is unknown and EVERY refreshed pack is treated as modified (an
+    epoch-only bump by a raw-pointer writer must still make a pending backward that saved the old pack fail loudly)."""
     global _param_epoch
     _param_epoch += 1
+    _epoch_origin[_param_epoch] = None if params is None else frozenset(p.data_ptr() for p in params)
+    for k in [k for k in _epoch_origin if k < _param_epoch - 256]:
+        del _epoch_origin[k]
+
+
+def _epoch_touched(old_epoch, ptrs):
+    """did a bump since `old_epoch` (possibly) write one of the parameters at `ptrs`?"""
+    for ep in range(old_epoch + 1, _param_epoch + 1):
+        org = _epoch_origin.get(ep, None)
+        if org is None or any(q in org for q in ptrs):
+            return True
+    return False
 
 
 def _cached(key, params, build):
@@ -269,8 +287,11 @@ def _refresh_packs(device):
     bumped = []
     for e, ps in live:
         new = _pver(ps)
-        if e.ver[1] != new[1]:           # this pack's own parameters moved on (the epoch alone also changes when ANOTHER model in the
-            v = e.value                  # process stepped: its bytes are rewritten identically, its pending backward stays valid — ADVICE r04)
+        # this pack's own parameters moved on: their `_version` changed, or a raw-pointer writer named them in bump_param_epoch, or a
+        # writer of unknown origin bumped the epoch.  (The epoch also changes when ANOTHER model in the process stepped through
+        # FusedClipAdam, which names its parameters: that pack's bytes are rewritten identically, its pending backward stays valid.)
+        if e.ver[1] != new[1] or (e.ver[0] != new[0] and _epoch_touched(e.ver[0], [v[0] for v in new[1]])):
+            v = e.value
             bumped += [v.hi, v.lo] if isinstance(v, Split) else [v]
         e.ver = new
     # the packs were rewritten IN PLACE by a raw launch: tell autograd, so that a backward still holding one of them from an earlier
@@ -758,6 +779,15 @@ def ctr_mix(fea, wmix, B, C, acc=None, out_dtype=torch.float32):
     call("ctr_mix", fea=fea, out=out, wmix=wmix, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C,
          fea_dtype=dtype_code(fea), accumulate=1 if acc is not None else 0, out_dtype=dtype_code(out))
     return out
+
+
+def ctr_weights(rawlog, w0, b0, w2, b2, B, T):
+    """rawlog fp32 [B, nH, T, N]; w0 [T, nH*nH], b0 [T, nH], w2 [T, nH], b2 [T, 1] fp32 packs -> wmix fp32 [B, T, T] (mtt_ctr_weights:
+    the per-task MLP over the head dimension of the prompt<->prompt raw logits, taskprompter.py:482-484)."""
+    nH, N = rawlog.shape[1], rawlog.shape[3]
+    wmix = torch.empty(B, T, T, dtype=torch.float32, device=rawlog.device)
+    call("ctr_weights", rawlog=rawlog, w0=w0, b0=b0, w2=w2, b2=b2, wmix=wmix, B=B, T=T, nH=nH, N=N)
+    return wmix
 
 
 def bilinear(x, B, C, Hin, Win, Hout, Wout, out_dtype, nchw=False):

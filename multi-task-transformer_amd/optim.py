@@ -166,7 +166,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         """After a replay: the graph wrote the parameters behind torch's back — same bookkeeping as the end of step()."""
         for _, _, plist in self._captured:
             torch.autograd.graph.increment_version(plist)
-        ops.bump_param_epoch()
+        ops.bump_param_epoch([p for _, _, plist in self._captured for p in plist])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -221,7 +221,7 @@ class FusedClipAdam(torch.optim.Optimizer):
             # on `_version`) and the pack cache of ops.py that they changed
             if not capturing:
                 torch.autograd.graph.increment_version(plist)
-        ops.bump_param_epoch()
+        ops.bump_param_epoch([p for g_ in self.param_groups for p in g_["params"]])
         self.last_grad_norm = total_sq.sqrt()
         return loss if loss is not None else self.last_grad_norm
 

@@ -370,14 +370,10 @@ class TaskPrompter(nn.Module):
         """[B, T, T] mixing weights: per-head MLP on the prompt<->prompt raw logits (:482-484); identity without ctr."""
         if not self.p.use_ctr:
             return torch.eye(T, dtype=torch.float32, device=rawlog.device)[None].expand(B, T, T).contiguous()
-        names = self.p.TASKS.NAMES
-        z = rawlog[:, :, :, :T].permute(0, 2, 3, 1)                                   # [B, t, s, nH]
-        W0 = torch.stack([self.ctr_attn_conv[il][t][0].weight.flatten(1) for t in names])   # [T, nH, nH]
-        b0 = torch.stack([self.ctr_attn_conv[il][t][0].bias for t in names])
-        W2 = torch.stack([self.ctr_attn_conv[il][t][2].weight.flatten() for t in names])     # [T, nH]
-        b2 = torch.stack([self.ctr_attn_conv[il][t][2].bias for t in names]).flatten()
-        z = torch.nn.functional.gelu(torch.einsum('btsh,tjh->btsj', z, W0) + b0[None, :, None, :])
-        return (torch.einsum('btsj,tj->bts', z, W2) + b2[None, :, None]).contiguous()
+        from . import autograd_path
+        mods = [self.ctr_attn_conv[il][t] for t in self.p.TASKS.NAMES]
+        return autograd_path.CtrWeightsFn.apply(rawlog, B, T, ('ctrw', il), *[m[0].weight for m in mods], *[m[0].bias for m in mods],
+                                                *[m[2].weight for m in mods], *[m[2].bias for m in mods])
 
     def _bn_fold(self, bns, conv_biases, tag):
         return bn_fold(bns, conv_biases, tag)

@@ -360,6 +360,83 @@ def ctr_mix(**kw):
     _wr(kw["out"], idx, out)
 
 
+def _ctrw_views(kw):
+    B, T, nH, N = kw["B"], kw["T"], kw["nH"], kw["N"]
+    idx = ((torch.arange(B)[:, None, None, None] * nH + torch.arange(nH)[None, :, None, None]) * T + torch.arange(T)[None, None, :, None]) * N \
+        + torch.arange(T)[None, None, None, :]
+    z = _rd(kw["rawlog"], idx).permute(0, 2, 3, 1)                          # [B, t, s, nH]
+    w0 = _rd(kw["w0"], torch.arange(T * nH * nH)).view(T, nH, nH)
+    b0 = _rd(kw["b0"], torch.arange(T * nH)).view(T, nH)
+    w2 = _rd(kw["w2"], torch.arange(T * nH)).view(T, nH)
+    b2 = _rd(kw["b2"], torch.arange(T))
+    return z, w0, b0, w2, b2, idx
+
+
+def _ctrw_math(z, w0, b0, w2, b2):
+    hid = _gelu(torch.einsum("btsh,tjh->btsj", z, w0) + b0[None, :, None, :])
+    return torch.einsum("btsj,tj->bts", hid, w2) + b2[None, :, None]
+
+
+def ctr_weights(**kw):
+    z, w0, b0, w2, b2, _ = _ctrw_views(kw)
+    out = _ctrw_math(z, w0, b0, w2, b2)
+    _wr(kw["wmix"], torch.arange(out.numel()), out.reshape(-1))
+
+
+def ctr_weights_bwd(**kw):
+    dwmix, drawlog, dw0, db0, dw2, db2 = kw["xargs"]
+    z, w0, b0, w2, b2, idx = _ctrw_views(kw)
+    g = _rd(dwmix, torch.arange(z.shape[0] * z.shape[1] * z.shape[2])).view(z.shape[:3])
+    with torch.enable_grad():
+        leaves = [t.clone().requires_grad_(True) for t in (z, w0, b0, w2, b2)]
+        grads = torch.autograd.grad((_ctrw_math(*leaves) * g).sum(), leaves)
+    _wr(drawlog, idx, grads[0].permute(0, 3, 1, 2))                           # only the first T columns are written
+    for dst, gr in zip((dw0, db0, dw2, db2), grads[1:]):
+        _wr(dst, torch.arange(gr.numel()), gr.reshape(-1))
+
+
+def _detloss_elem(x, kw):
+    """element-wise loss of mtt_detloss_desc as a differentiable fp64 expression (det_losses.py:102-123, :183-224)"""
+    N, Cn = kw["N"], kw["C"]
+    if kw["kind"] == 0:
+        tgt = flat(kw["target"])[0][kw["target"].storage_offset():kw["target"].storage_offset() + N].long()
+        onehot = torch.nn.functional.one_hot(tgt, Cn + 1)[:, :Cn].double()
+        p = torch.sigmoid(x)
+        pt = (1 - p) * onehot + p * (1 - onehot)
+        fw = (kw["alpha"] * onehot + (1 - kw["alpha"]) * (1 - onehot)) * pt.pow(kw["gamma"])
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(x, onehot, reduction="none") * fw
+    else:
+        y = _rd(kw["target"], torch.arange(N * Cn)).view(N, Cn)
+        d = (x - y).abs()
+        loss = torch.where(d < kw["beta"], 0.5 * d * d / kw["beta"], d - 0.5 * kw["beta"])
+    if kw.get("wmode", 0) == 1:
+        loss = loss * _rd(kw["weight"], torch.arange(N)).view(N, 1)
+    elif kw.get("wmode", 0) == 2:
+        loss = loss * _rd(kw["weight"], torch.arange(N * Cn)).view(N, Cn)
+    return loss
+
+
+def detloss_fwd(**kw):
+    N, Cn = kw["N"], kw["C"]
+    x = _rd(kw["pred"], torch.arange(N * Cn)).view(N, Cn)
+    loss = _detloss_elem(x, kw)
+    if kw.get("out") is not None:
+        _wr(kw["out"], torch.arange(N * Cn), loss.reshape(-1))
+    if kw.get("sum") is not None:
+        _wr(kw["sum"], torch.arange(1), loss.sum().reshape(1))
+
+
+def detloss_bwd(**kw):
+    gscale, gelem, scale, dpred = kw["xargs"]
+    N, Cn = kw["N"], kw["C"]
+    x = _rd(kw["pred"], torch.arange(N * Cn)).view(N, Cn)
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        up = _rd(gelem, torch.arange(N * Cn)).view(N, Cn) * scale if gelem is not None else _rd(gscale, torch.arange(1))[0] * scale
+        (g,) = torch.autograd.grad((_detloss_elem(xr, kw) * up).sum(), xr)
+    _wr(dpred, torch.arange(N * Cn), g.reshape(-1))
+
+
 def _src(o, n_in, n_out):
     scale = torch.tensor(n_in / n_out, dtype=torch.float32)
     s = (torch.arange(n_out, dtype=torch.float32) + 0.5) * scale - 0.5
@@ -1107,12 +1184,13 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=wina
               dwconv3x3s2=dwconv3x3s2, avgpool_ceil=avgpool_ceil, layernorm_mt=layernorm_mt, attn_msg=attn_msg, attn_msg_bwd=attn_msg_bwd,
               convt3x3s2_gather=convt3x3s2_gather, dwconv3x3s2_bwd=dwconv3x3s2_bwd, avgpool_ceil_bwd=avgpool_ceil_bwd,
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
-              loss_fwd=loss_fwd, loss_bwd=loss_bwd, chanattn_bwd=chanattn_bwd, conv3s2_nchw_bwd=conv3s2_nchw_bwd, segcopy=segcopy)
+              loss_fwd=loss_fwd, loss_bwd=loss_bwd, chanattn_bwd=chanattn_bwd, conv3s2_nchw_bwd=conv3s2_nchw_bwd, segcopy=segcopy,
+              ctr_weights=ctr_weights, ctr_weights_bwd=ctr_weights_bwd, detloss_fwd=detloss_fwd, detloss_bwd=detloss_bwd)
 _POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, colsum_batched=colsum_batched, add_rows=add_rows, rowscale_cast=rowscale_cast, rowscale_cast_colsum=rowscale_cast_colsum)
 
 
 def call(name, **kw):
-    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd", "upconv4_gather", "winattn_bwd", "chanattn_bwd", "conv3s2_nchw_bwd") else torch.no_grad():
+    with torch.enable_grad() if name in ("dwconv3x3s2_bwd", "avgpool_ceil_bwd", "loss_bwd", "upconv4_gather", "winattn_bwd", "chanattn_bwd", "conv3s2_nchw_bwd", "ctr_weights_bwd", "detloss_bwd") else torch.no_grad():
         if name in _POS:
             return _POS[name](kw["args"])
         return _TABLE[name](**kw)

@@ -714,6 +714,28 @@ def row_cases():
         cases.append((f"colsum_batched_half_{dt}", "colsum_batched",
                       dict(args=[src.reshape(-1)[304:], torch.full((Zb, c_), 3.0), r_, c_, ld_, dt, Zb, r_ * ld_, c_, scratch(Zb * 1536 * ld_)]), TOL_ROW))
         cases.append((f"add_rows_{dt}", "add_rows", dict(args=[rnd(g, 30, 24, dtype=DT[dt]), rnd(g, 30, 32), 30, 20, 24, 32, dt, 0.5]), TOL_ROW))
+    # cross-task reweighting weights (ABI 10): the per-task MLP over the head dimension of the prompt<->prompt raw logits, forward and backward
+    # (drawlog: only the first T columns are written — the 7.0 fill of the other columns must survive; weight gradients WRITTEN over stale 9.0)
+    for (B, T, nH, N) in ((63, 6, 16, 1030), (3, 2, 2, 10), (5, 4, 12, 260)):
+        raw = rnd(g, B, nH, T, N, scale=3.0)
+        kw = dict(rawlog=raw, w0=rnd(g, T, nH * nH, scale=0.4), b0=rnd(g, T, nH), w2=rnd(g, T, nH, scale=0.5), b2=rnd(g, T, 1),
+                  wmix=torch.full((B, T, T), 9.0), B=B, T=T, nH=nH, N=N)
+        cases.append((f"ctr_weights_{B}x{T}x{nH}", "ctr_weights", kw, dict(f32=2e-6, bf16=5e-3)))
+        kb = dict(kw, wmix=None, xargs=[rnd(g, B, T, T), torch.full((B, nH, T, N), 7.0), torch.full((T, nH * nH), 9.0), torch.full((T, nH), 9.0),
+                                        torch.full((T, nH), 9.0), torch.full((T, 1), 9.0)])
+        cases.append((f"ctr_weights_bwd_{B}x{T}x{nH}", "ctr_weights_bwd", kb, dict(f32=5e-6, bf16=5e-3)))
+    # detection-branch losses (ABI 10): element-wise map + deterministic sum, and the gradient with a device scalar / an element-wise upstream
+    for (kind, N, C, wmode) in ((0, 349, 10, 0), (0, 5000, 3, 1), (0, 777, 10, 2), (1, 349, 7, 0), (1, 4100, 2, 2), (1, 600, 9, 1)):
+        pred = rnd(g, N, C, scale=2.5)
+        target = torch.randint(0, C + 1, (N,), generator=g) if kind == 0 else pred + rnd(g, N, C, scale=0.3)
+        weight = None if wmode == 0 else (torch.rand(N, generator=g) + 0.1 if wmode == 1 else torch.rand(N, C, generator=g) + 0.1)
+        base = dict(pred=pred, target=target, weight=weight, N=N, C=C, kind=kind, wmode=wmode, gamma=2.0 if N % 2 else 1.5, alpha=0.25, beta=1.0 / 9.0)
+        cases.append((f"detloss_fwd_k{kind}_w{wmode}_{N}", "detloss_fwd",
+                      dict(base, out=torch.full((N, C), 9.0), sum=torch.full((1,), 9.0), ws=scratch(4096)), dict(f32=3e-6, bf16=5e-3)))
+        cases.append((f"detloss_bwd_scalar_k{kind}_w{wmode}_{N}", "detloss_bwd",
+                      dict(base, out=None, sum=None, ws=None, xargs=[torch.tensor([1.7]), None, 0.37, torch.full((N, C), 9.0)]), dict(f32=5e-6, bf16=5e-3)))
+        cases.append((f"detloss_bwd_elem_k{kind}_w{wmode}_{N}", "detloss_bwd",
+                      dict(base, out=None, sum=None, ws=None, xargs=[None, rnd(g, N, C), 2.0, torch.full((N, C), 9.0)]), dict(f32=5e-6, bf16=5e-3)))
     return cases
 
 

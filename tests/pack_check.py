@@ -141,11 +141,22 @@ def check_refresh(device):
     with torch.no_grad():
         for p in ws:
             p.mul_(0.5)
-    ops.bump_param_epoch()
+    ops.bump_param_epoch(ws)                                                      # (what FusedClipAdam.step does: it names its parameters)
     n1 = ops.pack_refreshes
     assert ops.pack_conv3(cs, bf, 'rc') is c and ops.pack_refreshes == n1 + 1     # the epoch moved: refreshed (identical bytes) ...
     assert c._version == vc and a._version > va                                  # ... but only the changed pack's version moved
     same(ops.pack_linear(ws, bf, 'r'), _ref_linear(ws, torch.bfloat16))
+    # a raw-pointer writer torch cannot see (no `_version` change) — named parameters: their packs' versions move, the others' do not;
+    # unknown origin: EVERY pack is treated as rewritten, so that a pending backward holding an old pack fails loudly
+    va, vc = a._version, c._version
+    for p in cs:
+        p.data.view(-1)[0:1].copy_(torch.full((1,), 3.0, device=device))
+    ops.bump_param_epoch(cs)
+    assert ops.pack_conv3(cs, bf, 'rc') is c and c._version > vc and a._version == va
+    same(c, _ref_conv3(cs, torch.bfloat16, False))
+    va, vc = a._version, c._version
+    ops.bump_param_epoch()
+    assert ops.pack_linear(ws, bf, 'r') is a and a._version > va and c._version > vc
 
 
 def check_unpack(device):

@@ -234,6 +234,38 @@ def test_conv_head_as_one_node_keeps_its_gradient_maps_in_the_backwards_dtype(em
         assert all(abs(a[k][0] - b[k][0]) <= 1e-6 * max(a[k][1], 1e-12) + 1e-12 for k in a), "x3: the node fusion must not change the arithmetic"
 
 
+def test_fused_head_and_fuse_tail_nodes_with_frozen_inputs(emulated):
+    """ConvHeadFn / FuseTailFn run other Functions' forward / backward as STAGES with a stand-in ctx: with part of their inputs
+    frozen (requires_grad = False: head convs, one task's fea_fuse tail, every BatchNorm affine) the step must still run, frozen tensors
+    get no gradient and every other parameter gets exactly the gradient of the all-trainable run."""
+    import mtt_amd
+    from oracle import taskprompter_oracle as tpo  # noqa: F401
+    from tests.golden.make_golden import loss_of
+    cfg = configs.taskprompter("mini_ctr")
+    meta, _ = conftest.load_golden("mini_ctr")
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    x = weights.synth_images(2, cfg["img_size"], 2)
+
+    def run(freeze):
+        model = conftest.build_product_model(cfg, "x3f", "cpu")
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        frozen = [k for k, q in model.named_parameters() if freeze(k)]
+        for k, q in model.named_parameters():
+            q.requires_grad_(k not in frozen)
+        loss_of(model(x)).backward()
+        return {k: (None if q.grad is None else q.grad.clone()) for k, q in model.named_parameters()}, frozen
+
+    full, _ = run(lambda k: False)
+    part, frozen = run(lambda k: "mt_proj.0" in k or ".fea_fuse.1.depth." in k or ".mt_proj.1." in k or "fea_fuse.2.edge.2." in k)
+    assert len(frozen) > 10
+    for k, gfull in full.items():
+        if k in frozen:
+            assert part[k] is None, k
+        else:
+            assert part[k] is not None and torch.equal(part[k], gfull), k
+
+
 def test_bf16_training_uses_flash_attention_backward(emulated, monkeypatch):
     """bf16 mode routes the attention backward to mtt_attn_bwd (flash, no N x N buffer); gradients stay bf16-accurate."""
     import mtt_amd

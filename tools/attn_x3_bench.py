@@ -41,25 +41,7 @@ def timed(fn, iters=10):
     return statistics.median(ts)
 
 
-def attn_variant(variant):
-    """the split-plane x3 forward with an explicit mtt_attn_desc.variant (3 = MTT_ATTN_FAST_V1: the three-phase kernel of round 5)"""
-    out = ops.Split.empty((B * N, C), dev)
-    rawlog = torch.empty(B, nH, T, N, dtype=torch.float32, device=dev)
-    lse = torch.empty(B, nH, N, dtype=torch.float32, device=dev)
-    ops.call("attn_fwd", qkv=qs.hi, out=out.hi, rawlog=rawlog, lse=lse, B=B, N=N, nH=nH, T=T, dtype=2, prec=1, scale=64 ** -0.5, qkv_lo=qs.lo,
-             out_lo=out.lo, variant=variant)
-    return out, rawlog, lse
-
-
-t3old = timed(lambda: attn_variant(3))
 t3 = timed(lambda: ops.attention(qs, B, N, nH, T, x3f, want_lse=True))
-t3old2 = timed(lambda: attn_variant(3))
-t3b = timed(lambda: ops.attention(qs, B, N, nH, T, x3f, want_lse=True))
-oo, ro, lo_ = attn_variant(3)
-on, rn, ln = ops.attention(qs, B, N, nH, T, x3f, want_lse=True)
-print(f"x3 forward: three-phase kernel (round 5) {t3old:.0f} / {t3old2:.0f} us, pipelined kernel {t3:.0f} / {t3b:.0f} us; new vs old: out "
-      f"{float(((on.hi.float() + on.lo.float()) - (oo.hi.float() + oo.lo.float())).norm() / (oo.hi.float() + oo.lo.float()).norm()):.2e}, "
-      f"rawlog max abs {float((rn - ro).abs().max()):.2e}, lse max abs {float((ln - lo_).abs().max()):.2e}", flush=True)
 tb = timed(lambda: ops.attention(qh, B, N, nH, T, ops.Prec("bf16"), want_lse=True))
 o3, raw3, lse3 = ops.attention(qs, B, N, nH, T, x3f, want_lse=True)
 # reference: fp64 softmax attention of the first image / two heads on the summed planes

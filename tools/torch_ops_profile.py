@@ -1,5 +1,5 @@
 """Which torch (non-libmtt) ops run inside one training step, with input shapes: finds glue that should be fused or removed.
-Usage (GPU box): python tools/torch_ops_profile.py [batch]"""
+Usage (GPU box): python tools/torch_ops_profile.py [batch] [prec]    (the product's own criterion and optimizer, as bench.py's step)"""
 import os
 import sys
 
@@ -8,15 +8,15 @@ import torch  # noqa: E402
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 import mtt_amd  # noqa: E402
-from oracle import losses_oracle  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+PREC = sys.argv[2] if len(sys.argv) > 2 else "x3f"
 dev = torch.device("cuda")
 p = mtt_amd.factory.make_p(mtt_amd.factory.TASK_ORDER, (512, 512), backbone="TaskPrompter_vitL", head="conv", embed_dim=300,
-                           final_embed_dim=350, chan_nheads=1, use_ctr=True, prec="bf16")
+                           final_embed_dim=350, chan_nheads=1, use_ctr=True, prec=PREC)
 model = mtt_amd.factory.get_model(p).to(dev).train()
-crit = losses_oracle.MultiTaskLoss(p, p.TASKS.NAMES).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=2e-5, fused=True)
+crit = mtt_amd.losses.FusedMultiTaskLoss(p, p.TASKS.NAMES).to(dev)
+opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=2e-5, weight_decay=1e-6, max_norm=10.0)
 x = torch.randn(B, 3, 512, 512, device=dev)
 gt = mtt_amd.losses.synthetic_targets(p, B, 512, 512, dev)
 
@@ -25,10 +25,10 @@ def step():
     loss = crit(model(x), gt)["total"]
     opt.zero_grad(set_to_none=True)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
     opt.step()
 
 
+step()
 step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
