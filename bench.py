@@ -20,7 +20,7 @@ it (1.5e-2) and x3f meets it (2.6e-5) — forward = 3 bf16 MFMAs per product on 
                  these images (the oracle runs inside the cpu_baseline subprocess)
   fast_mode    — the bf16 mode (BASELINE.json's configs and north_star's 40 % target are stated on it), measured in the same process with
                  the same steps / warm-up: images/s, fwd ms/img, its own roofline (gemm_dma_kernel<1>) and its own parity (which fails 1e-3)
-  full_fp32_mode — the fully fp32-class step (x3 forward AND backward: gradients match the oracle's autograd to 6e-5), 3 steps
+  full_fp32_mode — the fully fp32-class step (x3 forward AND backward: gradients match the oracle's autograd to 6e-5), 10 steps
   torch_rocm_baseline — stock PyTorch-ROCm (the reference's op graph through hipBLASLt / MIOpen / ATen) on the same GPU, fp32 and bf16 autocast
   ref_batch    — the headline step at the reference's own per-GPU batch (trBatch: 2), eager and replayed from one hipGraph
   cpu_baseline — the CPU oracle (restatement of the reference, `kind: "port"`) timed on this box's host cores on a
@@ -110,7 +110,7 @@ def parse():
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg (the oracle's torch ops on the GPU)")
     ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only latency leg (profiling runs: every launch then belongs to a training step)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the bf16 sub-record (fast_mode) of a tolerance-compliant headline run")
-    ap.add_argument("--no-x3-mode", action="store_true", help="skip the fully fp32-class sub-record (full_fp32_mode: x3 forward and backward, 3 steps)")
+    ap.add_argument("--no-x3-mode", action="store_true", help="skip the fully fp32-class sub-record (full_fp32_mode: x3 forward and backward, up to 10 steps)")
     ap.add_argument("--torch-baseline-worker", default=None, help="(internal) subprocess leg of torch_rocm_baseline: 'fp32' or 'bf16'")
     ap.add_argument("--no-fuse-upsample", action="store_true",
                     help="A/B: materialise the x4-upsampled task features and run ConvHead's 3x3 conv on them (the reference's operation order)")
@@ -121,6 +121,8 @@ def parse():
     ap.add_argument("--cpu-roofline", action="store_true",
                     help="(host-logic tests, --device cpu only) keep the instrumented roofline step — wall-clock stamps instead of HIP events — so "
                          "that a gloo run exercises what every rank does around it under DDP")
+    ap.add_argument("--no-gelu-daux", action="store_true",
+                    help="A/B: GELU'(z) evaluated in the fc2 input-gradient epilogue (round 5) instead of stored by the fc1 epilogue (round 6)")
     ap.add_argument("--graphed-worker", action="store_true", help="(internal) the subprocess leg of ref_batch.graphed")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
@@ -574,6 +576,8 @@ def main():
         mtt_amd.taskprompter.TaskPrompterWrapper.fuse_upsample = False
     if a.gemm_variant is not None:
         mtt_amd.ops.GEMM_VARIANT = a.gemm_variant
+    if a.no_gelu_daux:
+        mtt_amd.autograd_path.GELU_DAUX = False
     if a.measure_no_repack:
         mtt_amd.ops.bump_param_epoch = lambda *a, **k: None
         torch.autograd.graph.increment_version = lambda *x, **k: None
@@ -734,7 +738,7 @@ def main():
     if solo and not a.no_x3_mode and a.prec != "x3":
         keep = (a.steps, a.warmup, a.no_fwd, a.no_roofline)
         try:
-            a.steps, a.warmup, a.no_fwd, a.no_roofline = min(3, a.steps), 1, True, True
+            a.steps, a.warmup, a.no_fwd, a.no_roofline = min(10, a.steps), 1, True, True      # 10 steps of ~1.3 s (3 were too few)
             r3 = run_mode("x3", False)
             full = dict(mode="x3", dtype=MODE_DTYPE["x3"], arithmetic=MODE_TEXT["x3"], images_per_s=round(r3["images_per_s"], 3),
                         ms_per_step=round(r3["ms_per_step"], 3), steps=r3["steps"], warmup=r3["warmup"], per_gpu_batch=batch, loss=r3["loss"],

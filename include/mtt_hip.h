@@ -49,7 +49,13 @@ enum {
   MTT_OP_CONV_K = 2,/* A only: implicit im2col, r = output pixel, k = (tap, ci)                   */
   MTT_OP_CONV_R = 3 /* B only: implicit im2col^T, k = pixel (reduction), r = (tap, ci)            */
 };
-enum { MTT_ACT_NONE = 0, MTT_ACT_GELU = 1, MTT_ACT_RELU = 2, MTT_ACT_GELU_BWD = 3, MTT_ACT_RELU_BWD = 4 };
+enum { MTT_ACT_NONE = 0, MTT_ACT_GELU = 1, MTT_ACT_RELU = 2, MTT_ACT_GELU_BWD = 3, MTT_ACT_RELU_BWD = 4,
+       /* ABI 10 — the GELU of a bf16-arithmetic backward with its derivative taken in the FORWARD: the fc1 epilogue has z in registers and
+        * stores GELU'(z) (instead of z) next to GELU(z); the fc2 input-gradient epilogue is then one multiply per element instead of an
+        * erf + exp evaluation (that epilogue ran ~25 VALU instructions per element against a 16-step K loop).  Same bytes, same bf16
+        * storage rounding class: GELU' in [-0.13, 1.13] rounded to bf16 vs GELU'(bf16(z)). */
+       MTT_ACT_GELU_DAUX = 5 /* D = GELU(z), aux_out = GELU'(z)   (aux_out required) */,
+       MTT_ACT_MUL_AUX = 6   /* D = epi(acc) * aux_in              (aux_in required) */ };
 enum { MTT_STORE_ROWS = 0, MTT_STORE_PIXSHUF2 = 1 };
 /* kernel selection of mtt_gemm / mtt_attn_fwd: AUTO = the library's policy (a pure function of the descriptor); the other values
  * force one kernel where it is applicable (tests of a kernel on small shapes, A/B measurements).  There is no process-global switch and

@@ -20,7 +20,7 @@ ABI_VERSION = 10
 F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_DAUX, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 STORE_ROWS, STORE_PIXSHUF2 = 0, 1
 GEMM_AUTO, GEMM_GENERAL, GEMM_DMA256, GEMM_DMA128, GEMM_GENERAL_EPILOGUE = 0, 1, 3, 4, 11
 ATTN_AUTO, ATTN_PLAIN = 0, 1

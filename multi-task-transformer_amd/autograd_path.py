@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from . import bn as bn_mod
 from . import _lib, ops
-from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code  # noqa: F401
+from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_GELU_DAUX, ACT_MUL_AUX, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code  # noqa: F401
 
 pad8 = ops.pad8
 SPLITK_MIN_ROWS = 4096      # reduction length from which few-tile weight gradients are split over the batch dimension
@@ -228,6 +228,7 @@ def _enc_dgrad(dy, weight, wpack2d, M, N_in, K_out, prec, out_dtype, tag, colsum
 
 
 FAST_BWD = True
+GELU_DAUX = True            # MlpHalfFn with a bf16 backward: fc1 stores GELU'(z), the fc2 dgrad epilogue multiplies (tests / A-B runs set it to False)
 FAST_MIN_DIM, FAST_MIN_ROWS = 256, 1024      # below these the general (transposing-stager) kernels are used
 
 
@@ -318,7 +319,8 @@ class AttnHalfFn(Function):
 
     @staticmethod
     def forward(ctx, XT, g1, b1, eps, Wqkv, bqkv, Wproj, bproj, Wtt, btt, Wtt1, btt1, rowscale, geo, prec, tag):
-        B, N, nH, T, h, w, nwin = geo
+        B, N, nH, T, h, w, nwin = geo[:7]
+        side = geo[7] if len(geo) > 7 else True              # False: no consumer of this block's channel logits (not a tap): skip that pass
         C, hw = nH * 64, h * w
         chan = Wtt is not None
         split = prec.split                       # x3f: x3 products on pre-split planes (LDS-DMA kernel), bf16 backward on the hi planes
@@ -349,7 +351,8 @@ class AttnHalfFn(Function):
                 cq = ops.linear(xp32, wt, hw, prec, bias=btt[None], M=B * T)[0]
             else:
                 cq = ops.linear(xn_c, wt, hw, prec, bias=btt[None], a_rows=(T, N * C, C), M=B * T)[0]
-            rawchan = ops.chan_logits(cq, xn_c, B, T, N, C, (h, w), (nwin, nwin))
+            if side:
+                rawchan = ops.chan_logits(cq, xn_c, B, T, N, C, (h, w), (nwin, nwin))
             pr = XT2.view(B, N, C)[:, :T]
             ops.linear(cq, wt1, C, prec, bias=btt1[None], out=pr, d_rows=(T, N * C, C), resid=pr, rowscale=rowscale, n_prompt=T,
                        M=B * T)
@@ -357,6 +360,10 @@ class AttnHalfFn(Function):
                               xp32 if chan and split else None)
         ctx.geo, ctx.prec, ctx.eps, ctx.chan = geo, prec, eps, chan
         ctx.params = (Wqkv, Wproj, Wtt, Wtt1)
+        # the two logit side channels are consumed only at the four taps (cal_task_feature); for the other 20 blocks autograd would hand
+        # backward() MATERIALISED ZERO gradients for them — and the channel-attention backward kernel (227 us per block at the benchmark's
+        # batch) would run on zeros.  Without materialisation those gradients arrive as None and their branches are skipped.
+        ctx.set_materialize_grads(False)
         z = torch.zeros(0, device=XT.device)
         return XT2, (rawlog if rawlog is not None else z), (rawchan if rawchan is not None else z)
 
@@ -364,9 +371,11 @@ class AttnHalfFn(Function):
     def backward(ctx, dXT2, drawlog, drawchan):
         XT, g1, mean, rstd, xn, qkv, ao, wq, wp, rowscale, lse, cq, wt, wt1, xp32 = ctx.saved_tensors
         Wqkv_, Wproj_, Wtt_, Wtt1_ = ctx.params
-        B, N, nH, T, h, w, nwin = ctx.geo
+        B, N, nH, T, h, w, nwin = ctx.geo[:7]
         prec, C, M, hw = ctx.prec.bwd, nH * 64, B * N, h * w
         xn_c = xn              # the rows the channel attention's backward reads: the bf16 hi plane in the x3f mode (its backward IS bf16)
+        if dXT2 is None:                                        # (set_materialize_grads(False): only when the block output were unused)
+            dXT2 = torch.zeros_like(XT)
         dXT2 = dXT2.contiguous()
         # ---- spatial attention ---------------------------------------------------------------------------------
         g, dbproj = _scaled_colsum(dXT2, rowscale, N, T, prec)
@@ -431,13 +440,18 @@ class MlpHalfFn(Function):
         xn2, mean, rstd = ops.layernorm(XT2, g2, b2n, eps, prec, save_stats=True, out_dtype="split" if split else None)
         w1 = ops.pack_linear_split([W1], tag + ('fc1',)) if split else ops.pack_linear([W1], prec, tag + ('fc1',))
         w2 = ops.pack_linear_split([W2], tag + ('fc2',)) if split else ops.pack_linear([W2], prec, tag + ('fc2',))
-        z = torch.empty(B * N, Hd, dtype=prec.bwd.adt, device=XT2.device)          # pre-activation for GELU' (bf16 when the backward is bf16)
-        hmid = ops.linear(xn2, w1, Hd, prec, bias=b1[None], act=ACT_GELU, aux_out=z, out_dtype="split" if split else None)[0]
+        # what the backward's GELU' needs.  fp32-class backward (x3): the pre-activation z in fp32, GELU'(z) evaluated in the fc2 dgrad
+        # epilogue.  bf16 backward (bf16, x3f): GELU'(z) itself, taken HERE where z is in registers in fp32 and stored as bf16 (the same
+        # bytes as bf16(z)) — the fc2 dgrad epilogue is then one multiply per element instead of an erf + exp evaluation on 64 890 x 4 096
+        # elements per block (GELU_DAUX: the derivative with the forward, round 6)
+        z = torch.empty(B * N, Hd, dtype=prec.bwd.adt, device=XT2.device)
+        daux = GELU_DAUX and z.dtype == torch.bfloat16
+        hmid = ops.linear(xn2, w1, Hd, prec, bias=b1[None], act=ACT_GELU_DAUX if daux else ACT_GELU, aux_out=z, out_dtype="split" if split else None)[0]
         XT3 = torch.empty_like(XT2)
         ops.linear(hmid, w2, C, prec, bias=b2[None], out=XT3, resid=XT2, d_rows=(N, N * C, C), rowscale=rowscale, n_prompt=T,
                    M=B * N)
         ctx.save_for_backward(XT2, g2, mean, rstd, ops._hi(xn2), z, ops._hi(hmid), ops._hi(w1), ops._hi(w2), rowscale)
-        ctx.geo, ctx.prec, ctx.eps = geo, prec, eps
+        ctx.geo, ctx.prec, ctx.eps, ctx.daux = geo, prec, eps, daux
         ctx.params = (W1, W2)
         return XT3
 
@@ -451,8 +465,8 @@ class MlpHalfFn(Function):
         g, db2 = _scaled_colsum(dXT3, rowscale, N, T, prec)
         W1_, W2_ = ctx.params
         dW2, _ = _enc_wgrad(g, hmid, C, Hd, prec, bias=False)
-        dz, db1 = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', colsum=True, act=ACT_GELU_BWD, aux_in=z, aux_dtype=dtype_code(z),
-                             ldaux=Hd)
+        dz, db1 = _enc_dgrad(g, W2_, w2[0], M, Hd, C, prec, prec.adt, 'fc2', colsum=True, act=ACT_MUL_AUX if ctx.daux else ACT_GELU_BWD, aux_in=z,
+                             aux_dtype=dtype_code(z), ldaux=Hd)
         dW1, _ = _enc_wgrad(dz, xn2, Hd, C, prec, bias=False)
         dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
         dXT2, dg2, dbn2 = _ln_bwd_join(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps)
@@ -503,7 +517,10 @@ class ModulateFn(Function):
         ctx.save_for_backward(xsrc, rawlog, rawchan)
         ctx.geo = geo
         if split:
+            # the lo plane carries no gradient; without set_materialize_grads(False) autograd would hand backward() a materialised ZERO
+            # tensor of its shape anyway (1.6 GB per tap at the benchmark's batch: 0.85 ms of fills per step, profiles/r06_torch_ops_g_*.log)
             ctx.mark_non_differentiable(mod.lo)
+            ctx.set_materialize_grads(False)
             return mod.hi, mod.lo
         return mod
 
@@ -554,6 +571,7 @@ class BLinearFn(Function):
         ctx.meta = (Z, N, layout, kmap, prec, [tuple(w.shape) for w in ws])
         if isinstance(out, ops.Split):
             ctx.mark_non_differentiable(out.lo)
+            ctx.set_materialize_grads(False)             # no zero tensor for the lo plane's (non-existent) gradient
             return out.hi, out.lo
         return out
 
@@ -1071,6 +1089,24 @@ def _drop_scales(model, blk, i, B, device):
     return torch.stack([d[2], d[0]], 1).contiguous(), torch.stack([d[3], d[1]], 1).contiguous()
 
 
+def _drop_tables(model, B, device):
+    """_drop_scales of EVERY block from one Bernoulli draw per step ([depth, 4, B] instead of depth x [4, B]: the per-block form cost ~8 tiny
+    launches per block, 0.4 ms per step at depth 24).  -> list of (rs_attn, rs_mlp) per block; (None, None) where the rate is 0 / in eval."""
+    blocks = list(model.blocks)
+    rates = [float(blk.drop_path_rate) for blk in blocks]
+    if getattr(model, "_drop_override", None) is not None or not model.training or max(rates) <= 0.0:
+        return [_drop_scales(model, blk, i, B, device) for i, blk in enumerate(blocks)]
+    cache = getattr(model, "_drop_keep_cache", None)
+    if cache is None or cache[0] != (tuple(rates), B, str(device)):
+        keep = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=device).view(-1, 1, 1)
+        cache = model._drop_keep_cache = ((tuple(rates), B, str(device)), keep, keep.expand(len(rates), 4, B).contiguous())
+    _, keep, probs = cache
+    d = torch.bernoulli(probs) / keep                                           # [depth, 4, B]
+    att = torch.stack([d[:, 2], d[:, 0]], 2)                                    # [depth, B, 2] (prompt rows, patch rows)
+    mlp = torch.stack([d[:, 3], d[:, 1]], 2)
+    return [(att[i], mlp[i]) if r > 0.0 else (None, None) for i, r in enumerate(rates)]
+
+
 def _bn_act(y, bns, C, act, training):
     return BnActStackFn.apply(y, C, act, training, list(bns), *[bn.weight for bn in bns], *[bn.bias for bn in bns])
 
@@ -1129,13 +1165,14 @@ def backbone_forward(model, img, upsample=True):
                             model.task_prompts, (B, N, T, hw), prec)
     acc = None
     rawlog = rawchan = None
+    drops = _drop_tables(model, B, img.device)
     for i, blk in enumerate(model.blocks):
         a = blk.attn
-        rs_attn, rs_mlp = _drop_scales(model, blk, i, B, img.device)
+        rs_attn, rs_mlp = drops[i]
         XT2, rawlog, rawchan = AttnHalfFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, a.qkv.weight, a.qkv.bias,
                                                 a.proj.weight, a.proj.bias, a.token_trans.weight, a.token_trans.bias,
-                                                a.token_trans1.weight, a.token_trans1.bias, rs_attn, (B, N, nH, T, h, w, nwin), prec,
-                                                ('blk', i))
+                                                a.token_trans1.weight, a.token_trans1.bias, rs_attn,
+                                                (B, N, nH, T, h, w, nwin, model._side_channels_used(i)), prec, ('blk', i))
         XT = MlpHalfFn.apply(XT2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
                              blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp, (B, N, T), prec, ('blk', i))
         if (i + 1) in model.select_list:

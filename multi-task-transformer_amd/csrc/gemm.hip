@@ -357,7 +357,17 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha * cs[j] + sh[j];
         if (full_chunk) {
-          if (d.aux_out) {
+          if (d.act == MTT_ACT_GELU_DAUX) {                    // aux_out = GELU'(z), D = GELU(z)
+            float a8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gelu_both_f(v[j], v[j], a8[j]);
+            if (d.aux_dtype == MTT_F32) {
+              *(float4*)((float*)d.aux_out + auxoff) = make_float4(a8[0], a8[1], a8[2], a8[3]);
+              *(float4*)((float*)d.aux_out + auxoff + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
+            } else {
+              *(u32x4*)((bf16_t*)d.aux_out + auxoff) = (u32x4){pack2(a8[0], a8[1]), pack2(a8[2], a8[3]), pack2(a8[4], a8[5]), pack2(a8[6], a8[7])};
+            }
+          } else if (d.aux_out) {
             if (d.aux_dtype == MTT_F32) {
               *(float4*)((float*)d.aux_out + auxoff) = make_float4(v[0], v[1], v[2], v[3]);
               *(float4*)((float*)d.aux_out + auxoff + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -368,6 +378,16 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
           if (d.act == MTT_ACT_GELU) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+          } else if (d.act == MTT_ACT_MUL_AUX) {
+            if (d.aux_dtype == MTT_F32) {
+              const float4 z0 = *(const float4*)((const float*)d.aux_in + auxoff);
+              const float4 z1 = *(const float4*)((const float*)d.aux_in + auxoff + 4);
+              v[0] *= z0.x; v[1] *= z0.y; v[2] *= z0.z; v[3] *= z0.w; v[4] *= z1.x; v[5] *= z1.y; v[6] *= z1.z; v[7] *= z1.w;
+            } else {
+              const u32x4 u = *(const u32x4*)((const bf16_t*)d.aux_in + auxoff);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { v[2 * t] *= lo_of(u[t]); v[2 * t + 1] *= hi_of(u[t]); }
+            }
           } else if (d.act == MTT_ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
@@ -415,8 +435,13 @@ MTT_DEV void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned char*
             float w = 0.0f;
             if (n < d.N) {
               w = v[j];
-              if (d.aux_out) st_elem(d.aux_out, auxoff + j, d.aux_dtype, w);
+              if (d.act == MTT_ACT_GELU_DAUX) {
+                float dg;
+                gelu_both_f(w, w, dg);
+                st_elem(d.aux_out, auxoff + j, d.aux_dtype, dg);
+              } else if (d.aux_out) st_elem(d.aux_out, auxoff + j, d.aux_dtype, w);
               if (d.act == MTT_ACT_GELU) w = gelu_f(w);
+              else if (d.act == MTT_ACT_MUL_AUX) w *= ld_elem(d.aux_in, auxoff + j, d.aux_dtype);
               else if (d.act == MTT_ACT_RELU) w = fmaxf(w, 0.0f);
               else if (d.act == MTT_ACT_GELU_BWD) w *= gelu_grad_f(ld_elem(d.aux_in, auxoff + j, d.aux_dtype));
               else if (d.act == MTT_ACT_RELU_BWD) w = ld_elem(d.aux_in, auxoff + j, d.aux_dtype) > 0.0f ? w : 0.0f;
@@ -486,9 +511,10 @@ __host__ __device__ inline int epilogue_kind_of(const mtt_gemm_desc& d) {
     if (d.resid || d.rowscale) return -1;
     return d.d_dtype == MTT_SPLIT ? 5 : 0;
   }
-  if (d.act == MTT_ACT_GELU && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && !auxi) return 2;
-  if (d.act == MTT_ACT_GELU && d.d_dtype == MTT_SPLIT && !d.resid && !d.rowscale && !auxi) return 6;
-  if (d.act == MTT_ACT_GELU_BWD && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && auxi && !auxo) return 4;
+  const bool gelu = d.act == MTT_ACT_GELU || (d.act == MTT_ACT_GELU_DAUX && auxo);
+  if (gelu && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && !auxi) return 2;
+  if (gelu && d.d_dtype == MTT_SPLIT && !d.resid && !d.rowscale && !auxi) return 6;
+  if ((d.act == MTT_ACT_GELU_BWD || d.act == MTT_ACT_MUL_AUX) && d.d_dtype == MTT_BF16 && !d.resid && !d.rowscale && auxi && !auxo) return 4;
   return -1;
 }
 MTT_DEV int fast_epilogue_kind(const mtt_gemm_desc& d, int m0, int n0, int tbm, int tbn) {
@@ -555,15 +581,27 @@ MTT_DEV void gemm_epilogue_fast(const GemmP& p, f32x4 (&acc)[MT][NTL], unsigned 
       float v[8] = {fmaf(lo4.x, cs[0], sh[0]), fmaf(lo4.y, cs[1], sh[1]), fmaf(lo4.z, cs[2], sh[2]), fmaf(lo4.w, cs[3], sh[3]),
                     fmaf(hi4.x, cs[4], sh[4]), fmaf(hi4.y, cs[5], sh[5]), fmaf(hi4.z, cs[6], sh[6]), fmaf(hi4.w, cs[7], sh[7])};
       if (KIND == 2 || KIND == 6) {
-        if (d.aux_out)
-          *(u32x4*)((bf16_t*)d.aux_out + (zAux + m * d.ldaux)) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        if (d.act == MTT_ACT_GELU_DAUX) {                       // (workgroup-uniform) aux_out = GELU'(z) for a one-multiply backward epilogue
+          float a8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+          for (int j = 0; j < 8; ++j) gelu_both_f(v[j], v[j], a8[j]);
+          *(u32x4*)((bf16_t*)d.aux_out + (zAux + m * d.ldaux)) = (u32x4){pack2(a8[0], a8[1]), pack2(a8[2], a8[3]), pack2(a8[4], a8[5]), pack2(a8[6], a8[7])};
+        } else {
+          if (d.aux_out)
+            *(u32x4*)((bf16_t*)d.aux_out + (zAux + m * d.ldaux)) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        }
       }
       if (KIND == 4) {
         const u32x4 u = za[i];
-        v[0] *= gelu_grad_f(lo_of(u.x)); v[1] *= gelu_grad_f(hi_of(u.x)); v[2] *= gelu_grad_f(lo_of(u.y)); v[3] *= gelu_grad_f(hi_of(u.y));
-        v[4] *= gelu_grad_f(lo_of(u.z)); v[5] *= gelu_grad_f(hi_of(u.z)); v[6] *= gelu_grad_f(lo_of(u.w)); v[7] *= gelu_grad_f(hi_of(u.w));
+        if (d.act == MTT_ACT_MUL_AUX) {                         // (workgroup-uniform) aux_in = GELU'(z) from the forward
+          v[0] *= lo_of(u.x); v[1] *= hi_of(u.x); v[2] *= lo_of(u.y); v[3] *= hi_of(u.y);
+          v[4] *= lo_of(u.z); v[5] *= hi_of(u.z); v[6] *= lo_of(u.w); v[7] *= hi_of(u.w);
+        } else {
+          v[0] *= gelu_grad_f(lo_of(u.x)); v[1] *= gelu_grad_f(hi_of(u.x)); v[2] *= gelu_grad_f(lo_of(u.y)); v[3] *= gelu_grad_f(hi_of(u.y));
+          v[4] *= gelu_grad_f(lo_of(u.z)); v[5] *= gelu_grad_f(hi_of(u.z)); v[6] *= gelu_grad_f(lo_of(u.w)); v[7] *= gelu_grad_f(hi_of(u.w));
+        }
       }
       if (KIND == 3) {
         if (d.rowscale) {
@@ -1883,6 +1921,9 @@ extern "C" int mtt_gemm(const mtt_gemm_desc* dd, void* stream) {
   if ((d.lda % 8) || (d.ldb % 8)) return MTT_E_ALIGN;
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return MTT_E_ALIGN;
   if ((d.aux_in || d.aux_out) && (d.ldaux <= 0 || (d.ldaux % 8))) return MTT_E_BADARG;
+  if (d.act < MTT_ACT_NONE || d.act > MTT_ACT_MUL_AUX) return MTT_E_BADARG;
+  if ((d.act == MTT_ACT_GELU_DAUX && !d.aux_out) || ((d.act == MTT_ACT_MUL_AUX || d.act == MTT_ACT_GELU_BWD || d.act == MTT_ACT_RELU_BWD) && !d.aux_in))
+    return MTT_E_BADARG;
   if ((d.ldd % 8) || ((uintptr_t)d.D & 15) || (d.d_bs % 8) || (d.d_zo % 8) || (d.d_zi % 8)) return MTT_E_ALIGN;
   if (d.resid && ((d.ldr % 4) || ((uintptr_t)d.resid & 15) || (d.r_bs % 4))) return MTT_E_ALIGN;
   const bool conv = d.a_op == MTT_OP_CONV_K || d.b_op == MTT_OP_CONV_R;

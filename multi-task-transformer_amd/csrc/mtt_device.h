@@ -73,6 +73,12 @@ MTT_DEV float fast_erf(float x) {
   return x * p * __builtin_amdgcn_rcpf(q);
 }
 MTT_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// GELU(x) and GELU'(x) together (one erf): the fc1 epilogue of MTT_ACT_GELU_DAUX
+MTT_DEV void gelu_both_f(float x, float& g, float& dg) {
+  const float c = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
+  g = x * c;
+  dg = fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), c);
+}
 MTT_DEV float gelu_grad_f(float x) {
   return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }

@@ -193,6 +193,12 @@ class TaskPrompter(nn.Module):
     def _tap_index(self, idx):
         return self.select_list.index(idx + 1)
 
+    def _side_channels_used(self, idx):
+        """are block idx's logit side channels (rawlog / rawchan) read by cal_task_feature?  Only the tap blocks' and the last block's are
+        (taskprompter.py:405-417); the other blocks still compute the channel attention's prompt update, but its raw logits — one more
+        pass over the block's tokens — would be dead compute."""
+        return (idx + 1) in self.select_list or idx == len(self.blocks) - 1
+
     def load_pretrained(self, checkpoint_path, prefix=''):
         """taskprompter.py:385-386: import a Google/Flax ViT .npz into the encoder (prompts / decoders keep their initialisation)."""
         from .checkpoints import load_flax_vit_npz
@@ -263,7 +269,7 @@ class TaskPrompter(nn.Module):
         a = blk.attn
         tag = ('blk', i)
         if prec.split and self.gprec is None:
-            return self._block_split(blk, tag, XT, B, N, T, grid, nwin)
+            return self._block_split(blk, tag, XT, B, N, T, grid, nwin, self._side_channels_used(i))
         xn, _, _ = ops.layernorm(XT, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps, prec)
         qkv = ops.linear(xn, ops.pack_linear([a.qkv.weight], pe, tag + ('qkv',)), 3 * C, pe,
                          bias=a.qkv.bias.detach()[None], out_dtype=adt)[0]
@@ -279,8 +285,10 @@ class TaskPrompter(nn.Module):
         # channel attention: queries token_trans(norm1(prompts)), keys norm1(x)^T, windowed (:216-250)
         cq = ops.linear(xn, ops.pack_linear([a.token_trans.weight], ps, tag + ('tt',)), hw, ps,
                         bias=a.token_trans.bias.detach()[None], a_rows=(T, N * C, C), M=B * T, out_dtype=ps.adt)[0]
-        xnc = xn if ps.adt == xn.dtype else ops.cast2d(xn, xn.shape[0], C, C, ps.adt, ldd=C)
-        rawchan = ops.chan_logits(cq, xnc, B, T, N, C, grid, (nwin, nwin))
+        rawchan = None
+        if self._side_channels_used(i):
+            xnc = xn if ps.adt == xn.dtype else ops.cast2d(xn, xn.shape[0], C, C, ps.adt, ldd=C)
+            rawchan = ops.chan_logits(cq, xnc, B, T, N, C, grid, (nwin, nwin))
         pr = XT2.view(B, N, C)[:, :T]
         ops.linear(cq, ops.pack_linear([a.token_trans1.weight], ps, tag + ('tt1',)), C, ps,
                    bias=a.token_trans1.bias.detach()[None], out=pr, d_rows=(T, N * C, C), resid=pr, M=B * T)
@@ -292,7 +300,7 @@ class TaskPrompter(nn.Module):
                    bias=blk.mlp.fc2.bias.detach()[None], out=XT3, resid=XT2)
         return XT3, rawlog, rawchan
 
-    def _block_split(self, blk, tag, XT, B, N, T, grid, nwin):
+    def _block_split(self, blk, tag, XT, B, N, T, grid, nwin, side=True):
         """the block in the x3f mode (inference): the same x3 products, the four big Linears on the LDS-DMA kernel over pre-split
         hi / lo planes (ops.Split) written by the producing kernels (LayerNorm, qkv / fc1 epilogues, attention)."""
         prec, C, nH = self.prec, self.embed_dim, self.num_heads
@@ -308,7 +316,7 @@ class TaskPrompter(nn.Module):
         # per image are gathered into a small fp32 matrix
         cq = ops.linear(ops.prompt_rows32(xs, B, N, T, C), ops.pack_linear([a.token_trans.weight], prec, tag + ('tt',)), hw, prec,
                         bias=a.token_trans.bias.detach()[None], M=B * T)[0]
-        rawchan = ops.chan_logits(cq, xs, B, T, N, C, grid, (nwin, nwin))
+        rawchan = ops.chan_logits(cq, xs, B, T, N, C, grid, (nwin, nwin)) if side else None
         pr = XT2.view(B, N, C)[:, :T]
         ops.linear(cq, ops.pack_linear([a.token_trans1.weight], prec, tag + ('tt1',)), C, prec,
                    bias=a.token_trans1.bias.detach()[None], out=pr, d_rows=(T, N * C, C), resid=pr, M=B * T)

@@ -13,7 +13,7 @@ import torch
 
 F32, BF16, SPLIT = 0, 1, 2        # SPLIT: x = hi + lo, two bf16 planes (main pointer = hi, *_lo = lo)
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_DAUX, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 ROUND_BF16_OPERANDS = True   # emulate the f32->bf16 operand rounding of MTT_PREC_BF16
 
@@ -140,10 +140,15 @@ def gemm(**kw):
         auxrow = ((mrow // d_mb) * d_mb + (mrow % d_mb)) if d_mb and d_mb > 0 else mrow
         zaux = zo * g("aux_zo") + zi * g("aux_zi")
         aux_idx = zaux + auxrow[:, None] * g("ldaux") + ncol[None, :]
-        if kw.get("aux_out") is not None:
+        if act == ACT_GELU_DAUX:                                     # D = GELU(z), aux_out = GELU'(z)
+            _wr(kw["aux_out"], aux_idx, _gelu_grad(v))
+            v = _gelu(v)
+        elif kw.get("aux_out") is not None:
             _wr(kw["aux_out"], aux_idx, v)
         if act == ACT_GELU:
             v = _gelu(v)
+        elif act == ACT_MUL_AUX:
+            v = v * _rd(kw["aux_in"], aux_idx)
         elif act == ACT_RELU:
             v = torch.clamp_min(v, 0.0)
         elif act == ACT_GELU_BWD:

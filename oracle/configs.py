@@ -15,6 +15,7 @@ CS2 = (("semseg", 19), ("depth", 1))
 VIT = {  # (embed_dim, depth, heads, select_list)
     "nano": (64, 4, 1, (1, 2, 3)),       # test-only: checkpoint-import fixtures
     "tiny": (128, 4, 2, (1, 2, 3)),      # test-only miniature, same code path
+    "tiny6": (128, 6, 2, (2, 4, 5)),     # test-only: blocks 0 and 2 are NOT taps (their logit side channels have no consumer, as 20 of ViT-L's 24)
     "small": (384, 12, 6, (3, 6, 9)),
     "base": (768, 12, 12, (3, 6, 9)),    # taskprompter.py:683
     "large": (1024, 24, 16, (6, 12, 18)),  # taskprompter.py:675, vit.py:560
@@ -46,6 +47,10 @@ def taskprompter(name):
         # the 64 x 96 input (fixture tests/golden/mini_ctr_dd.npz from the unmodified reference; same state-dict contract as mini_ctr)
         "mini_ctr_dd": dict(backbone="tiny", img_size=(64, 96), tasks=PASCAL6, embed_dim=44, final_embed_dim=52,
                             chan_nheads=1, use_ctr=True, prompt_len=1, head="conv", dd_label_map_size=(40, 56), contract_of="mini_ctr"),
+        # six blocks, taps after blocks 2 / 4 / 5 + the last: the product skips the channel-logit pass and the side-channel gradients of the
+        # non-tap blocks (round 6); no reference fixture: product vs oracle
+        "mini_skip": dict(backbone="tiny6", img_size=(64, 96), tasks=NYUD4, embed_dim=48, final_embed_dim=40,
+                          chan_nheads=4, use_ctr=True, prompt_len=1, head="conv"),
         "mini_win": dict(backbone="tiny", img_size=(64, 96), tasks=NYUD4, embed_dim=48, final_embed_dim=40,
                          chan_nheads=4, use_ctr=False, prompt_len=1, head="conv"),
         "mini_deconv": dict(backbone="tiny", img_size=(64, 64), tasks=CS2, embed_dim=30, final_embed_dim=36,

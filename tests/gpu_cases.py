@@ -211,6 +211,17 @@ def gemm_cases():
                                                                           resid=rnd(g, M, 520), ldr=520, n_store=N), TOL_BF))
         cases.append((f"gemm_epi_kind4_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528, act=3,
                                                                aux_in=rnd(g, M, 536, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
+        # ABI 10: GELU with its derivative taken in the forward (act 5: D = GELU(z), aux_out = GELU'(z)) and the one-multiply backward epilogue
+        # (act 6: D = acc * aux_in) — the specialised kinds 2 / 4 on interior tiles, the general epilogue on the ragged ones
+        cases.append((f"gemm_epi_kind2_daux_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528,
+                                                                    colshift=rnd(g, N), act=5, aux_out=torch.full((M, 536), 3.0, dtype=torch.bfloat16),
+                                                                    aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
+        cases.append((f"gemm_epi_kind4_mulaux_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528, act=6,
+                                                                      aux_in=rnd(g, M, 536, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=536, n_store=N), TOL_BF))
+        cases.append((f"gemm_colsum_kind4_mulaux_v{v}", "gemm", dict(common, D=torch.full((M, 528), 7.0, dtype=torch.bfloat16), d_dtype=BF16, ldd=528, act=6,
+                                                                        aux_in=rnd(g, M, 536, dtype=torch.bfloat16), aux_dtype=BF16, ldaux=536, n_store=N,
+                                                                        colsum_out=torch.full((N + 3,), 9.0),
+                                                                        colsum_ws=scratch(((M + 127) // 128) * ((N + 7) // 8 * 8))), dict(TOL_BF, f32=2e-4)))
         # column sums of the stored tile from the epilogue (colsum_out: the bias gradient of the layer whose output gradient D is) —
         # specialised kinds 0 / 4 on interior tiles + the general epilogue on the ragged ones, fp32 D through the general epilogue
         # (a 1-ulp flip of one rounded bf16 element moves a column sum by ~1e-5 of its magnitude: the fp32 bound is looser than for plain stores)
@@ -244,6 +255,10 @@ def gemm_cases():
                                                                         D_lo=torch.full((M, ldd), 5.0, dtype=torch.bfloat16), d_dtype=SPLIT, ldd=ldd,
                                                                         colshift=rnd(g, N), act=1, aux_out=torch.full((M, ldd + 8), 3.0, dtype=torch.bfloat16),
                                                                         aux_dtype=BF16, ldaux=ldd + 8), TOL_SPLIT_D))
+        cases.append((f"gemm_split_gelu_daux_{M}x{N}x{K}", "gemm", dict(common, D=torch.full((M, ldd), 7.0, dtype=torch.bfloat16),
+                                                                         D_lo=torch.full((M, ldd), 5.0, dtype=torch.bfloat16), d_dtype=SPLIT, ldd=ldd,
+                                                                         colshift=rnd(g, N), act=5, aux_out=torch.full((M, ldd + 8), 3.0, dtype=torch.bfloat16),
+                                                                         aux_dtype=BF16, ldaux=ldd + 8), TOL_SPLIT_D))
         XT = rnd(g, M, ldd)
         cases.append((f"gemm_split_resid_{M}x{N}x{K}", "gemm", dict(common, D=XT, d_dtype=F32, ldd=ldd, d_mb=100, d_bs=100 * ldd, colshift=rnd(g, N),
                                                                      resid=XT, ldr=ldd, r_mb=100, r_bs=100 * ldd, rowscale=torch.rand(M // 100 + 1, 2, generator=g),
@@ -383,6 +398,7 @@ def gemm_cases():
                   lda=Nf, ldb=Kf, ldd=Kf, batch=1, batch_inner=1, alpha=1.0, act=3,
                   aux_in=rnd(g, M, Kf, dtype=DT[adt]), aux_dtype=adt, ldaux=Kf)
         cases.append((f"gemm_dgrad_{'x3' if prec else 'bf16'}", "gemm", kw, TOL_X3 if prec else TOL_BF))
+        cases.append((f"gemm_dgrad_mulaux_{'x3' if prec else 'bf16'}", "gemm", dict(kw, act=6, D=torch.zeros(M, Kf, dtype=DT[adt])), TOL_X3 if prec else TOL_BF))
     # 6. wgrad layout (both row-contig, reduction over tokens not a multiple of 8)
     for prec, adt in ((0, BF16), (1, F32)):
         Mtok, Nf, Kf = 203, 72, 40

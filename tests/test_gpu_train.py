@@ -6,7 +6,7 @@ import train_check
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv"])
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv", "mini_skip"])
 def test_gradients_x3(name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -29,7 +29,7 @@ def test_gradients_bf16_are_bf16_accurate(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv", "mini_p32"])
+@pytest.mark.parametrize("name", ["mini_ctr", "mini_win", "mini_deconv", "mini_p32", "mini_skip"])
 def test_gradients_x3f_forward_exact_backward_bf16(name):
     """x3f: the forward is the x3 arithmetic (1e-3 per head; split planes through the LDS-DMA kernel for the encoder Linears), the
     backward is bf16 on the hi planes — gradients are bf16-accurate, computed from fp32-class activations."""

@@ -234,6 +234,31 @@ def test_conv_head_as_one_node_keeps_its_gradient_maps_in_the_backwards_dtype(em
         assert all(abs(a[k][0] - b[k][0]) <= 1e-6 * max(a[k][1], 1e-12) + 1e-12 for k in a), "x3: the node fusion must not change the arithmetic"
 
 
+@pytest.mark.parametrize("prec,ftol,gtol", [("x3", 5e-5, 1e-3), ("x3f", 5e-5, None)])
+def test_non_tap_blocks_skip_their_dead_side_channels(emulated, monkeypatch, prec, ftol, gtol):
+    """Six blocks of which two are not taps (as 20 of ViT-L's 24): their channel-logit pass is not launched and their rawlog / rawchan
+    gradients arrive as None (set_materialize_grads(False)) — outputs and every gradient still match the oracle, which computes the
+    reference's full graph (taskprompter.py:216-250 for every block)."""
+    import mtt_amd
+    import train_check
+    seen = []
+    inner = mtt_amd.ops.call
+    monkeypatch.setattr(mtt_amd.ops, "call", lambda name, **kw: (seen.append(name), inner(name, **kw))[1])
+    fwd, errs = train_check.grad_errors("mini_skip", prec, "cpu")
+    assert max(fwd.values()) < ftol, fwd
+    assert seen.count("chan_logits") == 4 and seen.count("chan_logits_bwd") == 4          # taps (blocks 1, 3, 4) + the last block; not 6
+    if gtol is not None:
+        worst, med = train_check.summarize(errs)
+        assert worst[0] < 1e-2 and med < gtol, (worst, med)
+    else:
+        train_check.assert_per_param(errs, "x3f")
+    model = conftest.build_product_model(configs.taskprompter("mini_skip"), prec, "cpu").eval()
+    seen.clear()
+    with torch.no_grad():
+        model(weights.synth_images(1, (64, 96), 3))
+    assert seen.count("chan_logits") == 4
+
+
 def test_fused_head_and_fuse_tail_nodes_with_frozen_inputs(emulated):
     """ConvHeadFn / FuseTailFn run other Functions' forward / backward as STAGES with a stand-in ctx: with part of their inputs
     frozen (requires_grad = False: head convs, one task's fea_fuse tail, every BatchNorm affine) the step must still run, frozen tensors

@@ -34,5 +34,11 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=40,
-                                                         max_shapes_column_width=70))
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0]
+rows.sort(key=lambda e: -e.device_time_total)
+print("aten ops with device time in one training step (B = %d, %s), by input shape:" % (B, PREC))
+tot = 0.0
+for e in rows[:70]:
+    tot += e.device_time_total
+    print("%9.1f us  x%-4d  %-28s %s" % (e.device_time_total, e.count, e.key, str(e.input_shapes)[:150]))
+print("sum of the listed rows: %.2f ms" % (tot / 1e3))
