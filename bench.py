@@ -121,6 +121,9 @@ def parse():
     ap.add_argument("--cpu-roofline", action="store_true",
                     help="(host-logic tests, --device cpu only) keep the instrumented roofline step — wall-clock stamps instead of HIP events — so "
                          "that a gloo run exercises what every rank does around it under DDP")
+    ap.add_argument("--no-head-prologue", action="store_true",
+                    help="A/B: ConvHead's BatchNorm + GELU as a pass of their own writing the fp32 activated map (round 5) instead of riding on the "
+                         "prediction GEMM's operand load (round 6)")
     ap.add_argument("--no-gelu-daux", action="store_true",
                     help="A/B: GELU'(z) evaluated in the fc2 input-gradient epilogue (round 5) instead of stored by the fc1 epilogue (round 6)")
     ap.add_argument("--graphed-worker", action="store_true", help="(internal) the subprocess leg of ref_batch.graphed")
@@ -578,6 +581,8 @@ def main():
         mtt_amd.ops.GEMM_VARIANT = a.gemm_variant
     if a.no_gelu_daux:
         mtt_amd.autograd_path.GELU_DAUX = False
+    if a.no_head_prologue:
+        mtt_amd.autograd_path.HEAD_PROLOGUE = False
     if a.measure_no_repack:
         mtt_amd.ops.bump_param_epoch = lambda *a, **k: None
         torch.autograd.graph.increment_version = lambda *x, **k: None

@@ -126,6 +126,14 @@ typedef struct {
                                             GELU' epilogue IS fc1's output gradient), taken in the epilogue instead of re-reading D.  Per
                                             row-block partials go to colsum_ws (>= mtt_gemm_colsum_ws_floats(d) floats) and are summed in
                                             block order (deterministic).  batch == 1, MTT_STORE_ROWS only. */
+  /* ABI 10 — A-operand PROLOGUE of the exact-fp32 tall GEMM (the kernel behind variant 11: fp32 operands, N <= 32 outputs, batch == 1):
+   * the A element of channel k enters the product as act_a(A[m, k] * a_scale[k] + a_shift[k]) — BatchNorm (batch statistics folded into a
+   * per-channel scale / shift, K floats each; padding channels: scale = shift = 0) + activation applied while the operand is loaded, so the
+   * normalised + activated map of a conv head (8.7 GB in fp32 at the benchmark's batch) is never written in fp32 nor re-read: ConvHead's
+   * BatchNorm + GELU + 1x1 prediction (taskprompter.py:692-694) is ONE pass over the conv output.  a_aux16 (optional): the transformed
+   * operand rounded to bf16, [M, ld_a16] — what the bf16 backward of that layer reads (weight gradient of the predictions).
+   * a_scale == NULL: no prologue.  Other kernels return MTT_E_UNSUPPORTED when it is set. */
+  const float* a_scale; const float* a_shift; int32_t a_act; void* a_aux16; int64_t ld_a16;
 } mtt_gemm_desc;
 size_t mtt_gemm_colsum_ws_floats(const mtt_gemm_desc* d);
 

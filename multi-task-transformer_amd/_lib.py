@@ -56,6 +56,7 @@ class GemmDesc(C.Structure):
         ("variant", i32),
         ("A_lo", ptr), ("B_lo", ptr), ("D_lo", ptr),
         ("colsum_out", ptr), ("colsum_ws", ptr),
+        ("a_scale", ptr), ("a_shift", ptr), ("a_act", i32), ("a_aux16", ptr), ("ld_a16", i64),
     ]
 
 

@@ -839,6 +839,7 @@ class TaskHeadsFn(Function):
             n = wshapes[z][0]
             g = dps[z].contiguous().view(rows, -1)
             Kp = packs[z].shape[-1]
+            ga = g                                                # the weight gradient's dy operand
             if (prec.name == "bf16" and FAST_BWD and HEAD_DGRAD_DMA and dy.dtype == torch.bfloat16 and rows >= FAST_MIN_ROWS and g.shape[1] % 8 == 0
                     and Kp == ld):
                 # dya = g W is an outer-product-like GEMM (K = n <= 21 classes, a million rows): bound by the 0.7 GB it writes.  bf16 copies of
@@ -850,9 +851,11 @@ class TaskHeadsFn(Function):
                 g16 = ops.cast2d(g, rows, n, g.stride(0), torch.bfloat16, ldd=npad, zero_pad=True)
                 wT = _pad_last(packs[z][0].t(), npad).to(torch.bfloat16)                         # [ld, pad8(n)] (tiny)
                 _gemm(g16, wT, dy[z], rows, ld, npad, prec, lda=npad, ldb=npad, ldd=ld, n_store=ld, variant=_lib.GEMM_DMA128)
+                if y.dtype == torch.bfloat16:                     # (the activated map saved as bf16: ConvHeadFn's prologue form) both operands bf16
+                    ga = g16
             else:
                 _gemm(g, packs[z][0], dy[z], rows, ld, n, prec, b_op=OP_R, lda=g.shape[1], ldb=Kp, ldd=ld, n_store=ld)
-            dW = _wgrad(g, y[z], n, Kp, prec)
+            dW = _wgrad(ga, y[z], n, Kp, prec)
             dws.append(dW[:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
             dbs.append(_colsum(g, n))
         return (dy, None, None) + tuple(dws) + tuple(dbs)
@@ -901,8 +904,34 @@ class ConvHeadFn(Function):
         c1, c2, c3 = _SubCtx(), _SubCtx(), _SubCtx()
         Stage1 = UpConv3x3Fn if kind == 'up' else Conv3x3Fn
         y = Stage1.forward(c1, fea, geo, prec, tag1, *cw, *cb)
-        ya = BnActStackFn.forward(c2, y, C, act, training, bns, *bg, *bb)
-        preds = TaskHeadsFn.forward(c3, ya, prec, ptag, *pw, *pb)
+        Zy, rows, ld = y.shape
+        if (HEAD_PROLOGUE and training and prec.split and y.dtype == torch.float32
+                and all(ops.head_prologue_ok(rows, ld, w.shape[0], ld) for w in pw)):
+            # x3f training (round 6): BatchNorm + activation ride on the prediction GEMM's operand load (mtt_gemm_desc.a_scale): the activated
+            # map is never written in fp32 (8.7 GB at the benchmark's batch) nor re-read — one pass over the conv output yields the fp32-class
+            # predictions and the bf16 copy of the activated map that the bf16 backward needs for the predictions' weight gradients.
+            # Same saved-tensor layout as the three-stage form, so the backward below is unchanged (it sees a bf16 `ya`).
+            gammas, betas = torch.stack([g.detach() for g in bg]), torch.stack([b.detach() for b in bb])
+            mean, rstd, scale = bn_mod.train_stats(y, C, bns)
+            a_sc = torch.zeros(Zy, ld, dtype=torch.float32, device=y.device)
+            a_sh = torch.zeros(Zy, ld, dtype=torch.float32, device=y.device)
+            a_sc[:, :C] = rstd * gammas
+            a_sh[:, :C] = betas - mean * a_sc[:, :C]
+            ya16 = torch.empty(Zy, rows, ld, dtype=torch.bfloat16, device=y.device)
+            preds, packs = [], []
+            for z in range(Zy):
+                n = pw[z].shape[0]
+                wp = ops.pack_linear([pw[z]], prec, (ptag, z))
+                preds.append(ops.linear(y[z], wp, n, prec, bias=pb[z][None], out_dtype=torch.float32, a_affine=(a_sc[z], a_sh[z], act, ya16[z])))
+                packs.append(wp)
+            preds = tuple(preds)
+            c2.save_for_backward(y, mean, rstd, gammas, betas)
+            c2.meta = (C, act, training, scale, bns)
+            c3.save_for_backward(ya16, *packs)
+            c3.meta = (prec, [tuple(w.shape) for w in pw])
+        else:
+            ya = BnActStackFn.forward(c2, y, C, act, training, bns, *bg, *bb)
+            preds = TaskHeadsFn.forward(c3, ya, prec, ptag, *pw, *pb)
         n1, n2 = len(c1.saved_tensors), len(c2.saved_tensors)
         ctx.save_for_backward(*c1.saved_tensors, *c2.saved_tensors, *c3.saved_tensors)
         ctx.sub = (n1, n2, c1.meta, c2.meta, c3.meta, Z, Stage1)
@@ -1183,6 +1212,7 @@ def backbone_forward(model, img, upsample=True):
 
 
 FUSE_HEAD_NODE = True      # ConvHead as one autograd node (ConvHeadFn); tests set it to False for the three-node form
+HEAD_PROLOGUE = True       # ... whose x3f training forward applies BatchNorm + activation in the prediction GEMM's operand load (A/B: False)
 
 
 def upsample4(acc, B, h, w, prec):

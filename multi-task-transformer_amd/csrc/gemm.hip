@@ -1355,6 +1355,13 @@ int launch_ringc(const GemmP& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int F32N_RB = 4;            // 32-row blocks per wave
+// the A prologue of one 4-channel chunk: a <- act(a * scale + shift), optionally stored rounded to bf16 (8 bytes per lane)
+MTT_DEV void f32n_prologue(float4& a, const float4 sc, const float4 sh, int act, bf16_t* a16, int64_t off16) {
+  a.x = fmaf(a.x, sc.x, sh.x); a.y = fmaf(a.y, sc.y, sh.y); a.z = fmaf(a.z, sc.z, sh.z); a.w = fmaf(a.w, sc.w, sh.w);
+  if (act == MTT_ACT_GELU) { a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w); }
+  else if (act == MTT_ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  if (a16) *(u32x2*)(a16 + off16) = (u32x2){pack2(a.x, a.y), pack2(a.z, a.w)};
+}
 __global__ __launch_bounds__(256, 2) void gemm_f32n_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* wl = (float4*)smem;                                        // [K / 4][32] chunks of 4 k
@@ -1369,6 +1376,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32n_kernel(const GemmP p) {
     const int n = t & 31, q = t >> 5;
     wl[t] = n < d.N ? *(const float4*)(W + (int64_t)n * d.ldb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // A prologue (mtt_gemm_desc.a_scale): per-channel scale / shift chunks behind the weights, [K / 4] float4 each
+  const bool pro = d.a_scale != nullptr;
+  float4* const scl = wl + K4 * 32;
+  float4* const shl = scl + K4;
+  if (pro)
+    for (int t = threadIdx.x; t < K4; t += 256) { scl[t] = *(const float4*)(d.a_scale + 4 * t); shl[t] = *(const float4*)(d.a_shift + 4 * t); }
+  bf16_t* const a16 = (bf16_t*)d.a_aux16;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -1391,6 +1405,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32n_kernel(const GemmP p) {
       for (int u = 0; u < 4; ++u) a[u] = *(const float4*)(ar + 8 * (i + u));
 #pragma unroll
       for (int u = 0; u < 4; ++u) b[u] = wl[(2 * (i + u) + h) * 32 + r];
+      if (pro) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f32n_prologue(a[u], scl[2 * (i + u) + h], shl[2 * (i + u) + h], d.a_act, a16, row * d.ld_a16 + 8 * (i + u) + 4 * h);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
@@ -1400,7 +1418,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32n_kernel(const GemmP p) {
       }
     }
     for (; i < steps; ++i) {
-      const float4 a = *(const float4*)(ar + 8 * i), b = wl[(2 * i + h) * 32 + r];
+      float4 a = *(const float4*)(ar + 8 * i);
+      const float4 b = wl[(2 * i + h) * 32 + r];
+      if (pro) f32n_prologue(a, scl[2 * i + h], shl[2 * i + h], d.a_act, a16, row * d.ld_a16 + 8 * i + 4 * h);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
@@ -1419,14 +1439,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32n_kernel(const GemmP p) {
 
 static bool f32n_ok(const mtt_gemm_desc& d) {
   return d.prec == MTT_PREC_X3 && d.a_dtype == MTT_F32 && d.b_dtype == MTT_F32 && d.d_dtype == MTT_F32 && d.a_op == MTT_OP_K && d.b_op == MTT_OP_K &&
-         d.N <= 32 && d.K % 8 == 0 && d.K <= 1024 && d.M >= 2048 && d.store_mode == MTT_STORE_ROWS && d.a_mb <= 0 && d.d_mb <= 0 && !d.resid &&
+         d.N <= 32 && d.K % 8 == 0 && d.K <= 1024 && (d.M >= 2048 || d.a_scale) && d.store_mode == MTT_STORE_ROWS && d.a_mb <= 0 && d.d_mb <= 0 && !d.resid &&
          !d.aux_in && !d.aux_out && !d.colscale && !d.rowscale && !d.colsum_out && d.act == MTT_ACT_NONE && d.alpha == 1.0f &&
-         (d.variant == MTT_GEMM_AUTO) && d.lda % 4 == 0 && d.ldb % 4 == 0;
+         (d.variant == MTT_GEMM_AUTO) && d.lda % 4 == 0 && d.ldb % 4 == 0 &&
+         (!d.a_scale || (d.a_shift && d.batch <= 1 && (d.a_act == MTT_ACT_NONE || d.a_act == MTT_ACT_GELU || d.a_act == MTT_ACT_RELU) &&
+                         (!d.a_aux16 || (d.ld_a16 % 4 == 0 && d.ld_a16 >= d.K && !((uintptr_t)d.a_aux16 & 7))) &&
+                         !(((uintptr_t)d.a_scale | (uintptr_t)d.a_shift) & 15)));
 }
 int launch_f32n(const GemmP& p, hipStream_t stream) {
-  const int smem = p.d.K * 32 * 4;
+  const int smem = p.d.K * 32 * 4 + 2 * p.d.K * 4;                  // weights + the prologue's scale / shift vectors
   static std::atomic<unsigned long long> done{0};
-  if (int e = mtt_ensure_dyn_lds((const void*)gemm_f32n_kernel, 1024 * 32 * 4, done)) return e;
+  if (int e = mtt_ensure_dyn_lds((const void*)gemm_f32n_kernel, 1024 * 32 * 4 + 2 * 1024 * 4, done)) return e;
   const int64_t rows_per_wg = 4 * F32N_RB * 32;
   dim3 grid((unsigned)((p.d.M + rows_per_wg - 1) / rows_per_wg), 1, p.d.batch);
   hipLaunchKernelGGL(gemm_f32n_kernel, grid, dim3(256), smem, stream, p);
@@ -1853,6 +1876,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
     // pre-split planes exist for ONE kernel: both operands split, reduction-contiguous, whole 32-deep K steps (at least two), fast addressing
     const bool both = d.prec == MTT_PREC_X3 && d.a_dtype == MTT_SPLIT && d.b_dtype == MTT_SPLIT && d.b_op == MTT_OP_K && d.A_lo && d.B_lo &&
                       d.store_mode == MTT_STORE_ROWS;
+    if (d.a_scale) return MTT_E_UNSUPPORTED;
     if (both && d.a_op == MTT_OP_K && dma_fastaddr_ok(d, MTT_RING ? 32 : 64) && d.K >= 64 && d.K / 64 * 3 < 32768) return 8;
     // ... and its implicit-GEMM form for the 3x3 convs: channel pitch a multiple of 32 (a K step inside one tap), pixel rows of pitch lda
     if (both && d.a_op == MTT_OP_CONV_K && d.conv.Cp % 32 == 0 && d.conv.Cp <= 4096 && d.K == 9 * d.conv.Cp && d.a_mb <= 0 &&
@@ -1860,6 +1884,7 @@ static int gemm_variant_for(const mtt_gemm_desc& d) {
     return MTT_E_UNSUPPORTED;
   }
   if (f32n_ok(d)) return 11;
+  if (d.a_scale) return MTT_E_UNSUPPORTED;             // the A prologue exists in that kernel only
   if (d.prec != MTT_PREC_BF16 || d.a_dtype != MTT_BF16 || d.b_dtype != MTT_BF16) return 0;
   // 12: the bf16 implicit-GEMM 3x3 conv on the LDS-DMA ring (gemm_ringc_kernel): channel pitch a multiple of 32, pixel rows of pitch lda,
   // 32-bit element offsets; enough rows and columns for 256 x 256 tiles (small maps stay on the register-staged 128 x 128 kernel)

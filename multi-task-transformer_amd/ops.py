@@ -526,7 +526,7 @@ def stack_vec(vs, tag):
 # ---------------------------------------------------------------------------------------------
 def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, M=None,
            a_rows=None, d_rows=None, resid=None, r_rows=None, rowscale=None, n_prompt=0, aux_out=None, aux_in=None,
-           colscale=None, alpha=1.0, batch_inner=1, d_z=None, ldd=None, n_store=None):
+           colscale=None, alpha=1.0, batch_inner=1, d_z=None, ldd=None, n_store=None, a_affine=None):
     """out[z] = epi(x[z] @ wpack[z]^T)  (mtt_gemm, both operands reduction-contiguous).
 
     x: [Z, M, lda] / [M, lda] (broadcast over Z) — or, with a_rows=(mb, bs, ld), any view whose first
@@ -595,8 +595,17 @@ def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=No
         az = aux.stride(0) if aux.dim() == 3 else 0
         kw.update(aux_out=aux_out, aux_in=aux_in, aux_dtype=dtype_code(aux), ldaux=aux.shape[-1],
                   aux_zo=az * batch_inner, aux_zi=az if batch_inner > 1 else 0)
+    if a_affine is not None:          # (scale [K], shift [K], act, bf16 side copy or None): the A prologue of the exact-fp32 tall GEMM (head_prologue_ok)
+        sc, sh, a_act, a16 = a_affine
+        kw.update(a_scale=sc, a_shift=sh, a_act=a_act, a_aux16=a16, ld_a16=a16.stride(-2) if a16 is not None else 0)
     call("gemm", **kw)
     return out
+
+
+def head_prologue_ok(rows, K, n, lda):
+    """can mtt_gemm apply BatchNorm + activation while loading the A operand (mtt_gemm_desc.a_scale)?  Only its exact-fp32 tall kernel does
+    (gemm_f32n_kernel: fp32 operands, at most 32 outputs, K <= 1024 in whole 8-chunks; with a prologue it takes any row count)."""
+    return n <= 32 and K % 8 == 0 and K <= 1024 and rows >= 1 and lda % 4 == 0
 
 
 SPLIT_CONV_MAX_ELEMS = 2 ** 31 - 1          # gemm_variant_for: (int64) M * lda < 2^31 for variant 9 (tests lower it to force chunks)

@@ -124,6 +124,12 @@ def gemm(**kw):
             Bm = _rd(B, zb + (k + dy * W + dx) * ldb + ci, ok)
         else:
             raise ValueError("bad b_op")
+        if kw.get("a_scale") is not None:                           # A prologue (variant 11 only): act(A * scale[k] + shift[k]), bf16 side copy
+            assert a_op == OP_K and batch == 1 and prec == 1 and N <= 32, "A prologue: the exact-fp32 tall GEMM only"
+            kk = torch.arange(K)
+            Am = _act(Am * _rd(kw["a_scale"], kk)[None, :] + _rd(kw["a_shift"], kk)[None, :], g("a_act"))
+            if kw.get("a_aux16") is not None:
+                _wr(kw["a_aux16"], m * g("ld_a16") + k, Am)
         if prec == 0 and ROUND_BF16_OPERANDS:
             Am, Bm = _bf16_round(Am), _bf16_round(Bm)
         v = alpha * (Am @ Bm.T)                                       # [M, N] fp64

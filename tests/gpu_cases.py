@@ -318,6 +318,17 @@ def gemm_cases():
                   d_dtype=F32, prec=1, lda=K + 8, ldb=K, ldd=ldd, batch=Zc, batch_inner=1, a_zo=M * (K + 8), b_zo=N * K, d_zo=M * ldd, alpha=1.0,
                   colshift=rnd(g, Zc, N), col_zo=N, n_store=(N + 7) // 8 * 8)
         cases.append((f"gemm_f32n_{M}x{N}x{K}_z{Zc}", "gemm", kw, TOL_X3))
+    # ... and with the A PROLOGUE of ABI 10 (mtt_gemm_desc.a_scale): BatchNorm scale / shift + GELU / ReLU / nothing applied to the operand
+    # while it is loaded, the transformed operand stored rounded to bf16 (a_aux16; untouched 3.0 fill in its pitch padding) — the head
+    # predictions' shape, a ragged small M (the prologue form takes any row count), K = 1024 without the side copy
+    for (M, N, K, a_act, aux) in ((5000, 21, 352, 1, True), (349, 7, 352, 1, True), (3000, 3, 1024, 2, False), (700, 32, 64, 0, True)):
+        ldd = (N + 7) // 8 * 8 + 8
+        sc = rnd(g, K).abs() + 0.3; sh = rnd(g, K); sc[K - 2:] = 0.0; sh[K - 2:] = 0.0          # (channel padding: scale = shift = 0)
+        kw = dict(A=rnd(g, M, K + 8), B=rnd(g, N, K), D=torch.full((M, ldd), 7.0), M=M, N=N, K=K, a_op=OP_K, b_op=OP_K, a_dtype=F32, b_dtype=F32,
+                  d_dtype=F32, prec=1, lda=K + 8, ldb=K, ldd=ldd, batch=1, batch_inner=1, alpha=1.0, colshift=rnd(g, N), n_store=(N + 7) // 8 * 8,
+                  a_scale=sc, a_shift=sh, a_act=a_act, a_aux16=torch.full((M, K + 16), 3.0, dtype=torch.bfloat16) if aux else None,
+                  ld_a16=K + 16 if aux else 0)
+        cases.append((f"gemm_f32n_prologue_{M}x{N}x{K}_act{a_act}", "gemm", kw, TOL_X3))
     # 1e''. bf16 arithmetic on fp32-STORED operands (rounded while staged: general kernel MODE 3 = f32 x f32, MODE 4 = bf16 x f32), in the
     #       layouts the bf16 backward of the x3-forward training mode uses them: dgrad (OP_K x OP_R), wgrad (OP_R x OP_R), conv dgrad / wgrad
     for tag, adt, bdt in (("f32f32", F32, F32), ("bf16f32", BF16, F32)):

@@ -291,6 +291,51 @@ def test_fused_head_and_fuse_tail_nodes_with_frozen_inputs(emulated):
             assert part[k] is not None and torch.equal(part[k], gfull), k
 
 
+def test_conv_head_prologue_form_matches_the_three_stage_form(emulated, monkeypatch):
+    """ConvHeadFn in x3f training (round 6): BatchNorm + GELU applied while the prediction GEMM loads its operand (mtt_gemm_desc.a_scale),
+    no bn_apply launch and no fp32 activated map for the heads; the backward reads the bf16 side copy.  Predictions equal the three-stage
+    form's to fp32 rounding, every gradient stays inside the x3f per-parameter bound, BatchNorm running statistics are updated alike."""
+    import importlib
+    import mtt_amd
+    import train_check
+    ap = importlib.import_module("multi-task-transformer_amd.autograd_path")
+    seen = []
+    inner = mtt_amd.ops.call
+
+    def spy(name, **kw):
+        seen.append((name, kw.get("a_scale") is not None, kw.get("rows")))
+        return inner(name, **kw)
+    monkeypatch.setattr(mtt_amd.ops, "call", spy)
+    cfg = configs.taskprompter("mini_ctr")
+    meta, _ = conftest.load_golden("mini_ctr")
+    sd = weights.synth_state_dict(meta["contract"], 0)
+    x = weights.synth_images(2, cfg["img_size"], 2)
+
+    def run(flag):
+        monkeypatch.setattr(ap, "HEAD_PROLOGUE", flag)
+        seen.clear()
+        model = conftest.build_product_model(cfg, "x3f", "cpu")
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        out = model(x)
+        calls = list(seen)
+        return out, {k: v.clone() for k, v in model.state_dict().items() if "running_" in k}, calls
+
+    of, bf, cf = run(True)
+    op, bp, cp = run(False)
+    T = len(cfg["tasks"])
+    assert sum(1 for n, pro, _ in cf if n == "gemm" and pro) == T and not any(pro for _, pro, _ in cp)
+    head_rows = 2 * 16 * cfg["img_size"][0] // 16 * cfg["img_size"][1] // 16
+    assert sum(1 for n, _, r in cp if n == "bn_apply" and r == head_rows) == 1 and not any(n == "bn_apply" and r == head_rows for n, _, r in cf)
+    for t in of:
+        assert float((of[t].detach() - op[t].detach()).norm() / op[t].detach().norm()) < 2e-6, t
+    for k in bf:
+        assert torch.equal(bf[k], bp[k]), k
+    monkeypatch.setattr(ap, "HEAD_PROLOGUE", True)
+    _, errs = train_check.grad_errors("mini_ctr", "x3f", "cpu")
+    train_check.assert_per_param(errs, "x3f")
+
+
 def test_bf16_training_uses_flash_attention_backward(emulated, monkeypatch):
     """bf16 mode routes the attention backward to mtt_attn_bwd (flash, no N x N buffer); gradients stay bf16-accurate."""
     import mtt_amd
