@@ -121,9 +121,6 @@ def parse():
     ap.add_argument("--cpu-roofline", action="store_true",
                     help="(host-logic tests, --device cpu only) keep the instrumented roofline step — wall-clock stamps instead of HIP events — so "
                          "that a gloo run exercises what every rank does around it under DDP")
-    ap.add_argument("--no-precast", action="store_true",
-                    help="A/B: every backward node casts its incoming residual gradient itself (round 5) instead of taking the bf16 copy + column sums "
-                         "the producing LayerNorm backward wrote (round 6)")
     ap.add_argument("--no-head-prologue", action="store_true",
                     help="A/B: ConvHead's BatchNorm + GELU as a pass of their own writing the fp32 activated map (round 5) instead of riding on the "
                          "prediction GEMM's operand load (round 6)")
@@ -586,8 +583,6 @@ def main():
         mtt_amd.autograd_path.GELU_DAUX = False
     if a.no_head_prologue:
         mtt_amd.autograd_path.HEAD_PROLOGUE = False
-    if a.no_precast:
-        mtt_amd.autograd_path.PRECAST = False
     if a.measure_no_repack:
         mtt_amd.ops.bump_param_epoch = lambda *a, **k: None
         torch.autograd.graph.increment_version = lambda *x, **k: None

@@ -195,12 +195,6 @@ typedef struct {
   float* ws;
   void* y_lo;                    /* fwd, y_dtype == MTT_SPLIT: lo plane of y (same pitch ldy) */
   float* y32; int64_t ldy32;     /* fwd, optional: an additional fp32 copy of y (consumers that want the exact rows next to the split planes) */
-  /* ABI 10, bwd (fused kernel, C <= 1024) — the NEXT layer's operand produced with dx: g16[row, c] = bf16(dx[row, c] * rowscale(row)) and
-   * gsum[c] = sum over rows of the values AS STORED in g16.  dx of a pre-LN residual block is the gradient of the previous block half's output,
-   * whose backward starts by casting exactly this to bf16 (scaled by ITS DropPath row scale) and summing its columns (the bias gradient of
-   * its output Linear): done here, dx is not re-read (266 MB per call at the benchmark's batch).  rowscale: NULL (= 1) or [groups, 2] as in
-   * mtt_gemm_desc (row m -> group m / g_mb, column 0 for the first g_nprompt rows of a group, 1 for the rest).  g16 == NULL: off. */
-  void* g16; int64_t ldg; const float* g_rowscale; int32_t g_mb; int32_t g_nprompt; float* gsum;
 } mtt_ln_desc;
 size_t mtt_layernorm_bwd_ws_floats(int64_t rows, int32_t C);
 int mtt_layernorm_fwd(const mtt_ln_desc* d, void* stream);

@@ -76,8 +76,7 @@ class LnDesc(C.Structure):
     _fields_ = [("x", ptr), ("y", ptr), ("gamma", ptr), ("beta", ptr), ("mean", ptr), ("rstd", ptr),
                 ("dy", ptr), ("dx", ptr), ("dgamma", ptr), ("dbeta", ptr),
                 ("rows", i64), ("C", i32), ("ldx", i64), ("ldy", i64), ("y_dtype", i32), ("eps", f32), ("dx_in", ptr), ("ws", ptr),
-                ("y_lo", ptr), ("y32", ptr), ("ldy32", i64),
-                ("g16", ptr), ("ldg", i64), ("g_rowscale", ptr), ("g_mb", i32), ("g_nprompt", i32), ("gsum", ptr)]
+                ("y_lo", ptr), ("y32", ptr), ("ldy32", i64)]
 
 
 class ChanLogitDesc(C.Structure):

@@ -50,9 +50,6 @@ def _scaled_colsum(g, rowscale, mb, n_prompt, prec):
     stream), so the cast that prepares it for the bf16 GEMMs yields that layer's bias gradient in the same pass (mtt_rowscale_cast_colsum).
     Falls back to a separate column sum when no cast is needed."""
     cols = g.shape[1]
-    hit = _precast.pop(g.data_ptr(), None) if _precast else None
-    if hit is not None and hit[0] == g._version and hit[1] == tuple(g.shape) and hit[2] is rowscale and prec.adt == torch.bfloat16:
-        return hit[3], hit[4]                  # written by the LayerNorm backward that produced g (same tensor, untouched since)
     if (rowscale is None and (g.dtype == prec.adt or not FAST_BWD)) or cols % 8 or g.stride(0) % 8:
         out = _scaled(g, rowscale, mb, n_prompt, prec)
         return out, _colsum(out, cols)
@@ -300,33 +297,15 @@ def attention_bwd_flash(qkv, ao, lse, dao, drawlog, B, N, nH, T, prec):
     return dqkv
 
 
-PRECAST = True              # LayerNorm backward also writes the next backward node's bf16 operand + bias column sums (tests / A-B runs: False)
-_precast = {}               # data_ptr of a residual gradient -> (its tensor version, shape, rowscale it was scaled with, bf16 copy, column sums)
-
-
-def _ln_bwd_join(dres, x, dy, gamma, mean, rstd, eps, pre=None, prec=None):
+def _ln_bwd_join(dres, x, dy, gamma, mean, rstd, eps):
     """-> (dres + LayerNorm backward of dy, dgamma, dbeta): the residual-stream gradient joined with the LayerNorm branch's in the
     same pass that computes the latter (one read of dres, one write of the sum).  Out of place: `dres` is the grad_output autograd
-    handed to the Function and may be shared with hooks / retain_grad / other consumers, so it is never written.
-    pre = (rowscale, mb, n_prompt) of the backward node that receives the result (known when the result has that ONE consumer): the kernel
-    then also stores what that node would compute first — the bf16 copy scaled by its DropPath row scale and its column sums
-    (_scaled_colsum: 85 us and a re-read of 266 MB per call at the benchmark's batch) — and _scaled_colsum picks it up from `_precast`."""
+    handed to the Function and may be shared with hooks / retain_grad / other consumers, so it is never written."""
     dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     out = torch.empty_like(dres)
-    kw = {}
-    C = x.shape[1]
-    do_pre = (PRECAST and pre is not None and prec is not None and prec.name == "bf16" and FAST_BWD and C <= 1024 and C % 8 == 0
-              and dy.stride(0) % 4 == 0 and x.device.type != "meta")
-    if do_pre:
-        g16 = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
-        gsum = torch.empty(C, dtype=torch.float32, device=out.device)
-        kw = dict(g16=g16, ldg=g16.stride(0), g_rowscale=pre[0], g_mb=pre[1], g_nprompt=pre[2], gsum=gsum)
     ops.call("layernorm_bwd", x=x, dy=dy, gamma=gamma, mean=mean, rstd=rstd, dx=out, dx_in=dres, dgamma=dg, dbeta=db,
-             rows=x.shape[0], C=C, ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=eps,
-             ws=ops.ln_bwd_ws(x.shape[0], C, x.device), **kw)
-    if do_pre:
-        _precast.clear()                       # at most one pending hand-over: the next _scaled_colsum on THIS tensor takes it
-        _precast[out.data_ptr()] = (out._version, tuple(out.shape), pre[0], g16, gsum)
+             rows=x.shape[0], C=x.shape[1], ldx=x.stride(0), ldy=dy.stride(0), y_dtype=dtype_code(dy), eps=eps,
+             ws=ops.ln_bwd_ws(x.shape[0], x.shape[1], x.device))
     return out, dg, db
 
 
@@ -342,7 +321,6 @@ class AttnHalfFn(Function):
     def forward(ctx, XT, g1, b1, eps, Wqkv, bqkv, Wproj, bproj, Wtt, btt, Wtt1, btt1, rowscale, geo, prec, tag):
         B, N, nH, T, h, w, nwin = geo[:7]
         side = geo[7] if len(geo) > 7 else True              # False: no consumer of this block's channel logits (not a tap): skip that pass
-        ctx.pre = geo[8] if len(geo) > 8 else None           # (rowscale,) of the ONE backward node that receives this node's input gradient
         C, hw = nH * 64, h * w
         chan = Wtt is not None
         split = prec.split                       # x3f: x3 products on pre-split planes (LDS-DMA kernel), bf16 backward on the hi planes
@@ -447,7 +425,7 @@ class AttnHalfFn(Function):
                 _gemm(dcq, wt[0], dp, B * T, C, hw, prec, b_op=OP_R, lda=hwp, ldb=wt.shape[-1], ldd=C, d_mb=T, d_bs=N * C,
                       resid=dp, r_mb=T, r_bs=N * C, ldr=C, n_store=C)
         # ---- norm1 backward accumulated into the residual gradient ------------------------------------------------
-        dXT, dg1, db1 = _ln_bwd_join(dXT2, XT, dxn, g1, mean, rstd, ctx.eps, pre=(ctx.pre[0], N, T) if ctx.pre is not None else None, prec=prec)
+        dXT, dg1, db1 = _ln_bwd_join(dXT2, XT, dxn, g1, mean, rstd, ctx.eps)
         return (dXT, dg1, db1, None, dWqkv, dbqkv, dWproj, dbproj, dWtt, dbtt, dWtt1, dbtt1, None, None, None, None)
 
 
@@ -456,8 +434,7 @@ class MlpHalfFn(Function):
 
     @staticmethod
     def forward(ctx, XT2, g2, b2n, eps, W1, b1, W2, b2, rowscale, geo, prec, tag):
-        B, N, T = geo[:3]
-        ctx.pre = geo[3] if len(geo) > 3 else None
+        B, N, T = geo
         C, Hd = W1.shape[1], W1.shape[0]
         split = prec.split and C % 64 == 0 and Hd % 64 == 0          # LDS-DMA x3 GEMM: whole 64-deep K tiles (else the register-staged x3 kernels)
         xn2, mean, rstd = ops.layernorm(XT2, g2, b2n, eps, prec, save_stats=True, out_dtype="split" if split else None)
@@ -481,7 +458,7 @@ class MlpHalfFn(Function):
     @staticmethod
     def backward(ctx, dXT3):
         XT2, g2, mean, rstd, xn2, z, hmid, w1, w2, rowscale = ctx.saved_tensors
-        B, N, T = ctx.geo[:3]
+        B, N, T = ctx.geo
         prec, M = ctx.prec.bwd, B * N
         C, Hd = xn2.shape[1], z.shape[1]
         dXT3 = dXT3.contiguous()
@@ -492,7 +469,7 @@ class MlpHalfFn(Function):
                              aux_dtype=dtype_code(z), ldaux=Hd)
         dW1, _ = _enc_wgrad(dz, xn2, Hd, C, prec, bias=False)
         dxn2 = _enc_dgrad(dz, W1_, w1[0], M, C, Hd, prec, prec.adt, 'fc1')
-        dXT2, dg2, dbn2 = _ln_bwd_join(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps, pre=(ctx.pre[0], N, T) if ctx.pre is not None else None, prec=prec)
+        dXT2, dg2, dbn2 = _ln_bwd_join(dXT3, XT2, dxn2, g2, mean, rstd, ctx.eps)
         return dXT2, dg2, dbn2, None, dW1, db1, dW2, db2, None, None, None, None
 
 
@@ -1218,20 +1195,15 @@ def backbone_forward(model, img, upsample=True):
     acc = None
     rawlog = rawchan = None
     drops = _drop_tables(model, B, img.device)
-    _precast.clear()
     for i, blk in enumerate(model.blocks):
         a = blk.attn
         rs_attn, rs_mlp = drops[i]
-        # who receives this block's input gradients in the backward: the previous block's MLP half (unless that block's output also feeds a
-        # tap: its gradient is then a sum autograd forms) / this block's attention half — _ln_bwd_join pre-casts for them
-        pre_attn = (drops[i - 1][1],) if (i >= 1 and i not in model.select_list) else None
-        pre_mlp = (rs_attn,)
         XT2, rawlog, rawchan = AttnHalfFn.apply(XT, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, a.qkv.weight, a.qkv.bias,
                                                 a.proj.weight, a.proj.bias, a.token_trans.weight, a.token_trans.bias,
                                                 a.token_trans1.weight, a.token_trans1.bias, rs_attn,
-                                                (B, N, nH, T, h, w, nwin, model._side_channels_used(i), pre_attn), prec, ('blk', i))
+                                                (B, N, nH, T, h, w, nwin, model._side_channels_used(i)), prec, ('blk', i))
         XT = MlpHalfFn.apply(XT2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
-                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp, (B, N, T, pre_mlp), prec, ('blk', i))
+                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp, (B, N, T), prec, ('blk', i))
         if (i + 1) in model.select_list:
             acc = _task_features(model, XT, rawlog, rawchan, model._tap_index(i), B, acc)
     xf = LayerNormFn.apply(XT, model.norm.weight, model.norm.bias, model.norm.eps, prec, torch.float32)

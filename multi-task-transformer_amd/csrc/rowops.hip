@@ -157,17 +157,16 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const mtt_ln_desc d) {
 // backward, fused (C <= 1024): one read of x and dy per row.  A wave owns a row at a time (4 float4 chunks per lane kept in
 // registers between the statistics pass and the dx pass) and keeps per-column partial sums of dgamma / dbeta for all its rows;
 // the 4 waves are combined through LDS and the block writes one partial row to the workspace (merged by ln_dgb_final_kernel).
-template <bool G16>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, int rows_per_block) {
-  __shared__ float part[4][G16 ? 3 : 2][1024];
+  __shared__ float part[4][2][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C4 = d.C >> 2;
-  float4 ga[4], ag[4], ab[4], ac[4];
+  float4 ga[4], ag[4], ab[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c4 = lane + 64 * k;
     ga[k] = c4 < C4 ? ((const float4*)d.gamma)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = make_float4(0.f, 0.f, 0.f, 0.f); ac[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < d.rows ? r0 + rows_per_block : d.rows;
@@ -197,11 +196,6 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, 
       }
     }
     s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
-    float rs = 1.0f;
-    if (G16 && d.g_rowscale) {
-      const int64_t q = d.g_mb > 0 ? row / d.g_mb : 0, rem = d.g_mb > 0 ? row - q * d.g_mb : row;
-      rs = d.g_rowscale[q * 2 + (rem >= d.g_nprompt ? 1 : 0)];
-    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c4 = lane + 64 * k;
@@ -211,28 +205,19 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, 
         o.x += rstd * (g[k].x - s1 - xh[k].x * s2); o.y += rstd * (g[k].y - s1 - xh[k].y * s2);
         o.z += rstd * (g[k].z - s1 - xh[k].z * s2); o.w += rstd * (g[k].w - s1 - xh[k].w * s2);
         *dx = o;
-        if (G16) {                                             // the next layer's bf16 operand + its column sums (of the stored values)
-          const u32x2 w = (u32x2){pack2(o.x * rs, o.y * rs), pack2(o.z * rs, o.w * rs)};
-          *(u32x2*)((bf16_t*)d.g16 + row * d.ldg + c4 * 4) = w;
-          ac[k].x += lo_of(w[0]); ac[k].y += hi_of(w[0]); ac[k].z += lo_of(w[1]); ac[k].w += hi_of(w[1]);
-        }
       }
     }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c4 = lane + 64 * k;
-    if (c4 < C4) {
-      *(float4*)&part[wave][0][c4 * 4] = ag[k]; *(float4*)&part[wave][1][c4 * 4] = ab[k];
-      if (G16) *(float4*)&part[wave][2][c4 * 4] = ac[k];
-    }
+    if (c4 < C4) { *(float4*)&part[wave][0][c4 * 4] = ag[k]; *(float4*)&part[wave][1][c4 * 4] = ab[k]; }
   }
   __syncthreads();
-  constexpr int NP = G16 ? 3 : 2;
-  float* wsb = d.ws + (int64_t)blockIdx.x * NP * d.C;
+  float* wsb = d.ws + (int64_t)blockIdx.x * 2 * d.C;
   for (int c = threadIdx.x; c < d.C; c += 256) {
-#pragma unroll
-    for (int q = 0; q < NP; ++q) wsb[q * d.C + c] = (part[0][q][c] + part[1][q][c]) + (part[2][q][c] + part[3][q][c]);
+    wsb[c] = (part[0][0][c] + part[1][0][c]) + (part[2][0][c] + part[3][0][c]);
+    wsb[d.C + c] = (part[0][1][c] + part[1][1][c]) + (part[2][1][c] + part[3][1][c]);
   }
 }
 
@@ -240,19 +225,19 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const mtt_ln_desc d, 
 // grid (C / 32, 2): blockIdx.y = 0 sums the dgamma partials, 1 the dbeta partials; 8 row groups x 4 independent accumulators per lane keep
 // 32 loads in flight per lane (the one-accumulator form ran the 8 MB of partials of an encoder LayerNorm at 0.2 TB/s from 32 workgroups);
 // fixed summation order.
-__global__ __launch_bounds__(256) void ln_dgb_final_kernel(const float* ws, float* dgamma, float* dbeta, int C, int nblk, int np = 2, float* gsum = nullptr) {
+__global__ __launch_bounds__(256) void ln_dgb_final_kernel(const float* ws, float* dgamma, float* dbeta, int C, int nblk) {
   __shared__ float sh[8][32];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
-  const float* src = ws + (int64_t)blockIdx.y * C + c;
+  const float* src = ws + (blockIdx.y ? C : 0) + c;
   float t[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     int b = pl;
     for (; b + 24 < nblk; b += 32) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] += src[(int64_t)(b + 8 * u) * np * C];
+      for (int u = 0; u < 4; ++u) t[u] += src[(int64_t)(b + 8 * u) * 2 * C];
     }
-    for (; b < nblk; b += 8) t[0] += src[(int64_t)b * np * C];
+    for (; b < nblk; b += 8) t[0] += src[(int64_t)b * 2 * C];
   }
   float v = (t[0] + t[1]) + (t[2] + t[3]);
   sh[pl][cl] = v;
@@ -260,7 +245,7 @@ __global__ __launch_bounds__(256) void ln_dgb_final_kernel(const float* ws, floa
   if (pl == 0 && c < C) {
 #pragma unroll
     for (int l = 1; l < 8; ++l) v += sh[l][cl];
-    (blockIdx.y == 0 ? dgamma : (blockIdx.y == 1 ? dbeta : gsum))[c] = v;
+    (blockIdx.y ? dbeta : dgamma)[c] = v;
   }
 }
 
@@ -1536,7 +1521,7 @@ static void ln_bwd_cfg(const mtt_ln_desc* d, bool& fused, int& nblk, int& rpb) {
 }
 extern "C" size_t mtt_layernorm_bwd_ws_floats(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  return (size_t)2048 * 3 * (size_t)C;                   // upper bound over the kernel choices (<= 2048 row blocks, 3 partial rows with g16)
+  return (size_t)2048 * 2 * (size_t)C;                   // upper bound over both kernel choices (<= 2048 row blocks)
 }
 extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
   if (!d || !d->x || !d->dy || !d->gamma || !d->mean || !d->rstd || d->rows <= 0 || d->C <= 0) return MTT_E_BADARG;
@@ -1544,11 +1529,8 @@ extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
   if (d->dgamma && (!d->dbeta || !d->ws)) return MTT_E_BADARG;
   bool fused; int nblk, rpb;
   ln_bwd_cfg(d, fused, nblk, rpb);
-  const bool g16 = d->g16 != nullptr;
-  if (g16 && (!fused || !d->gsum || (d->ldg % 4) || ((uintptr_t)d->g16 & 7) || (d->g_rowscale && d->g_mb <= 0))) return MTT_E_UNSUPPORTED;
   if (fused) {
-    if (g16) hipLaunchKernelGGL(ln_bwd_fused_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, S_, *d, rpb);
-    else hipLaunchKernelGGL(ln_bwd_fused_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, S_, *d, rpb);
+    hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)nblk), dim3(256), 0, S_, *d, rpb);
   } else {
     if (d->dx) hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, S_, *d);
     if (d->dgamma) {
@@ -1557,8 +1539,7 @@ extern "C" int mtt_layernorm_bwd(const mtt_ln_desc* d, void* stream) {
     }
   }
   if (d->dgamma)
-    hipLaunchKernelGGL(ln_dgb_final_kernel, dim3((unsigned)((d->C + 31) / 32), g16 ? 3 : 2), dim3(256), 0, S_, (const float*)d->ws, d->dgamma, d->dbeta,
-                       d->C, nblk, g16 ? 3 : 2, d->gsum);
+    hipLaunchKernelGGL(ln_dgb_final_kernel, dim3((unsigned)((d->C + 31) / 32), 2), dim3(256), 0, S_, (const float*)d->ws, d->dgamma, d->dbeta, d->C, nblk);
   return LAUNCH_OK();
 }
 

@@ -302,16 +302,7 @@ def layernorm_bwd(**kw):
     if kw.get("dx") is not None:
         dx = rstd * (gm - gm.mean(-1, keepdim=True) - xh * (gm * xh).mean(-1, keepdim=True))
         idx = r * kw["ldx"] + c
-        tot = _rd(kw["dx_in"] if kw.get("dx_in") is not None else kw["dx"], idx) + dx
-        _wr(kw["dx"], idx, tot)
-        if kw.get("g16") is not None:                                # ABI 10: the next layer's bf16 operand (the STORED fp32 dx, scaled) + its column sums
-            v = tot.float().double()
-            if kw.get("g_rowscale") is not None:
-                rr = torch.arange(rows)
-                mb = kw["g_mb"]
-                v = v * _rd(kw["g_rowscale"], (rr // mb) * 2 + ((rr % mb) >= kw["g_nprompt"]).long())[:, None]
-            _wr(kw["g16"], r * kw["ldg"] + c, v)
-            _wr(kw["gsum"], torch.arange(Cn), _bf16_round(v).sum(0))
+        _wr(kw["dx"], idx, _rd(kw["dx_in"] if kw.get("dx_in") is not None else kw["dx"], idx) + dx)
     if kw.get("dgamma") is not None:
         ci = torch.arange(Cn)
         _wr(kw["dgamma"], ci, (dy * xh).sum(0))

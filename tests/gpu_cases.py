@@ -540,19 +540,8 @@ def row_cases():
         mean = x.mean(-1); rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
         kw = dict(x=x, dy=rnd(g, rows, C, dtype=DT[ydt]), gamma=rnd(g, C), mean=mean, rstd=rstd, dx=rnd(g, rows, C),
                   dgamma=torch.full((C,), 3.0), dbeta=torch.full((C,), 3.0), rows=rows, C=C, ldx=C, ldy=C, y_dtype=ydt, eps=1e-6,
-                  ws=scratch(2048 * 3 * C))
+                  ws=scratch(2048 * 2 * C))
         cases.append((f"ln_bwd_{ydt}", "layernorm_bwd", kw, TOL_ROW))
-        # ABI 10: the fused kernel also writes the next node's operand g16 = bf16(dx * rowscale(row)) and its column sums (several row blocks,
-        # row groups of 103 with 6 prompt rows; with and without a row scale; dx_in given: the residual-join form).  A 1-ulp flip of one
-        # rounded bf16 element moves a column sum by ~1e-5 of its magnitude: the fp32 bound of gsum is the column-sum bound.
-        for (rows3, C3, rs) in ((5 * 103, 1024, True), (700, 256, False)):
-            x3 = rnd(g, rows3, C3)
-            mean3 = x3.mean(-1); rstd3 = torch.rsqrt(x3.var(-1, unbiased=False) + 1e-6)
-            kw = dict(x=x3, dy=rnd(g, rows3, C3, dtype=DT[ydt]), gamma=rnd(g, C3), mean=mean3, rstd=rstd3, dx=torch.full((rows3, C3), 5.0), dx_in=rnd(g, rows3, C3),
-                      dgamma=torch.full((C3,), 3.0), dbeta=torch.full((C3,), 3.0), rows=rows3, C=C3, ldx=C3, ldy=C3, y_dtype=ydt, eps=1e-6,
-                      ws=scratch(2048 * 3 * C3), g16=torch.full((rows3, C3 + 8), 2.0, dtype=torch.bfloat16), ldg=C3 + 8,
-                      g_rowscale=torch.rand(5, 2, generator=g) if rs else None, g_mb=103 if rs else 0, g_nprompt=6, gsum=torch.full((C3,), 9.0))
-            cases.append((f"ln_bwd_g16_{ydt}_{rows3}x{C3}", "layernorm_bwd", kw, dict(TOL_ROW, f32=2e-4)))
         # parameter gradients only (no dx): the column-parallel kernel with 16 row lanes per block combined in LDS
         x = rnd(g, 300, 64)
         mean = x.mean(-1); rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
