@@ -1,19 +1,32 @@
 #!/bin/bash
-# round 6, session 11: ConvHead prologue form (BatchNorm + GELU in the prediction GEMM's operand load): kernel cases, parity, same-box A/B
+# GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
+# round 6, FINAL-1: the whole -m gpu suite + smoke(), the driver-style bench line, the kernel trace of the same step, the PMC traffic passes
+# (re-measured on the final csrc/gemm.hip) and the SQ counters of the GEMM / attention kernels.
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "f32n" > $O/r06_pytest_k_f32n.log 2>&1; echo "f32n ops rc $?"; tail -3 $O/r06_pytest_k_f32n.log
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_model.py -x -q -m gpu -k "not trajectory and not swin" > $O/r06_pytest_k_train.log 2>&1; echo "train rc $?"; tail -3 $O/r06_pytest_k_train.log
-timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_configs.py -x -q -m gpu -k "ns6 or cfg2 or cfg3" > $O/r06_pytest_k_full.log 2>&1; echo "fullsize rc $?"; tail -3 $O/r06_pytest_k_full.log
-COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-ref-batch --no-torch-baseline --no-fast-mode --no-x3-mode --no-fwd --no-roofline"
-for v in "" "--no-head-prologue" "" "--no-head-prologue"; do
-  timeout 300 python bench.py $COMMON $v > $O/r06_bench_k_tmp.log 2>&1
-  python - "$O/r06_bench_k_tmp.log" "prologue:${v:-on}" <<'PY'
-import json, sys
-l = [x for x in open(sys.argv[1]) if x.startswith('{')]
-if not l:
-    print(sys.argv[2], "NO LINE"); print(open(sys.argv[1]).read()[-1500:])
-else:
-    d = json.loads(l[-1]); print(sys.argv[2], d['value'], d['ms_per_step'], d['peak_hbm_gb'])
+rm -f $O/parity_report.jsonl $O/pmc_traffic.json
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/r06_pytest_q_full.log 2>&1; echo "full suite rc $?"; tail -3 $O/r06_pytest_q_full.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke_q.log 2>&1; echo "smoke rc $?"; tail -2 $O/r06_smoke_q.log
+timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r06_bench_q_driver_style.log 2> $O/r06_bench_q_driver_style.err; echo "bench rc $?"
+python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r06_bench_q_driver_style.log') if x.startswith('{')]
+if l:
+    d=json.loads(l[-1])
+    print({k:d[k] for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
+    r=d['roofline']; print({k:v for k,v in r.items() if k in ('achieved','frac','frac_mfma_issued','traffic','traffic_note','launches','kernel_ms_per_step')})
+    print('fast', d['fast_mode'] and {k:d['fast_mode'].get(k) for k in ('images_per_s','fwd_ms_per_img','error')}, 'parity', d['parity'] and d['parity'].get('worst_head_rel_err'))
+    print('x3', d['full_fp32_mode'])
+    print('ref_batch', d['ref_batch'])
 PY
-done 2>&1 | tee $O/r06_bench_k_head_prologue_ab.log
+cd /tmp; export TMPDIR=/tmp
+Q="--no-cpu-baseline --no-torch-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-fwd --no-roofline"
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_q -o q -- python $REPO/bench.py --steps 3 --warmup 1 $Q > $O/r06_prof_q_run.log 2>&1
+python $REPO/tools/prof_summary.py /tmp/prof_q 5 > $O/r06_train_ns6_b126_x3f_final.txt 2>&1
+head -4 $O/r06_train_ns6_b126_x3f_final.txt | cut -c1-150
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f -o f -- python $REPO/bench.py --steps 1 --warmup 1 $Q > $O/r06_pmc_f_run.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w -o w -- python $REPO/bench.py --steps 1 --warmup 1 $Q > $O/r06_pmc_w_run.log 2>&1
+cd $REPO
+python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w 'gemm_ring3_kernel' $O/pmc_traffic.json
+python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w 'gemm_dma_kernel<1>' $O/pmc_traffic.json
+cat $O/pmc_traffic.json | head -40
