@@ -300,7 +300,7 @@ int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream);   /* in = dout, ou
  *   stats     : mean_out[z][c] = batch mean, m2_out[z][c] = sum_r (x - mean)^2 (centred; biased variance = m2 / rows).  Two-level
  *               deterministic reduction through the caller's workspace `ws` (mtt_bn_reduce_ws_floats(rows, C, Z) floats); no atomics,
  *               nothing to zero.  (mean, m2, rows) triplets of several ranks merge exactly (SyncBatchNorm) with Chan's update.
- *   apply     : y = act((x-mean)*rstd*gamma+beta), channels C..pad8(C) written as zeros.
+ *   apply     : y = act((x-mean)*rstd*gamma+beta), channels C..ld-1 written as zeros.
  *   bwd_reduce: dsum[z][c] = sum_r du, dsumxh[z][c] = sum_r du*xhat with du = dy*act'(u)   (same workspace, written not accumulated)
  *   bwd_apply : dx = gamma*rstd*(du - dsum/rows - xhat*dsumxh/rows)   (multi-rank: pass the all-reduced sums scaled by rows/rows_total) */
 typedef struct {

@@ -854,7 +854,7 @@ class TaskHeadsFn(Function):
                 if y.dtype == torch.bfloat16:                     # (the activated map saved as bf16: ConvHeadFn's prologue form) both operands bf16
                     ga = g16
             else:
-                _gemm(g, packs[z][0], dy[z], rows, ld, n, prec, b_op=OP_R, lda=g.shape[1], ldb=Kp, ldd=ld, n_store=ld)
+                _gemm(g, packs[z][0], dy[z], rows, min(ld, Kp), n, prec, b_op=OP_R, lda=g.shape[1], ldb=Kp, ldd=ld, n_store=ld)
             dW = _wgrad(ga, y[z], n, Kp, prec)
             dws.append(dW[:, :math.prod(wshapes[z][1:])].reshape(wshapes[z]))
             dbs.append(_colsum(g, n))

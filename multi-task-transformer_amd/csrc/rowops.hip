@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256) void bn_final_kernel(const mtt_bn_desc d, int 
 // division in the loop), 256 / C8 rows in flight per block.
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_rowwise_kernel(const mtt_bn_desc d, int rows_per_block) {
-  const int C8 = (d.C + 7) >> 3;
+  const int C8 = (int)(d.ld >> 3);                         // the whole pitch: channels C .. ld-1 are written as zeros
   const int lanes = C8 >= 256 ? 1 : 256 / C8;
   const int c8_0 = C8 >= 256 ? threadIdx.x : threadIdx.x % C8;
   const int rl = C8 >= 256 ? 0 : threadIdx.x / C8;
@@ -1649,6 +1649,8 @@ extern "C" int mtt_bilinear_bwd(const mtt_resize_desc* d, void* stream) {
   if (!d->out_nchw && (d->ld_in % 8)) return MTT_E_ALIGN;
   const int sc = d->out_nchw && d->Hin > 1 && d->Win > 1 && d->Hout % d->Hin == 0 && d->Wout % d->Win == 0 && d->Hout / d->Hin == d->Wout / d->Win &&
                  !((uintptr_t)d->in & 7) ? d->Hout / d->Hin : 0;
+  // (an integer-scale NHWC twin with constant tent weights was built and measured in round 6: cfg4's 17 stage resizes 98.8 vs 100.4 ms over
+  // five passes — they are bound by re-reading the fp32 gradient maps, not by the weight evaluation: profiles/r06_train_cfg4_b32_x3f_s.txt)
   const dim3 grid((unsigned)((cols + 255) / 256), d->Hin, d->B);
   if (sc == 4) hipLaunchKernelGGL(bilinear_bwd_nchw_int_kernel<4>, grid, dim3(256), 0, S_, *d);
   else if (sc == 2) hipLaunchKernelGGL(bilinear_bwd_nchw_int_kernel<2>, grid, dim3(256), 0, S_, *d);
@@ -1664,7 +1666,7 @@ static int colreduce_cfg(const mtt_bn_desc* d, int& nblk, int& rpb) {
   return 0;
 }
 static void bn_rowwise_cfg(const mtt_bn_desc* d, int& nblk, int& rpb) {
-  const int C8 = (d->C + 7) / 8;
+  const int C8 = (int)(d->ld / 8);
   const int lanes = C8 >= 256 ? 1 : 256 / C8;
   int64_t nb = (d->rows + 4 * lanes - 1) / (4 * lanes); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;   // >= 4 rows per lane
   rpb = (int)((d->rows + nb - 1) / nb);

@@ -334,7 +334,7 @@ class TransformerDecoder(nn.Module):
                 buf[:, :Co0] = se0.weight.detach().permute(2, 3, 1, 0).reshape(9, Co0, C)      # [ci, co, ky, kx] -> [tap, co, ci]
                 return ops.pack_matrix(buf.reshape(9 * Co0p, C), prec)[None]
         wall = ops._cached(('se0', prec.name, id(se0.weight)), [se0.weight], build_wall)
-        yall = ops.linear(taps[0], wall, 9 * Co0p, prec)[0]
+        yall = ops.linear(taps[0], wall, 9 * Co0p, prec, ldd=9 * Co0p)[0]
         bias0 = ops._cached(('se0b', id(se0.bias)), [se0.bias],
                             lambda: torch.cat([se0.bias.detach(), se0.bias.new_zeros(Co0p - Co0)]).contiguous())
         back0 = torch.empty(B * 4 * h * w, Co0p, dtype=prec.adt, device=dev)
@@ -505,7 +505,7 @@ class TransformerDecoder(nn.Module):
                           lambda: self._pack_head_cols(at.proj.weight, D, heads, hd, hdp, prec))
         om = torch.empty(T, B * nq, Dp, dtype=prec.adt, device=dev)
         ops.call("gemm", A=o, B=wpo, D=om, M=B * nq, N=D, K=Dh, a_op=OP_K, b_op=OP_K, a_dtype=dtype_code(o), b_dtype=dtype_code(wpo),
-                 d_dtype=dtype_code(om), prec=prec.code, lda=Dh, ldb=Dh, ldd=Dp, a_mb=nq, a_bs=T * nq * Dh, batch=T, batch_inner=1,
+                 d_dtype=dtype_code(om), prec=prec.code, lda=Dh, ldb=wpo.shape[-1], ldd=Dp, a_mb=nq, a_bs=T * nq * Dh, batch=T, batch_inner=1,
                  a_zo=nq * Dh, b_zo=0, d_zo=B * nq * Dp, alpha=1.0, colshift=at.proj.bias.detach(), n_store=Dp)
         # bilinear upsample of the attention output to the stage grid + residual (invpt.py:300-307)
         X2 = Xf.clone()

@@ -69,7 +69,7 @@ class ConvT3x3s2Fn(Function):
                 buf[:, :Co] = weight.detach().permute(2, 3, 1, 0).reshape(9, Co, C)           # [ci, co, ky, kx] -> [tap, co, ci]
                 return ops.pack_matrix(buf.reshape(9 * Cop, C), prec)[None]
         wall = ops._cached(('se0', prec.name, id(weight)), [weight], build)
-        yall = ops.linear(x, wall, 9 * Cop, prec)[0]
+        yall = ops.linear(x, wall, 9 * Cop, prec, ldd=9 * Cop)[0]
         bpad = torch.zeros(Cop, dtype=torch.float32, device=x.device)
         bpad[:Co] = bias
         out = torch.empty(B * 4 * H * W, Cop, dtype=prec.adt, device=x.device)
@@ -312,8 +312,9 @@ class MultiScaleSumFn(Function):
 
 
 def _check8(*dims):
-    if any(d % 8 for d in dims):
-        raise NotImplementedError(f"InvPT training path needs channel / head dims that are multiples of 8, got {dims}")
+    if any(d != pad8(d) for d in dims):
+        raise NotImplementedError("InvPT training path needs channel / head dims that are their own channel pitch (multiples of 8; of 32 from "
+                                  f"{ops.PITCH32_FROM} channels on), got {dims}")
 
 
 def vit_taps(vit, img):

@@ -17,8 +17,14 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, OP_CONV_K, OP_CONV_R, OP_K, OP_R, PREC_BF16, PREC_X3, SPLIT)
 
 
+PITCH32_FROM = 1 << 30     # channel counts >= this take a pitch that is a multiple of 32 (see pad8)
+
+
 def pad8(n):
-    return (n + 7) // 8 * 8
+    """The channel pitch of a map with n channels: the next multiple of 8 — of 32 from PITCH32_FROM channels on, so that the K loop of a GEMM or
+    3x3 implicit GEMM reading the map is whole 32-deep LDS-DMA steps (176 -> 192, 232 -> 256, 456 -> 480, 784 -> 800: the split-plane / ring
+    kernels instead of the register-staged ones).  Every kernel writes the channels C..ld-1 of its output maps as zeros."""
+    return (n + 31) // 32 * 32 if n >= PITCH32_FROM else (n + 7) // 8 * 8
 
 
 DEFAULT_PREC = "x3f"        # arithmetic mode of a model whose config does not name one (`p.mtt_prec`): the tolerance-compliant mode
@@ -171,7 +177,7 @@ def cast_rows(src2d, dst_dtype):
 def pack_matrix(w2d, prec):
     """[N, K] fp32 -> [N, pad8(K)] in the activation dtype (zero padded); the lazily cached one-off packs (InvPT, deconv heads)."""
     N, K = w2d.shape
-    if prec.adt == torch.float32 and K % 8 == 0 and w2d.is_contiguous():
+    if prec.adt == torch.float32 and K == pad8(K) and w2d.is_contiguous():
         return w2d
     return cast2d(w2d.contiguous(), N, K, K, prec.adt)
 
@@ -393,7 +399,7 @@ def pack_linear(weights, prec, tag):
     """List of Z parameters [N, K] (or 1x1 conv [N, K, 1, 1]) -> one [Z, N, Kp] buffer in the activation dtype (zero padded)."""
     N, K = _w2d(weights[0])
     Kp, Z = pad8(K), len(weights)
-    if prec.adt == torch.float32 and Z == 1 and K % 8 == 0 and weights[0].is_contiguous():
+    if prec.adt == torch.float32 and Z == 1 and K == Kp and weights[0].is_contiguous():
         return weights[0].detach().reshape(1, N, K)               # fp32 storage: the parameter itself is the operand
     return seg_pack((tag, prec.name, tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, N, Kp, dtype=prec.adt, device=weights[0].device),
@@ -550,7 +556,7 @@ def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=No
         a_mb, a_bs, lda = 0, 0, xv.shape[2]
         a_z = xv.stride(0) if xv.shape[0] > 1 else 0
         assert xv.shape[0] in (1, Z) and lda >= Kp
-    Np = pad8(N)
+    Np = ldd if (out is None and ldd is not None) else pad8(N)      # a new output takes the channel pitch of N — or the caller's (composite widths: 9 tap planes)
     if out is None:
         out = Split.empty((Z, M, Np), x.device) if out_dtype == "split" else torch.empty(Z, M, Np, dtype=out_dtype or prec.adt, device=x.device)
     oh = _hi(out)
@@ -683,7 +689,7 @@ def upconv3x3(x, w9, Co, B, h, w, prec, *, bias=None, colscale=None, act=ACT_NON
         Z, M, Kp = x.shape
         x = split_cast(x.reshape(Z * M, Kp))
         x = Split(x.hi.view(Z, M, Kp), x.lo.view(Z, M, Kp))
-    z = linear(x, w9, w9.shape[1], prec, out_dtype=torch.float32 if isinstance(w9, Split) else None)
+    z = linear(x, w9, w9.shape[1], prec, out_dtype=torch.float32 if isinstance(w9, Split) else None, ldd=w9.shape[1])   # nine planes of pitch Cop each
     return upconv4_expand(z, Co, B, h, w, bias=bias, colscale=colscale, act=act)
 
 
@@ -785,7 +791,8 @@ def ctr_mix(fea, wmix, B, C, acc=None, out_dtype=torch.float32):
     """fea [T, rows, ld]; wmix fp32 [B, T, T] -> acc (+)= mix.  Returns [T, rows, ld] in fp32 (or `out_dtype` bf16 when there is no `acc`)."""
     T, rows, ld = fea.shape
     out = acc if acc is not None else torch.empty(T, rows, ld, dtype=out_dtype, device=fea.device)
-    call("ctr_mix", fea=fea, out=out, wmix=wmix, T=T, B=B, rows_per_b=rows // B, ld=ld, C=C,
+    # the mix is linear and the padding channels of `fea` are zero: run it over the whole pitch, so that `out`'s padding is written (as zeros) too
+    call("ctr_mix", fea=fea, out=out, wmix=wmix, T=T, B=B, rows_per_b=rows // B, ld=ld, C=ld,
          fea_dtype=dtype_code(fea), accumulate=1 if acc is not None else 0, out_dtype=dtype_code(out))
     return out
 

@@ -184,8 +184,8 @@ def _lin(model, x, layer, tag, out_dtype=None):
         if key not in _zero_bias:
             _zero_bias[key] = torch.zeros(layer.weight.shape[0], dtype=torch.float32, device=x.device)
         bias = _zero_bias[key]
-    if x.shape[-1] % 8:                                   # reduction length not a multiple of 8 (chan_kv on a 6 x 9 map): zero columns
-        x = torch.nn.functional.pad(x, (0, 8 - x.shape[-1] % 8))
+    if x.shape[-1] != ops.pad8(x.shape[-1]):              # reduction length off the channel pitch (chan_kv on a 6 x 9 map): zero columns
+        x = torch.nn.functional.pad(x, (0, ops.pad8(x.shape[-1]) - x.shape[-1]))
     y = BLinearFn.apply(x, layer.weight.shape[0], 'plain', None, out_dtype, model.prec, tag, None, layer.weight, bias)
     return y[0][:, :layer.weight.shape[0]]
 

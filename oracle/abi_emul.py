@@ -520,7 +520,7 @@ def _bn_maps(kw):
 
 
 def _bn_pad(kw, t, idx):
-    C8 = (kw["C"] + 7) // 8 * 8
+    C8 = kw["ld"]                   # the whole pitch
     if C8 > kw["C"]:
         pad = idx[:, :1] + torch.arange(kw["C"], C8)[None, :]
         _wr(t, pad, torch.zeros(kw["rows"], C8 - kw["C"], dtype=torch.float64))

@@ -680,6 +680,12 @@ def row_cases():
             kw = {"in": rnd(g, 2, C, sc * Hi, sc * Wi), "out": rnd(g, 2 * Hi * Wi, ld), "B": 2, "C": C, "Hin": Hi, "Win": Wi, "Hout": sc * Hi,
                   "Wout": sc * Wi, "ld_in": ld, "ld_out": 0, "in_dtype": F32, "out_dtype": F32, "out_nchw": 1, "accumulate": 1}
             cases.append((f"bilinear_bwd_nchw_x{sc}_{dt}_{Hi}x{Wi}_c{C}", "bilinear_bwd", kw, TOL_ROW))
+        # integer scales of the NHWC form (InvPT stage resizes, the x4 / x2 feature upsamples), ragged 8-channel groups, 2 x 2 maps
+        for (Hi, Wi, sc, C) in ((6, 10, 2, 20), (2, 2, 4, 9), (3, 5, 2, 8), (7, 3, 4, 33)):
+            ld = (C + 7) // 8 * 8
+            kw = {"in": rnd(g, 2 * sc * Hi * sc * Wi, ld, dtype=DT[dt]), "out": rnd(g, 2 * Hi * Wi, ld), "B": 2, "C": C, "Hin": Hi, "Win": Wi,
+                  "Hout": sc * Hi, "Wout": sc * Wi, "ld_in": ld, "ld_out": ld, "in_dtype": dt, "out_dtype": F32, "out_nchw": 0, "accumulate": 1}
+            cases.append((f"bilinear_bwd_nhwc_x{sc}_{dt}_{Hi}x{Wi}_c{C}", "bilinear_bwd", kw, TOL_ROW))
     for dt in (F32, BF16):
         rows, C, ld = 300, 52, 56
         x = rnd(g, rows, ld, dtype=DT[dt]); x[:, C:] = 0

@@ -7,7 +7,8 @@ from mtt_amd import ops
 
 
 def pad8(n):
-    return (n + 7) // 8 * 8
+    import mtt_amd
+    return mtt_amd.ops.pad8(n)              # the product's channel-pitch rule (multiples of 8; of 32 from ops.PITCH32_FROM channels on)
 
 
 def _params(device, shapes, seed=0):

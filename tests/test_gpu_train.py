@@ -65,6 +65,9 @@ def _two_steps_bitwise(cfg, prec, B, kind):
     import conftest
     import mtt_amd
     from oracle import weights
+    if kind == "IP":
+        import train_check
+        train_check.skip_unless_own_pitch(cfg)
     model = conftest.build_product_model(cfg, prec, "cuda")
     contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
     sd = {k: v.cuda() for k, v in weights.synth_state_dict(contract, 0).items()}
