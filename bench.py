@@ -131,6 +131,9 @@ def parse():
                          "prediction GEMM's operand load (round 6)")
     ap.add_argument("--no-gelu-daux", action="store_true",
                     help="A/B: GELU'(z) evaluated in the fc2 input-gradient epilogue (round 5) instead of stored by the fc1 epilogue (round 6)")
+    ap.add_argument("--pitch32-from", type=int, default=None,
+                    help="A/B: ops.PITCH32_FROM — channel counts from this value on take a channel pitch that is a multiple of 32 (a huge value = the "
+                         "multiple-of-8 pitch of rounds 1-5 everywhere)")
     ap.add_argument("--graphed-worker", action="store_true", help="(internal) the subprocess leg of ref_batch.graphed")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (256 threads thrash on this workload)")
@@ -586,6 +589,8 @@ def main():
         mtt_amd.ops.GEMM_VARIANT = a.gemm_variant
     if a.no_gelu_daux:
         mtt_amd.autograd_path.GELU_DAUX = False
+    if a.pitch32_from is not None:
+        mtt_amd.ops.PITCH32_FROM = a.pitch32_from
     if a.no_head_prologue:
         mtt_amd.autograd_path.HEAD_PROLOGUE = False
     if a.measure_no_repack:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 10
+#define MTT_ABI_VERSION 11
 
 /* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
  * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
@@ -507,6 +507,9 @@ int mtt_gather_rows(const mtt_gather_desc* d, void* stream);
 typedef struct {
   const void* qkv; void* out; float* rawmap; const float* bias; const float* mask; const int32_t* pix;
   int32_t nwin, nW, nH, T, ws2, dtype; float scale; int64_t map_ld, map_off;
+  int32_t mfma;                  /* ABI 11, fp32 storage only: 1 = matrix-core arithmetic — forward: every product as 3 bf16 MFMAs on hi / lo split
+                                    operands (fp32-class, the x3 / x3f modes); backward: bf16 MFMAs (the bf16 backward of the x3f mode).
+                                    0 = the exact fp32 VALU kernels.  bf16 storage always runs on the matrix cores. */
 } mtt_winattn_desc;
 int mtt_winattn_fwd(const mtt_winattn_desc* d, void* stream);
 /* backward (d as in the forward, d->out = the forward's output): dout (dtype) [nwin, N, nH*32]; drawmap fp32 = gradient of rawmap (same

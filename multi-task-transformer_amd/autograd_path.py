@@ -540,6 +540,10 @@ class ModulateFn(Function):
 
 
 # =================================================================================================
+AUTO_SPLIT = True             # A/B switch of BLinearFn's own split pass (x3f, fp32 inputs)
+AUTO_SPLIT_MIN_ROWS = 2048
+
+
 class BLinearFn(Function):
     """Task-batched linear / 1x1 conv: y[z] = x[z] @ W[z]^T + b[z].  layout 'plain' -> [Z, M, pad8(N)];
     'catpair' -> [Z/2, M, 2*pad8(N)] (z = 2t+s written at column offset s*pad8(N): the reference's
@@ -553,7 +557,16 @@ class BLinearFn(Function):
         Z = len(wb) // 2
         ws, bs = wb[:Z], wb[Z:]
         xin = ops.Split(x, xlo) if xlo is not None else x
-        if xlo is not None:
+        # x3f with an fp32 input nobody split yet (the Swin / InvPT Linears: window tokens, attention outputs, merged patches): one
+        # split pass, then the split-plane LDS-DMA kernel instead of the register-staged x3 one (which splits every tile of both operands
+        # while staging: 8.6 % of the Swin-B step); the hi plane is saved as the backward's bf16 operand instead of the fp32 rows
+        auto = (xlo is None and AUTO_SPLIT and prec.split and x.dtype == torch.float32 and x.is_contiguous() and layout == 'plain'
+                and kmap is None and out_dtype != "split" and x.shape[-2] >= AUTO_SPLIT_MIN_ROWS
+                and ops.split_gemm_ok(ops._w2d(ws[0])[1]) and x.shape[-1] == ops._w2d(ws[0])[1])
+        if auto:
+            sp = ops.split_cast(x.view(-1, x.shape[-1]))
+            xin = ops.Split(sp.hi.view(x.shape), sp.lo.view(x.shape))
+        if xlo is not None or auto:
             wpack = ops.pack_linear_split(list(ws), tag) if kmap is None else ops.pack_kmap_split(list(ws), N, kmap[0], kmap[1], tag)
         elif kmap is None:
             wpack = ops.pack_linear(list(ws), prec, tag)
@@ -567,8 +580,8 @@ class BLinearFn(Function):
             ops.linear(xin, wpack, N, prec, bias=bias, out=out, batch_inner=2, d_z=(M * 2 * Np, Np), ldd=2 * Np, n_store=Np)
         else:
             out = ops.linear(xin, wpack, N, prec, bias=bias, out_dtype=out_dtype)
-        ctx.save_for_backward(x, ops._hi(wpack))          # split: the hi planes ARE the bf16 operands of the (bf16) backward
-        ctx.meta = (Z, N, layout, kmap, prec, [tuple(w.shape) for w in ws])
+        ctx.save_for_backward(xin.hi if auto else x, ops._hi(wpack))   # split: the hi planes ARE the bf16 operands of the (bf16) backward
+        ctx.meta = (Z, N, layout, kmap, prec, [tuple(w.shape) for w in ws], x.dtype)
         if isinstance(out, ops.Split):
             ctx.mark_non_differentiable(out.lo)
             ctx.set_materialize_grads(False)             # no zero tensor for the lo plane's (non-existent) gradient
@@ -578,9 +591,8 @@ class BLinearFn(Function):
     @staticmethod
     def backward(ctx, dy, *_):
         x, wpack = ctx.saved_tensors
-        Z, N, layout, kmap, prec, wshapes = ctx.meta
+        Z, N, layout, kmap, prec, wshapes, xdt = ctx.meta
         prec = prec.bwd
-        xdt = x.dtype
         x, dy = _to_bwd(x, prec), _to_bwd(dy.contiguous(), prec)
         M, Np, Kp = x.shape[-2], pad8(N), wpack.shape[-1]
         if layout == 'catpair':

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const mtt_gather_desc 
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };     // 16-byte load that only promises 4-byte alignment
 
 template <int NKT>
-__global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_desc d) {
+__global__ __launch_bounds__(256, 2) void winattn_bf16_kernel(const mtt_winattn_desc d) {
   constexpr int NP = NKT * 16, PITCH = NP + 8;     // V^T rows: NP keys (+ 8 bf16 of padding: 2-way instead of 8-way bank conflicts)
   __shared__ __attribute__((aligned(16))) bf16_t vT[32 * PITCH];
   const int nH = d.nH, T = d.T, ws2 = d.ws2, N = T + ws2, C = nH * 32, ld = 3 * C;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_des
   for (int key = tid; key < NP; key += 256) {
     u32x4 v4[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v4[q] = key < N ? *(const u32x4*)(base + 2 * C + (int64_t)key * ld + q * 8) : (u32x4){0u, 0u, 0u, 0u};
+    for (int q = 0; q < 4; ++q) v4[q] = key < N ? *(const u32x4*)(base + (2 * C + key * ld + q * 8)) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -111,12 +111,12 @@ __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_des
   for (int qt = wave; qt < nqt; qt += 4) {
     const int query = qt * 16 + li;
     const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
-    const u32x4 qf = query < N ? *(const u32x4*)(base + (int64_t)query * ld + lg * 8) : zero4;
+    const u32x4 qf = query < N ? *(const u32x4*)(base + (query * ld + lg * 8)) : zero4;
     f32x4 s[NKT];
 #pragma unroll
     for (int j = 0; j < NKT; ++j) {
       const int krow = j * 16 + li;
-      const u32x4 kf = krow < N ? *(const u32x4*)(base + C + (int64_t)krow * ld + lg * 8) : zero4;
+      const u32x4 kf = krow < N ? *(const u32x4*)(base + (C + krow * ld + lg * 8)) : zero4;
       s[j] = mfma16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});
     }
     // raw prompt logits -> image layout
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_des
       const int kb = j * 16 + lg * 4;
       float add[4] = {0.f, 0.f, 0.f, 0.f};
       if (qwin && kb >= T && kb + 3 < N) {
-        const int64_t o = (int64_t)(query - T) * ws2 + (kb - T);
+        const int o = (query - T) * ws2 + (kb - T);               // 32-bit offsets from uniform bases
         const F4u bb = *(const F4u*)(bias_h + o);
         add[0] = bb.x; add[1] = bb.y; add[2] = bb.z; add[3] = bb.w;
         if (mask_w) { const F4u mm = *(const F4u*)(mask_w + o); add[0] += mm.x; add[1] += mm.y; add[2] += mm.z; add[3] += mm.w; }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void winattn_bf16_kernel(const mtt_winattn_des
         for (int r = 0; r < 4; ++r) {
           const int key = kb + r;
           if (key >= T && key < N) {
-            const int64_t o = (int64_t)(query - T) * ws2 + (key - T);
+            const int o = (query - T) * ws2 + (key - T);
             add[r] = bias_h[o] + (mask_w ? mask_w[o] : 0.f);
           }
         }
@@ -681,12 +681,420 @@ extern "C" int mtt_gather_rows(const mtt_gather_desc* d, void* stream) {
   return (int)hipGetLastError();
 }
 
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Window attention on fp32 storage with matrix-core arithmetic (mtt_winattn_desc.mfma = 1, round 6): the structure of winattn_bf16_kernel
+// with every product as three bf16 MFMAs on hi / lo split operands (Qh Kh + Qh Kl + Ql Kh; Ph Vh + Ph Vl + Pl Vh; fp32 accumulate,
+// fp32-class products like the x3 GEMMs).  Q / K rows are split in registers from 32-byte fp32 loads, V^T goes to LDS as two planes,
+// P is split in registers.  Replaces the one-thread-per-query exact VALU kernel in the x3f / x3 forward (9 % of the Swin-B x3f step).
+// ------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void winattn_x3_kernel(const mtt_winattn_desc d) {
+  constexpr int NP = NKT * 16, PITCH = NP + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t vTh[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t vTl[32 * PITCH];
+  const int nH = d.nH, T = d.T, ws2 = d.ws2, N = T + ws2, C = nH * 32, ld = 3 * C;
+  const int win = blockIdx.x / nH, h = blockIdx.x % nH;
+  const int wl = win % d.nW, b = win / d.nW;
+  const float* base = (const float*)d.qkv + (int64_t)win * N * ld + h * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+
+  for (int key = tid; key < NP; key += 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x4 hi, lo;
+      load8<true>(base, 2 * C + key * ld + q * 8, MTT_F32, key < N, hi, lo);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vTh[(q * 8 + 2 * e) * PITCH + key] = (bf16_t)(hi[e] & 0xffffu);
+        vTh[(q * 8 + 2 * e + 1) * PITCH + key] = (bf16_t)(hi[e] >> 16);
+        vTl[(q * 8 + 2 * e) * PITCH + key] = (bf16_t)(lo[e] & 0xffffu);
+        vTl[(q * 8 + 2 * e + 1) * PITCH + key] = (bf16_t)(lo[e] >> 16);
+      }
+    }
+  }
+  __syncthreads();
+
+  const float* bias_h = d.bias + (int64_t)h * ws2 * ws2;
+  const float* mask_w = d.mask ? d.mask + (int64_t)wl * ws2 * ws2 : nullptr;
+  const int nqt = (N + 15) / 16;
+  const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int query = qt * 16 + li;
+    u32x4 qh, ql;
+    load8<true>(base, query * ld + lg * 8, MTT_F32, query < N, qh, ql);
+    f32x4 s[NKT];
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int krow = j * 16 + li;
+      u32x4 kh, kl;
+      load8<true>(base, C + krow * ld + lg * 8, MTT_F32, krow < N, kh, kl);
+      s[j] = mfma16(kh, qh, mfma16(kh, ql, mfma16(kl, qh, z4)));
+    }
+    if (qt == 0 && li < T && d.rawmap) {
+      float* row = d.rawmap + (((int64_t)b * nH + h) * T + li) * d.map_ld + d.map_off;
+      const int32_t* px = d.pix + (int64_t)wl * ws2;
+#pragma unroll
+      for (int j = 0; j < NKT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = j * 16 + lg * 4 + r;
+          if (key >= T && key < N) {
+            const int pp = px[key - T];
+            if (pp >= 0) row[pp] = s[j][r];
+          }
+        }
+    }
+    const bool qwin = query >= T && query < N;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int kb = j * 16 + lg * 4;
+      float add[4] = {0.f, 0.f, 0.f, 0.f};
+      if (qwin && kb >= T && kb + 3 < N) {
+        const int o = (query - T) * ws2 + (kb - T);
+        const F4u bb = *(const F4u*)(bias_h + o);
+        add[0] = bb.x; add[1] = bb.y; add[2] = bb.z; add[3] = bb.w;
+        if (mask_w) { const F4u mm = *(const F4u*)(mask_w + o); add[0] += mm.x; add[1] += mm.y; add[2] += mm.z; add[3] += mm.w; }
+      } else if (qwin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + r;
+          if (key >= T && key < N) {
+            const int o = (query - T) * ws2 + (key - T);
+            add[r] = bias_h[o] + (mask_w ? mask_w[o] : 0.f);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[j][r] * d.scale + add[r];
+        if (kb + r >= N) v = -INFINITY;
+        s[j][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = groups_max(mx);
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = expf(s[j][r] - mx);
+        s[j][r] = pv;
+        l += pv;
+      }
+    l = groups_sum(l);
+    f32x4 o[2] = {z4, z4};
+#pragma unroll
+    for (int c = 0; c < NKT / 2; ++c) {
+      const f32x4 a = s[2 * c], e = s[2 * c + 1];
+      const u32x4 ph = (u32x4){pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(e[0], e[1]), pack2(e[2], e[3])};
+      const u32x4 pl = (u32x4){pack2(a[0] - lo_of(ph[0]), a[1] - hi_of(ph[0])), pack2(a[2] - lo_of(ph[1]), a[3] - hi_of(ph[1])),
+                               pack2(e[0] - lo_of(ph[2]), e[1] - hi_of(ph[2])), pack2(e[2] - lo_of(ph[3]), e[3] - hi_of(ph[3]))};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int off = (dt * 16 + li) * PITCH + 32 * c + 4 * lg;
+        const u32x2 h0 = *(const u32x2*)(vTh + off), h1 = *(const u32x2*)(vTh + off + 16);
+        const u32x2 l0 = *(const u32x2*)(vTl + off), l1 = *(const u32x2*)(vTl + off + 16);
+        const u32x4 vh = (u32x4){h0[0], h0[1], h1[0], h1[1]}, vl = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+        o[dt] = mfma16(vh, ph, mfma16(vh, pl, mfma16(vl, ph, o[dt])));
+      }
+    }
+    if (query < N) {
+      const float inv = 1.0f / l;
+      float* op = (float*)d.out + ((int64_t)win * N + query) * C + h * 32 + lg * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) *(float4*)(op + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window attention backward on the matrix cores (round 6; bf16 products, fp32 accumulate and softmax algebra): bf16 storage, or fp32
+// storage with mtt_winattn_desc.mfma = 1 (the bf16 backward of the x3f mode; operands are rounded while loaded).  One workgroup per
+// (window, head), two passes in the forward kernel's swapped-product layout so that the softmax statistics stay per-lane scalars and no
+// N x N tile goes through LDS:
+//   pass 1, a wave per 16-query tile (lane = one query, 4 keys per tile):  S^T = K Q^T, dP^T = V dO^T (one 16x16x32 MFMA per tile each),
+//           row max / 1 / sum / D = dO . O -> LDS,  g = scale P (dP - D) + draw,  dS_out,  dQ^T += K^T g^T with the C layout of two g tiles
+//           as the B fragment (K^T from LDS in the matching key permutation);
+//   pass 2, a wave per 16-key tile (lane = one key, 4 queries per tile):   S = Q K^T, dP = dO V^T recomputed with the operands swapped,
+//           P from the stored statistics,  dV^T += dO^T P,  dK^T += Q^T g  (dO^T, Q^T from LDS).
+// 7 MFMAs per 16 x 16 tile pair instead of the exact VALU kernel's 5 x 32 FMAs per score (that kernel: 22 % of the Swin-B x3f step).
+// ------------------------------------------------------------------------------------------------
+// 8 consecutive elements at p + off (32-bit element offset from a per-workgroup base: scalar base + 32-bit lane offset addressing) as packed
+// bf16; branch-free: a row beyond the window reads offset 0 and is zeroed afterwards
+template <bool F32>
+MTT_DEV u32x4 wa_frag(const void* p, int off, bool ok) {
+  Raw8<F32> r;
+  off = ok ? off : 0;
+  if constexpr (F32) {
+    r.v0 = *(const float4*)((const float*)p + off);
+    r.v1 = *(const float4*)((const float*)p + off + 4);
+  } else {
+    r.r0 = *(const u32x4*)((const bf16_t*)p + off);
+  }
+  u32x4 hi, lo;
+  cvt8<false, F32>(ok, r, hi, lo);
+  return hi;
+}
+template <int NKT, bool F32>
+__global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_winattn_desc d, const void* dout, const float* drawmap, void* dqkv, float* dS_out) {
+  constexpr int NP = NKT * 16, PITCH = NP + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t kT[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t qT[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t gT[32 * PITCH];       // dO^T
+  __shared__ __attribute__((aligned(16))) float mrow[NP];
+  __shared__ __attribute__((aligned(16))) float linv[NP];
+  __shared__ __attribute__((aligned(16))) float Drow[NP];
+  const int nH = d.nH, T = d.T, ws2 = d.ws2, N = T + ws2, C = nH * 32, ld = 3 * C;
+  const int win = blockIdx.x / nH, h = blockIdx.x % nH;
+  const int wl = win % d.nW, b = win / d.nW;
+  const int64_t base = (int64_t)win * N * ld + h * 32, obase = (int64_t)win * N * C + h * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int dt_ = F32 ? MTT_F32 : MTT_BF16;
+  const int es = F32 ? 4 : 2;
+  const void* Qb = (const char*)d.qkv + base * es;            // this (window, head)'s Q rows; K at + C, V at + 2 C elements; row pitch ld
+  const void* Gb = (const char*)dout + obase * es;            // dO rows (pitch C)
+  const void* Ob = (const char*)d.out + obase * es;           // O rows
+  void* Db = (char*)dqkv + base * es;                         // dQ | dK | dV rows
+
+  for (int row = tid; row < NP; row += 256) {
+    const bool ok = row < N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x4 k4 = wa_frag<F32>(Qb, C + row * ld + q * 8, ok);
+      const u32x4 q4 = wa_frag<F32>(Qb, row * ld + q * 8, ok);
+      const u32x4 g4 = wa_frag<F32>(Gb, row * C + q * 8, ok);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        kT[(q * 8 + 2 * e) * PITCH + row] = (bf16_t)(k4[e] & 0xffffu); kT[(q * 8 + 2 * e + 1) * PITCH + row] = (bf16_t)(k4[e] >> 16);
+        qT[(q * 8 + 2 * e) * PITCH + row] = (bf16_t)(q4[e] & 0xffffu); qT[(q * 8 + 2 * e + 1) * PITCH + row] = (bf16_t)(q4[e] >> 16);
+        gT[(q * 8 + 2 * e) * PITCH + row] = (bf16_t)(g4[e] & 0xffffu); gT[(q * 8 + 2 * e + 1) * PITCH + row] = (bf16_t)(g4[e] >> 16);
+      }
+    }
+  }
+  __syncthreads();
+
+  const float* bias_h = d.bias + (int64_t)h * ws2 * ws2;
+  const float* mask_w = d.mask ? d.mask + (int64_t)wl * ws2 * ws2 : nullptr;
+  const int32_t* px = d.pix + (int64_t)wl * ws2;
+  const float* draw_b = drawmap ? drawmap + ((int64_t)b * nH + h) * T * d.map_ld + d.map_off : nullptr;
+  float* dS_wh = dS_out ? dS_out + ((int64_t)win * nH + h) * ws2 * ws2 : nullptr;
+  const int ntile = (N + 15) / 16;
+  const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- pass 1: a wave per query tile ----
+  for (int qt = wave; qt < ntile; qt += 4) {
+    const int query = qt * 16 + li;
+    const bool qok = query < N;
+    const u32x4 qf = wa_frag<F32>(Qb, query * ld + lg * 8, qok);
+    const u32x4 gf = wa_frag<F32>(Gb, query * C + lg * 8, qok);
+    float Dq = 0.f;
+    if (qok) {
+      float g8[8], o8[8];
+      ld8g(Gb, query * C + lg * 8, dt_, g8);
+      ld8g(Ob, query * C + lg * 8, dt_, o8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Dq = fmaf(g8[e], o8[e], Dq);
+    }
+    Dq = groups_sum(Dq);
+    f32x4 s[NKT];
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int krow = j * 16 + li;
+      const u32x4 kf = wa_frag<F32>(Qb, C + krow * ld + lg * 8, krow < N);
+      s[j] = mfma16(kf, qf, z4);
+      if (NKT > 6 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound what the scheduler hoists (the 256-register cap: no spills)
+    }
+    const bool qwin = query >= T && qok;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int kb = j * 16 + lg * 4;
+      float add[4] = {0.f, 0.f, 0.f, 0.f};
+      if (qwin && kb >= T && kb + 3 < N) {
+        const int o = (query - T) * ws2 + (kb - T);                  // 32-bit offsets from uniform bases (no per-tile 64-bit pointers kept live)
+        const F4u bb = *(const F4u*)(bias_h + o);
+        add[0] = bb.x; add[1] = bb.y; add[2] = bb.z; add[3] = bb.w;
+        if (mask_w) { const F4u mm = *(const F4u*)(mask_w + o); add[0] += mm.x; add[1] += mm.y; add[2] += mm.z; add[3] += mm.w; }
+      } else if (qwin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + r;
+          if (key >= T && key < N) {
+            const int o = (query - T) * ws2 + (key - T);
+            add[r] = bias_h[o] + (mask_w ? mask_w[o] : 0.f);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[j][r] * d.scale + add[r];
+        if (kb + r >= N) v = -INFINITY;
+        s[j][r] = v;
+        mx = fmaxf(mx, v);
+      }
+      if (NKT > 6 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    mx = groups_max(mx);
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(s[j][r] - mx);
+        s[j][r] = pv;
+        l += pv;
+      }
+    l = groups_sum(l);
+    const float inv = 1.0f / l;
+    if (lg == 0) { mrow[query] = mx; linv[query] = qok ? inv : 0.f; Drow[query] = Dq; }
+    // g = scale P (dP - D) + draw  (kept in s), dS_out
+    const bool has_draw = draw_b && query < T;
+    const int drow_off = query * (int)d.map_ld;
+    const bool has_ds = dS_wh && qwin;
+    const int ds_off = (query - T) * ws2 - T;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int kb = j * 16 + lg * 4;
+      const int vrow = j * 16 + li;                      // dP^T tile j = V_j dO^T, consumed at once (no N-long dP row is kept)
+      const u32x4 vf = wa_frag<F32>(Qb, 2 * C + vrow * ld + lg * 8, vrow < N);
+      const f32x4 dpj = mfma16(vf, gf, z4);
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ds[r] = s[j][r] * inv * (dpj[r] - Dq);
+        float g = d.scale * ds[r];
+        if (has_draw) {
+          const int key = kb + r;
+          if (key >= T && key < N) {
+            const int pp = px[key - T];
+            if (pp >= 0) g += draw_b[drow_off + pp];
+          }
+        }
+        s[j][r] = qok ? g : 0.f;
+      }
+      if (has_ds) {
+        if (kb >= T && kb + 3 < N) *(F4u*)(dS_wh + (ds_off + kb)) = (F4u){ds[0], ds[1], ds[2], ds[3]};
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (kb + r >= T && kb + r < N) dS_wh[ds_off + kb + r] = ds[r];
+        }
+      }
+      if (NKT > 6 && (j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 o[2] = {z4, z4};
+#pragma unroll
+    for (int c = 0; c < NKT / 2; ++c) {
+      const u32x4 gb = (u32x4){pack2(s[2 * c][0], s[2 * c][1]), pack2(s[2 * c][2], s[2 * c][3]),
+                               pack2(s[2 * c + 1][0], s[2 * c + 1][1]), pack2(s[2 * c + 1][2], s[2 * c + 1][3])};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16_t* kr = kT + (dt * 16 + li) * PITCH + 32 * c + 4 * lg;
+        const u32x2 lo = *(const u32x2*)kr, hi = *(const u32x2*)(kr + 16);
+        o[dt] = mfma16((u32x4){lo[0], lo[1], hi[0], hi[1]}, gb, o[dt]);
+      }
+    }
+    if (qok) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int at = query * ld + dt * 16 + lg * 4;
+        if (F32) *(float4*)((float*)Db + at) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        else *(u32x2*)((bf16_t*)Db + at) = (u32x2){pack2(o[dt][0], o[dt][1]), pack2(o[dt][2], o[dt][3])};
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2: a wave per key tile ----
+  for (int kt = wave; kt < ntile; kt += 4) {
+    const int key = kt * 16 + li;
+    const bool kok = key < N;
+    const u32x4 kf = wa_frag<F32>(Qb, C + key * ld + lg * 8, kok);
+    const u32x4 vf = wa_frag<F32>(Qb, 2 * C + key * ld + lg * 8, kok);
+    f32x4 dv[2] = {z4, z4}, dk[2] = {z4, z4};
+#pragma unroll 1
+    for (int c = 0; c < NKT / 2; ++c) {                 // (not unrolled: the scheduler would hoist every pair's four fragment loads — spills under the 2-workgroups-per-CU register cap)
+      f32x4 pt[2], gt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * c + u;
+        const int qrow = t * 16 + li;
+        const u32x4 qa = wa_frag<F32>(Qb, qrow * ld + lg * 8, qrow < N);
+        const u32x4 ga = wa_frag<F32>(Gb, qrow * C + lg * 8, qrow < N);
+        const f32x4 sv = mfma16(qa, kf, z4);
+        const f32x4 dpv = mfma16(ga, vf, z4);
+        const int q0 = t * 16 + lg * 4;
+        const float4 m4 = *(const float4*)(mrow + q0), l4 = *(const float4*)(linv + q0), D4 = *(const float4*)(Drow + q0);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w}, DD[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = q0 + r;
+          float pv = 0.f, g = 0.f;
+          if (q < N && kok) {
+            float v = sv[r] * d.scale;
+            if (q >= T && key >= T) {
+              const int o = (q - T) * ws2 + (key - T);
+              v += bias_h[o];
+              if (mask_w) v += mask_w[o];
+            }
+            pv = __expf(v - mm[r]) * ll[r];
+            g = d.scale * pv * (dpv[r] - DD[r]);
+            if (draw_b && q < T && key >= T) {
+              const int pp = px[key - T];
+              if (pp >= 0) g += draw_b[q * (int)d.map_ld + pp];
+            }
+          }
+          pt[u][r] = pv; gt[u][r] = g;
+        }
+      }
+      const u32x4 pb = (u32x4){pack2(pt[0][0], pt[0][1]), pack2(pt[0][2], pt[0][3]), pack2(pt[1][0], pt[1][1]), pack2(pt[1][2], pt[1][3])};
+      const u32x4 gb = (u32x4){pack2(gt[0][0], gt[0][1]), pack2(gt[0][2], gt[0][3]), pack2(gt[1][0], gt[1][1]), pack2(gt[1][2], gt[1][3])};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int off = (dt * 16 + li) * PITCH + 32 * c + 4 * lg;
+        const u32x2 g0 = *(const u32x2*)(gT + off), g1 = *(const u32x2*)(gT + off + 16);
+        const u32x2 q0_ = *(const u32x2*)(qT + off), q1_ = *(const u32x2*)(qT + off + 16);
+        dv[dt] = mfma16((u32x4){g0[0], g0[1], g1[0], g1[1]}, pb, dv[dt]);
+        dk[dt] = mfma16((u32x4){q0_[0], q0_[1], q1_[0], q1_[1]}, gb, dk[dt]);
+      }
+    }
+    if (kok) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int ak = C + key * ld + dt * 16 + lg * 4, av = ak + C;
+        if (F32) {
+          *(float4*)((float*)Db + ak) = make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+          *(float4*)((float*)Db + av) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+        } else {
+          *(u32x2*)((bf16_t*)Db + ak) = (u32x2){pack2(dk[dt][0], dk[dt][1]), pack2(dk[dt][2], dk[dt][3])};
+          *(u32x2*)((bf16_t*)Db + av) = (u32x2){pack2(dv[dt][0], dv[dt][1]), pack2(dv[dt][2], dv[dt][3])};
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
 extern "C" int mtt_winattn_fwd(const mtt_winattn_desc* d, void* stream) {
   if (!d || !d->qkv || !d->out || !d->bias || !d->pix || d->nwin <= 0 || d->nW <= 0 || d->nH <= 0 || d->T < 0 || d->ws2 <= 0) return MTT_E_BADARG;
   if (d->nwin % d->nW) return MTT_E_BADARG;
   const int N = d->T + d->ws2;
   if (N > 160 || d->T > 16) return MTT_E_UNSUPPORTED;
   const dim3 grid((unsigned)(d->nwin * d->nH));
+  if (d->dtype == MTT_F32 && d->mfma) {
+    if (((uintptr_t)d->qkv & 15) || ((uintptr_t)d->out & 15)) return MTT_E_ALIGN;
+    if (N <= 32) hipLaunchKernelGGL(winattn_x3_kernel<2>, grid, dim3(256), 0, S_, *d);
+    else if (N <= 64) hipLaunchKernelGGL(winattn_x3_kernel<4>, grid, dim3(256), 0, S_, *d);
+    else if (N <= 96) hipLaunchKernelGGL(winattn_x3_kernel<6>, grid, dim3(256), 0, S_, *d);
+    else hipLaunchKernelGGL(winattn_x3_kernel<10>, grid, dim3(256), 0, S_, *d);
+    return (int)hipGetLastError();
+  }
   if (d->dtype == MTT_F32) {
     const int smem = N * 33 * 4 * 2;
     hipLaunchKernelGGL(winattn_f32_kernel, grid, dim3(256), smem, S_, *d);
@@ -705,6 +1113,15 @@ extern "C" int mtt_winattn_bwd(const mtt_winattn_desc* d, const void* dout, cons
   if (d->nwin % d->nW) return MTT_E_BADARG;
   const int N = d->T + d->ws2;
   if (N > 160) return MTT_E_UNSUPPORTED;
+  const dim3 grid((unsigned)(d->nwin * d->nH));
+  if (d->dtype == MTT_BF16 || d->mfma) {               // matrix-core backward: bf16 storage, or fp32 storage in the x3f mode's bf16 backward
+    if (((uintptr_t)d->qkv & 15) || ((uintptr_t)d->out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return MTT_E_ALIGN;
+#define MTT_WB(NKT_) do { if (d->dtype == MTT_F32) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<NKT_, true>), grid, dim3(256), 0, S_, *d, dout, drawmap, dqkv, dS_out); \
+                          else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<NKT_, false>), grid, dim3(256), 0, S_, *d, dout, drawmap, dqkv, dS_out); } while (0)
+    if (N <= 32) MTT_WB(2); else if (N <= 64) MTT_WB(4); else if (N <= 96) MTT_WB(6); else MTT_WB(10);
+#undef MTT_WB
+    return (int)hipGetLastError();
+  }
   const int smem = (5 * N * 33 + 3 * N) * 4;
   static std::atomic<unsigned long long> done{0};
   if (int e = mtt_ensure_dyn_lds((const void*)winattn_bwd_kernel, smem, done)) return e;

@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, OP_CONV_K, OP_CONV_R, OP_K, OP_R, PREC_BF16, PREC_X3, SPLIT)
 
 
-PITCH32_FROM = 1 << 30     # channel counts >= this take a pitch that is a multiple of 32 (see pad8)
+PITCH32_FROM = 129         # channel counts >= this take a pitch that is a multiple of 32 (see pad8); 1 << 30 = the multiple-of-8 pitch everywhere
 
 
 def pad8(n):

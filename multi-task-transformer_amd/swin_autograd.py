@@ -20,6 +20,9 @@ from ._lib import ACT_GELU, dtype_code
 from .autograd_path import (BilinearFn, BLinearFn, Conv3x3Fn, LayerNormFn, MlpHalfFn, ModulateFn, _bn_act)
 
 
+WINATTN_MFMA = True        # A/B switch: False = the exact fp32 VALU window-attention kernels on fp32 storage (rounds 2-5)
+
+
 def _gather(src, dst, idx, rows, C, ld_src, ld_dst, B, src_bs, dst_bs, skip_neg=0):
     ops.call("gather_rows", src=src, dst=dst, idx=idx, rows=rows, C=C, ld_src=ld_src, ld_dst=ld_dst, src_dtype=dtype_code(src),
              dst_dtype=dtype_code(dst), B=B, src_bs=src_bs, dst_bs=dst_bs, idx_bs=0, skip_neg=skip_neg)
@@ -83,7 +86,7 @@ class MergeGatherFn(Function):
 
 class WinAttnFn(Function):
     @staticmethod
-    def forward(ctx, qkv, table, rel_index, mask, pix, geo):
+    def forward(ctx, qkv, table, rel_index, mask, pix, geo, prec=None):
         B, nW, nH, T, ws2, N = geo
         Nw, C = T + ws2, nH * 32
         bias = table.detach()[rel_index.view(-1)].view(ws2, ws2, nH).permute(2, 0, 1).contiguous().float()
@@ -91,7 +94,10 @@ class WinAttnFn(Function):
         rawlog = torch.zeros(B, nH, T, N, dtype=torch.float32, device=qkv.device)
         kw = dict(qkv=qkv, out=out, bias=bias, mask=mask, pix=pix, nwin=B * nW, nW=nW, nH=nH, T=T, ws2=ws2, dtype=dtype_code(qkv),
                   scale=32 ** -0.5, map_ld=N, map_off=T)
-        ops.call("winattn_fwd", rawmap=rawlog, **kw)
+        # fp32 storage (x3 / x3f): the forward's products as 3 bf16 MFMAs on split operands (fp32-class, like the x3 GEMMs); the backward of
+        # the x3f mode is the bf16 one (matrix cores), x3's the exact fp32 kernel
+        ops.call("winattn_fwd", rawmap=rawlog, mfma=1 if qkv.dtype == torch.float32 and WINATTN_MFMA else 0, **kw)
+        kw["mfma"] = 1 if (qkv.dtype == torch.float32 and prec is not None and prec.bwd.name == "bf16" and WINATTN_MFMA) else 0
         ctx.kw, ctx.geo, ctx.rel_index = kw, geo, rel_index
         ctx.save_for_backward(table)
         return out, rawlog
@@ -108,7 +114,7 @@ class WinAttnFn(Function):
         ops.call("winattn_bwd", rawmap=None, xargs=[dout, drawlog.contiguous() if drawlog is not None else None, dqkv, dS], **kw)
         dbias = dS.sum(0).permute(1, 2, 0).reshape(ws2 * ws2, nH)
         dtable = torch.zeros_like(table).index_add_(0, ctx.rel_index.view(-1), dbias)
-        return dqkv, dtable, None, None, None, None
+        return dqkv, dtable, None, None, None, None, None
 
 
 def _chan_split(t, B, nh, nw, wh, ww):          # [B, X, ce] -> [B, nwin, X, wh*ww]   ('b t (nh h nw w) -> b (nh nw) t (h w)')
@@ -291,7 +297,7 @@ def _block(model, blk, tag, XT, B, T, res):
     chan_p = _lin(model, prompts.to(adt), blk.token_trans, tag + ('tt',), torch.float32)              # [B*T, ce]
     wtok = WindowGatherFn.apply(xn, True, part, rev, (B, N, T, nW, Nw, C))
     qkv = _lin(model, wtok, a.qkv, tag + ('qkv',)).contiguous()
-    ao, rawlog = WinAttnFn.apply(qkv, a.relative_position_bias_table, a.relative_position_index, blk.attn_mask, pix, (B, nW, nH, T, ws2, N))
+    ao, rawlog = WinAttnFn.apply(qkv, a.relative_position_bias_table, a.relative_position_index, blk.attn_mask, pix, (B, nW, nH, T, ws2, N), prec)
     ao_img = WindowGatherFn.apply(ao, False, part, rev, (B, N, T, nW, Nw, C))
     po = _lin(model, ao_img, a.proj, tag + ('proj',))                                                 # [B*N, C] activation dtype
     branch = po.float()
@@ -353,15 +359,20 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, res, C, hg):
     tar, F = p.level_embed_dim, p.final_embed_dim
     tarp = ops.pad8(tar)
     nwin = int(math.isqrt(p.chan_nheads))
-    mod = ModulateFn.apply(xsrc.contiguous(), rawlog, rawchan, (B, N, T, C, h, w, nwin, hg), prec)
+    sp = model._decoder_split(C)         # x3f: modulate and the fea_decode epilogue write hi / lo planes, both GEMMs on the split-plane kernel
+    mod = ModulateFn.apply(xsrc.contiguous(), rawlog, rawchan, (B, N, T, C, h, w, nwin, hg), prec, sp)
+    mod, mod_lo = mod if sp else (mod, None)
     dec_w, dec_b = [], []
     for t in names:
         dec_w += [model.fea_decode_spa[il][t][0].weight, model.fea_decode_chan[il][t][0].weight]
         dec_b += [model.fea_decode_spa[il][t][0].bias, model.fea_decode_chan[il][t][0].bias]
-    cat = BLinearFn.apply(mod, tar, 'catpair', None, None, prec, ('swtdec', il), None, *dec_w, *dec_b)
+    cat = BLinearFn.apply(mod, tar, 'catpair', None, "split" if sp else None, prec, ('swtdec', il), mod_lo, *dec_w, *dec_b)
+    cat, cat_lo = cat if sp else (cat, None)
+    del mod, mod_lo
     ff = [model.fea_fuse[il][t] for t in names]
     kmap = (2 * tarp, [(0, 0, tar), (tarp, tar, tar)])
-    y0 = BLinearFn.apply(cat, F, 'plain', kmap, None, prec, ('swtf0', il), None, *[m[0].weight for m in ff], *[m[0].bias for m in ff])
+    y0 = BLinearFn.apply(cat, F, 'plain', kmap, None, prec, ('swtf0', il), cat_lo, *[m[0].weight for m in ff], *[m[0].bias for m in ff])
+    del cat, cat_lo
     y0 = BilinearFn.apply(y0, (B, y0.shape[-1], h, w, 2 * h, 2 * w), prec.adt, False)
     y1 = Conv3x3Fn.apply(y0, (B, 2 * h, 2 * w, F, F), prec, ('swtf1', il), *[m[1].weight for m in ff], *[m[1].bias for m in ff])
     y1 = _bn_act(y1, [m[2] for m in ff], F, ACT_GELU, model.training)

@@ -260,10 +260,21 @@ class TaskPrompterSwin(nn.Module):
         return self._forward_nograd(img)
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------------
+    def _decoder_split(self, C):
+        """x3f: a level's fea_decode_* and fea_fuse[0] on the split-plane LDS-DMA kernel (`modulate` and the fea_decode epilogue write
+        hi / lo planes) — whole 32-deep K steps over the level's C channels and over the padded concatenation (TaskPrompter._decoder_split)."""
+        return self.prec.split and ops.split_gemm_ok(C) and ops.split_gemm_ok(2 * ops.pad8(self.p.level_embed_dim))
+
+    SPLIT_MIN_ROWS = 2048
+
     def _lin(self, x, layer, tag, **kw):
-        """x @ layer.weight^T (+ bias) through mtt_gemm; kw as ops.linear."""
-        N = layer.weight.shape[0]
+        """x @ layer.weight^T (+ bias) through mtt_gemm; kw as ops.linear.  x3f: a large fp32 operand is split into hi / lo planes by one
+        pass and the product runs on the split-plane LDS-DMA kernel (pre-split weight planes) instead of the register-staged x3 one."""
+        N, K = layer.weight.shape[0], layer.weight.shape[1]
         bias = layer.bias.detach()[None] if layer.bias is not None else None
+        if (self.prec.split and torch.is_tensor(x) and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[1] == K
+                and kw.get("a_rows") is None and x.shape[0] >= self.SPLIT_MIN_ROWS and ops.split_gemm_ok(K)):
+            return ops.linear(ops.split_cast(x), ops.pack_linear_split([layer.weight], tag), N, self.prec, bias=bias, **kw)
         return ops.linear(x, ops.pack_linear([layer.weight], self.prec, tag), N, self.prec, bias=bias, **kw)
 
     def _forward_nograd(self, img):
@@ -355,7 +366,7 @@ class TaskPrompterSwin(nn.Module):
         ao = torch.empty(B * nW * Nw, C, dtype=prec.adt, device=dev)
         rawlog = torch.zeros(B, nH, T, N, dtype=torch.float32, device=dev)
         ops.call("winattn_fwd", qkv=qkv, out=ao, rawmap=rawlog, bias=bias, mask=blk.attn_mask, pix=pix, nwin=B * nW, nW=nW, nH=nH, T=T,
-                 ws2=ws2, dtype=dtype_code(qkv), scale=32 ** -0.5, map_ld=N, map_off=T)
+                 ws2=ws2, dtype=dtype_code(qkv), scale=32 ** -0.5, map_ld=N, map_off=T, mfma=1 if qkv.dtype == torch.float32 else 0)
         # back to image order; prompt rows = mean over the windows (:208; the mean commutes with proj)
         ao_img = torch.empty(B * N, C, dtype=prec.adt, device=dev)
         _gather(ao, ao_img.view(B, N, C)[:, T:], rev, H * W, C, C, C, B, nW * Nw * C, N * C)
@@ -424,15 +435,17 @@ class TaskPrompterSwin(nn.Module):
         tar, F = p.level_embed_dim, p.final_embed_dim
         tarp = ops.pad8(tar)
         nwin = int(math.isqrt(p.chan_nheads))
-        mod = ops.modulate(xview, C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec, hg=hg)
+        sp = self._decoder_split(C)
+        mod = ops.modulate(xview, C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec, hg=hg, split=sp)
         dec_w, dec_b = [], []
         for t in names:
             dec_w += [self.fea_decode_spa[il][t][0].weight, self.fea_decode_chan[il][t][0].weight]
             dec_b += [self.fea_decode_spa[il][t][0].bias, self.fea_decode_chan[il][t][0].bias]
-        Wdec = ops.pack_linear(dec_w, prec, ('swdec', il))
+        Wdec = ops.pack_linear_split(dec_w, ('swdec', il)) if sp else ops.pack_linear(dec_w, prec, ('swdec', il))
         bdec = ops.stack_vec(dec_b, ('swdecb', il))
-        cat = torch.empty(T, B * hw, 2 * tarp, dtype=prec.adt, device=xsrc.device)
+        cat = ops.Split.empty((T, B * hw, 2 * tarp), xsrc.device) if sp else torch.empty(T, B * hw, 2 * tarp, dtype=prec.adt, device=xsrc.device)
         ops.linear(mod, Wdec, tar, prec, bias=bdec, out=cat, batch_inner=2, d_z=(B * hw * 2 * tarp, tarp), ldd=2 * tarp, n_store=tarp)
+        del mod
         f0 = [self.fea_fuse[il][t][0].weight for t in names]
 
         def build_f0():
@@ -443,9 +456,13 @@ class TaskPrompterSwin(nn.Module):
                     buf[i, :, :tar] = w2[:, :tar]
                     buf[i, :, tarp:tarp + tar] = w2[:, tar:]
                 return buf.to(prec.adt)
-        W0 = ops._cached(('swf0', il, prec.name, tuple(id(q) for q in f0)), f0, build_f0)
+        if sp:
+            W0 = ops.pack_kmap_split(f0, F, 2 * tarp, [(0, 0, tar), (tarp, tar, tar)], ('swf0', il))
+        else:
+            W0 = ops._cached(('swf0', il, prec.name, tuple(id(q) for q in f0)), f0, build_f0)
         b0 = ops.stack_vec([self.fea_fuse[il][t][0].bias for t in names], ('swf0b', il))
-        y0 = ops.linear(cat, W0, F, prec, bias=b0)                                  # 1x1s before the resize: they commute with it
+        y0 = ops.linear(cat, W0, F, prec, bias=b0, out_dtype=torch.float32 if sp else None)   # 1x1s before the resize: they commute with it
+        del cat
         y0 = ops.bilinear(y0, B, y0.shape[-1], h, w, 2 * h, 2 * w, prec.adt)        # :737 / :765
         ff = [self.fea_fuse[il][t] for t in names]
         Wc = ops.pack_conv3([m[1].weight for m in ff], prec, ('swf1', il))

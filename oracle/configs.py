@@ -74,6 +74,10 @@ def swin(name):
         # miniatures: same code paths (shifted windows with masks, 4 stages with patch merging, head dim 32 like Swin-B, DEConv heads)
         "mini_swin": dict(patch=4, window=4, embed=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8), img_size=(128, 192), img_ds_ratio=1.0,
                           tasks=CS2, level_embed_dim=24, final_embed_dim=40, chan_embed_dim=16, chan_nheads=4, prompt_len=1, head="deconv"),
+        # level width 32 (padded concatenation 64 = two 32-deep K steps) and final width 64: in x3f the task features' GEMMs / 3x3 convs and
+        # (with the row thresholds lowered by the test) the stage Linears run on split planes.  No reference fixture: product vs oracle.
+        "mini_swin_sp": dict(patch=4, window=4, embed=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8), img_size=(128, 192), img_ds_ratio=1.0,
+                             tasks=CS2, level_embed_dim=32, final_embed_dim=64, chan_embed_dim=16, chan_nheads=4, prompt_len=1, head="deconv"),
         # window 5 does not divide the 48 x 72 ... 6 x 9 grids (zero padding after norm1, also with the shift), 0.75 input resize,
         # 3 tasks, ConvHeads
         "mini_swin_pad": dict(patch=4, window=5, embed=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8), img_size=(256, 384), img_ds_ratio=0.75,

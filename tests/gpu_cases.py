@@ -895,10 +895,14 @@ def swin_cases():
                       bias=rnd(g, nH, ws2, ws2, scale=0.5), mask=mask, pix=pix, nwin=B * nW, nW=nW, nH=nH, T=T, ws2=ws2, dtype=dt,
                       scale=32 ** -0.5, map_ld=N, map_off=T)
             cases.append((f"winattn_{res[0]}x{res[1]}_w{window}_s{shift}_T{T}_h{nH}_{dt}", "winattn_fwd", kw, dict(f32=2e-5 if dt == F32 else 6e-3, bf16=1.5e-2)))
+            if dt == F32:     # the matrix-core form on fp32 storage (ABI 11): 3 bf16 MFMAs per product on hi / lo split operands — fp32-class
+                kw = dict(kw, out=torch.full((B * nW, Nw, Cc), 7.0), rawmap=torch.full((B, nH, T, N), 3.0), mfma=1)
+                cases.append((f"winattn_x3mfma_{res[0]}x{res[1]}_w{window}_s{shift}_T{T}_h{nH}", "winattn_fwd", kw, dict(f32=5e-5, bf16=1.5e-2)))
     # window attention backward (exact VALU kernel for both dtypes): dqkv and the window-part dS; with / without mask and raw-logit gradient
     for (res, window, shifted, T, nH, B, dt, with_raw) in (((8, 12), 4, True, 2, 2, 2, F32, True), ((7, 9), 5, True, 3, 1, 2, F32, True),
                                                            ((7, 9), 5, False, 3, 2, 1, BF16, True), ((12, 24), 12, True, 2, 2, 1, F32, False),
-                                                           ((12, 12), 12, False, 3, 1, 2, BF16, True)):
+                                                           ((12, 12), 12, False, 3, 1, 2, BF16, True), ((24, 24), 12, True, 2, 4, 1, BF16, True),
+                                                           ((24, 12), 12, True, 2, 2, 2, F32, True), ((7, 14), 7, False, 2, 3, 1, BF16, False)):
         ws, shift, Hp, Wp = sw.block_geometry(res, window, shifted)
         part, pix, rev = sw.window_tables(res, ws, shift, Hp, Wp, T, "cpu")
         mask = sw.shift_attn_mask(Hp, Wp, ws, shift)
@@ -911,6 +915,9 @@ def swin_cases():
         kw = dict(fkw, xargs=[rnd(g, B * nW, Nw, Cc).to(DT[dt]), rnd(g, B, nH, T, N) if with_raw else None,
                               torch.full((B * nW, Nw, 3 * Cc), 7.0, dtype=DT[dt]), torch.full((B * nW, nH, ws2, ws2), 7.0)])
         cases.append((f"winattn_bwd_{res[0]}x{res[1]}_w{window}_s{shift}_T{T}_h{nH}_{dt}", "winattn_bwd", kw, dict(f32=3e-5 if dt == F32 else 8e-3, bf16=1.5e-2)))
+        if dt == F32:         # the bf16 matrix-core backward on fp32 storage (the x3f mode's backward): operands rounded to bf16 while loaded
+            kw = dict(kw, mfma=1, xargs=[kw["xargs"][0], kw["xargs"][1], torch.full((B * nW, Nw, 3 * Cc), 7.0), torch.full((B * nW, nH, ws2, ws2), 7.0)])
+            cases.append((f"winattn_bwd_mfma_{res[0]}x{res[1]}_w{window}_s{shift}_T{T}_h{nH}", "winattn_bwd", kw, dict(f32=1.5e-2, bf16=1.5e-2)))
     # channel attention
     for (B, T, C, ce, nwin, kdt, has_b) in ((2, 2, 64, 16, 1, F32, True), (1, 3, 136, 64, 2, F32, True), (2, 2, 256, 256, 1, BF16, False), (1, 2, 1024, 256, 2, F32, True)):
         Cp = (C + 7) // 8 * 8

@@ -267,6 +267,17 @@ def test_swin_training_gradients(name, prec, fwd_tol, med_tol, worst_tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mini_swin_sp", "mini_swin", "mini_swin_pad"])
+def test_swin_x3f_split_planes_and_matrix_core_window_attention(name, monkeypatch):
+    """Swin in the tolerance-compliant mode on the device: split-plane Linears / task features, x3 MFMA window attention forward, bf16 MFMA
+    window attention backward — eval forward < 5e-5 per head vs the oracle, every parameter gradient within the x3f bound."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from test_host_cpu import check_swin_x3f_split_planes
+    check_swin_x3f_split_planes(name, "cuda", monkeypatch)
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(1500)
 def test_mixed_precision_training_trajectory_follows_the_fp32_reference_over_200_steps():
     """Does x3f TRAIN like the reference?  The reference trains in fp32 (no AMP); x3f = fp32-class forward + bf16

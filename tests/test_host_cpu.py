@@ -760,6 +760,52 @@ def test_swin_training_gradients_on_emulator(emulated, name):
     assert not dead, dead[:5]
 
 
+def check_swin_x3f_split_planes(name, device, monkeypatch):
+    """(shared with tests/test_gpu_train.py) TaskPrompter-Swin in the x3f mode (round 6): the stage Linears (one split pass + the split-plane
+    GEMM), the task features (modulate and the fea_decode epilogue write hi / lo planes) and the matrix-core window attention
+    (mtt_winattn_desc.mfma) against the oracle — eval forward fp32-class, training gradients within the per-parameter bound of the bf16
+    backward; with the row thresholds lowered so that the miniature takes the paths Swin-B takes."""
+    import mtt_amd
+    import train_check
+    from oracle import swin_oracle as swo
+    monkeypatch.setattr(mtt_amd.autograd_path, "AUTO_SPLIT_MIN_ROWS", 64)
+    monkeypatch.setattr(mtt_amd.taskprompter_swin.TaskPrompterSwin, "SPLIT_MIN_ROWS", 64)
+    seen = []
+    inner = mtt_amd.ops.call
+    monkeypatch.setattr(mtt_amd.ops, "call", lambda n, **kw: (seen.append((n, kw.get("a_dtype"), kw.get("mfma"), kw.get("out_lo") is not None)), inner(n, **kw))[1])
+    cfg = configs.swin(name)
+    model = conftest.build_product_model(cfg, "x3f", device)
+    contract = [(k, list(v.shape)) for k, v in model.state_dict().items() if k.rsplit(".", 1)[-1] not in weights.DERIVED_BUFFERS]
+    sd = weights.synth_state_dict(contract, 0)
+    model.load_state_dict({k: v.to(device) for k, v in sd.items()}, strict=False)
+    model.eval()
+    x = weights.synth_images(2, cfg["img_size"], 1)
+    with torch.no_grad():
+        out = model(x.to(device))
+    ref = swo.forward(sd, cfg, x)
+    for t, _ in cfg["tasks"]:
+        e = float((out[t].cpu() - ref[t]).norm() / ref[t].norm())
+        assert e < 5e-5, (t, e)
+    n_split = sum(1 for n, adt, _, _ in seen if n == "gemm" and adt == 2)
+    assert all(m == 1 for n, _, m, _ in seen if n == "winattn_fwd")
+    if name == "mini_swin_sp":
+        assert n_split >= 6 * 4 + 4 * 2, n_split           # qkv / proj / fc1 / fc2 of the six blocks with >= 64 channels, two task-feature GEMMs per level
+        assert sum(1 for n, _, _, lo in seen if n == "modulate" and lo) == 4
+    del seen[:]
+    fwd, errs, dead = train_check.swin_grad_errors(name, "x3f", device, contract=contract)
+    assert max(fwd.values()) < 5e-5, fwd
+    worst, med = train_check.summarize(errs, floor=1e-4)
+    print(f"PARITY swin-train {name} x3f fwd {max(fwd.values()):.3e} grad median {med:.3e} worst {worst[0]:.3e} ({worst[1]})")
+    assert med < 3e-2, (worst, med)
+    train_check.assert_per_param(errs, "x3f")
+    assert all(m == 1 for n, _, m, _ in seen if n in ("winattn_fwd", "winattn_bwd")) and any(n == "winattn_bwd" for n, *_ in seen)
+
+
+@pytest.mark.parametrize("name", ["mini_swin_sp", "mini_swin"])
+def test_swin_x3f_split_planes_on_emulator(emulated, monkeypatch, name):
+    check_swin_x3f_split_planes(name, "cpu", monkeypatch)
+
+
 def test_swin_training_with_droppath_masks(emulated):
     """The block's four independent DropPath draws (pixels / prompts x attention / MLP), injected into product and oracle alike."""
     import train_check
