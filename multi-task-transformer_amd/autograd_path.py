@@ -815,7 +815,8 @@ class BnActStackFn(Function):
 
 
 def bn_act_single(x, gamma, beta, bn, C, act, training):
-    return BnActStackFn.apply(x[None], C, act, training, [bn], gamma, beta)[0]
+    # (squeeze, not [0]: the backward of a select zero-fills and copies a whole map — 2.4 GB per head stage at the Swin-B benchmark shape)
+    return BnActStackFn.apply(x[None], C, act, training, [bn], gamma, beta).squeeze(0)
 
 
 class TaskHeadsFn(Function):
@@ -1257,11 +1258,12 @@ def heads_forward(kind, heads, fea, B, h4, w4, target, prec, training, lowres=Fa
         return outs
     F2 = F // 2
     tgt = target or (2 * h4, 2 * w4)
+    feas = fea.unbind(0)                  # one stack in the backward instead of a zero-filled [Z, ...] gradient per task
     for i, hd in enumerate(heads):
-        y = Deconv2x2Fn.apply(fea[i], hd.mt_proj[0].weight, hd.mt_proj[0].bias, (B, h4, w4), prec, 'hd0')
+        y = Deconv2x2Fn.apply(feas[i], hd.mt_proj[0].weight, hd.mt_proj[0].bias, (B, h4, w4), prec, 'hd0')
         y = bn_act_single(y, hd.mt_proj[1].weight, hd.mt_proj[1].bias, hd.mt_proj[1], F2, ACT_GELU, training)[None]
         y = Conv3x3Fn.apply(y, (B, 2 * h4, 2 * w4, F2, F2), prec, 'hd3', hd.mt_proj[3].weight, hd.mt_proj[3].bias)
-        y = bn_act_single(y[0], hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, training)[None]
+        y = bn_act_single(y.squeeze(0), hd.mt_proj[4].weight, hd.mt_proj[4].bias, hd.mt_proj[4], F2, ACT_GELU, training)[None]
         n_out = hd.linear_pred.weight.shape[0]
         pred = BLinearFn.apply(y, n_out, 'plain', None, torch.float32, prec, 'hp', None, hd.linear_pred.weight, hd.linear_pred.bias)
         outs.append(BilinearFn.apply(pred, (B, n_out, 2 * h4, 2 * w4, tgt[0], tgt[1]), torch.float32, True))

@@ -84,6 +84,43 @@ class MergeGatherFn(Function):
         return dXT, None, None, None
 
 
+class BlockResidualFn(Function):
+    """out = XT + rowscale * branch, prompt rows additionally + s_prompt * tt1 (taskprompter_swin.py:404-413: the attention branch's residual,
+    the prompts' channel-attention update and the block's first two DropPath draws) as ONE node: the row concatenations / slices it
+    replaces cost a zero-fill, a copy and an accumulate of a token-map-sized gradient each in the backward.
+    XT, branch fp32 [B*N, C]; tt1 fp32 [B*T, C] or None; s_pix, s_prompt fp32 [B] per-sample DropPath scales or None (= 1)."""
+
+    @staticmethod
+    def forward(ctx, XT, branch, tt1, s_pix, s_prompt, geo):
+        B, N, T, C = geo
+        rs = None
+        if s_pix is not None or s_prompt is not None:
+            rs = torch.ones(B, N, 1, dtype=torch.float32, device=XT.device)
+            if s_pix is not None:
+                rs[:, T:, 0] = s_pix[:, None]
+            if s_prompt is not None:
+                rs[:, :T, 0] = s_prompt[:, None]
+        out = XT + branch if rs is None else torch.addcmul(XT.view(B, N, C), branch.view(B, N, C), rs).view(B * N, C)
+        if tt1 is not None:
+            t3 = tt1.view(B, T, C)
+            out.view(B, N, C)[:, :T] += t3 if s_prompt is None else t3 * s_prompt[:, None, None]
+        ctx.geo, ctx.has_tt1 = geo, tt1 is not None
+        ctx.save_for_backward(rs, s_prompt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, T, C = ctx.geo
+        rs, s_prompt = ctx.saved_tensors
+        dout = dout.contiguous()
+        dbranch = dout if rs is None else (dout.view(B, N, C) * rs).view(B * N, C)
+        dtt1 = None
+        if ctx.has_tt1:
+            dtt1 = dout.view(B, N, C)[:, :T]
+            dtt1 = (dtt1 if s_prompt is None else dtt1 * s_prompt[:, None, None]).reshape(B * T, C)
+        return dout, dbranch, dtt1, None, None, None
+
+
 class WinAttnFn(Function):
     @staticmethod
     def forward(ctx, qkv, table, rel_index, mask, pix, geo, prec=None):
@@ -192,8 +229,8 @@ def _lin(model, x, layer, tag, out_dtype=None):
         bias = _zero_bias[key]
     if x.shape[-1] != ops.pad8(x.shape[-1]):              # reduction length off the channel pitch (chan_kv on a 6 x 9 map): zero columns
         x = torch.nn.functional.pad(x, (0, ops.pad8(x.shape[-1]) - x.shape[-1]))
-    y = BLinearFn.apply(x, layer.weight.shape[0], 'plain', None, out_dtype, model.prec, tag, None, layer.weight, bias)
-    return y[0][:, :layer.weight.shape[0]]
+    y = BLinearFn.apply(x, layer.weight.shape[0], 'plain', None, out_dtype, model.prec, tag, None, layer.weight, bias).squeeze(0)
+    return y if y.shape[1] == layer.weight.shape[0] else y[:, :layer.weight.shape[0]]     # (views: a select / full-range slice would cost a zero-fill + copy in the backward)
 
 
 def _inverse_merge_tables(res, T, device):
@@ -252,11 +289,11 @@ def backbone_forward(model, img):
     fea_levels.append(_task_features(model, xf, rawlog, rawchan, nl - 1, B, res, Cl, Cl // model.layers[-1].blocks[0].num_heads))
     h0, w0 = model.feature_hw
     Fp = fea_levels[0].shape[-1]
-    acc = None
-    for i, f in enumerate(fea_levels):
-        hi, wi = 2 * model.resolution[i][0], 2 * model.resolution[i][1]
-        up = BilinearFn.apply(f, (B, Fp, hi, wi, h0, w0), torch.float32, False)
-        acc = up if acc is None else acc + up
+    # every level resized to the finest one and summed as ONE node (the resizes accumulate into the fp32 sum inside the kernel; a level that
+    # already has the target size is added / differentiated as the identity): no [T, B*h0*w0, Fp] tensor per level, no add passes
+    from .invpt_autograd import MultiScaleSumFn
+    sizes = [(2 * model.resolution[i][0], 2 * model.resolution[i][1]) for i in range(len(fea_levels))]
+    acc = MultiScaleSumFn.apply((B, Fp, h0, w0, sizes), *[f.contiguous() for f in fea_levels])
     names = list(model.all_tasks)
     F = p.final_embed_dim
     accq = acc if adt == torch.float32 else acc.to(adt)
@@ -301,12 +338,6 @@ def _block(model, blk, tag, XT, B, T, res):
     ao_img = WindowGatherFn.apply(ao, False, part, rev, (B, N, T, nW, Nw, C))
     po = _lin(model, ao_img, a.proj, tag + ('proj',))                                                 # [B*N, C] activation dtype
     branch = po.float()
-    if drops is not None and blk.last_block:     # the last block's prompt output is not used: only the pixel rows are scaled
-        branch = (branch.view(B, N, C) * torch.cat([drops[0].new_ones(B, T), drops[0][:, None].expand(B, N - T)], 1)[:, :, None]).reshape(B * N, C)
-    elif drops is not None:                      # pixels: draw 0; prompts: draw 2 (applied below together with the channel term)
-        v = branch.view(B, N, C)
-        branch = torch.cat([v[:, :T], v[:, T:] * drops[0][:, None, None]], 1).reshape(B * N, C)
-    XT2 = XT + branch if (drops is None or blk.last_block) else None
     # channel attention: kv = chan_kv(x_attn^T) per image (taskprompter_swin.py:393-397)
     ce = model.p.chan_embed_dim
     nwin = int(math.isqrt(model.p.chan_nheads))
@@ -314,15 +345,14 @@ def _block(model, blk, tag, XT, B, T, res):
     xT = po.view(B, N, C)[:, T:].transpose(1, 2).reshape(B * C, H * W)
     kv = _lin(model, xT.contiguous(), blk.chan_kv, tag + ('ckv',), torch.float32).reshape(B, C, 2 * ce)
     rawchan, cx = ChanAttnFn.apply(q.contiguous(), kv.contiguous(), (B, T, C, ce, nwin))
+    tt1 = None
     if not blk.last_block:
         cp = _lin(model, cx.to(adt), blk.chan_proj, tag + ('cpj',), torch.float32)
         tt1 = _lin(model, cp.to(adt), blk.token_trans1, tag + ('tt1',), torch.float32)                # [B*T, C]
-        if drops is None:
-            v = XT2.view(B, N, C)
-            XT2 = torch.cat([v[:, :T] + tt1.reshape(B, T, C), v[:, T:]], 1).reshape(B * N, C)
-        else:
-            xv, bv = XT.view(B, N, C), branch.view(B, N, C)
-            XT2 = torch.cat([xv[:, :T] + (bv[:, :T] + tt1.reshape(B, T, C)) * drops[2][:, None, None], xv[:, T:] + bv[:, T:]], 1).reshape(B * N, C)
+    # residual: pixels + draw0 * branch; prompts + draw2 * (branch + channel term) — the last block's prompt output is not used downstream
+    # (its prompt rows take the unscaled branch, no channel term)
+    XT2 = BlockResidualFn.apply(XT, branch, tt1, None if drops is None else drops[0],
+                                None if (drops is None or blk.last_block) else drops[2], (B, N, T, C))
     rs_mlp = None if drops is None else torch.stack([drops[3], drops[1]], 1).contiguous()            # [B, 2]: prompt rows, pixel rows
     XT3 = MlpHalfFn.apply(XT2.contiguous(), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
                           blk.mlp.fc2.weight, blk.mlp.fc2.bias, rs_mlp, (B, N, T), prec, tag)
