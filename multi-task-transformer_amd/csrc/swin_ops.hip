@@ -840,12 +840,21 @@ MTT_DEV u32x4 wa_frag(const void* p, int off, bool ok) {
   cvt8<false, F32>(ok, r, hi, lo);
   return hi;
 }
+MTT_DEV void st_row(bf16_t* p, u32x4 v) { *(u32x2*)p = (u32x2){v[0], v[1]}; *(u32x2*)(p + 4) = (u32x2){v[2], v[3]}; }
+MTT_DEV u32x4 ld_row(const bf16_t* p) { const u32x2 a = *(const u32x2*)p, b = *(const u32x2*)(p + 4); return (u32x4){a[0], a[1], b[0], b[1]}; }
 template <int NKT, bool F32>
 __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_winattn_desc d, const void* dout, const float* drawmap, void* dqkv, float* dS_out) {
-  constexpr int NP = NKT * 16, PITCH = NP + 8;
+  // LDS (79.5 KB at NKT = 10: two workgroups per CU): the four operands row-major as bf16 (rows of 32 + 4 elements: 8-byte fragment
+  // reads) — every fragment of both passes comes from here (the first version re-read K / V per query tile and Q / dO per key tile from
+  // L2: ~1 MB per workgroup) — plus K^T, Q^T, dO^T for the products whose reduction runs over keys / queries
+  constexpr int NP = NKT * 16, PITCH = NP + 4, RP = 36;
   __shared__ __attribute__((aligned(16))) bf16_t kT[32 * PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t qT[32 * PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t gT[32 * PITCH];       // dO^T
+  __shared__ __attribute__((aligned(16))) bf16_t qR[NP * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t kR[NP * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t vR[NP * RP];
+  __shared__ __attribute__((aligned(16))) bf16_t gR[NP * RP];          // dO
   __shared__ __attribute__((aligned(16))) float mrow[NP];
   __shared__ __attribute__((aligned(16))) float linv[NP];
   __shared__ __attribute__((aligned(16))) float Drow[NP];
@@ -869,6 +878,8 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
       const u32x4 k4 = wa_frag<F32>(Qb, C + row * ld + q * 8, ok);
       const u32x4 q4 = wa_frag<F32>(Qb, row * ld + q * 8, ok);
       const u32x4 g4 = wa_frag<F32>(Gb, row * C + q * 8, ok);
+      const u32x4 v4 = wa_frag<F32>(Qb, 2 * C + row * ld + q * 8, ok);
+      st_row(qR + row * RP + q * 8, q4); st_row(kR + row * RP + q * 8, k4); st_row(vR + row * RP + q * 8, v4); st_row(gR + row * RP + q * 8, g4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         kT[(q * 8 + 2 * e) * PITCH + row] = (bf16_t)(k4[e] & 0xffffu); kT[(q * 8 + 2 * e + 1) * PITCH + row] = (bf16_t)(k4[e] >> 16);
@@ -891,8 +902,8 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
   for (int qt = wave; qt < ntile; qt += 4) {
     const int query = qt * 16 + li;
     const bool qok = query < N;
-    const u32x4 qf = wa_frag<F32>(Qb, query * ld + lg * 8, qok);
-    const u32x4 gf = wa_frag<F32>(Gb, query * C + lg * 8, qok);
+    const u32x4 qf = ld_row(qR + query * RP + lg * 8);            // (rows >= N are zeros in LDS)
+    const u32x4 gf = ld_row(gR + query * RP + lg * 8);
     float Dq = 0.f;
     if (qok) {
       float g8[8], o8[8];
@@ -906,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
 #pragma unroll
     for (int j = 0; j < NKT; ++j) {
       const int krow = j * 16 + li;
-      const u32x4 kf = wa_frag<F32>(Qb, C + krow * ld + lg * 8, krow < N);
+      const u32x4 kf = ld_row(kR + krow * RP + lg * 8);
       s[j] = mfma16(kf, qf, z4);
       if (NKT > 6 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound what the scheduler hoists (the 256-register cap: no spills)
     }
@@ -962,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
     for (int j = 0; j < NKT; ++j) {
       const int kb = j * 16 + lg * 4;
       const int vrow = j * 16 + li;                      // dP^T tile j = V_j dO^T, consumed at once (no N-long dP row is kept)
-      const u32x4 vf = wa_frag<F32>(Qb, 2 * C + vrow * ld + lg * 8, vrow < N);
+      const u32x4 vf = ld_row(vR + vrow * RP + lg * 8);
       const f32x4 dpj = mfma16(vf, gf, z4);
       float ds[4];
 #pragma unroll
@@ -1014,8 +1025,8 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
   for (int kt = wave; kt < ntile; kt += 4) {
     const int key = kt * 16 + li;
     const bool kok = key < N;
-    const u32x4 kf = wa_frag<F32>(Qb, C + key * ld + lg * 8, kok);
-    const u32x4 vf = wa_frag<F32>(Qb, 2 * C + key * ld + lg * 8, kok);
+    const u32x4 kf = ld_row(kR + key * RP + lg * 8);
+    const u32x4 vf = ld_row(vR + key * RP + lg * 8);
     f32x4 dv[2] = {z4, z4}, dk[2] = {z4, z4};
 #pragma unroll 1
     for (int c = 0; c < NKT / 2; ++c) {                 // (not unrolled: the scheduler would hoist every pair's four fragment loads — spills under the 2-workgroups-per-CU register cap)
@@ -1024,8 +1035,8 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * c + u;
         const int qrow = t * 16 + li;
-        const u32x4 qa = wa_frag<F32>(Qb, qrow * ld + lg * 8, qrow < N);
-        const u32x4 ga = wa_frag<F32>(Gb, qrow * C + lg * 8, qrow < N);
+        const u32x4 qa = ld_row(qR + qrow * RP + lg * 8);
+        const u32x4 ga = ld_row(gR + qrow * RP + lg * 8);
         const f32x4 sv = mfma16(qa, kf, z4);
         const f32x4 dpv = mfma16(ga, vf, z4);
         const int q0 = t * 16 + lg * 4;

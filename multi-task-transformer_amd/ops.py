@@ -17,7 +17,8 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, OP_CONV_K, OP_CONV_R, OP_K, OP_R, PREC_BF16, PREC_X3, SPLIT)
 
 
-PITCH32_FROM = 129         # channel counts >= this take a pitch that is a multiple of 32 (see pad8); 1 << 30 = the multiple-of-8 pitch everywhere
+PITCH32_FROM = 160         # channel counts >= this take a pitch that is a multiple of 32 (see pad8); 1 << 30 = the multiple-of-8 pitch everywhere.
+                           # (160: below it the rounding costs > 10 % of a map, and InvPT's 144-channel stage keeps its width as its pitch)
 
 
 def pad8(n):

@@ -27,8 +27,8 @@ def pytest_configure(config):
     if os.environ.get("MTT_TEST_GEMM_VARIANT"):
         import mtt_amd
         mtt_amd.ops.GEMM_VARIANT = int(os.environ["MTT_TEST_GEMM_VARIANT"])
-    # the multiple-of-32 channel pitch (ops.pad8) starts at 129 channels: no miniature has a map that wide, so the same suite runs a second
-    # time with MTT_TEST_PITCH32_FROM=9 (every ragged channel count of the miniatures then takes the wide pitch: 44 -> 64, 52 -> 64 ...)
+    # the multiple-of-32 channel pitch (ops.pad8) starts at 160 channels: no miniature has a map that wide, so the same suite runs a second
+    # time with MTT_TEST_PITCH32_FROM=33 (every ragged channel count of the miniatures then takes the wide pitch: 44 -> 64, 52 -> 64 ...)
     if os.environ.get("MTT_TEST_PITCH32_FROM"):
         import mtt_amd
         mtt_amd.ops.PITCH32_FROM = int(os.environ["MTT_TEST_PITCH32_FROM"])
