@@ -58,25 +58,25 @@ CONFIGS = {
             (512, 512), 126, 1046.8),
     "cfg2": ("TaskPrompter ViT-B/16, PASCAL-Context 5 tasks, 512x512, ConvHead, embed 780/1024, 4x4 channel windows, ctr (pascal_vitBp16_taskprompter.yml)",
              dict(tasks=PASCAL5, backbone="TaskPrompter_vitB", head="conv", embed_dim=780, final_embed_dim=1024, chan_nheads=16, use_ctr=True),
-             (512, 512), 24, 2306.7),
+             (512, 512), 96, 2306.7),
     "cfg3": ("TaskPrompter ViT-L/16, NYUD-v2 4 tasks, 448x576, ConvHead, embed 768/768, 4x4 channel windows, no ctr (nyud_vitLp16_taskprompter.yml)",
              dict(tasks=["semseg", "depth", "normals", "edge"], backbone="TaskPrompter_vitL", head="conv", embed_dim=768, final_embed_dim=768,
                   chan_nheads=16, use_ctr=False, num_output=dict(semseg=40)),
-             (448, 576), 24, 1679.3),
+             (448, 576), 96, 1679.3),
     "cfg4": ("InvPT ViT-L/16 (vit_large_patch16_384 + TransformerDecoder + MLPHead), PASCAL-Context 5 tasks + depth = 6 tasks, 512x512, "
              "embed 512 + 64, intermediate supervision (pascal_vitLp16.yml)",
              dict(tasks=PASCAL6, model="TransformerNet", backbone="vitL", head="mlp", embed_dim=512, PRED_OUT_NUM_CONSTANT=64,
                   mtt_resolution_downsample_rate=2, intermediate_supervision=True),
-             (512, 512), 32, 1465.4),
+             (512, 512), 64, 1465.4),
     "cfg5": ("TaskPrompter ViT-L/16, Cityscapes semseg(19) + depth, 1024x2048 (N = 8194 tokens), DEConvHead, embed 300/350, ctr",
              dict(tasks=["semseg", "depth"], backbone="TaskPrompter_vitL", head="deconv", embed_dim=300, final_embed_dim=350, chan_nheads=1,
                   use_ctr=True, num_output=dict(semseg=19)),
-             (1024, 2048), 4, 12543.0),
+             (1024, 2048), 16, 12543.0),
     "swinb": ("TaskPrompter Swin-B (taskprompter_swin_base_patch4_window12_384), Cityscapes semseg(19) + depth (cs_swinB_taskprompter.yml without "
               "the 3ddet task), 1024x2048 x 0.75, window 12, level 256 / final 450, DEConvHead; SURVEY.md §8f rank 3",
               dict(tasks=["semseg", "depth"], backbone="TaskPrompter_swinB", head="deconv", final_embed_dim=450, chan_nheads=1, img_ds_ratio=0.75,
                    level_embed_dim=256, chan_embed_dim=256, prompt_len=1, num_output=dict(semseg=19)),
-              (1024, 2048), 8, 3678.8),
+              (1024, 2048), 16, 3678.8),
 }
 
 

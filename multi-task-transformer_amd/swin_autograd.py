@@ -134,23 +134,25 @@ class WinAttnFn(Function):
         # fp32 storage (x3 / x3f): the forward's products as 3 bf16 MFMAs on split operands (fp32-class, like the x3 GEMMs); the backward of
         # the x3f mode is the bf16 one (matrix cores), x3's the exact fp32 kernel
         ops.call("winattn_fwd", rawmap=rawlog, mfma=1 if qkv.dtype == torch.float32 and WINATTN_MFMA else 0, **kw)
-        kw["mfma"] = 1 if (qkv.dtype == torch.float32 and prec is not None and prec.bwd.name == "bf16" and WINATTN_MFMA) else 0
-        ctx.kw, ctx.geo, ctx.rel_index = kw, geo, rel_index
-        ctx.save_for_backward(table)
+        # tensors go through save_for_backward — an OUTPUT kept on ctx directly is a reference cycle (node -> ctx -> out -> grad_fn = node) that
+        # is never collected: the step leaked a block's qkv + out (GBs per step at the Swin-B shape) until round 6
+        ctx.scalars = dict(nwin=B * nW, nW=nW, nH=nH, T=T, ws2=ws2, dtype=dtype_code(qkv), scale=32 ** -0.5, map_ld=N, map_off=T,
+                           mfma=1 if (qkv.dtype == torch.float32 and prec is not None and prec.bwd.name == "bf16" and WINATTN_MFMA) else 0)
+        ctx.geo, ctx.has_mask = geo, mask is not None
+        ctx.save_for_backward(table, qkv, out, bias, pix, rel_index, *([mask] if mask is not None else []))
         return out, rawlog
 
     @staticmethod
     def backward(ctx, dout, drawlog):
         B, nW, nH, T, ws2, N = ctx.geo
-        (table,) = ctx.saved_tensors
-        kw = ctx.kw
-        qkv = kw["qkv"]
+        table, qkv, out, bias, pix, rel_index = ctx.saved_tensors[:6]
+        kw = dict(ctx.scalars, qkv=qkv, out=out, bias=bias, pix=pix, mask=ctx.saved_tensors[6] if ctx.has_mask else None)
         dqkv = torch.empty_like(qkv)
         dS = torch.empty(B * nW, nH, ws2, ws2, dtype=torch.float32, device=qkv.device)
         dout = dout.contiguous()
         ops.call("winattn_bwd", rawmap=None, xargs=[dout, drawlog.contiguous() if drawlog is not None else None, dqkv, dS], **kw)
         dbias = dS.sum(0).permute(1, 2, 0).reshape(ws2 * ws2, nH)
-        dtable = torch.zeros_like(table).index_add_(0, ctx.rel_index.view(-1), dbias)
+        dtable = torch.zeros_like(table).index_add_(0, rel_index.view(-1), dbias)
         return dqkv, dtable, None, None, None, None, None
 
 

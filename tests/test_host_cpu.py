@@ -806,6 +806,32 @@ def test_swin_x3f_split_planes_on_emulator(emulated, monkeypatch, name):
     check_swin_x3f_split_planes(name, "cpu", monkeypatch)
 
 
+@pytest.mark.parametrize("family,name,prec", [("taskprompter", "mini_ctr", "x3f"), ("taskprompter", "mini_deconv", "bf16"), ("invpt", "mini8", "x3f"),
+                                              ("swin", "mini_swin", "x3f"), ("swin", "mini_swin_pad", "bf16")])
+def test_training_steps_do_not_accumulate_tensors(emulated, family, name, prec):
+    """Five training iterations: the bytes held by live tensors must be constant from the second step on.  (Until round 6 WinAttnFn kept its OUTPUT on
+    ctx — a reference cycle node -> ctx -> out -> grad_fn that no collector breaks: a block's qkv + out leaked per step, GBs at the Swin-B shape.)"""
+    import gc
+    import mtt_amd
+    cfg = getattr(configs, family)(name)
+    model = conftest.build_product_model(cfg, prec)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+    x = weights.synth_images(2, cfg["img_size"], 1)
+    held = []
+    for _ in range(5):
+        out = model(x)
+        loss = sum(v.float().sum() for v in out.values() if torch.is_tensor(v)) + sum(v.float().sum() for v in (out.get("inter_preds") or {}).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        mtt_amd.ops.bump_param_epoch()
+        del out, loss
+        gc.collect()
+        held.append(sum(o.numel() * o.element_size() for o in gc.get_objects() if torch.is_tensor(o)))
+    assert held[1] == held[2] == held[3] == held[4], held
+
+
 def test_swin_training_with_droppath_masks(emulated):
     """The block's four independent DropPath draws (pixels / prompts x attention / MLP), injected into product and oracle alike."""
     import train_check
