@@ -22,7 +22,20 @@ CASES = {
     # the DEFAULT mode (x3f) on decoder widths % 32: its Functions hand split planes to each other (two outputs, the lo plane without a
     # gradient) — DDP with find_unused_parameters=False must still see every parameter's gradient; bf16-class gradients
     "taskprompter_x3f_planes_2ranks": ("TP", "mini_p32", [[0], [1, 2]], "x3f", 1.5e-1),
+    # TaskPrompter-Swin in the default mode (round 6: split-plane Linears / task features, matrix-core window attention), unequal shares;
+    # its prompt outputs of the last block have no gradient in the reference either: find_unused_parameters
+    "swin_x3f_2ranks_unequal": ("SW", "mini_swin_sp", [[0, 1], [2]], "x3f", 1.5e-1),
 }
+
+
+def _cfg_of(kind, name):
+    from oracle import configs
+    return configs.taskprompter(name) if kind == "TP" else (configs.invpt(name) if kind == "IP" else configs.swin(name))
+
+
+def _contract_of(model):
+    from oracle import weights
+    return [(k, list(v.shape)) for k, v in model.state_dict().items() if k.rsplit(".", 1)[-1] not in weights.DERIVED_BUFFERS]
 
 
 def _mode(case):
@@ -65,10 +78,11 @@ def _worker_body(rank, world, port, case, q):
     from oracle import abi_emul, configs, weights
     mtt_amd.ops.call = abi_emul.call
     kind, name, shares = CASES[case][:3]
-    cfg = configs.taskprompter(name) if kind == "TP" else configs.invpt(name)
+    cfg = _cfg_of(kind, name)
+    if kind == "SW":                   # the miniature takes the split-plane paths Swin-B takes
+        mtt_amd.autograd_path.AUTO_SPLIT_MIN_ROWS = 64
     model = conftest.build_product_model(cfg, _mode(case)[0])
-    contract = [(k, list(v.shape)) for k, v in model.state_dict().items()]
-    model.load_state_dict(weights.synth_state_dict(contract, 0), strict=True)
+    model.load_state_dict(weights.synth_state_dict(_contract_of(model), 0), strict=kind != "SW")   # (Swin: geometry-derived buffers are not synthesised)
     model.train()
     for m in model.modules():          # DDP refuses nn.SyncBatchNorm on CPU modules: plain holders flagged for sync (same code path)
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
@@ -84,7 +98,7 @@ def _worker_body(rank, world, port, case, q):
             n_coll["gather"] += 1
         return ar(t, *a, **k)
     dist.all_reduce = counted_reduce
-    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=(kind == "IP"))
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=(kind in ("IP", "SW")))
     n_total = sum(len(s) for s in shares)
     rows = shares[rank]
     x = weights.synth_images(n_total, cfg["img_size"], 2)[rows]
@@ -125,14 +139,15 @@ def test_ddp_ranks_match_single_process(case):
     # single-process oracle gradients on the whole batch, same loss
     import conftest
     from oracle import configs, weights
-    cfg = configs.taskprompter(name) if kind == "TP" else configs.invpt(name)
-    contract = [(k, list(v.shape)) for k, v in conftest.build_product_model(cfg, "x3").state_dict().items()]
-    sd = weights.synth_state_dict(contract, 0)
+    cfg = _cfg_of(kind, name)
+    sd = weights.synth_state_dict(_contract_of(conftest.build_product_model(cfg, "x3")), 0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
     n_total = sum(len(s) for s in shares)
     x = weights.synth_images(n_total, cfg["img_size"], 2)
     if kind == "TP":
         from oracle import taskprompter_oracle as orc
+    elif kind == "SW":
+        from oracle import swin_oracle as orc
     else:
         from oracle import invpt_oracle as orc
     out = orc.forward(dict(sd, **params), cfg, x, training=True)

@@ -267,6 +267,39 @@ def test_swin_training_gradients(name, prec, fwd_tol, med_tol, worst_tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family,name,prec", [("taskprompter", "mini_ctr", "x3f"), ("taskprompter", "mini_deconv", "bf16"), ("invpt", "mini8", "x3f"),
+                                              ("swin", "mini_swin", "x3f"), ("swin", "mini_swin_pad", "bf16")])
+def test_device_memory_is_steady_over_training_steps(family, name, prec):
+    """The bytes allocated on the device after a training iteration (forward, backward, fused clip + Adam, pack refresh) are the same from the
+    second iteration on: no autograd node keeps tensors alive across steps (the emulator twin counts host tensors: tests/test_host_cpu.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gc
+    import conftest
+    import mtt_amd
+    from oracle import configs, weights
+    cfg = getattr(configs, family)(name)
+    if family == "invpt":
+        train_check.skip_unless_own_pitch(cfg)
+    model = conftest.build_product_model(cfg, prec, "cuda")
+    model.train()
+    opt = mtt_amd.optim.FusedClipAdam(model.parameters(), lr=1e-4, weight_decay=1e-6, max_norm=10.0)
+    x = weights.synth_images(2, cfg["img_size"], 1).cuda()
+    held = []
+    for _ in range(5):
+        out = model(x)
+        loss = sum(v.float().sum() for v in out.values() if torch.is_tensor(v)) + sum(v.float().sum() for v in (out.get("inter_preds") or {}).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        del out, loss
+        gc.collect()
+        torch.cuda.synchronize()
+        held.append(torch.cuda.memory_allocated())
+    assert held[1] == held[2] == held[3] == held[4], held
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["mini_swin_sp", "mini_swin", "mini_swin_pad"])
 def test_swin_x3f_split_planes_and_matrix_core_window_attention(name, monkeypatch):
     """Swin in the tolerance-compliant mode on the device: split-plane Linears / task features, x3 MFMA window attention forward, bf16 MFMA
