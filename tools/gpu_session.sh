@@ -1,20 +1,25 @@
 #!/bin/bash
-# round 6, FINAL-2d: Swin-B after the WinAttnFn reference-cycle fix: steady memory? batch 8 / 12 / 16 bare loops (8 steps), then the full line at 16
+# GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
+# round 6, FINAL-3: the whole -m gpu suite + smoke() + the driver-style bench line + the kernel trace of the same step on the final tree
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode"
-show() { python - $1 "$2" <<'PY'
-import json, sys
-l=[x for x in open(sys.argv[1]) if x.startswith('{')]
+rm -f $O/parity_report.jsonl
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/r06_pytest_ag_full.log 2>&1; echo "full suite rc $?"; tail -3 $O/r06_pytest_ag_full.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke_ag.log 2>&1; echo "smoke rc $?"; tail -1 $O/r06_smoke_ag.log
+timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r06_bench_ag_driver_style.log 2> $O/r06_bench_ag_driver_style.err; echo "bench rc $?"
+python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r06_bench_ag_driver_style.log') if x.startswith('{')]
 if l:
-    d=json.loads(l[-1]); f=d.get('fast_mode') or {}
-    print(sys.argv[2], d['config']['per_gpu_batch'], {k:d.get(k) for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')}, 'bf16', f.get('images_per_s'), 'parity', (d.get('parity') or {}).get('worst_head_rel_err'))
-else: print(sys.argv[2], 'NO LINE', open(sys.argv[1].replace('.log','.err')).read()[-600:])
+    d=json.loads(l[-1])
+    print({k:d[k] for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
+    r=d['roofline']; print({k:v for k,v in r.items() if k in ('achieved','frac','frac_mfma_issued','traffic','traffic_note','launches','kernel_ms_per_step')})
+    print('fast', d['fast_mode'] and {k:d['fast_mode'].get(k) for k in ('images_per_s','fwd_ms_per_img','error')}, 'parity', d['parity'] and d['parity'].get('worst_head_rel_err'))
+    print('x3', {k: d['full_fp32_mode'].get(k) for k in ('images_per_s','ms_per_step','per_gpu_batch')} if d.get('full_fp32_mode') else None)
+    print('roofline_bwd_gemm', (d.get('roofline_bwd_gemm') or {}).get('frac'), 'git', d.get('git'))
 PY
-}
-timeout 600 python -m pytest tests -m gpu -q -k "swin or Swin" 2>&1 | tail -2
-for b in 8 12 16; do
-  timeout 900 python bench.py --config swinb --batch $b --steps 6 --warmup 2 $B --no-fast-mode --no-parity --no-roofline > $O/t$b.log 2>$O/t$b.err; show $O/t$b.log "bare s6w2"
-done
-timeout 1200 python bench.py --config swinb --batch 16 --steps 6 --warmup 2 $B > $O/r06_bench_af_swinb_b16.log 2>$O/r06_bench_af_swinb_b16.err; show $O/r06_bench_af_swinb_b16.log "full b16"
-timeout 1200 python bench.py --config swinb --batch 8 --steps 6 --warmup 2 $B > $O/r06_bench_af_swinb_b8.log 2>$O/r06_bench_af_swinb_b8.err; show $O/r06_bench_af_swinb_b8.log "full b8"
+cd /tmp; export TMPDIR=/tmp
+Q="--no-cpu-baseline --no-torch-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-fwd --no-roofline"
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_q -o q -- python $REPO/bench.py --steps 3 --warmup 1 $Q > $O/r06_prof_ag_run.log 2>&1
+python $REPO/tools/prof_summary.py /tmp/prof_q 5 > $O/r06_train_ns6_b126_x3f_ag.txt 2>&1
+head -6 $O/r06_train_ns6_b126_x3f_ag.txt | cut -c1-150
