@@ -591,6 +591,8 @@ def main():
         mtt_amd.autograd_path.GELU_DAUX = False
     if a.pitch32_from is not None:
         mtt_amd.ops.PITCH32_FROM = a.pitch32_from
+    if os.environ.get("MTT_DECONV_SPLIT") is not None:       # A/B: ConvTranspose2d as split-plane GEMM + mtt_pixshuf2 (1, default) or the general kernel's pixel-shuffle store (0)
+        mtt_amd.ops.DECONV_SPLIT = os.environ["MTT_DECONV_SPLIT"] == "1"
     if a.no_head_prologue:
         mtt_amd.autograd_path.HEAD_PROLOGUE = False
     if a.measure_no_repack:

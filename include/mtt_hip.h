@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 11
+#define MTT_ABI_VERSION 12
 
 /* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
  * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
@@ -346,6 +346,12 @@ int mtt_segcopy(const mtt_segcopy_desc* d, void* stream);
 /* Small utilities: dtype cast / strided 2-D copy, column sums (bias gradients), axpy-style accumulate. */
 int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
                int src_dtype, int dst_dtype, int zero_pad_cols, void* stream);
+/* ABI 12.  Pixel shuffle of nn.ConvTranspose2d(k = 2, s = 2) (taskprompter.py:705) computed as a PLAIN GEMM z = x W4^T, W4 row (dy*2+dx)*Co + co:
+ *   out[((b*2H + 2y+dy)*2W + 2x+dx), co] = z[(b*H + y)*W + x, (dy*2+dx)*Co + co]   (co < Co; channels Co .. ldo-1 written as zeros)
+ * z [B*H*W, ldz] (z_dtype), out [B*2H*2W, ldo] (out_dtype); ldo % 8 == 0.  (mtt_gemm's MTT_STORE_PIXSHUF2 does the same inside the general
+ * kernel's epilogue; this pass lets the product run on the split-plane LDS-DMA kernel in the x3f mode.) */
+int mtt_pixshuf2(const void* z, void* out, int32_t B, int32_t H, int32_t W, int32_t Co, int64_t ldz, int64_t ldo, int z_dtype, int out_dtype,
+                 void* stream);
 /* dst[r,:] = rowscale[(r/mb)*2 + ((r%mb) >= n_prompt)] * src[r,:] with dtype cast (DropPath scale of a branch gradient) */
 int mtt_rowscale_cast(const void* src, void* dst, int64_t rows, int32_t cols, int64_t lds, int64_t ldd, int src_dtype, int dst_dtype,
                       const float* rowscale, int32_t mb, int32_t n_prompt, void* stream);

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -211,6 +211,7 @@ POSITIONAL = {
     "nms_bev": [ptr, C.c_int, f32, C.c_int, ptr, ptr, ptr, ptr],
     "cast2d": [ptr, ptr, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, ptr],
     "split_cast": [ptr, ptr, ptr, i64, i64, i64, i64, ptr],
+    "pixshuf2": [ptr, ptr, i32, i32, i32, i32, i64, i64, C.c_int, C.c_int, ptr],
     "colsum": [ptr, ptr, i64, i32, i64, C.c_int, ptr, ptr],
     "colsum_batched": [ptr, ptr, i64, i32, i64, C.c_int, i32, i64, i64, ptr, ptr],
     "add_rows": [ptr, ptr, i64, i32, i64, i64, C.c_int, f32, ptr],

@@ -1752,6 +1752,35 @@ extern "C" int mtt_cast2d(const void* src, void* dst, int64_t rows, int64_t cols
                      src_dtype, dst_dtype, zero_pad_cols);
   return LAUNCH_OK();
 }
+// Pixel shuffle of a ConvTranspose2d(k = 2, s = 2) computed as a plain GEMM: z [B*H*W, ldz] with column (dy*2+dx)*Co + co  ->
+// out [B*2H*2W, ldo] NHWC (channels Co .. ldo-1 zeros).  One lane per 4 output channels of an output pixel; a quad's 4 source columns are
+// consecutive inside one (dy, dx) block, read as scalars (the block offsets (dy*2+dx)*Co are not 16-byte aligned for odd Co).
+__global__ __launch_bounds__(256) void pixshuf2_kernel(const void* z, void* out, int B, int H, int W, int Co, int64_t ldz, int64_t ldo, int zdt, int odt) {
+  const int64_t quads = ldo >> 2;
+  const int64_t total = (int64_t)B * 4 * H * W * quads;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)(t % quads) * 4;
+    const int64_t opix = t / quads;
+    const int ox = (int)(opix % (2 * W));
+    const int64_t r1 = opix / (2 * W);
+    const int oy = (int)(r1 % (2 * H));
+    const int64_t b = r1 / (2 * H);
+    const int64_t zrow = (b * H + (oy >> 1)) * W + (ox >> 1);
+    const int q = (oy & 1) * 2 + (ox & 1);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = c0 + j < Co ? ld_elem(z, zrow * ldz + (int64_t)q * Co + c0 + j, zdt) : 0.f;
+    if (odt == MTT_F32) *(float4*)((float*)out + opix * ldo + c0) = make_float4(v[0], v[1], v[2], v[3]);
+    else *(u32x2*)((bf16_t*)out + opix * ldo + c0) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+  }
+}
+extern "C" int mtt_pixshuf2(const void* z, void* out, int32_t B, int32_t H, int32_t W, int32_t Co, int64_t ldz, int64_t ldo, int z_dtype, int out_dtype,
+                            void* stream) {
+  if (!z || !out || B <= 0 || H <= 0 || W <= 0 || Co <= 0 || ldz < 4 * (int64_t)Co || ldo < Co) return MTT_E_BADARG;
+  if ((ldo % 8) || ((uintptr_t)out & 15)) return MTT_E_ALIGN;
+  hipLaunchKernelGGL(pixshuf2_kernel, dim3(grid_for((int64_t)B * 4 * H * W * (ldo / 4))), dim3(256), 0, S_, z, out, B, H, W, Co, ldz, ldo, z_dtype, out_dtype);
+  return LAUNCH_OK();
+}
 extern "C" int mtt_add_rows(const void* src, float* dst, int64_t rows, int32_t cols, int64_t lds_, int64_t ldd, int src_dtype,
                             float alpha, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0) return MTT_E_BADARG;

@@ -694,10 +694,24 @@ def upconv3x3(x, w9, Co, B, h, w, prec, *, bias=None, colscale=None, act=ACT_NON
     return upconv4_expand(z, Co, B, h, w, bias=bias, colscale=colscale, act=act)
 
 
+DECONV_SPLIT = True        # A/B switch: False = ConvTranspose2d through the general kernel's pixel-shuffle store in every mode
+
+
 def deconv2x2(x, wpack, Co, Ci, B, H, W, prec, *, bias4=None, out_dtype=None):
     """ConvTranspose2d(k=2, s=2) as a GEMM with a pixel-shuffle store (taskprompter.py:705).
     x [B*H*W, Cip]; wpack [1, 4*Co, Cip] with n = (dy*2+dx)*Co + co; bias4 [4*Co].  -> [B*2H*2W, pad8(Co)]"""
     Cop = pad8(Co)
+    if (DECONV_SPLIT and prec.split and torch.is_tensor(x) and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+            and wpack.dtype == torch.float32 and x.shape[1] == wpack.shape[-1] and split_gemm_ok(x.shape[1]) and B * H * W >= 2048):
+        # x3f: the product as a PLAIN GEMM on the split-plane LDS-DMA kernel (the pixel-shuffle store exists in the general kernel's epilogue
+        # only, i.e. register-staged x3: 6.4 ms per task at the Swin-B shape), then one shuffle pass (mtt_pixshuf2)
+        wsp = getattr(wpack, "_mtt_split", None)          # lives and dies with the pack (rebuilt after every parameter update)
+        if wsp is None:
+            wsp = wpack._mtt_split = split_cast(wpack[0].contiguous())
+        z = linear(split_cast(x), Split(wsp.hi[None], wsp.lo[None]), 4 * Co, prec, bias=None if bias4 is None else bias4[None], out_dtype=torch.float32)
+        out = torch.empty(B * 4 * H * W, Cop, dtype=out_dtype or prec.adt, device=x.device)
+        call("pixshuf2", args=[z[0], out, B, H, W, Co, z.shape[-1], Cop, dtype_code(z), dtype_code(out)])
+        return out
     out = torch.zeros(B * 4 * H * W, Cop, dtype=out_dtype or prec.adt, device=x.device)
     kw = dict(A=x, B=wpack, D=out, M=B * H * W, N=4 * Co, K=wpack.shape[-1], a_op=OP_K, b_op=OP_K,
               a_dtype=dtype_code(x), b_dtype=dtype_code(wpack), d_dtype=dtype_code(out), prec=prec.code,

@@ -571,6 +571,17 @@ def cast2d(args):
         _wr(dst, r * ldd + torch.arange(cols, ldd)[None, :], torch.zeros(rows, ldd - cols, dtype=torch.float64))
 
 
+def pixshuf2(args):
+    z, out, B, H, W, Co, ldz, ldo = args[:8]
+    b, y, x, dy, dx, c = torch.meshgrid(torch.arange(B), torch.arange(H), torch.arange(W), torch.arange(2), torch.arange(2), torch.arange(Co), indexing="ij")
+    src = ((b * H + y) * W + x) * ldz + (dy * 2 + dx) * Co + c
+    opix = (b * 2 * H + 2 * y + dy) * (2 * W) + 2 * x + dx
+    _wr(out, (opix * ldo + c).reshape(-1), _rd(z, src.reshape(-1)))
+    if ldo > Co:
+        pad = (opix[..., :1] * ldo + torch.arange(Co, ldo)).reshape(-1)
+        _wr(out, pad, torch.zeros(pad.numel(), dtype=torch.float64))
+
+
 def split_cast(args):
     src, hi, lo, rows, cols, lds, ldd = args[:7]
     r, c = torch.arange(rows)[:, None], torch.arange(cols)[None, :]
@@ -1197,7 +1208,7 @@ _TABLE = dict(gather_rows=gather_rows, winattn_fwd=winattn_fwd, winattn_bwd=wina
               convt3x3s2_gather_bwd=convt3x3s2_gather_bwd, attn_bwd=attn_bwd, grad_sqnorm=grad_sqnorm, adam_step=adam_step, loss_label_stats=loss_label_stats,
               loss_fwd=loss_fwd, loss_bwd=loss_bwd, chanattn_bwd=chanattn_bwd, conv3s2_nchw_bwd=conv3s2_nchw_bwd, segcopy=segcopy,
               ctr_weights=ctr_weights, ctr_weights_bwd=ctr_weights_bwd, detloss_fwd=detloss_fwd, detloss_bwd=detloss_bwd)
-_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, colsum=colsum, colsum_batched=colsum_batched, add_rows=add_rows, rowscale_cast=rowscale_cast, rowscale_cast_colsum=rowscale_cast_colsum)
+_POS = dict(boxes_overlap_bev=boxes_overlap_bev, nms_bev=nms_bev, patchify=patchify, resize_nchw=resize_nchw, patchify16=patchify16, cast2d=cast2d, split_cast=split_cast, pixshuf2=pixshuf2, colsum=colsum, colsum_batched=colsum_batched, add_rows=add_rows, rowscale_cast=rowscale_cast, rowscale_cast_colsum=rowscale_cast_colsum)
 
 
 def call(name, **kw):

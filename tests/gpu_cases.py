@@ -880,6 +880,10 @@ def swin_cases():
         kw = dict(src=win, dst=dst[:, T:, 8:], idx=rev, rows=res[0] * res[1], C=C, ld_src=C, ld_dst=C + 8, src_dtype=BF16, dst_dtype=F32,
                   B=B, src_bs=nW * Nw * C, dst_bs=N * (C + 8), idx_bs=0)
         cases.append((f"gather_reverse_{res[0]}x{res[1]}_w{window}_s{shift}", "gather_rows", kw, TOL_ROW))
+    # pixel shuffle of the ConvTranspose2d GEMM (ABI 12): odd Co (unaligned (dy, dx) blocks), wide output pitch, both dtypes
+    for (B_, H_, W_, Co_, ldz_, ldo_, zdt, odt) in ((2, 3, 5, 18, 72, 24, F32, F32), (1, 4, 4, 225 // 9, 104, 32, F32, BF16), (2, 2, 3, 7, 32, 8, BF16, F32)):
+        kw = dict(args=[rnd(g, B_ * H_ * W_, ldz_, dtype=DT[zdt]), torch.full((B_ * 4 * H_ * W_, ldo_), 7.0, dtype=DT[odt]), B_, H_, W_, Co_, ldz_, ldo_, zdt, odt])
+        cases.append((f"pixshuf2_{B_}x{H_}x{W_}_c{Co_}_{zdt}{odt}", "pixshuf2", kw, TOL_ROW))
     # window attention
     for (res, window, shifted, T, nH, B, dts) in (((8, 12), 4, True, 2, 2, 2, (BF16, F32)), ((7, 9), 5, True, 3, 1, 2, (BF16, F32)),
                                                   ((7, 14), 7, False, 2, 3, 1, (BF16, F32)), ((9, 9), 9, False, 3, 2, 2, (BF16,)),

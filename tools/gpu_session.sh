@@ -1,25 +1,23 @@
 #!/bin/bash
-# GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
-# round 6, FINAL-3: the whole -m gpu suite + smoke() + the driver-style bench line + the kernel trace of the same step on the final tree
+# round 6, session 31: ConvTranspose2d as a split-plane GEMM + mtt_pixshuf2 (x3f): op parity, Swin / cfg5 model parity, A/B benches
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-rm -f $O/parity_report.jsonl
-timeout 2400 python -m pytest tests/ -q -m gpu > $O/r06_pytest_ag_full.log 2>&1; echo "full suite rc $?"; tail -3 $O/r06_pytest_ag_full.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke_ag.log 2>&1; echo "smoke rc $?"; tail -1 $O/r06_smoke_ag.log
-timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r06_bench_ag_driver_style.log 2> $O/r06_bench_ag_driver_style.err; echo "bench rc $?"
-python - <<'PY'
-import json
-l=[x for x in open('gpurun_out/r06_bench_ag_driver_style.log') if x.startswith('{')]
+timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "pixshuf" 2>&1 | tail -3
+timeout 1500 python -m pytest tests -m gpu -q -k "swin or Swin or deconv or cfg5" 2>&1 | tail -4
+B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-roofline"
+show() { python - $1 "$2" <<'PY'
+import json, sys
+l=[x for x in open(sys.argv[1]) if x.startswith('{')]
 if l:
-    d=json.loads(l[-1])
-    print({k:d[k] for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
-    r=d['roofline']; print({k:v for k,v in r.items() if k in ('achieved','frac','frac_mfma_issued','traffic','traffic_note','launches','kernel_ms_per_step')})
-    print('fast', d['fast_mode'] and {k:d['fast_mode'].get(k) for k in ('images_per_s','fwd_ms_per_img','error')}, 'parity', d['parity'] and d['parity'].get('worst_head_rel_err'))
-    print('x3', {k: d['full_fp32_mode'].get(k) for k in ('images_per_s','ms_per_step','per_gpu_batch')} if d.get('full_fp32_mode') else None)
-    print('roofline_bwd_gemm', (d.get('roofline_bwd_gemm') or {}).get('frac'), 'git', d.get('git'))
+    d=json.loads(l[-1]); print(sys.argv[2], d['config']['per_gpu_batch'], {k:d.get(k) for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
+else: print(sys.argv[2], 'NO LINE', open(sys.argv[1].replace('.log','.err')).read()[-600:])
 PY
-cd /tmp; export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-torch-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-fwd --no-roofline"
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_q -o q -- python $REPO/bench.py --steps 3 --warmup 1 $Q > $O/r06_prof_ag_run.log 2>&1
-python $REPO/tools/prof_summary.py /tmp/prof_q 5 > $O/r06_train_ns6_b126_x3f_ag.txt 2>&1
-head -6 $O/r06_train_ns6_b126_x3f_ag.txt | cut -c1-150
+}
+for rep in 1 2; do
+for ds in 1 0; do
+  MTT_DECONV_SPLIT=$ds timeout 900 python bench.py --config swinb --steps 5 --warmup 2 $B > $O/r06_bench_ah_swinb_ds$ds.log 2>$O/r06_bench_ah_swinb_ds$ds.err; show $O/r06_bench_ah_swinb_ds$ds.log "swinb deconv_split=$ds"
+done
+done
+for ds in 1 0; do
+  MTT_DECONV_SPLIT=$ds timeout 900 python bench.py --config cfg5 --steps 3 --warmup 1 $B > $O/r06_bench_ah_cfg5_ds$ds.log 2>$O/r06_bench_ah_cfg5_ds$ds.err; show $O/r06_bench_ah_cfg5_ds$ds.log "cfg5 deconv_split=$ds"
+done
