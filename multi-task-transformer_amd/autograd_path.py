@@ -18,7 +18,7 @@ from . import bn as bn_mod
 from . import _lib, ops
 from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_GELU_DAUX, ACT_MUL_AUX, ACT_NONE, F32, OP_CONV_R, OP_K, OP_R, dtype_code  # noqa: F401
 
-pad8 = ops.pad8
+pitch = ops.pitch
 SPLITK_MIN_ROWS = 4096      # reduction length from which few-tile weight gradients are split over the batch dimension
 WGRAD_MAX_SLICES, WGRAD_TARGET_WGS = 192, 512        # _wgrad's split-K: up to two workgroups per CU (round 4: 64, 256)
 
@@ -262,7 +262,7 @@ class LayerNormFn(Function):
 # =================================================================================================
 def attention_bwd(qkv, dao, drawlog, B, N, nH, T, prec):
     """Backward of ops.attention: recompute P per (batch, head) with the batched GEMM + row softmax."""
-    C, Np, Z = nH * 64, pad8(N), B * nH
+    C, Np, Z = nH * 64, pitch(N), B * nH
     dev, adt = qkv.device, prec.adt
     scale = 64 ** -0.5
     S = torch.empty(Z, N, Np, dtype=adt, device=dev)
@@ -545,8 +545,8 @@ AUTO_SPLIT_MIN_ROWS = 2048
 
 
 class BLinearFn(Function):
-    """Task-batched linear / 1x1 conv: y[z] = x[z] @ W[z]^T + b[z].  layout 'plain' -> [Z, M, pad8(N)];
-    'catpair' -> [Z/2, M, 2*pad8(N)] (z = 2t+s written at column offset s*pad8(N): the reference's
+    """Task-batched linear / 1x1 conv: y[z] = x[z] @ W[z]^T + b[z].  layout 'plain' -> [Z, M, pitch(N)];
+    'catpair' -> [Z/2, M, 2*pitch(N)] (z = 2t+s written at column offset s*pitch(N): the reference's
     torch.cat([spa, chan], dim=1), taskprompter.py:471).  kmap = optional (Kp, [(dst0, src0, len), ...])
     column remap used when the input is such a padded concatenation."""
 
@@ -573,7 +573,7 @@ class BLinearFn(Function):
         else:
             wpack = ops.pack_kmap(list(ws), N, kmap[0], kmap[1], prec, tag)
         bias = ops.stack_vec(list(bs), (tag, 'b'))
-        M, Np = x.shape[-2], pad8(N)
+        M, Np = x.shape[-2], pitch(N)
         if layout == 'catpair':
             shape = (Z // 2, M, 2 * Np)
             out = ops.Split.empty(shape, x.device) if out_dtype == "split" else torch.empty(shape, dtype=out_dtype or prec.adt, device=x.device)
@@ -594,7 +594,7 @@ class BLinearFn(Function):
         Z, N, layout, kmap, prec, wshapes, xdt = ctx.meta
         prec = prec.bwd
         x, dy = _to_bwd(x, prec), _to_bwd(dy.contiguous(), prec)
-        M, Np, Kp = x.shape[-2], pad8(N), wpack.shape[-1]
+        M, Np, Kp = x.shape[-2], pitch(N), wpack.shape[-1]
         if layout == 'catpair':
             az = dict(batch=Z, batch_inner=2, a_zo=M * 2 * Np, a_zi=Np)
             lda = 2 * Np
@@ -605,11 +605,11 @@ class BLinearFn(Function):
         bi = az['batch_inner']
         dx = torch.empty(Z, M, Kp, dtype=getattr(ctx, "grad_dtype", None) or xdt, device=x.device)       # (a stage of FuseTailFn: the backward's dtype)
         if prec.name == "bf16" and FAST_BWD and dy.dtype == torch.bfloat16 and M >= FAST_MIN_ROWS and Kp >= 128:
-            # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T.  The reduction runs over pad8(N) columns of dy:
-            # the padding columns [N, pad8(N)) meet zero rows of W^T, but 0 * NaN is NaN, so they must hold FINITE values.  Invariant of
+            # dgrad on the LDS-DMA kernels: reduction-contiguous transposed pack W^T.  The reduction runs over pitch(N) columns of dy:
+            # the padding columns [N, pitch(N)) meet zero rows of W^T, but 0 * NaN is NaN, so they must hold FINITE values.  Invariant of
             # this file: every producer of a task-stack gradient writes its padding channels as zeros (conv / linear dgrads through
             # n_store = pitch, bn_bwd_apply, ctr_mix, upconv4_gather, cast2d with zero_pad) — never torch.empty garbage.
-            wT = _pad_last(wpack.transpose(1, 2), Np)                  # [Z, Kp, pad8(N)]: a few MB, once per backward of this node
+            wT = _pad_last(wpack.transpose(1, 2), Np)                  # [Z, Kp, pitch(N)]: a few MB, once per backward of this node
             if wT.dtype != torch.bfloat16:                             # x3f: the forward's pack is fp32
                 wT = wT.to(torch.bfloat16)
             _gemm(dy, wT, dx, M, Kp, Np, prec, lda=lda, ldb=Np, ldd=Kp, b_zo=wT.stride(0) * bi, b_zi=wT.stride(0) if bi > 1 else 0,
@@ -726,7 +726,7 @@ class Conv3x3Fn(Function):
 
 class UpConv3x3Fn(Function):
     """F.interpolate(x, scale_factor=4, 'bilinear') -> task-batched Conv2d(3x3, padding 1) (+bias) on the LOW-resolution task stack
-    x [Z, B*h*w, pad8(Ci)] (taskprompter.py:420 -> ConvHead.mt_proj[0], :692), "taps first" (include/mtt_hip.h, mtt_upconv_desc):
+    x [Z, B*h*w, pitch(Ci)] (taskprompter.py:420 -> ConvHead.mt_proj[0], :692), "taps first" (include/mtt_hip.h, mtt_upconv_desc):
     forward = ONE GEMM with the nine stacked tap matrices + the expansion kernel; backward = the gather kernel + the input / weight
     gradient GEMMs of that linear layer on the h x w map.  geo = (B, h, w, Co, Ci)."""
 
@@ -821,7 +821,7 @@ def bn_act_single(x, gamma, beta, bn, C, act, training):
 
 class TaskHeadsFn(Function):
     """The per-task 1x1 prediction convs (different output widths) on a task stack y [Z, rows, ld]: returns Z fp32 maps
-    [1, rows, pad8(n_z)].  One Function so that the backward writes each task's input gradient straight into its slice of a
+    [1, rows, pitch(n_z)].  One Function so that the backward writes each task's input gradient straight into its slice of a
     single dy buffer (taskprompter.py:694 linear_pred / transformer_decoder.py:130)."""
 
     @staticmethod
@@ -856,13 +856,13 @@ class TaskHeadsFn(Function):
             if (prec.name == "bf16" and FAST_BWD and HEAD_DGRAD_DMA and dy.dtype == torch.bfloat16 and rows >= FAST_MIN_ROWS and g.shape[1] % 8 == 0
                     and Kp == ld):
                 # dya = g W is an outer-product-like GEMM (K = n <= 21 classes, a million rows): bound by the 0.7 GB it writes.  bf16 copies of
-                # the two small operands (g [rows, pad8(n)], W^T [ld, pad8(n)]) put it on the 128-row LDS-DMA kernel instead of the
+                # the two small operands (g [rows, pitch(n)], W^T [ld, pitch(n)]) put it on the 128-row LDS-DMA kernel instead of the
                 # register-staged one (423 us per task at the benchmark's batch); padding columns of g are zeros (BilinearFn.backward)
-                # only the n real columns are copied, the padding columns [n, pad8(n)) are written as zeros by the cast itself: the reduction
-                # runs over pad8(n) columns and 0 * NaN is NaN, so the K padding must not depend on what the producer left there
+                # only the n real columns are copied, the padding columns [n, pitch(n)) are written as zeros by the cast itself: the reduction
+                # runs over pitch(n) columns and 0 * NaN is NaN, so the K padding must not depend on what the producer left there
                 npad = g.shape[1]
                 g16 = ops.cast2d(g, rows, n, g.stride(0), torch.bfloat16, ldd=npad, zero_pad=True)
-                wT = _pad_last(packs[z][0].t(), npad).to(torch.bfloat16)                         # [ld, pad8(n)] (tiny)
+                wT = _pad_last(packs[z][0].t(), npad).to(torch.bfloat16)                         # [ld, pitch(n)] (tiny)
                 _gemm(g16, wT, dy[z], rows, ld, npad, prec, lda=npad, ldb=npad, ldd=ld, n_store=ld, variant=_lib.GEMM_DMA128)
                 if y.dtype == torch.bfloat16:                     # (the activated map saved as bf16: ConvHeadFn's prologue form) both operands bf16
                     ga = g16
@@ -1060,7 +1060,7 @@ class CtrWeightsFn(Function):
 
 
 class Deconv2x2Fn(Function):
-    """ConvTranspose2d(k=2, s=2) = GEMM with a pixel-shuffle store (taskprompter.py:705).  x [B*H*W, Cip] -> [B*2H*2W, pad8(Co)]."""
+    """ConvTranspose2d(k=2, s=2) = GEMM with a pixel-shuffle store (taskprompter.py:705).  x [B*H*W, Cip] -> [B*2H*2W, pitch(Co)]."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, geo, prec, tag):
@@ -1078,7 +1078,7 @@ class Deconv2x2Fn(Function):
         x, Wd = ctx.saved_tensors
         (B, H, W), prec, Ci, Co = ctx.meta
         prec = prec.bwd
-        N4, N4p = 4 * Co, pad8(4 * Co)
+        N4, N4p = 4 * Co, pitch(4 * Co)
         # pixel-unshuffle of the gradient (pure re-indexing): g4[(b,y,x), (dy*2+dx)*Co + co] = dy[b, 2y+dy, 2x+dx, co]
         g4 = torch.zeros(B * H * W, N4p, dtype=dy.dtype, device=dy.device)
         g4[:, :N4] = dy.view(B, H, 2, W, 2, -1)[..., :Co].permute(0, 1, 3, 2, 4, 5).reshape(B * H * W, N4)
@@ -1160,7 +1160,7 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
     h, w = model.resolution
     N = T + h * w
     tar, F = p.embed_dim, p.final_embed_dim
-    tarp = pad8(tar)
+    tarp = pitch(tar)
     nwin = int(math.isqrt(model.chan_nheads))
     sp = model._decoder_split()          # x3f: modulate and the fea_decode epilogue write hi / lo planes, both GEMMs on the split-plane kernel
     mod = ModulateFn.apply(xsrc, rawlog, rawchan, (B, N, T, C, h, w, nwin), prec, sp)
@@ -1194,8 +1194,8 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, acc):
 
 
 def backbone_forward(model, img, upsample=True):
-    """Autograd twin of TaskPrompter._forward_nograd -> [T, B*4h*4w, pad8(F)] task features (upsample=False: the fp32 h x w sums
-    [T, B*h*w, pad8(F)] before the x4 resize, for heads that fuse it)."""
+    """Autograd twin of TaskPrompter._forward_nograd -> [T, B*4h*4w, pitch(F)] task features (upsample=False: the fp32 h x w sums
+    [T, B*h*w, pitch(F)] before the x4 resize, for heads that fuse it)."""
     p, prec = model.p, model.prec
     B = img.shape[0]
     assert tuple(img.shape[-2:]) == tuple(model.patch_embed.img_size)
@@ -1233,7 +1233,7 @@ def upsample4(acc, B, h, w, prec):
 
 
 def heads_forward(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False):
-    """Autograd twin of taskprompter.run_heads: fea [Z, B*h4*w4, pad8(F)] (lowres: [Z, B*(h4/4)*(w4/4), pad8(F)], ConvHeads only) ->
+    """Autograd twin of taskprompter.run_heads: fea [Z, B*h4*w4, pitch(F)] (lowres: [Z, B*(h4/4)*(w4/4), pitch(F)], ConvHeads only) ->
     list of fp32 NCHW predictions."""
     F = heads[0].mt_proj[0].weight.shape[0]
     outs = []

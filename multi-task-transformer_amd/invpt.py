@@ -5,7 +5,7 @@ executed on the libmtt_hip.so kernels.
 Schedule (differs from the reference's op graph):
   * ViT: one fp32 token buffer [B, 1+hw, C] (cls first), LayerNorm -> qkv GEMM -> flash attention -> proj GEMM
     (+residual) -> LayerNorm -> fc1+GELU -> fc2 (+residual); taps are copies of the patch rows.
-  * Decoder feature maps are task-major NHWC stacks [T, B*g*g, pad8(D)]; every per-task conv / BN / 1x1 is one
+  * Decoder feature maps are task-major NHWC stacks [T, B*g*g, pitch(D)]; every per-task conv / BN / 1x1 is one
     task-batched launch; the shared-weight Linears (proj_q/k/v, proj, MLP) run once over all tasks' tokens.
   * Cross-task attention (heads = 2, head dim D/2 not 64) uses the batched GEMM + row-softmax kernels on
     batch-major q/k/v ([B, T*q, .]) that the projection GEMMs produce through their row-group output mapping;
@@ -28,7 +28,7 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, F32, OP_K, OP_R, dtype_code
 from .taskprompter import Mlp, PatchEmbed, _init_vit_weights, _prec_of, trunc_normal_
 
 BATCHNORM = nn.SyncBatchNorm      # invpt.py:14, transformer_decoder.py:13 (parameter holder; statistics are computed by the kernels)
-pad8 = ops.pad8
+pitch = ops.pitch
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -307,7 +307,7 @@ class TransformerDecoder(nn.Module):
         return out, ip
 
     def forward_nhwc(self, taps, B):
-        """taps: 4 contiguous [B*hw, C] maps.  -> (features [T, B*8mh*8mw, pad8(E)], {task: inter_pred [B*mh*mw, pad8(n)] fp32})."""
+        """taps: 4 contiguous [B*hw, C] maps.  -> (features [T, B*8mh*8mw, pitch(E)], {task: inter_pred [B*mh*mw, pitch(n)] fp32})."""
         if torch.is_grad_enabled() and (any(t.requires_grad for t in taps) or any(q.requires_grad for q in self.parameters())):
             from . import invpt_autograd
             f, inter = invpt_autograd.decoder_forward(self, taps, B)
@@ -326,7 +326,7 @@ class TransformerDecoder(nn.Module):
 
         # ---- multi-scale skip features (scale_embed[2] is dead in the reference: skipped) -------------------
         se0, se1 = self.scale_embed[0], self.scale_embed[1]
-        Co0, Co0p = dims[2], pad8(dims[2])
+        Co0, Co0p = dims[2], pitch(dims[2])
 
         def build_wall():
             with torch.no_grad():
@@ -358,7 +358,7 @@ class TransformerDecoder(nn.Module):
             y = ops.conv3x3(xin, W0, C, C, B, mh, mw, prec, bias=sh, colscale=sc, act=ACT_RELU)
             sc, sh = _fold([m[1].bn1 for m in pd], None, 'pd1bn')
             y = ops.conv3x3(y, W1, Ed, C, B, mh, mw, prec, bias=sh, colscale=sc, act=ACT_RELU)
-        Edp = pad8(Ed)
+        Edp = pitch(Ed)
         inter, xs = {}, []
         for i, t in enumerate(names):
             n_out = p.TASKS.NUM_OUTPUT[t]
@@ -373,16 +373,16 @@ class TransformerDecoder(nn.Module):
                              lambda mp=mp: ops.pack_matrix(mp.weight.detach().reshape(E, -1)[:, Ed:].contiguous(), prec)[None])
             part = ops.linear(y[i], wa, E, prec, bias=mp.bias.detach()[None], out_dtype=torch.float32)[0]
             xs.append(ops.linear(inter[t], wb, E, prec, resid=part)[0])      # f32 A operand is converted while staging
-        X = torch.stack(xs, 0)                                                              # [T, rows0, pad8(E)]
+        X = torch.stack(xs, 0)                                                              # [T, rows0, pitch(E)]
 
         # ---- InvPT stages --------------------------------------------------------------------------------------
         th, tw = mh * 8, mw * 8
-        Ep = pad8(E)
+        Ep = pitch(E)
         acc = torch.zeros(T, B * th * tw, Ep, dtype=torch.float32, device=dev)
         prev_score = None
         gh, gw = mh, mw
         for i in range(3):
-            D, Dp = dims[i], pad8(dims[i])
+            D, Dp = dims[i], pitch(dims[i])
             stage = self.invpt.invpt_stages[i]
             blk = stage.blocks[0]
             if i > 0:
@@ -444,14 +444,14 @@ class TransformerDecoder(nn.Module):
         rows = B * gh * gw
         dev = Xf.device
         hd = D // heads
-        hdp = pad8(hd)
+        hdp = pitch(hd)
         Dh = heads * hdp
         qh, qw = (gh - 1) // 2 + 1, (gw - 1) // 2 + 1
         kk = 2 ** (si + 1)
         kh_, kw_ = -(-gh // kk), -(-gw // kk)
         nq, nk = qh * qw, kh_ * kw_
         Q, K = T * nq, T * nk
-        Kp = pad8(K)
+        Kp = pitch(K)
         tag = ('ipb', si)
         xn = self._ln_padded(Xf, blk.norm1, D)
         # queries: depthwise 3x3 stride-2 conv + BN per task; keys / values: ceil-mode average pooling
@@ -552,7 +552,7 @@ class TransformerDecoder(nn.Module):
 
     @staticmethod
     def _pack_heads(lin, D, heads, hd, hdp, tag, prec):
-        """Linear [D, D] -> rows re-laid as heads padded to hdp: [heads*hdp, pad8(D)] (+ matching bias)."""
+        """Linear [D, D] -> rows re-laid as heads padded to hdp: [heads*hdp, pitch(D)] (+ matching bias)."""
         def build():
             with torch.no_grad():
                 Wt = torch.zeros(heads * hdp, D, dtype=torch.float32, device=lin.weight.device)

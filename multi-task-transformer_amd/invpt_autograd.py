@@ -20,7 +20,7 @@ from . import autograd_path
 from .autograd_path import (AttnHalfFn, MlpHalfFn, BLinearFn, BilinearFn, Conv3x3Fn, ConvHeadFn, LayerNormFn, TaskHeadsFn, _bn_act,
                             _colsum, _dgrad, _gemm, _wgrad)
 
-pad8 = ops.pad8
+pitch = ops.pitch
 
 
 # =================================================================================================
@@ -55,13 +55,13 @@ class VitEmbedFn(Function):
 
 class ConvT3x3s2Fn(Function):
     """ConvTranspose2d(k=3, s=2, p=1, output_padding=1) (transformer_decoder.py:60): one GEMM producing the 9 tap
-    products per input pixel, then a gather (+bias) into the 2x map.  x [B*H*W, C] -> [B*2H*2W, pad8(Co)]."""
+    products per input pixel, then a gather (+bias) into the 2x map.  x [B*H*W, C] -> [B*2H*2W, pitch(Co)]."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, geo, prec):
         B, H, W = geo
         C, Co = weight.shape[0], weight.shape[1]
-        Cop = pad8(Co)
+        Cop = pitch(Co)
 
         def build():
             with torch.no_grad():
@@ -148,13 +148,13 @@ def _heads_kw(B, heads):
 
 class ScoresFn(Function):
     """S[b, h] = alpha * q[b, :, h] k[b, :, h]^T on batch-major q [B, Q, D], k [B, K, D] (heads = column blocks of
-    width D/heads); fp32 scores [B, heads, Q, pad8(K)] (invpt.py:205)."""
+    width D/heads); fp32 scores [B, heads, Q, pitch(K)] (invpt.py:205)."""
 
     @staticmethod
     def forward(ctx, q, k, heads, alpha, prec):
         B, Q, D = q.shape
         K = k.shape[1]
-        hd, Kp = D // heads, pad8(k.shape[1])
+        hd, Kp = D // heads, pitch(k.shape[1])
         S = torch.empty(B, heads, Q, Kp, dtype=torch.float32, device=q.device)
         _gemm(q, k, S, Q, K, hd, prec, lda=D, ldb=D, ldd=Kp, a_zo=Q * D, a_zi=hd, b_zo=K * D, b_zi=hd, d_zo=heads * Q * Kp,
               d_zi=Q * Kp, alpha=alpha, n_store=Kp, **_heads_kw(B, heads))
@@ -169,7 +169,7 @@ class ScoresFn(Function):
         prec = prec.bwd
         B, Q, D = q.shape
         K = k.shape[1]
-        hd, Kp = D // heads, pad8(K)
+        hd, Kp = D // heads, pitch(K)
         dS = dS.contiguous()
         dq, dk = torch.empty_like(q), torch.empty_like(k)
         zs = dict(a_zo=heads * Q * Kp, a_zi=Q * Kp, **_heads_kw(B, heads))
@@ -181,7 +181,7 @@ class ScoresFn(Function):
 
 
 class SoftmaxFn(Function):
-    """Row softmax over the K valid columns of fp32 scores [B, heads, Q, pad8(K)] -> P (activation dtype)."""
+    """Row softmax over the K valid columns of fp32 scores [B, heads, Q, pitch(K)] -> P (activation dtype)."""
 
     @staticmethod
     def forward(ctx, S, K, prec):
@@ -312,7 +312,7 @@ class MultiScaleSumFn(Function):
 
 
 def _check8(*dims):
-    if any(d != pad8(d) for d in dims):
+    if any(d != pitch(d) for d in dims):
         raise NotImplementedError("InvPT training path needs channel / head dims that are their own channel pitch (multiples of 8; of 32 from "
                                   f"{ops.PITCH32_FROM} channels on), got {dims}")
 
@@ -384,8 +384,8 @@ def _block(dec, blk, si, Xf, B, T, D, gh, gw, prev_score):
 
 
 def decoder_forward(dec, taps, B, heads=None):
-    """Autograd twin of TransformerDecoder.forward_nhwc -> (features [T, B*8mh*8mw, E], {task: inter_pred [1, B*mh*mw, pad8(n)] fp32});
-    heads (the MLPHeads, in task order): -> (their predictions [1, B*8mh*8mw, pad8(n)] fp32 per task, inter_preds) instead of the features."""
+    """Autograd twin of TransformerDecoder.forward_nhwc -> (features [T, B*8mh*8mw, E], {task: inter_pred [1, B*mh*mw, pitch(n)] fp32});
+    heads (the MLPHeads, in task order): -> (their predictions [1, B*8mh*8mw, pitch(n)] fp32 per task, inter_preds) instead of the features."""
     p, prec = dec.p, dec.prec
     names = p.TASKS.NAMES
     T = len(names)
@@ -416,7 +416,7 @@ def decoder_forward(dec, taps, B, heads=None):
         mp = dec.invpt.mix_proj[t][0]                                                      # 1x1 on cat([feature, inter_pred])
         part = BLinearFn.apply(y[i][None], E, 'plain', (Ed, [(0, 0, Ed)]), torch.float32, prec, ('mixa', t), None, mp.weight, mp.bias)
         zero_b = ops._cached(('mixzb', t, id(mp.bias)), [], lambda: torch.zeros(E, dtype=torch.float32, device=mp.bias.device))
-        second = BLinearFn.apply(inter[t].to(prec.adt), E, 'plain', (pad8(n_out), [(0, Ed, n_out)]), torch.float32, prec, ('mixb', t), None,
+        second = BLinearFn.apply(inter[t].to(prec.adt), E, 'plain', (pitch(n_out), [(0, Ed, n_out)]), torch.float32, prec, ('mixb', t), None,
                                  mp.weight, zero_b)
         xs.append(part[0] + second[0])
     Xf = torch.stack(xs, 0)                                                                # fp32 [T, rows0, E]

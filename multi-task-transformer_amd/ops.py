@@ -1,7 +1,7 @@
 """Forward/backward building blocks of the hot path on top of the C ABI (`_lib.call`).
 
 Data layout: every activation is a token-major (NHWC) 2-D or 3-D torch tensor `[..., rows, ld]` whose
-last dim is the channel pitch `ld = pad8(C)`; channels >= C are kept at zero.  `Prec` selects the
+last dim is the channel pitch `ld = pitch(C)`; channels >= C are kept at zero.  `Prec` selects the
 arithmetic: BF16 = bf16 storage + bf16 MFMA (throughput path), X3 = fp32 storage + split-bf16 x3 MFMA
 (fp32-class accuracy: the 1e-3 parity gate).  The residual stream, logits side channels, statistics and
 all gradients of parameters are fp32 in both modes.
@@ -17,15 +17,18 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, OP_CONV_K, OP_CONV_R, OP_K, OP_R, PREC_BF16, PREC_X3, SPLIT)
 
 
-PITCH32_FROM = 160         # channel counts >= this take a pitch that is a multiple of 32 (see pad8); 1 << 30 = the multiple-of-8 pitch everywhere.
+PITCH32_FROM = 160         # channel counts >= this take a pitch that is a multiple of 32 (see pitch); 1 << 30 = the multiple-of-8 pitch everywhere.
                            # (160: below it the rounding costs > 10 % of a map, and InvPT's 144-channel stage keeps its width as its pitch)
 
 
-def pad8(n):
-    """The channel pitch of a map with n channels: the next multiple of 8 — of 32 from PITCH32_FROM channels on, so that the K loop of a GEMM or
+def pitch(n):
+    """The channel pitch of a map with n channels (`pad8` until round 6, when every pitch was the next multiple of 8): the next multiple of 8 — of 32 from PITCH32_FROM channels on, so that the K loop of a GEMM or
     3x3 implicit GEMM reading the map is whole 32-deep LDS-DMA steps (176 -> 192, 232 -> 256, 456 -> 480, 784 -> 800: the split-plane / ring
     kernels instead of the register-staged ones).  Every kernel writes the channels C..ld-1 of its output maps as zeros."""
     return (n + 31) // 32 * 32 if n >= PITCH32_FROM else (n + 7) // 8 * 8
+
+
+pad8 = pitch               # historical name (tools / tests)
 
 
 DEFAULT_PREC = "x3f"        # arithmetic mode of a model whose config does not name one (`p.mtt_prec`): the tolerance-compliant mode
@@ -89,11 +92,11 @@ def _hi(t):
 
 
 def split_cast(x2d, cols=None):
-    """fp32 [rows, ld] -> Split [rows, pad8(cols)] (mtt_split_cast)."""
+    """fp32 [rows, ld] -> Split [rows, pitch(cols)] (mtt_split_cast)."""
     rows = x2d.shape[0]
     cols = cols or x2d.shape[1]
-    out = Split.empty((rows, pad8(cols)), x2d.device)
-    call("split_cast", args=[x2d, out.hi, out.lo, rows, cols, x2d.stride(0), pad8(cols)])
+    out = Split.empty((rows, pitch(cols)), x2d.device)
+    call("split_cast", args=[x2d, out.hi, out.lo, rows, cols, x2d.stride(0), pitch(cols)])
     return out
 
 
@@ -158,7 +161,7 @@ def _cached(key, params, build):
 
 
 def cast2d(src, rows, cols, lds, dst_dtype, ldd=None, zero_pad=True):
-    ldd = ldd or pad8(cols)
+    ldd = ldd or pitch(cols)
     dst = torch.empty(rows, ldd, dtype=dst_dtype, device=src.device)
     call("cast2d", args=[src, dst, rows, cols, lds, ldd, dtype_code(src), dtype_code(dst), 1 if zero_pad else 0])
     return dst
@@ -176,9 +179,9 @@ def cast_rows(src2d, dst_dtype):
 
 
 def pack_matrix(w2d, prec):
-    """[N, K] fp32 -> [N, pad8(K)] in the activation dtype (zero padded); the lazily cached one-off packs (InvPT, deconv heads)."""
+    """[N, K] fp32 -> [N, pitch(K)] in the activation dtype (zero padded); the lazily cached one-off packs (InvPT, deconv heads)."""
     N, K = w2d.shape
-    if prec.adt == torch.float32 and K == pad8(K) and w2d.is_contiguous():
+    if prec.adt == torch.float32 and K == pitch(K) and w2d.is_contiguous():
         return w2d
     return cast2d(w2d.contiguous(), N, K, K, prec.adt)
 
@@ -399,7 +402,7 @@ def _check_sources(weights, ok):
 def pack_linear(weights, prec, tag):
     """List of Z parameters [N, K] (or 1x1 conv [N, K, 1, 1]) -> one [Z, N, Kp] buffer in the activation dtype (zero padded)."""
     N, K = _w2d(weights[0])
-    Kp, Z = pad8(K), len(weights)
+    Kp, Z = pitch(K), len(weights)
     if prec.adt == torch.float32 and Z == 1 and K == Kp and weights[0].is_contiguous():
         return weights[0].detach().reshape(1, N, K)               # fp32 storage: the parameter itself is the operand
     return seg_pack((tag, prec.name, tuple(id(w) for w in weights)), list(weights),
@@ -418,9 +421,9 @@ def pack_linear_T(weight, dtype, tag):
 
 
 def pack_linear_split(weights, tag):
-    """List of Z parameters [N, K] -> Split [Z, N, pad8(K)]: pre-split weight planes for the LDS-DMA x3 GEMM (x3f mode)."""
+    """List of Z parameters [N, K] -> Split [Z, N, pitch(K)]: pre-split weight planes for the LDS-DMA x3 GEMM (x3f mode)."""
     N, K = _w2d(weights[0])
-    Kp, Z = pad8(K), len(weights)
+    Kp, Z = pitch(K), len(weights)
     dev = weights[0].device
     return seg_pack((tag, 'split', tuple(id(w) for w in weights)), list(weights),
                     lambda: Split(torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, N, Kp, dtype=torch.bfloat16, device=dev)),
@@ -436,7 +439,7 @@ def pack_conv3(weights, prec, tag, transpose=False):
         # x3f forward: pre-split planes -> conv3x3 runs the split-plane implicit-GEMM kernel (an fp32 input is split by one pass first)
         return pack_conv3_split(weights, tag)
     R, Cin = (Ci, Co) if transpose else (Co, Ci)
-    Cp, Z = pad8(Cin), len(weights)
+    Cp, Z = pitch(Cin), len(weights)
     # logical box (r, tap, c): source W[co, ci, tap] has strides (Ci*9, 9, 1) over (co, ci, tap)
     s = (9, 1, Ci * 9) if transpose else (Ci * 9, 1, 9)
     return seg_pack((tag, prec.name, transpose, tuple(id(w) for w in weights)), list(weights),
@@ -446,9 +449,9 @@ def pack_conv3(weights, prec, tag, transpose=False):
 
 
 def pack_conv3_split(weights, tag):
-    """pack_conv3 as pre-split planes (Split [Z, Co, 9*pad8(Ci)], k = tap*Cip + ci) for the split-plane implicit-GEMM conv."""
+    """pack_conv3 as pre-split planes (Split [Z, Co, 9*pitch(Ci)], k = tap*Cip + ci) for the split-plane implicit-GEMM conv."""
     Co, Ci = weights[0].shape[:2]
-    Cp, Z = pad8(Ci), len(weights)
+    Cp, Z = pitch(Ci), len(weights)
     dev = weights[0].device
     return seg_pack((tag, 'split', 'conv3', tuple(id(w) for w in weights)), list(weights),
                     lambda: Split(torch.zeros(Z, Co, 9 * Cp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, Co, 9 * Cp, dtype=torch.bfloat16, device=dev)),
@@ -462,16 +465,16 @@ def split_conv_ok(Ci, Co=None):
     of 32 (a K step inside one tap), at most 4096 channels, and a weight operand within 32-bit element offsets; the pixel-row limit
     (M * pitch < 2^31) is met by conv3x3 through batch chunks.  Outside these the caller keeps the non-split pack and the register-staged
     x3 kernel."""
-    Cp = pad8(Ci)
+    Cp = pitch(Ci)
     return Cp % 32 == 0 and Cp <= 4096 and (Co is None or Co * 9 * Cp < 2 ** 31)
 
 
 def pack_upconv9(weights, prec, tag):
-    """List of Z conv weights [Co, Ci, 3, 3] -> [Z, 9*pad8(Co), pad8(Ci)]: row (ky*3+kx)*pad8(Co) + co holds W[co, :, ky, kx] — the nine
+    """List of Z conv weights [Co, Ci, 3, 3] -> [Z, 9*pitch(Co), pitch(Ci)]: row (ky*3+kx)*pitch(Co) + co holds W[co, :, ky, kx] — the nine
     tap matrices of the "taps first" form of upsample x4 + 3x3 conv (mtt_upconv_desc) stacked as ONE linear layer; rows of the channel
     padding are zero, so its output planes carry zero padding channels."""
     Co, Ci = weights[0].shape[:2]
-    Cop, Kp, Z = pad8(Co), pad8(Ci), len(weights)
+    Cop, Kp, Z = pitch(Co), pitch(Ci), len(weights)
     return seg_pack((tag, prec.name, 'up9', tuple(id(w) for w in weights)), list(weights),
                     lambda: torch.zeros(Z, 9 * Cop, Kp, dtype=prec.adt, device=weights[0].device),
                     lambda buf: [segment(w, 0, buf, z * 9 * Cop * Kp, (9, Co, Ci), (1, Ci * 9, 9), (Cop * Kp, Kp, 1)) for z, w in enumerate(weights)],
@@ -479,9 +482,9 @@ def pack_upconv9(weights, prec, tag):
 
 
 def pack_upconv9_split(weights, tag):
-    """pack_upconv9 as pre-split planes (Split [Z, 9*pad8(Co), pad8(Ci)]) for the split-plane GEMM."""
+    """pack_upconv9 as pre-split planes (Split [Z, 9*pitch(Co), pitch(Ci)]) for the split-plane GEMM."""
     Co, Ci = weights[0].shape[:2]
-    Cop, Kp, Z = pad8(Co), pad8(Ci), len(weights)
+    Cop, Kp, Z = pitch(Co), pitch(Ci), len(weights)
     dev = weights[0].device
     return seg_pack((tag, 'split', 'up9', tuple(id(w) for w in weights)), list(weights),
                     lambda: Split(torch.zeros(Z, 9 * Cop, Kp, dtype=torch.bfloat16, device=dev), torch.zeros(Z, 9 * Cop, Kp, dtype=torch.bfloat16, device=dev)),
@@ -538,7 +541,7 @@ def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=No
 
     x: [Z, M, lda] / [M, lda] (broadcast over Z) — or, with a_rows=(mb, bs, ld), any view whose first
     element is row 0 (then pass M).  wpack [Z, N, Kp]; bias / colscale fp32 [Z, N] (or [1, N] broadcast).
-    out: None -> new [Z, M, pad8(N)] in `out_dtype` (default activation dtype); else a tensor / base view
+    out: None -> new [Z, M, pitch(N)] in `out_dtype` (default activation dtype); else a tensor / base view
     addressed by d_rows=(mb, bs, ld) or, for a 3-D `out`, its own strides; d_z=(zo, zi) overrides the
     per-batch offsets of D (z = zo*batch_inner + zi).  resid fp32 is added in the epilogue (r_rows mapping,
     default = D's); may alias `out`."""
@@ -557,7 +560,7 @@ def linear(x, wpack, N, prec, *, bias=None, act=ACT_NONE, out=None, out_dtype=No
         a_mb, a_bs, lda = 0, 0, xv.shape[2]
         a_z = xv.stride(0) if xv.shape[0] > 1 else 0
         assert xv.shape[0] in (1, Z) and lda >= Kp
-    Np = ldd if (out is None and ldd is not None) else pad8(N)      # a new output takes the channel pitch of N — or the caller's (composite widths: 9 tap planes)
+    Np = ldd if (out is None and ldd is not None) else pitch(N)      # a new output takes the channel pitch of N — or the caller's (composite widths: 9 tap planes)
     if out is None:
         out = Split.empty((Z, M, Np), x.device) if out_dtype == "split" else torch.empty(Z, M, Np, dtype=out_dtype or prec.adt, device=x.device)
     oh = _hi(out)
@@ -619,7 +622,7 @@ SPLIT_CONV_MAX_ELEMS = 2 ** 31 - 1          # gemm_variant_for: (int64) M * lda 
 
 
 def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=ACT_NONE, dil=1, flip=0, out_dtype=None):
-    """x [Z, B*H*W, Cp] -> [Z, B*H*W, pad8(Co)]; wpack [Z, Co, 9*Cp]; bias/colscale [Z, Co] fp32.
+    """x [Z, B*H*W, Cp] -> [Z, B*H*W, pitch(Co)]; wpack [Z, Co, 9*Cp]; bias/colscale [Z, Co] fp32.
     Implicit GEMM (no im2col buffer): A rows are gathered per 16-byte channel chunk."""
     Z, rows, Cp = x.shape
     assert rows == B * H * W and wpack.shape[-1] == 9 * Cp
@@ -630,7 +633,7 @@ def conv3x3(x, wpack, Co, Ci, B, H, W, prec, *, bias=None, colscale=None, act=AC
         sp = split_cast(x.view(Z * rows, Cp))
         x = Split(sp.hi.view(Z, rows, Cp), sp.lo.view(Z, rows, Cp))
     assert isinstance(x, Split) == isinstance(wpack, Split), "split planes: both operands or neither"
-    Cop = pad8(Co)
+    Cop = pitch(Co)
     if out_dtype == "split":                     # the output as hi / lo planes (the split-plane kernel's epilogue kinds 5 / 6): feeds a split-plane GEMM
         assert isinstance(x, Split), "a split conv output needs the split-plane conv kernel"
         out = Split.empty((Z, rows, Cop), x.device)
@@ -685,7 +688,7 @@ def upconv3x3(x, w9, Co, B, h, w, prec, *, bias=None, colscale=None, act=ACT_NON
     """F.interpolate(x, scale_factor=4, 'bilinear') -> Conv2d(3x3, padding 1) on the LOW-resolution task stack x [Z, B*h*w, Cip]
     (taskprompter.py:420 -> :692) in its taps-first form: one GEMM with the nine stacked tap matrices, then the expansion kernel."""
     if isinstance(w9, Split) and not isinstance(x, Split):
-        # x3f: the nine-tap GEMM (N = 9 * pad8(Co): whole 256-wide tiles) on the split-plane LDS-DMA kernel; the fp32 task features are
+        # x3f: the nine-tap GEMM (N = 9 * pitch(Co): whole 256-wide tiles) on the split-plane LDS-DMA kernel; the fp32 task features are
         # split by one pass over the LOW-resolution stack (1 / 16 of the head maps)
         Z, M, Kp = x.shape
         x = split_cast(x.reshape(Z * M, Kp))
@@ -699,8 +702,8 @@ DECONV_SPLIT = True        # A/B switch: False = ConvTranspose2d through the gen
 
 def deconv2x2(x, wpack, Co, Ci, B, H, W, prec, *, bias4=None, out_dtype=None):
     """ConvTranspose2d(k=2, s=2) as a GEMM with a pixel-shuffle store (taskprompter.py:705).
-    x [B*H*W, Cip]; wpack [1, 4*Co, Cip] with n = (dy*2+dx)*Co + co; bias4 [4*Co].  -> [B*2H*2W, pad8(Co)]"""
-    Cop = pad8(Co)
+    x [B*H*W, Cip]; wpack [1, 4*Co, Cip] with n = (dy*2+dx)*Co + co; bias4 [4*Co].  -> [B*2H*2W, pitch(Co)]"""
+    Cop = pitch(Co)
     if (DECONV_SPLIT and prec.split and torch.is_tensor(x) and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
             and wpack.dtype == torch.float32 and x.shape[1] == wpack.shape[-1] and split_gemm_ok(x.shape[1]) and B * H * W >= 2048):
         # x3f: the product as a PLAIN GEMM on the split-plane LDS-DMA kernel (the pixel-shuffle store exists in the general kernel's epilogue

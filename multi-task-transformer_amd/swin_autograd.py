@@ -166,7 +166,7 @@ class ChanAttnFn(Function):
     @staticmethod
     def forward(ctx, q, kv, geo):
         B, T, C, ce, nwin = geo
-        Cp = ops.pad8(C)
+        Cp = ops.pitch(C)
         kvT = torch.zeros(B, 2 * ce, Cp, dtype=torch.float32, device=q.device)
         kvT[:, :, :C] = kv.transpose(1, 2)
         rawchan = torch.empty(B, T, nwin * nwin, C, dtype=torch.float32, device=q.device)
@@ -229,8 +229,8 @@ def _lin(model, x, layer, tag, out_dtype=None):
         if key not in _zero_bias:
             _zero_bias[key] = torch.zeros(layer.weight.shape[0], dtype=torch.float32, device=x.device)
         bias = _zero_bias[key]
-    if x.shape[-1] != ops.pad8(x.shape[-1]):              # reduction length off the channel pitch (chan_kv on a 6 x 9 map): zero columns
-        x = torch.nn.functional.pad(x, (0, ops.pad8(x.shape[-1]) - x.shape[-1]))
+    if x.shape[-1] != ops.pitch(x.shape[-1]):              # reduction length off the channel pitch (chan_kv on a 6 x 9 map): zero columns
+        x = torch.nn.functional.pad(x, (0, ops.pitch(x.shape[-1]) - x.shape[-1]))
     y = BLinearFn.apply(x, layer.weight.shape[0], 'plain', None, out_dtype, model.prec, tag, None, layer.weight, bias).squeeze(0)
     return y if y.shape[1] == layer.weight.shape[0] else y[:, :layer.weight.shape[0]]     # (views: a select / full-range slice would cost a zero-fill + copy in the backward)
 
@@ -249,7 +249,7 @@ def _inverse_merge_tables(res, T, device):
 
 
 def backbone_forward(model, img):
-    """Autograd twin of TaskPrompterSwin._forward_nograd -> [T, B*h0*w0, pad8(F)] task features."""
+    """Autograd twin of TaskPrompterSwin._forward_nograd -> [T, B*h0*w0, pitch(F)] task features."""
     from . import taskprompter_swin as sw
     p, prec = model.p, model.prec
     adt = prec.adt
@@ -265,7 +265,7 @@ def backbone_forward(model, img):
     ps = model.patch_embed.patch_size[0]
     gh, gw = model.patch_grid
     C = model.embed_dim
-    Kp = ops.pad8(3 * ps * ps)
+    Kp = ops.pitch(3 * ps * ps)
     cols = torch.empty(B * gh * gw, Kp, dtype=adt, device=dev)
     ops.call("patchify", args=[img, cols, B, img.shape[-2], img.shape[-1], ps, Kp, dtype_code(cols)])
     pe = _lin(model, cols, model.patch_embed.proj, 'swpe', torch.float32)
@@ -389,7 +389,7 @@ def _task_features(model, xsrc, rawlog, rawchan, il, B, res, C, hg):
     h, w = res
     N = T + h * w
     tar, F = p.level_embed_dim, p.final_embed_dim
-    tarp = ops.pad8(tar)
+    tarp = ops.pitch(tar)
     nwin = int(math.isqrt(p.chan_nheads))
     sp = model._decoder_split(C)         # x3f: modulate and the fea_decode epilogue write hi / lo planes, both GEMMs on the split-plane kernel
     mod = ModulateFn.apply(xsrc.contiguous(), rawlog, rawchan, (B, N, T, C, h, w, nwin, hg), prec, sp)

@@ -214,8 +214,8 @@ class TaskPrompter(nn.Module):
         return out, {}
 
     def forward_nhwc(self, img, upsample=True):
-        """-> [T, B*4h*4w, pad8(F)] activation-dtype task features (x4-upsampled sum over the 4 taps; taskprompter.py:420).
-        upsample=False stops before the resize: fp32 [T, B*h*w, pad8(F)], for heads that fuse it into their first conv."""
+        """-> [T, B*4h*4w, pitch(F)] activation-dtype task features (x4-upsampled sum over the 4 taps; taskprompter.py:420).
+        upsample=False stops before the resize: fp32 [T, B*h*w, pitch(F)], for heads that fuse it into their first conv."""
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             from . import autograd_path
             return autograd_path.backbone_forward(self, img, upsample)
@@ -334,14 +334,14 @@ class TaskPrompter(nn.Module):
         prec, pf = self._gp('side'), self._gp('fuse')          # fea_decode_* belong to 'side', fea_fuse to 'fuse' (== self.prec unless attributing)
         names = p.TASKS.NAMES
         tar, F = p.embed_dim, p.final_embed_dim
-        tarp = ops.pad8(tar)
+        tarp = ops.pitch(tar)
         dec_w, dec_b = [], []
         for t in names:
             dec_w += [self.fea_decode_spa[il][t][0].weight, self.fea_decode_chan[il][t][0].weight]
             dec_b += [self.fea_decode_spa[il][t][0].bias, self.fea_decode_chan[il][t][0].bias]
         bdec = ops.stack_vec(dec_b, ('decb', il))
         f0 = [self.fea_fuse[il][t][0].weight for t in names]
-        # fea_fuse[0] reads torch.cat([spa, chan], 1) (:471): its K = 2*tar columns land at 0 and pad8(tar) of the padded concatenation
+        # fea_fuse[0] reads torch.cat([spa, chan], 1) (:471): its K = 2*tar columns land at 0 and pitch(tar) of the padded concatenation
         if self._decoder_split():
             Wdec = ops.pack_linear_split(dec_w, ('dec', il))
             W0 = ops.pack_kmap_split(f0, F, 2 * tarp, [(0, 0, tar), (tarp, tar, tar)], ('f0', il))
@@ -364,15 +364,15 @@ class TaskPrompter(nn.Module):
         writes the padded concatenation as planes (the register-staged x3 kernel split the fp32 operands of every tile while staging:
         3.2 -> 2.3 ms and 1.2 -> 0.85 ms per tap at B = 63, profiles/r04_dec_x3_bench_g.log).  Needs whole 32-deep K steps."""
         return (self.prec.split and self.gprec is None and ops.split_gemm_ok(self.embed_dim)
-                and ops.split_gemm_ok(2 * ops.pad8(self.p.embed_dim)))
+                and ops.split_gemm_ok(2 * ops.pitch(self.p.embed_dim)))
 
     def _decoder_conv_split(self):
         """... and fea_fuse[1] (3x3) on its implicit-GEMM form: fea_fuse[0]'s epilogue writes y0 as planes (channel pitch % 32 == 0)."""
         return self._decoder_split() and ops.split_conv_ok(self.p.final_embed_dim)
 
     def _fuse4_split(self):
-        """... and, in eval mode only, fea_fuse[4] on planes written by the BN-folded conv epilogue (K = pad8(F) a multiple of 32)."""
-        return (not self.training) and self._decoder_conv_split() and ops.split_gemm_ok(ops.pad8(self.p.final_embed_dim))
+        """... and, in eval mode only, fea_fuse[4] on planes written by the BN-folded conv epilogue (K = pitch(F) a multiple of 32)."""
+        return (not self.training) and self._decoder_conv_split() and ops.split_gemm_ok(ops.pitch(self.p.final_embed_dim))
 
     def _ctr_weights(self, rawlog, il, B, T):
         """[B, T, T] mixing weights: per-head MLP on the prompt<->prompt raw logits (:482-484); identity without ctr."""
@@ -399,7 +399,7 @@ class TaskPrompter(nn.Module):
         h, w = self.resolution
         hw, N = h * w, T + h * w
         tar, F = p.embed_dim, p.final_embed_dim
-        tarp, Fp = ops.pad8(tar), ops.pad8(F)
+        tarp, Fp = ops.pitch(tar), ops.pitch(F)
         nwin = int(math.isqrt(self.chan_nheads))
         Wdec, bdec, W0, b0, Wc, bc, W4, b4 = self._decoder_packs(il)
         sp = self._decoder_split()
@@ -462,9 +462,9 @@ def taskprompter_vit_base_patch16_384(pretrained=False, **kwargs):
 
 def _to_rows(x, prec):
     """Reference-layout feature map [B, C, H, W] (any strides; our own channels-last views are copied once) -> NHWC rows
-    [1, B*H*W, pad8(C)] in the activation dtype with zero channel padding."""
+    [1, B*H*W, pitch(C)] in the activation dtype with zero channel padding."""
     B, C, H, W = x.shape
-    Cp = ops.pad8(C)
+    Cp = ops.pitch(C)
     rows = torch.zeros(1, B * H * W, Cp, dtype=prec.adt, device=x.device)
     rows.view(B, H, W, Cp)[..., :C] = x.permute(0, 2, 3, 1)
     return rows
@@ -508,10 +508,10 @@ class DEConvHead(_HeadBase):
 
 
 def run_heads(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False):
-    """The per-task prediction heads of one kind on the task stack fea [Z, B*h4*w4, pad8(F)] -> list of fp32 NCHW predictions resized to
+    """The per-task prediction heads of one kind on the task stack fea [Z, B*h4*w4, pitch(F)] -> list of fp32 NCHW predictions resized to
     `target` (None: the head's native resolution).  ConvHead: ONE task-batched 3x3 conv + BN + GELU, then the 1x1s (taskprompter.py:
     688-698); DEConvHead: ConvT 2x2 s2 as a pixel-shuffle GEMM + BN + GELU + 3x3 + BN + GELU + 1x1 (:700-715).
-    lowres (ConvHeads only): fea is the backbone's result BEFORE its x4 resize, [Z, B*(h4/4)*(w4/4), pad8(F)], and the resize is fused
+    lowres (ConvHeads only): fea is the backbone's result BEFORE its x4 resize, [Z, B*(h4/4)*(w4/4), pitch(F)], and the resize is fused
     into the 3x3 conv in its taps-first form (ops.upconv3x3) — the upsampled features are never materialised."""
     if torch.is_grad_enabled() and (fea.requires_grad or any(q.requires_grad for hd in heads for q in hd.parameters())):
         from . import autograd_path
@@ -526,7 +526,7 @@ def run_heads(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False)
         if lowres:
             if fea.dtype != prec.adt:
                 fea = ops.cast_rows(fea.reshape(-1, fea.shape[-1]), prec.adt).view(fea.shape)
-            sp9 = prec.split and ops.split_gemm_ok(ops.pad8(conv_w[0].shape[1]))
+            sp9 = prec.split and ops.split_gemm_ok(ops.pitch(conv_w[0].shape[1]))
             W9 = ops.pack_upconv9_split(conv_w, 'hc9') if sp9 else ops.pack_upconv9(conv_w, prec, 'hc9')
 
             def conv(**epi):
@@ -556,7 +556,7 @@ def run_heads(kind, heads, fea, B, h4, w4, target, prec, training, lowres=False)
                          lambda wt=wt: ops.pack_matrix(wt.detach().permute(2, 3, 1, 0).reshape(4 * F2, F), prec)[None])
         b4v = ops._cached(('hd0b', id(hd.mt_proj[0].bias)), [hd.mt_proj[0].bias],
                           lambda hd=hd: hd.mt_proj[0].bias.detach().repeat(4).contiguous())
-        y = ops.deconv2x2(fea[i], Wd, F2, F, B, h4, w4, prec, bias4=b4v)[None]      # [1, B*2h4*2w4, pad8(F2)]
+        y = ops.deconv2x2(fea[i], Wd, F2, F, B, h4, w4, prec, bias4=b4v)[None]      # [1, B*2h4*2w4, pitch(F2)]
         Wc = ops.pack_conv3([hd.mt_proj[3].weight], prec, 'hd3')
         bc = hd.mt_proj[3].bias.detach()[None].contiguous()
         if training:

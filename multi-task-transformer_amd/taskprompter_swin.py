@@ -263,7 +263,7 @@ class TaskPrompterSwin(nn.Module):
     def _decoder_split(self, C):
         """x3f: a level's fea_decode_* and fea_fuse[0] on the split-plane LDS-DMA kernel (`modulate` and the fea_decode epilogue write
         hi / lo planes) — whole 32-deep K steps over the level's C channels and over the padded concatenation (TaskPrompter._decoder_split)."""
-        return self.prec.split and ops.split_gemm_ok(C) and ops.split_gemm_ok(2 * ops.pad8(self.p.level_embed_dim))
+        return self.prec.split and ops.split_gemm_ok(C) and ops.split_gemm_ok(2 * ops.pitch(self.p.level_embed_dim))
 
     SPLIT_MIN_ROWS = 2048
 
@@ -294,7 +294,7 @@ class TaskPrompterSwin(nn.Module):
         C = self.embed_dim
         N = T + gh * gw
         # ---- patch embed (+ patch_norm) into the token buffer, prompts first -------------------------------------------------------
-        Kp = ops.pad8(3 * ps * ps)
+        Kp = ops.pitch(3 * ps * ps)
         cols = torch.empty(B * gh * gw, Kp, dtype=prec.adt, device=dev)
         ops.call("patchify", args=[img, cols, B, img.shape[-2], img.shape[-1], ps, Kp, dtype_code(cols)])
         XT = torch.empty(B * N, C, dtype=torch.float32, device=dev)
@@ -378,8 +378,8 @@ class TaskPrompterSwin(nn.Module):
         ce = self.p.chan_embed_dim
         nwin = int(math.isqrt(self.p.chan_nheads))
         q = self._lin(chan_p, blk.chan_q, tag + ('cq',), out_dtype=torch.float32)[0]                     # [B*T, ce]
-        Wkv = ops.pack_linear([blk.chan_kv.weight], prec, tag + ('ckv',))                                # [1, 2ce, pad8(HW)]
-        Cp = ops.pad8(C)
+        Wkv = ops.pack_linear([blk.chan_kv.weight], prec, tag + ('ckv',))                                # [1, 2ce, pitch(HW)]
+        Cp = ops.pitch(C)
         pov = po.view(B, N, C)[:, T:]
         K = H * W
         Ks = _split_k(K)                                                        # the reduction axis is the pixel count (73 728 at the first
@@ -426,14 +426,14 @@ class TaskPrompterSwin(nn.Module):
         return XT2, raw2, rc2.view(B, T, nwin2, -1)[..., :2 * C].contiguous()
 
     def _task_features(self, xsrc, xview, rawlog, rawchan, il, B, res, C, hg):
-        """cal_task_feature (taskprompter_swin.py:715-777) for all tasks -> [T, B*2h*2w, pad8(F)] activation dtype."""
+        """cal_task_feature (taskprompter_swin.py:715-777) for all tasks -> [T, B*2h*2w, pitch(F)] activation dtype."""
         p, prec = self.p, self.prec
         names = self.all_tasks
         T = len(names)
         h, w = res
         hw, N = h * w, T + h * w
         tar, F = p.level_embed_dim, p.final_embed_dim
-        tarp = ops.pad8(tar)
+        tarp = ops.pitch(tar)
         nwin = int(math.isqrt(p.chan_nheads))
         sp = self._decoder_split(C)
         mod = ops.modulate(xview, C, N * C, rawlog, rawchan, B, T, N, C, (h, w), (nwin, nwin), prec, hg=hg, split=sp)

@@ -1,23 +1,21 @@
 #!/bin/bash
-# round 6, session 31: ConvTranspose2d as a split-plane GEMM + mtt_pixshuf2 (x3f): op parity, Swin / cfg5 model parity, A/B benches
+# GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
+# round 6, FINAL-4 (ABI 12 tree): the whole -m gpu suite + the miniatures on the wide pitch + smoke(), the Swin-B and cfg5 bench lines with all legs
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "pixshuf" 2>&1 | tail -3
-timeout 1500 python -m pytest tests -m gpu -q -k "swin or Swin or deconv or cfg5" 2>&1 | tail -4
-B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-roofline"
-show() { python - $1 "$2" <<'PY'
+rm -f $O/parity_report.jsonl
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/r06_pytest_ai_full.log 2>&1; echo "full suite rc $?"; tail -2 $O/r06_pytest_ai_full.log
+MTT_TEST_PITCH32_FROM=33 timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_train.py tests/test_gpu_ops.py -q -m gpu > $O/r06_pytest_ai_wide_pitch.log 2>&1; echo "wide-pitch suite rc $?"; tail -1 $O/r06_pytest_ai_wide_pitch.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke_ai.log 2>&1; echo "smoke rc $?"; tail -1 $O/r06_smoke_ai.log | cut -c1-200
+B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode"
+for c in swinb cfg5; do
+  timeout 1500 python bench.py --config $c --steps 6 --warmup 2 $B > $O/r06_bench_ai_$c.log 2> $O/r06_bench_ai_$c.err; echo "$c rc $?"
+  python - $O/r06_bench_ai_$c.log $c <<'PY'
 import json, sys
 l=[x for x in open(sys.argv[1]) if x.startswith('{')]
 if l:
-    d=json.loads(l[-1]); print(sys.argv[2], d['config']['per_gpu_batch'], {k:d.get(k) for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
-else: print(sys.argv[2], 'NO LINE', open(sys.argv[1].replace('.log','.err')).read()[-600:])
+    d=json.loads(l[-1]); f=d.get('fast_mode') or {}
+    print(sys.argv[2], 'batch', d['config']['per_gpu_batch'], {k:d.get(k) for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')}, 'bf16', f.get('images_per_s'), f.get('fwd_ms_per_img'), 'parity', (d.get('parity') or {}).get('worst_head_rel_err'))
+else: print(sys.argv[2], 'NO LINE', open(sys.argv[1].replace('.log','.err')).read()[-800:])
 PY
-}
-for rep in 1 2; do
-for ds in 1 0; do
-  MTT_DECONV_SPLIT=$ds timeout 900 python bench.py --config swinb --steps 5 --warmup 2 $B > $O/r06_bench_ah_swinb_ds$ds.log 2>$O/r06_bench_ah_swinb_ds$ds.err; show $O/r06_bench_ah_swinb_ds$ds.log "swinb deconv_split=$ds"
-done
-done
-for ds in 1 0; do
-  MTT_DECONV_SPLIT=$ds timeout 900 python bench.py --config cfg5 --steps 3 --warmup 1 $B > $O/r06_bench_ah_cfg5_ds$ds.log 2>$O/r06_bench_ah_cfg5_ds$ds.err; show $O/r06_bench_ah_cfg5_ds$ds.log "cfg5 deconv_split=$ds"
 done
