@@ -296,7 +296,9 @@ def test_device_memory_is_steady_over_training_steps(family, name, prec):
         gc.collect()
         torch.cuda.synchronize()
         held.append(torch.cuda.memory_allocated())
-    assert held[1] == held[2] == held[3] == held[4], held
+    # (the caching allocator rounds block sizes and the weight packs are rebuilt every step: a fraction of a percent of jitter, no trend;
+    # the leak this guards against grew the footprint by a block's qkv + out — tens of percent — per step)
+    assert max(held[1:]) - min(held[1:]) <= 0.01 * held[1], held
 
 
 @pytest.mark.gpu
