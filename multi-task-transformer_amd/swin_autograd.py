@@ -20,6 +20,7 @@ from ._lib import ACT_GELU, dtype_code
 from .autograd_path import (BilinearFn, BLinearFn, Conv3x3Fn, LayerNormFn, MlpHalfFn, ModulateFn, _bn_act)
 
 
+CHAN_KV_FN = True          # A/B switch: False = chan_kv through BLinearFn on a transposed copy of the pixel rows (rounds 2-5)
 WINATTN_MFMA = True        # A/B switch: False = the exact fp32 VALU window-attention kernels on fp32 storage (rounds 2-5)
 
 
@@ -191,6 +192,60 @@ class ChanAttnFn(Function):
         return dq, dkvT[:, :, :C].transpose(1, 2), None
 
 
+class ChanKvFn(Function):
+    """kv[b] = chan_kv(x_attn[b]^T) (taskprompter_swin.py:393-397): W [2ce, HW] applied to the TRANSPOSED pixel rows of the attention branch, i.e.
+    kvT[b] = W x_b + bias with the pixels as the reduction axis (73 728 at Swin-B's first stage).  As three GEMMs on the token-major rows
+    themselves — no transposed copy of the map: forward = split-K over the pixels (slabs summed; the BLinearFn form ran K = HW on 16-32
+    workgroups: 3.9 ms per block of stage 0 at the benchmark shape), dx_b = W^T dkvT_b written into the pixel rows of the token buffer,
+    dW = sum_b dkvT_b x_b^T as one batch of B GEMMs with fp32 slabs.  po [B*N, C] (activation dtype) -> kv fp32 [B, C, 2ce]."""
+
+    @staticmethod
+    def forward(ctx, po, weight, bias, geo, prec, tag):
+        from ._lib import F32, OP_K, OP_R
+        from .taskprompter_swin import _split_k
+        B, N, T, C, HW = geo
+        ce2 = weight.shape[0]
+        Wkv = ops.pack_linear([weight], prec, tag)                               # [1, 2ce, pitch(HW)]
+        Cp = ops.pitch(C)
+        pov = po.view(B, N, C)[:, T:]
+        Ks = _split_k(HW)
+        S = HW // Ks
+        slabs = torch.empty(B, S, ce2, Cp, dtype=torch.float32, device=po.device)
+        ops.call("gemm", A=Wkv, B=pov, D=slabs, M=ce2, N=C, K=Ks, a_op=OP_K, b_op=OP_R, a_dtype=dtype_code(Wkv), b_dtype=dtype_code(po), d_dtype=F32,
+                 prec=prec.code, lda=Wkv.shape[-1], ldb=C, ldd=Cp, batch=B * S, batch_inner=S, a_zo=0, a_zi=Ks, b_zo=N * C, b_zi=Ks * C,
+                 d_zo=S * ce2 * Cp, d_zi=ce2 * Cp, alpha=1.0, n_store=Cp)
+        kvT = slabs.sum(1) if S > 1 else slabs.view(B, ce2, Cp)
+        if bias is not None:
+            kvT = kvT + bias.detach()[None, :, None]
+        ctx.save_for_backward(po, Wkv)
+        ctx.meta = (geo, prec, weight.shape, bias is not None)
+        return kvT[:, :, :C].transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, dkv):
+        from ._lib import F32, OP_K, OP_R
+        po, Wkv = ctx.saved_tensors
+        (B, N, T, C, HW), prec, wshape, has_bias = ctx.meta
+        prec = prec.bwd
+        ce2 = wshape[0]
+        ldw = Wkv.shape[-1]
+        dkvT = dkv.transpose(1, 2).contiguous().float()                          # [B, 2ce, C] (small)
+        # dx_b [HW, C] = W^T dkvT_b -> the pixel rows of the token-buffer gradient (prompt rows: no gradient through chan_kv)
+        dpo = torch.empty(B * N, C, dtype=po.dtype, device=po.device)
+        dpo.view(B, N, C)[:, :T].zero_()
+        ops.call("gemm", A=Wkv, B=dkvT, D=dpo.view(B, N, C)[:, T:], M=HW, N=C, K=ce2, a_op=OP_R, b_op=OP_R, a_dtype=dtype_code(Wkv), b_dtype=F32,
+                 d_dtype=dtype_code(dpo), prec=prec.code, lda=ldw, ldb=C, ldd=C, batch=B, batch_inner=1, a_zo=0, b_zo=ce2 * C, d_zo=N * C,
+                 alpha=1.0, n_store=C)
+        # dW = sum_b dkvT_b [2ce, C] x_b^T [C, HW]: B GEMMs (reduction over the C channels of one image each), fp32 slabs summed
+        slabs = torch.empty(B, ce2, ldw, dtype=torch.float32, device=po.device)
+        ops.call("gemm", A=dkvT, B=po.view(B, N, C)[:, T:], D=slabs, M=ce2, N=HW, K=C, a_op=OP_K, b_op=OP_K, a_dtype=F32, b_dtype=dtype_code(po),
+                 d_dtype=F32, prec=prec.code, lda=C, ldb=C, ldd=ldw, batch=B, batch_inner=1, a_zo=ce2 * C, b_zo=N * C, d_zo=ce2 * ldw, alpha=1.0,
+                 n_store=ldw)
+        dW = slabs.sum(0)[:, :HW].reshape(wshape)
+        dbias = dkvT.sum((0, 2)) if has_bias else None
+        return dpo, dW, dbias, None, None, None
+
+
 class Conv3s2Fn(Function):
     """PatchMerging.spa_attn_ds on the raw prompt-logit maps [B, nH, T, T + H*W] -> [B, nH, T, T + H*W/4]."""
 
@@ -344,8 +399,11 @@ def _block(model, blk, tag, XT, B, T, res):
     ce = model.p.chan_embed_dim
     nwin = int(math.isqrt(model.p.chan_nheads))
     q = _lin(model, chan_p.to(adt), blk.chan_q, tag + ('cq',), torch.float32)
-    xT = po.view(B, N, C)[:, T:].transpose(1, 2).reshape(B * C, H * W)
-    kv = _lin(model, xT.contiguous(), blk.chan_kv, tag + ('ckv',), torch.float32).reshape(B, C, 2 * ce)
+    if CHAN_KV_FN and (H * W) % 8 == 0 and C % 8 == 0:
+        kv = ChanKvFn.apply(po, blk.chan_kv.weight, blk.chan_kv.bias, (B, N, T, C, H * W), prec, tag + ('ckv',))
+    else:                                        # a pixel count off the 8-element granule (6 x 9 maps of the miniatures): the transposed-copy form
+        xT = po.view(B, N, C)[:, T:].transpose(1, 2).reshape(B * C, H * W)
+        kv = _lin(model, xT.contiguous(), blk.chan_kv, tag + ('ckv',), torch.float32).reshape(B, C, 2 * ce)
     rawchan, cx = ChanAttnFn.apply(q.contiguous(), kv.contiguous(), (B, T, C, ce, nwin))
     tt1 = None
     if not blk.last_block:

@@ -1,21 +1,22 @@
 #!/bin/bash
-# GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
-# round 6, FINAL-4 (ABI 12 tree): the whole -m gpu suite + the miniatures on the wide pitch + smoke(), the Swin-B and cfg5 bench lines with all legs
+# round 6, session 34: Swin chan_kv as a split-K autograd node: parity, same-box A/B
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-rm -f $O/parity_report.jsonl
-timeout 2400 python -m pytest tests/ -q -m gpu > $O/r06_pytest_ai_full.log 2>&1; echo "full suite rc $?"; tail -2 $O/r06_pytest_ai_full.log
-MTT_TEST_PITCH32_FROM=33 timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_train.py tests/test_gpu_ops.py -q -m gpu > $O/r06_pytest_ai_wide_pitch.log 2>&1; echo "wide-pitch suite rc $?"; tail -1 $O/r06_pytest_ai_wide_pitch.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke_ai.log 2>&1; echo "smoke rc $?"; tail -1 $O/r06_smoke_ai.log | cut -c1-200
-B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode"
-for c in swinb cfg5; do
-  timeout 1500 python bench.py --config $c --steps 6 --warmup 2 $B > $O/r06_bench_ai_$c.log 2> $O/r06_bench_ai_$c.err; echo "$c rc $?"
-  python - $O/r06_bench_ai_$c.log $c <<'PY'
+timeout 1500 python -m pytest tests -m gpu -q -k "swin or Swin" 2>&1 | tail -4
+B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-roofline"
+show() { python - $1 "$2" <<'PY'
 import json, sys
 l=[x for x in open(sys.argv[1]) if x.startswith('{')]
 if l:
-    d=json.loads(l[-1]); f=d.get('fast_mode') or {}
-    print(sys.argv[2], 'batch', d['config']['per_gpu_batch'], {k:d.get(k) for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')}, 'bf16', f.get('images_per_s'), f.get('fwd_ms_per_img'), 'parity', (d.get('parity') or {}).get('worst_head_rel_err'))
-else: print(sys.argv[2], 'NO LINE', open(sys.argv[1].replace('.log','.err')).read()[-800:])
+    d=json.loads(l[-1]); print(sys.argv[2], d['config']['per_gpu_batch'], {k:d.get(k) for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
+else: print(sys.argv[2], 'NO LINE', open(sys.argv[1].replace('.log','.err')).read()[-900:])
 PY
+}
+for rep in 1 2; do
+for v in 1 0; do
+  MTT_CHAN_KV_FN=$v timeout 900 python bench.py --config swinb --steps 5 --warmup 2 $B > $O/r06_bench_ak_swinb_ckv$v.log 2>$O/r06_bench_ak_swinb_ckv$v.err; show $O/r06_bench_ak_swinb_ckv$v.log "swinb x3f chan_kv_fn=$v"
+done
+done
+for v in 1 0; do
+  MTT_CHAN_KV_FN=$v timeout 900 python bench.py --config swinb --prec bf16 --steps 5 --warmup 2 $B > $O/r06_bench_ak_swinb_bf16_ckv$v.log 2>$O/r06_bench_ak_swinb_bf16_ckv$v.err; show $O/r06_bench_ak_swinb_bf16_ckv$v.log "swinb bf16 chan_kv_fn=$v"
 done
