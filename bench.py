@@ -591,6 +591,9 @@ def main():
         mtt_amd.autograd_path.GELU_DAUX = False
     if a.pitch32_from is not None:
         mtt_amd.ops.PITCH32_FROM = a.pitch32_from
+    if os.environ.get("MTT_WINATTN_BIAST") is not None:      # A/B: transposed bias table for the window-attention backward's key-owner pass
+        import importlib
+        importlib.import_module(mtt_amd.__name__ + ".swin_autograd").WINATTN_BIAST = os.environ["MTT_WINATTN_BIAST"] == "1"
     if os.environ.get("MTT_CHAN_KV_FN") is not None:         # A/B: Swin chan_kv as the split-K node (1, default) or through BLinearFn on a transposed copy (0)
         import importlib
         importlib.import_module(mtt_amd.__name__ + ".swin_autograd").CHAN_KV_FN = os.environ["MTT_CHAN_KV_FN"] == "1"

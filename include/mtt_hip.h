@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MTT_ABI_VERSION 12
+#define MTT_ABI_VERSION 13
 
 /* MTT_SPLIT: an fp32-class value stored as TWO bf16 planes of identical layout, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
  * (~16 mantissa bits).  The main pointer of an operand addresses the hi plane, its `*_lo` companion the lo plane.  The hi plane alone is
@@ -516,6 +516,9 @@ typedef struct {
   int32_t mfma;                  /* ABI 11, fp32 storage only: 1 = matrix-core arithmetic — forward: every product as 3 bf16 MFMAs on hi / lo split
                                     operands (fp32-class, the x3 / x3f modes); backward: bf16 MFMAs (the bf16 backward of the x3f mode).
                                     0 = the exact fp32 VALU kernels.  bf16 storage always runs on the matrix cores. */
+  const float* biasT;            /* ABI 13, optional (mtt_winattn_bwd, matrix-core kernels): bias with its last two axes transposed, fp32 [nH, ws2, ws2] —
+                                    the key-owner pass then reads bias / mask of 4 consecutive queries with one 16-byte load each (the shift mask
+                                    must be symmetric, as Swin's region mask is).  NULL = strided scalar loads. */
 } mtt_winattn_desc;
 int mtt_winattn_fwd(const mtt_winattn_desc* d, void* stream);
 /* backward (d as in the forward, d->out = the forward's output): dout (dtype) [nwin, N, nH*32]; drawmap fp32 = gradient of rawmap (same

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtt_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 F32, BF16, SPLIT = 0, 1, 2
 PREC_BF16, PREC_X3 = 0, 1
 OP_K, OP_R, OP_CONV_K, OP_CONV_R = 0, 1, 2, 3
@@ -168,7 +168,7 @@ class GatherDesc(C.Structure):
 class WinAttnDesc(C.Structure):
     _fields_ = [("qkv", ptr), ("out", ptr), ("rawmap", ptr), ("bias", ptr), ("mask", ptr), ("pix", ptr),
                 ("nwin", i32), ("nW", i32), ("nH", i32), ("T", i32), ("ws2", i32), ("dtype", i32), ("scale", f32),
-                ("map_ld", i64), ("map_off", i64), ("mfma", i32)]
+                ("map_ld", i64), ("map_off", i64), ("mfma", i32), ("biasT", ptr)]
 
 
 class ChanAttnDesc(C.Structure):

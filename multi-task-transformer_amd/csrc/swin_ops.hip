@@ -891,6 +891,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
   __syncthreads();
 
   const float* bias_h = d.bias + (int64_t)h * ws2 * ws2;
+  const float* biasT_h = d.biasT ? d.biasT + (int64_t)h * ws2 * ws2 : nullptr;
   const float* mask_w = d.mask ? d.mask + (int64_t)wl * ws2 * ws2 : nullptr;
   const int32_t* px = d.pix + (int64_t)wl * ws2;
   const float* draw_b = drawmap ? drawmap + ((int64_t)b * nH + h) * T * d.map_ld + d.map_off : nullptr;
@@ -1042,13 +1043,23 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
         const int q0 = t * 16 + lg * 4;
         const float4 m4 = *(const float4*)(mrow + q0), l4 = *(const float4*)(linv + q0), D4 = *(const float4*)(Drow + q0);
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w}, DD[4] = {D4.x, D4.y, D4.z, D4.w};
+        // bias + mask of this lane's (4 consecutive queries, one key): with the TRANSPOSED bias table (mtt_winattn_desc.biasT, ABI 13) one 16-byte
+        // load each (the shift mask is symmetric), else four strided scalar loads each
+        float add[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool vec = biasT_h && kok && key >= T && q0 >= T && q0 + 3 < N;
+        if (vec) {
+          const int o = (key - T) * ws2 + (q0 - T);
+          const F4u bb = *(const F4u*)(biasT_h + o);
+          add[0] = bb.x; add[1] = bb.y; add[2] = bb.z; add[3] = bb.w;
+          if (mask_w) { const F4u mm4 = *(const F4u*)(mask_w + o); add[0] += mm4.x; add[1] += mm4.y; add[2] += mm4.z; add[3] += mm4.w; }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = q0 + r;
           float pv = 0.f, g = 0.f;
           if (q < N && kok) {
-            float v = sv[r] * d.scale;
-            if (q >= T && key >= T) {
+            float v = sv[r] * d.scale + add[r];
+            if (!vec && q >= T && key >= T) {
               const int o = (q - T) * ws2 + (key - T);
               v += bias_h[o];
               if (mask_w) v += mask_w[o];

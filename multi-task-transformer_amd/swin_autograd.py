@@ -21,6 +21,7 @@ from .autograd_path import (BilinearFn, BLinearFn, Conv3x3Fn, LayerNormFn, MlpHa
 
 
 CHAN_KV_FN = True          # A/B switch: False = chan_kv through BLinearFn on a transposed copy of the pixel rows (rounds 2-5)
+WINATTN_BIAST = True       # A/B switch: the transposed bias table for the key-owner pass of the matrix-core window-attention backward (ABI 13)
 WINATTN_MFMA = True        # A/B switch: False = the exact fp32 VALU window-attention kernels on fp32 storage (rounds 2-5)
 
 
@@ -140,14 +141,16 @@ class WinAttnFn(Function):
         ctx.scalars = dict(nwin=B * nW, nW=nW, nH=nH, T=T, ws2=ws2, dtype=dtype_code(qkv), scale=32 ** -0.5, map_ld=N, map_off=T,
                            mfma=1 if (qkv.dtype == torch.float32 and prec is not None and prec.bwd.name == "bf16" and WINATTN_MFMA) else 0)
         ctx.geo, ctx.has_mask = geo, mask is not None
-        ctx.save_for_backward(table, qkv, out, bias, pix, rel_index, *([mask] if mask is not None else []))
+        biasT = bias.transpose(1, 2).contiguous() if (WINATTN_BIAST and (ctx.scalars["mfma"] or qkv.dtype == torch.bfloat16)) else bias.new_empty(0)
+        ctx.save_for_backward(table, qkv, out, bias, pix, rel_index, biasT, *([mask] if mask is not None else []))
         return out, rawlog
 
     @staticmethod
     def backward(ctx, dout, drawlog):
         B, nW, nH, T, ws2, N = ctx.geo
-        table, qkv, out, bias, pix, rel_index = ctx.saved_tensors[:6]
-        kw = dict(ctx.scalars, qkv=qkv, out=out, bias=bias, pix=pix, mask=ctx.saved_tensors[6] if ctx.has_mask else None)
+        table, qkv, out, bias, pix, rel_index, biasT = ctx.saved_tensors[:7]
+        kw = dict(ctx.scalars, qkv=qkv, out=out, bias=bias, pix=pix, mask=ctx.saved_tensors[7] if ctx.has_mask else None,
+                  biasT=biasT if biasT.numel() else None)
         dqkv = torch.empty_like(qkv)
         dS = torch.empty(B * nW, nH, ws2, ws2, dtype=torch.float32, device=qkv.device)
         dout = dout.contiguous()

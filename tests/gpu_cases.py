@@ -922,6 +922,9 @@ def swin_cases():
         if dt == F32:         # the bf16 matrix-core backward on fp32 storage (the x3f mode's backward): operands rounded to bf16 while loaded
             kw = dict(kw, mfma=1, xargs=[kw["xargs"][0], kw["xargs"][1], torch.full((B * nW, Nw, 3 * Cc), 7.0), torch.full((B * nW, nH, ws2, ws2), 7.0)])
             cases.append((f"winattn_bwd_mfma_{res[0]}x{res[1]}_w{window}_s{shift}_T{T}_h{nH}", "winattn_bwd", kw, dict(f32=1.5e-2, bf16=1.5e-2)))
+            kw = dict(kw, biasT=kw["bias"].transpose(1, 2).contiguous(),        # ABI 13: the transposed bias table (16-byte loads in the key-owner pass)
+                      xargs=[kw["xargs"][0], kw["xargs"][1], torch.full((B * nW, Nw, 3 * Cc), 7.0), torch.full((B * nW, nH, ws2, ws2), 7.0)])
+            cases.append((f"winattn_bwd_mfma_biasT_{res[0]}x{res[1]}_w{window}_s{shift}_T{T}_h{nH}", "winattn_bwd", kw, dict(f32=1.5e-2, bf16=1.5e-2)))
     # channel attention
     for (B, T, C, ce, nwin, kdt, has_b) in ((2, 2, 64, 16, 1, F32, True), (1, 3, 136, 64, 2, F32, True), (2, 2, 256, 256, 1, BF16, False), (1, 2, 1024, 256, 2, F32, True)):
         Cp = (C + 7) // 8 * 8
