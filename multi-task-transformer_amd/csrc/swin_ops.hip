@@ -689,11 +689,15 @@ namespace {
 // fp32-class products like the x3 GEMMs).  Q / K rows are split in registers from 32-byte fp32 loads, V^T goes to LDS as two planes,
 // P is split in registers.  Replaces the one-thread-per-query exact VALU kernel in the x3f / x3 forward (9 % of the Swin-B x3f step).
 // ------------------------------------------------------------------------------------------------
+MTT_DEV void st_row(bf16_t* p, u32x4 v) { *(u32x2*)p = (u32x2){v[0], v[1]}; *(u32x2*)(p + 4) = (u32x2){v[2], v[3]}; }
+MTT_DEV u32x4 ld_row(const bf16_t* p) { const u32x2 a = *(const u32x2*)p, b = *(const u32x2*)(p + 4); return (u32x4){a[0], a[1], b[0], b[1]}; }
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void winattn_x3_kernel(const mtt_winattn_desc d) {
-  constexpr int NP = NKT * 16, PITCH = NP + 8;
+  constexpr int NP = NKT * 16, PITCH = NP + 8, RP = 36;
   __shared__ __attribute__((aligned(16))) bf16_t vTh[32 * PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t vTl[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t kRh[NP * RP];         // K rows split ONCE per workgroup (every query tile re-read and re-split them
+  __shared__ __attribute__((aligned(16))) bf16_t kRl[NP * RP];         // from L2 before: 10 x the loads and the VALU split work)
   const int nH = d.nH, T = d.T, ws2 = d.ws2, N = T + ws2, C = nH * 32, ld = 3 * C;
   const int win = blockIdx.x / nH, h = blockIdx.x % nH;
   const int wl = win % d.nW, b = win / d.nW;
@@ -705,6 +709,8 @@ __global__ __launch_bounds__(256, 2) void winattn_x3_kernel(const mtt_winattn_de
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       u32x4 hi, lo;
+      load8<true>(base, C + key * ld + q * 8, MTT_F32, key < N, hi, lo);
+      st_row(kRh + key * RP + q * 8, hi); st_row(kRl + key * RP + q * 8, lo);
       load8<true>(base, 2 * C + key * ld + q * 8, MTT_F32, key < N, hi, lo);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -729,8 +735,7 @@ __global__ __launch_bounds__(256, 2) void winattn_x3_kernel(const mtt_winattn_de
 #pragma unroll
     for (int j = 0; j < NKT; ++j) {
       const int krow = j * 16 + li;
-      u32x4 kh, kl;
-      load8<true>(base, C + krow * ld + lg * 8, MTT_F32, krow < N, kh, kl);
+      const u32x4 kh = ld_row(kRh + krow * RP + lg * 8), kl = ld_row(kRl + krow * RP + lg * 8);
       s[j] = mfma16(kh, qh, mfma16(kh, ql, mfma16(kl, qh, z4)));
     }
     if (qt == 0 && li < T && d.rawmap) {
@@ -840,8 +845,6 @@ MTT_DEV u32x4 wa_frag(const void* p, int off, bool ok) {
   cvt8<false, F32>(ok, r, hi, lo);
   return hi;
 }
-MTT_DEV void st_row(bf16_t* p, u32x4 v) { *(u32x2*)p = (u32x2){v[0], v[1]}; *(u32x2*)(p + 4) = (u32x2){v[2], v[3]}; }
-MTT_DEV u32x4 ld_row(const bf16_t* p) { const u32x2 a = *(const u32x2*)p, b = *(const u32x2*)(p + 4); return (u32x4){a[0], a[1], b[0], b[1]}; }
 template <int NKT, bool F32>
 __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_winattn_desc d, const void* dout, const float* drawmap, void* dqkv, float* dS_out) {
   // LDS (79.5 KB at NKT = 10: two workgroups per CU): the four operands row-major as bf16 (rows of 32 + 4 elements: 8-byte fragment
