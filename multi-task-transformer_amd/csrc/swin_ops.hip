@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void winattn_x3_kernel(const mtt_winattn_de
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
 
-  for (int key = tid; key < NP; key += 256) {
+  for (int key = tid; key < NP; key += 256) {          // (a lane per (row, 8-dim chunk) instead — as in the backward's prologue — measured 3 % slower here)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       u32x4 hi, lo;
@@ -874,10 +874,13 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const mtt_wina
   const void* Ob = (const char*)d.out + obase * es;           // O rows
   void* Db = (char*)dqkv + base * es;                         // dQ | dK | dV rows
 
-  for (int row = tid; row < NP; row += 256) {
+  // one (row, 8-dim chunk) per lane and iteration: 4 NP work items over all 256 lanes (a lane per ROW left 96-110 lanes idle and each
+  // active one with 16 loads + 112 LDS stores in a row), 4 consecutive lanes cover a row's 128 contiguous bytes
+  for (int it = tid; it < 4 * NP; it += 256) {
+    const int row = it >> 2;
     const bool ok = row < N;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    {
+      const int q = it & 3;
       const u32x4 k4 = wa_frag<F32>(Qb, C + row * ld + q * 8, ok);
       const u32x4 q4 = wa_frag<F32>(Qb, row * ld + q * 8, ok);
       const u32x4 g4 = wa_frag<F32>(Gb, row * C + q * 8, ok);

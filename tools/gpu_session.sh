@@ -2,7 +2,7 @@
 # round 6, session 39: x3 window-attention forward with K split once per workgroup into LDS: parity + kernel time + Swin bench
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "winattn" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "winattn" 2>&1 | tail -2; echo ops-done
 timeout 1500 python -m pytest tests -m gpu -q -k "swin or Swin" 2>&1 | tail -2
 B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-roofline"
 timeout 900 python bench.py --config swinb --steps 5 --warmup 2 $B > $O/r06_bench_ap_swinb.log 2>$O/r06_bench_ap_swinb.err
