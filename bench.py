@@ -591,6 +591,8 @@ def main():
         mtt_amd.autograd_path.GELU_DAUX = False
     if a.pitch32_from is not None:
         mtt_amd.ops.PITCH32_FROM = a.pitch32_from
+    if os.environ.get("MTT_MLP_SPLIT_RULE64") is not None:   # A/B: MlpHalfFn's split-plane condition of rounds 3-5 (channel counts % 64)
+        mtt_amd.autograd_path.MLP_SPLIT_RULE64 = os.environ["MTT_MLP_SPLIT_RULE64"] == "1"
     if os.environ.get("MTT_WINATTN_BIAST") is not None:      # A/B: transposed bias table for the window-attention backward's key-owner pass
         import importlib
         importlib.import_module(mtt_amd.__name__ + ".swin_autograd").WINATTN_BIAST = os.environ["MTT_WINATTN_BIAST"] == "1"

@@ -436,7 +436,9 @@ class MlpHalfFn(Function):
     def forward(ctx, XT2, g2, b2n, eps, W1, b1, W2, b2, rowscale, geo, prec, tag):
         B, N, T = geo
         C, Hd = W1.shape[1], W1.shape[0]
-        split = prec.split and C % 64 == 0 and Hd % 64 == 0          # LDS-DMA x3 GEMM: whole 64-deep K tiles (else the register-staged x3 kernels)
+        # the split-plane kernel: whole 32-deep K steps (InvPT's 288-channel stage included; else register-staged x3).  MLP_SPLIT_RULE64: the rule of
+        # rounds 3-5 (multiples of 64), for A/B runs
+        split = prec.split and ((C % 64 == 0 and Hd % 64 == 0) if MLP_SPLIT_RULE64 else (ops.split_gemm_ok(C) and ops.split_gemm_ok(Hd)))
         xn2, mean, rstd = ops.layernorm(XT2, g2, b2n, eps, prec, save_stats=True, out_dtype="split" if split else None)
         w1 = ops.pack_linear_split([W1], tag + ('fc1',)) if split else ops.pack_linear([W1], prec, tag + ('fc1',))
         w2 = ops.pack_linear_split([W2], tag + ('fc2',)) if split else ops.pack_linear([W2], prec, tag + ('fc2',))
@@ -540,6 +542,7 @@ class ModulateFn(Function):
 
 
 # =================================================================================================
+MLP_SPLIT_RULE64 = False
 AUTO_SPLIT = True             # A/B switch of BLinearFn's own split pass (x3f, fp32 inputs)
 AUTO_SPLIT_MIN_ROWS = 2048
 
