@@ -1,18 +1,8 @@
 #!/bin/bash
-# round 6, session 41: MlpHalfFn on split planes for channel counts % 32 (InvPT's 288-channel stage): cfg4 parity + same-box A/B
+# GPU session of the moment (overwritten per session; history in git).  Run as: gpurun --timeout N -- bash tools/gpu_session.sh
+# round 6, FINAL-8 (last tree): the whole -m gpu suite + smoke()
 cd "$GRAFT_REPO_ROOT" || exit 1
 REPO="$GRAFT_REPO_ROOT"; O=$REPO/gpurun_out; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -k "cfg4 or invpt or cfg1" 2>&1 | tail -3
-B="--no-torch-baseline --no-cpu-baseline --no-ref-batch --no-x3-mode --no-fast-mode --no-parity --no-roofline"
-for rep in 1 2; do
-for v in 0 1; do
-  MTT_MLP_SPLIT_RULE64=$v timeout 900 python bench.py --config cfg4 --steps 5 --warmup 2 $B > $O/r06_bench_ar_cfg4_rule64_$v.log 2>$O/r06_bench_ar_cfg4_rule64_$v.err
-  python - $O/r06_bench_ar_cfg4_rule64_$v.log "cfg4 rule64=$v" <<'PY'
-import json, sys
-l=[x for x in open(sys.argv[1]) if x.startswith('{')]
-if l:
-    d=json.loads(l[-1]); print(sys.argv[2], d['config']['per_gpu_batch'], {k:d.get(k) for k in ('value','ms_per_step','fwd_ms_per_img','peak_hbm_gb')})
-else: print(sys.argv[2], 'NO LINE', open(sys.argv[1].replace('.log','.err')).read()[-900:])
-PY
-done
-done
+rm -f $O/parity_report.jsonl
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/r06_pytest_as_full.log 2>&1; echo "full suite rc $?"; tail -2 $O/r06_pytest_as_full.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke_as.log 2>&1; echo "smoke rc $?"; tail -1 $O/r06_smoke_as.log | cut -c1-200
